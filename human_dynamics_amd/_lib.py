@@ -1,0 +1,130 @@
+"""ctypes binding of libhmmr_hip.so (include/hmmr_hip.h).
+
+There is no CPU fallback: if the shared library has not been built
+(`python -m human_dynamics_amd.build`) `load()` raises, and every compute
+entry point of the package goes through `load()`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libhmmr_hip.so")
+
+HMMR_F32, HMMR_BF16 = 0, 1
+RESNET_UNITS = 16
+RESNET_PROF_SLOTS = 64
+MAX_TEMPORAL_BLOCKS = 8
+MAX_REGRESSORS = 8
+
+_vp, _fp, _ip = C.c_void_p, C.c_void_p, C.c_void_p   # all device pointers travel as void*
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("in_", _vp), ("w", _vp), ("scale", _fp), ("shift", _fp), ("res", _vp), ("out", _vp),
+        ("out2", _vp), ("scale2", _fp), ("shift2", _fp),
+        ("in_dtype", C.c_int), ("out_dtype", C.c_int),
+        ("n_img", C.c_int), ("hin", C.c_int), ("win", C.c_int), ("cin", C.c_int),
+        ("in_img_stride", C.c_int64), ("in_row_stride", C.c_int), ("in_px_stride", C.c_int),
+        ("kh", C.c_int), ("kw", C.c_int), ("sy", C.c_int), ("sx", C.c_int), ("py", C.c_int), ("px", C.c_int),
+        ("ho", C.c_int), ("wo", C.c_int), ("cout", C.c_int), ("ldo", C.c_int),
+        ("ldr", C.c_int), ("res_strided", C.c_int), ("res_img_stride", C.c_int64),
+        ("res_row_stride", C.c_int), ("res_px_stride", C.c_int),
+        ("relu", C.c_int), ("tile", C.c_int),
+    ]
+
+
+class Layer(C.Structure):
+    _fields_ = [("w", _vp), ("scale", _fp), ("shift", _fp)]
+
+
+class ResnetUnit(C.Structure):
+    _fields_ = [("conv1", Layer), ("conv2", Layer), ("conv3", Layer), ("shortcut", Layer),
+                ("next_scale", _fp), ("next_shift", _fp),
+                ("c_in", C.c_int), ("base", C.c_int), ("depth", C.c_int), ("stride", C.c_int)]
+
+
+class ResnetWeights(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("stem", Layer), ("pool_scale", _fp), ("pool_shift", _fp),
+                ("unit", ResnetUnit * RESNET_UNITS), ("post_scale", _fp), ("post_shift", _fp)]
+
+
+class TemporalBlock(C.Structure):
+    _fields_ = [("gn1_gamma", _fp), ("gn1_beta", _fp), ("conv1", Layer),
+                ("gn2_gamma", _fp), ("gn2_beta", _fp), ("conv2", Layer)]
+
+
+class TemporalWeights(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("num_blocks", C.c_int), ("block", TemporalBlock * MAX_TEMPORAL_BLOCKS)]
+
+
+class IefRegressor(C.Structure):
+    _fields_ = [("nd", C.c_int), ("fc1_phi", Layer), ("fc1_theta", Layer), ("fc2", Layer), ("fc3", Layer)]
+
+
+class IefWeights(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("num_regressors", C.c_int), ("num_stages", C.c_int),
+                ("reg", IefRegressor * MAX_REGRESSORS), ("mean_theta", _fp)]
+
+
+class SmplConsts(C.Structure):
+    _fields_ = [("num_verts", C.c_int), ("num_kps", C.c_int), ("lbs_nnz", C.c_int),
+                ("dirs", _fp), ("j_template", _fp), ("j_shapedirs", _fp), ("parents", _ip),
+                ("lbs_idx", _ip), ("lbs_w", _fp), ("kreg_ptr", _ip), ("kreg_idx", _ip), ("kreg_val", _fp)]
+
+
+# name -> (restype, argtypes); mirrors include/hmmr_hip.h one to one
+SIGNATURES = {
+    "hmmr_abi_version": (C.c_int, []),
+    "hmmr_last_error": (C.c_char_p, []),
+    "hmmr_conv_gemm": (C.c_int, [C.POINTER(ConvDesc), _vp]),
+    "hmmr_resnet50_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "hmmr_resnet50_fwd": (C.c_int, [C.POINTER(ResnetWeights), _fp, C.c_int, _fp, _vp, C.c_size_t, _vp,
+                                    C.POINTER(C.c_float)]),
+    "hmmr_temporal_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "hmmr_temporal_fwd": (C.c_int, [C.POINTER(TemporalWeights), _fp, C.c_int, C.c_int, _fp, _vp, C.c_size_t, _vp]),
+    "hmmr_groupnorm_relu": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp]),
+    "hmmr_ief_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "hmmr_ief_fwd": (C.c_int, [C.POINTER(IefWeights), _fp, C.c_int, _fp, _vp, C.c_size_t, _vp]),
+    "hmmr_smpl_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "hmmr_smpl_fwd": (C.c_int, [C.POINTER(SmplConsts), _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int,
+                                _fp, _fp, _fp, _fp, _vp, C.c_size_t, _vp]),
+}
+
+_lib = None
+
+
+class HmmrError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libhmmr_hip.so and bind every symbol of the header.  Raises if the
+    library is missing -- there is deliberately no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HmmrError("%s not found: build it with `python -m human_dynamics_amd.build` "
+                        "(the HIP library is mandatory; there is no CPU fallback)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if the .so does not export it
+        fn.restype, fn.argtypes = res, args
+    if lib.hmmr_abi_version() != 1:
+        raise HmmrError("libhmmr_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().hmmr_last_error()
+        raise HmmrError("%s failed (%d): %s" % (what or "hmmr call", rc, msg.decode() if msg else "?"))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None) as a ctypes-compatible int."""
+    return None if t is None else t.data_ptr()

@@ -144,7 +144,9 @@ def make_synthetic_weights(seed=0, num_conv_layers=3, delta_t_values=(-5, 5),
             w["fc2_res/%s/biases" % k] = (rng.standard_normal(FEAT_DIM) * 0.1).astype(np.float32)
     # ---- mean theta (src/evaluation/tester.py:118-152) ----------------------
     w["mean_param"] = make_mean_theta(seed + 1000)[None, :]
-    return w
+    # checkpoint variables are float32 (NumPy-2 scalar promotion would otherwise
+    # leave some of the products above in float64)
+    return {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in w.items()}
 
 
 def make_mean_theta(seed=1000):

@@ -1,0 +1,61 @@
+"""Build libhmmr_hip.so (gfx950) in-tree with hipcc.
+
+    python -m human_dynamics_amd.build [--force]
+
+hipcc cross-compiles without a GPU; the resulting .so is git-ignored but
+travels with the working tree to the GPU box.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+LIB = os.path.join(HERE, "libhmmr_hip.so")
+SOURCES = ["api.cpp", "gemm_conv.hip", "resnet.hip", "temporal.hip", "ief.hip", "smpl.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC,
+         "-Wall", "-Wno-unused-function"]
+
+
+def _newer(src, dst):
+    return (not os.path.exists(dst)) or os.path.getmtime(src) > os.path.getmtime(dst)
+
+
+def _deps():
+    return [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "hmmr_hip.h")]
+
+
+def build(force=False, verbose=True):
+    objs, jobs = [], []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+        objs.append(o)
+        if force or _newer(s, o) or any(_newer(d, o) for d in _deps()):
+            lang = ["-x", "hip"] if src.endswith(".hip") else []
+            jobs.append([HIPCC] + FLAGS + lang + ["-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n%s\n%s" % (" ".join(cmd), r.stdout))
+        if verbose and r.stdout.strip():
+            print(r.stdout)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            list(ex.map(run, jobs))
+    if jobs or force or not os.path.exists(LIB):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,78 @@
+// Shared device/host helpers for the HMMR gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+#define HMMR_WAVE 64
+
+// Error plumbing shared by all translation units (defined in api.cpp).
+void hmmr_set_error(const char* fmt, ...);
+
+#define HMMR_CHECK_HIP(expr)                                                         \
+    do {                                                                             \
+        hipError_t _e = (expr);                                                      \
+        if (_e != hipSuccess) {                                                      \
+            hmmr_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),    \
+                           __FILE__, __LINE__);                                      \
+            return -2;                                                               \
+        }                                                                            \
+    } while (0)
+
+#define HMMR_REQUIRE(cond, ...)                                                      \
+    do {                                                                             \
+        if (!(cond)) {                                                               \
+            hmmr_set_error(__VA_ARGS__);                                             \
+            return -1;                                                               \
+        }                                                                            \
+    } while (0)
+
+// XCD-aware, bijective remap of a 1-D block id: the hardware dispatches block
+// b to XCD b % 8; give each XCD a contiguous range of logical ids so tiles
+// that share an operand panel hit the same private L2 (speed only).
+__device__ __forceinline__ int xcd_remap(int b, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = b & 7, i = b >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + i;
+}
+
+template <typename T> struct elem_traits;
+template <> struct elem_traits<float> {
+    static constexpr int EPS = 4;      // elements per 16-byte slot
+    __device__ static __forceinline__ float to_f32(float v) { return v; }
+    __device__ static __forceinline__ float from_f32(float v) { return v; }
+};
+template <> struct elem_traits<bf16_t> {
+    static constexpr int EPS = 8;
+    __device__ static __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+    __device__ static __forceinline__ bf16_t from_f32(float v) { return (bf16_t)v; }
+};
+
+// 8 consecutive elements <-> 8 floats
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+    const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+    v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+__device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
+    const bf16x8 a = *(const bf16x8*)p;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+}
+__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+    f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+    *(f32x4*)p = a;
+    *(f32x4*)(p + 4) = b;
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
+    bf16x8 a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (bf16_t)v[i];
+    *(bf16x8*)p = a;
+}

@@ -1,0 +1,322 @@
+// Implicit-GEMM convolution / fully-connected kernel for gfx950 (MI355X).
+//
+//   out[m, n] = epi( sum_k A[m, k] * W[n, k] )
+//
+// A is gathered on the fly from an NHWC activation tensor (m = (img, oy, ox),
+// k = (ky, kx, ci)); W is the filter bank packed K-contiguous per output
+// channel.  One kernel serves every conv of the slim ResNet-v2-50 (1x1, 3x3
+// stride 1/2, and the 7x7 stem re-expressed as an 8-tap x 32-"channel" conv on
+// a zero-padded RGBX image), the [3,1] temporal convs of f_movie and the IEF
+// fully-connected layers (reference: src/models.py:65-74, 102-113, 173-184).
+//
+// gfx950 mapping
+//   * 256 threads = 4 waves (64 lanes each) per workgroup; block tile BM x BN,
+//     K advanced 128 BYTES per step (64 bf16 or 32 fp32 per row);
+//   * operands are staged HBM -> VGPR -> LDS in 16-byte slots, one full 128-B
+//     line per tile row (8 lanes per row => every wave-load covers 8 complete
+//     lines); next tile's loads are issued before the MFMAs of the current
+//     tile and written to the other LDS buffer after them (one barrier/step);
+//   * LDS rows are 128 B, slot index XOR-swizzled with (row>>1)&7 so that the
+//     16 lanes serviced together by ds_read_b128 hit 16 distinct 16-B slots of
+//     the 256-B bank row (conflict-free fragment reads);
+//   * MFMA 32x32 tiles: v_mfma_f32_32x32x16_bf16 (bf16 in, fp32 accumulate) or
+//     v_mfma_f32_32x32x2_f32 (exact fp32: bitwise an fmaf chain);
+//   * epilogue: accumulators -> LDS (fp32) -> each lane owns 8 consecutive
+//     output channels of one row: folded-BN scale/shift, residual add, ReLU,
+//     optional second output relu(bn_next(v)) (the next unit's `preact`), all
+//     as 16-byte coalesced accesses;
+//   * 1-D grid remapped so that each XCD (private 4 MiB L2) walks a contiguous
+//     range of tiles that share A rows.
+#include "common.h"
+#include "hmmr_hip.h"
+
+struct ConvArgs {
+    const void* in; const void* w; const float* scale; const float* shift;
+    const void* res; void* out; void* out2; const float* scale2; const float* shift2;
+    int M, K, cout, ldo, ldr;
+    int Wo, HoWo, Hin, Win;
+    long long in_img_stride; int in_row_stride, in_px_stride;
+    int cin_log2, KW, SY, SX, PY, PX;
+    int res_strided; long long res_img_stride; int res_row_stride, res_px_stride;
+    int relu, tiles_n, n_tiles;
+};
+
+template <typename TA> struct Frag;
+template <> struct Frag<float>  { typedef f32x4 type; };
+template <> struct Frag<bf16_t> { typedef bf16x8 type; };
+
+__device__ __forceinline__ f32x16 mma(const f32x4& a, const f32x4& b, f32x16 c) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], c, 0, 0, 0);
+    return c;
+}
+__device__ __forceinline__ f32x16 mma(const bf16x8& a, const bf16x8& b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+template <typename TA, typename TO, int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
+    static_assert(WGM * WGN == 4, "4 waves per workgroup");
+    constexpr int EPS = elem_traits<TA>::EPS;     // elements per 16-B slot
+    constexpr int BKE = 8 * EPS;                  // elements per 128-B K step
+    constexpr int TM = BM / WGM, TN = BN / WGN;   // wave tile
+    constexpr int FM = TM / 32, FN = TN / 32;     // 32x32 fragments per wave
+    constexpr int PA = BM / 32, PB = BN / 32;     // staging passes (32 rows per pass)
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    typedef typename Frag<TA>::type frag_t;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int L = xcd_remap(blockIdx.x, a.n_tiles);
+    const int m0 = (L / a.tiles_n) * BM;
+    const int n0 = (L % a.tiles_n) * BN;
+
+    // ---- staging geometry: 8 lanes per row (one 128-B line), 32 rows per pass
+    const int slot = tid & 7, r0 = tid >> 3;
+    const int wslot = (slot ^ ((r0 >> 1) & 7)) << 4;           // swizzled byte offset in the row
+    const TA* __restrict__ in = (const TA*)a.in;
+    const TA* __restrict__ wt = (const TA*)a.w;
+
+    long long abase[PA]; int aiy[PA], aix[PA];
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+        const int m = m0 + r0 + 32 * p;
+        if (m < a.M) {
+            const int img = m / a.HoWo, rem = m - img * a.HoWo;
+            const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+            abase[p] = (long long)img * a.in_img_stride;
+            aiy[p] = oy * a.SY - a.PY;
+            aix[p] = ox * a.SX - a.PX;
+        } else {
+            abase[p] = 0; aiy[p] = -(1 << 28); aix[p] = 0;       // always out of bounds -> zeros
+        }
+    }
+    const TA* wrow = wt + (long long)(n0 + r0) * a.K + slot * EPS;
+
+    u32x4 ra[PA], rb[PB];
+    const int cin_mask = (1 << a.cin_log2) - 1;
+
+    auto load_tile = [&](int kt) {
+        const int k = kt * BKE + slot * EPS;
+        const int tap = k >> a.cin_log2, ci = k & cin_mask;
+        int ky, kx;
+        if (a.KW == 1) { ky = tap; kx = 0; }
+        else if (a.KW == 3) { ky = (int)(((unsigned)tap * 43691u) >> 17); kx = tap - 3 * ky; }
+        else { ky = tap / a.KW; kx = tap - ky * a.KW; }
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const int iy = aiy[p] + ky, ix = aix[p] + kx;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if ((unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win)
+                v = *(const u32x4*)(in + abase[p] + (long long)iy * a.in_row_stride +
+                                    (long long)ix * a.in_px_stride + ci);
+            ra[p] = v;
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p)
+            rb[p] = *(const u32x4*)(wrow + (long long)(32 * p) * a.K + kt * BKE);
+    };
+    auto store_tile = [&](int buf) {
+        char* sa = smem + buf * STAGE;
+        char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int p = 0; p < PA; ++p) *(u32x4*)(sa + (r0 + 32 * p) * 128 + wslot) = ra[p];
+#pragma unroll
+        for (int p = 0; p < PB; ++p) *(u32x4*)(sb + (r0 + 32 * p) * 128 + wslot) = rb[p];
+    };
+
+    // ---- fragment geometry
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int fsw = (lr >> 1) & 7;
+    const int a_row_off = (wm * TM + lr) * 128;
+    const int b_row_off = A_BYTES + (wn * TN + lr) * 128;
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = a.K / BKE;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const char* sbuf = smem + cur * STAGE;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int so = (((2 * c + lh) ^ fsw) << 4);
+            frag_t fa[FM], fb[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) fa[i] = *(const frag_t*)(sbuf + a_row_off + i * 32 * 128 + so);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) fb[j] = *(const frag_t*)(sbuf + b_row_off + j * 32 * 128 + so);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = mma(fa[i], fb[j], acc[i][j]);
+        }
+        if (kt + 1 < nk) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulators -> LDS as fp32 [BM][BN]
+    float* sc = (float*)smem;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int col = wn * TN + j * 32 + lr;
+                sc[row * BN + col] = acc[i][j][r];
+            }
+    __syncthreads();
+
+    constexpr int VPR = BN / 8;                   // 8-channel vectors per row
+    TO* __restrict__ out = (TO*)a.out;
+    TO* __restrict__ out2 = (TO*)a.out2;
+    const TO* __restrict__ res = (const TO*)a.res;
+#pragma unroll 2
+    for (int it = 0; it < (BM * VPR) / 256; ++it) {
+        const int idx = it * 256 + tid;
+        const int row = idx / VPR, col = (idx % VPR) * 8;
+        const int m = m0 + row, n = n0 + col;
+        if (m >= a.M || n >= a.cout) continue;
+        float v[8];
+        load8(sc + row * BN + col, v);
+        if (a.scale) {
+            float s[8]; load8(a.scale + n, s);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= s[j];
+        }
+        if (a.shift) {
+            float s[8]; load8(a.shift + n, s);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += s[j];
+        }
+        const bool full = (n + 8 <= a.cout);
+        if (res) {
+            long long ro;
+            if (a.res_strided) {
+                const int img = m / a.HoWo, rem = m - img * a.HoWo;
+                const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+                ro = (long long)img * a.res_img_stride + (long long)oy * a.res_row_stride +
+                     (long long)ox * a.res_px_stride + n;
+            } else {
+                ro = (long long)m * a.ldr + n;
+            }
+            if (full) {
+                float rr[8]; load8(res + ro, rr);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += rr[j];
+            } else {
+                for (int j = 0; j < 8 && n + j < a.cout; ++j) v[j] += elem_traits<TO>::to_f32(res[ro + j]);
+            }
+        }
+        if (a.relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        const long long oo = (long long)m * a.ldo + n;
+        if (out) {
+            if (full) store8(out + oo, v);
+            else for (int j = 0; j < 8 && n + j < a.cout; ++j) out[oo + j] = elem_traits<TO>::from_f32(v[j]);
+        }
+        if (out2) {
+            float s2[8], b2[8], u[8];
+            load8(a.scale2 + n, s2); load8(a.shift2 + n, b2);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) u[j] = fmaxf(v[j] * s2[j] + b2[j], 0.f);
+            if (full) store8(out2 + oo, u);
+            else for (int j = 0; j < 8 && n + j < a.cout; ++j) out2[oo + j] = elem_traits<TO>::from_f32(u[j]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------- //
+// Host side
+// ------------------------------------------------------------------------- //
+template <typename TA, typename TO, int BM, int BN, int WGM, int WGN>
+static int launch_cfg(const ConvArgs& base, hipStream_t stream) {
+    ConvArgs a = base;
+    const int tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_n = (a.cout + BN - 1) / BN;
+    a.n_tiles = tiles_m * a.tiles_n;
+    constexpr int kloop = 2 * (BM + BN) * 128, epi = BM * BN * 4;
+    constexpr int lds = kloop > epi ? kloop : epi;
+    auto kern = conv_gemm_kernel<TA, TO, BM, BN, WGM, WGN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HMMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.n_tiles), dim3(256), lds, stream, a);
+    HMMR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+template <typename TA, typename TO>
+static int launch_typed(const ConvArgs& a, int tile, hipStream_t stream) {
+    if (tile == 0) {
+        // pick the largest tile that still gives every CU (256) >= ~2 workgroups
+        const long long t128 = (long long)((a.M + 127) / 128) * ((a.cout + 127) / 128);
+        const long long t12864 = (long long)((a.M + 127) / 128) * ((a.cout + 63) / 64);
+        if (a.cout >= 128 && a.cout % 128 == 0 && t128 >= 512) tile = 1;
+        else if (t12864 >= 512) tile = 2;
+        else tile = 3;
+    }
+    switch (tile) {
+        case 1: return launch_cfg<TA, TO, 128, 128, 2, 2>(a, stream);
+        case 2: return launch_cfg<TA, TO, 128, 64, 2, 2>(a, stream);
+        case 3: return launch_cfg<TA, TO, 64, 64, 2, 2>(a, stream);
+        default: hmmr_set_error("hmmr_conv_gemm: bad tile %d", tile); return -1;
+    }
+}
+
+static int ilog2_exact(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return ((1 << l) == v) ? l : -1;
+}
+
+extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
+    HMMR_REQUIRE(d && d->in && d->w && (d->out || d->out2), "hmmr_conv_gemm: null operand");
+    const int esz = d->in_dtype == HMMR_BF16 ? 2 : 4;
+    const int eps = 16 / esz;
+    const int cl2 = ilog2_exact(d->cin);
+    HMMR_REQUIRE(cl2 >= 0 && d->cin % eps == 0, "hmmr_conv_gemm: cin=%d must be a power of two >= %d", d->cin, eps);
+    const int K = d->kh * d->kw * d->cin;
+    HMMR_REQUIRE(K % (8 * eps) == 0, "hmmr_conv_gemm: K=%d must be a multiple of %d", K, 8 * eps);
+    HMMR_REQUIRE(d->ldo % 8 == 0, "hmmr_conv_gemm: ldo=%d must be a multiple of 8", d->ldo);
+    HMMR_REQUIRE(d->in_px_stride % eps == 0 && d->in_row_stride % eps == 0 && d->in_img_stride % eps == 0,
+                 "hmmr_conv_gemm: input strides must keep 16-byte alignment");
+    HMMR_REQUIRE(!d->res || d->res_strided || d->ldr % 8 == 0, "hmmr_conv_gemm: ldr must be a multiple of 8");
+    HMMR_REQUIRE(!d->out2 || (d->scale2 && d->shift2), "hmmr_conv_gemm: out2 needs scale2/shift2");
+    ConvArgs a;
+    a.in = d->in; a.w = d->w; a.scale = d->scale; a.shift = d->shift; a.res = d->res;
+    a.out = d->out; a.out2 = d->out2; a.scale2 = d->scale2; a.shift2 = d->shift2;
+    a.M = d->n_img * d->ho * d->wo; a.K = K; a.cout = d->cout; a.ldo = d->ldo; a.ldr = d->ldr;
+    a.Wo = d->wo; a.HoWo = d->ho * d->wo; a.Hin = d->hin; a.Win = d->win;
+    a.in_img_stride = d->in_img_stride; a.in_row_stride = d->in_row_stride; a.in_px_stride = d->in_px_stride;
+    a.cin_log2 = cl2; a.KW = d->kw; a.SY = d->sy; a.SX = d->sx; a.PY = d->py; a.PX = d->px;
+    a.res_strided = d->res_strided; a.res_img_stride = d->res_img_stride;
+    a.res_row_stride = d->res_row_stride; a.res_px_stride = d->res_px_stride;
+    a.relu = d->relu; a.tiles_n = 0; a.n_tiles = 0;
+    if (a.M <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (d->in_dtype == HMMR_BF16 && d->out_dtype == HMMR_BF16) return launch_typed<bf16_t, bf16_t>(a, d->tile, s);
+    if (d->in_dtype == HMMR_BF16 && d->out_dtype == HMMR_F32) return launch_typed<bf16_t, float>(a, d->tile, s);
+    if (d->in_dtype == HMMR_F32 && d->out_dtype == HMMR_F32) return launch_typed<float, float>(a, d->tile, s);
+    if (d->in_dtype == HMMR_F32 && d->out_dtype == HMMR_BF16) return launch_typed<float, bf16_t>(a, d->tile, s);
+    hmmr_set_error("hmmr_conv_gemm: unsupported dtypes %d -> %d", d->in_dtype, d->out_dtype);
+    return -1;
+}

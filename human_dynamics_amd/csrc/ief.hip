@@ -1,0 +1,141 @@
+// IEF regressors for gfx950: batch_pred_omega / call_hmr_ief / hmr_ief /
+// encoder_fc3_dropout (src/models.py:80-116, 233-267, 299-415), inference mode
+// (dropout = identity), use_optcam=True, use_delta_from_pred=True.
+//
+//   theta <- theta + fc3(relu(fc2(relu(fc1([phi, theta])))))      x num_stages
+//
+// fc1 acts on concat([phi, theta]) (models.py:402).  It is evaluated as
+// phi.W1[:2048] + b1 (ONCE per regressor: phi does not change over the
+// stages) plus theta.W1[2048:] per stage (K padded to 128).  The theta state
+// and its small GEMM stay fp32 in every mode; the K=2048/1024 GEMMs take the
+// struct's dtype.  All GEMMs go through the implicit-GEMM kernel.
+#include "common.h"
+#include "hmmr_hip.h"
+
+static constexpr int LDT = 128;      // row stride of the zero-padded theta state
+
+template <typename TO>
+__global__ void cast_rows_kernel(const float* __restrict__ in, TO* __restrict__ out, long long n8) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    float v[8];
+    load8(in + i * 8, v);
+    store8(out + i * 8, v);
+}
+
+// theta0[m, :] = [src(row m or broadcast)[off : off+nd], 0...]
+__global__ void ief_init_theta_kernel(const float* __restrict__ src, int ld_src, int off, int nd,
+                                      float* __restrict__ theta, int m) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)m * LDT) return;
+    const int row = (int)(i / LDT), col = (int)(i % LDT);
+    theta[i] = col < nd ? src[(long long)row * ld_src + off + col] : 0.f;
+}
+
+// omega_out[m, 85]: present regressor -> theta[:, :85];
+// delta regressor -> [1, 0, 0, theta[:, :72], omega0[:, 75:85]]  (models.py:367-371)
+__global__ void ief_finalize_kernel(const float* __restrict__ theta, const float* __restrict__ omega0,
+                                    int is_delta, float* __restrict__ out, int m) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)m * 85) return;
+    const int row = (int)(i / 85), col = (int)(i % 85);
+    float v;
+    if (!is_delta) v = theta[(long long)row * LDT + col];
+    else if (col == 0) v = 1.f;
+    else if (col < 3) v = 0.f;
+    else if (col < 75) v = theta[(long long)row * LDT + (col - 3)];
+    else v = omega0[(long long)row * 85 + col];
+    out[i] = v;
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct IefBufs { size_t xin, pre, h1, h2, th[2], total; };
+static IefBufs ief_layout(int m, int dtype) {
+    const size_t e = dtype == HMMR_BF16 ? 2 : 4;
+    IefBufs b; size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    b.xin = take((size_t)m * 2048 * e);
+    b.pre = take((size_t)m * 1024 * e);
+    b.h1 = take((size_t)m * 1024 * e);
+    b.h2 = take((size_t)m * 1024 * e);
+    b.th[0] = take((size_t)m * LDT * 4);
+    b.th[1] = take((size_t)m * LDT * 4);
+    b.total = off;
+    return b;
+}
+
+extern "C" size_t hmmr_ief_workspace_bytes(int m, int num_regressors, int dtype) {
+    (void)num_regressors;
+    return m > 0 ? ief_layout(m, dtype).total : 0;
+}
+
+static hmmr_conv_desc_t fc_desc(const void* in, int in_dtype, int m, int k, const hmmr_layer_t& l,
+                                void* out, int out_dtype, int cout, int ldo) {
+    hmmr_conv_desc_t d = {};
+    d.in = in; d.w = l.w; d.scale = l.scale; d.shift = l.shift; d.out = out;
+    d.in_dtype = in_dtype; d.out_dtype = out_dtype;
+    d.n_img = m; d.hin = d.win = 1; d.cin = k;
+    d.in_img_stride = k; d.in_row_stride = k; d.in_px_stride = k;
+    d.kh = d.kw = 1; d.sy = d.sx = 1; d.ho = d.wo = 1; d.cout = cout; d.ldo = ldo;
+    return d;
+}
+
+extern "C" int hmmr_ief_fwd(const hmmr_ief_weights_t* w, const float* strips, int m, float* omegas,
+                            void* ws, size_t ws_bytes, void* stream) {
+    HMMR_REQUIRE(w && strips && omegas && ws, "hmmr_ief_fwd: null argument");
+    HMMR_REQUIRE(m > 0, "hmmr_ief_fwd: m must be positive");
+    HMMR_REQUIRE(w->num_regressors >= 1 && w->num_regressors <= HMMR_MAX_REGRESSORS, "hmmr_ief_fwd: bad num_regressors");
+    HMMR_REQUIRE(w->reg[0].nd == 85, "hmmr_ief_fwd: regressor 0 must predict 85-D omega");
+    HMMR_REQUIRE(ws_bytes >= hmmr_ief_workspace_bytes(m, w->num_regressors, w->dtype), "hmmr_ief_fwd: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const IefBufs L = ief_layout(m, w->dtype);
+    char* base = (char*)ws;
+    const void* xin = strips;
+    if (w->dtype == HMMR_BF16) {
+        const long long n8 = (long long)m * 2048 / 8;
+        hipLaunchKernelGGL(cast_rows_kernel<bf16_t>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, strips,
+                           (bf16_t*)(base + L.xin), n8);
+        HMMR_CHECK_HIP(hipGetLastError());
+        xin = base + L.xin;
+    }
+    void* pre = base + L.pre; void* h1 = base + L.h1; void* h2 = base + L.h2;
+    float* th[2] = {(float*)(base + L.th[0]), (float*)(base + L.th[1])};
+    const unsigned gth = (unsigned)(((long long)m * LDT + 255) / 256);
+    const unsigned gfin = (unsigned)(((long long)m * 85 + 255) / 256);
+    for (int r = 0; r < w->num_regressors; ++r) {
+        const hmmr_ief_regressor_t& R = w->reg[r];
+        HMMR_REQUIRE(R.nd == 85 || R.nd == 72, "hmmr_ief_fwd: regressor %d has nd=%d", r, R.nd);
+        float* out_r = omegas + (size_t)r * m * 85;
+        // starting point: mean theta (tester.py:181) or omega0[:, 3:75] (models.py:349-356)
+        if (r == 0)
+            hipLaunchKernelGGL(ief_init_theta_kernel, dim3(gth), dim3(256), 0, s, w->mean_theta, 0, 0, 85, th[0], m);
+        else
+            hipLaunchKernelGGL(ief_init_theta_kernel, dim3(gth), dim3(256), 0, s, (const float*)omegas, 85, 3, 72, th[0], m);
+        HMMR_CHECK_HIP(hipGetLastError());
+        HMMR_CHECK_HIP(hipMemsetAsync(th[1], 0, (size_t)m * LDT * 4, s));
+        // pre = phi . W1[:2048] + b1
+        hmmr_conv_desc_t d = fc_desc(xin, w->dtype, m, 2048, R.fc1_phi, pre, w->dtype, 1024, 1024);
+        if (hmmr_conv_gemm(&d, s)) return -2;
+        int cur = 0;
+        for (int st = 0; st < w->num_stages; ++st) {
+            // h1 = relu(pre + theta . W1[2048:])
+            d = fc_desc(th[cur], HMMR_F32, m, LDT, R.fc1_theta, h1, w->dtype, 1024, 1024);
+            d.res = pre; d.ldr = 1024; d.relu = 1;
+            if (hmmr_conv_gemm(&d, s)) return -2;
+            // h2 = relu(h1 . W2 + b2)
+            d = fc_desc(h1, w->dtype, m, 1024, R.fc2, h2, w->dtype, 1024, 1024);
+            d.relu = 1;
+            if (hmmr_conv_gemm(&d, s)) return -2;
+            // theta' = theta + h2 . W3 + b3
+            d = fc_desc(h2, w->dtype, m, 1024, R.fc3, th[cur ^ 1], HMMR_F32, R.nd, LDT);
+            d.res = th[cur]; d.ldr = LDT;
+            if (hmmr_conv_gemm(&d, s)) return -2;
+            cur ^= 1;
+        }
+        hipLaunchKernelGGL(ief_finalize_kernel, dim3(gfin), dim3(256), 0, s, (const float*)th[cur],
+                           (const float*)omegas, r != 0, out_r, m);
+        HMMR_CHECK_HIP(hipGetLastError());
+    }
+    return 0;
+}

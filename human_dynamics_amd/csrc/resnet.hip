@@ -1,0 +1,283 @@
+// ResNet-v2-50 image encoder for gfx950: encoder_resnet (src/models.py:50-77)
+// -> tf.contrib.slim.nets.resnet_v2.resnet_v2_50(num_classes=None,
+// is_training=False).  Layer semantics restated in SURVEY.md App. A.
+//
+// All 53 convolutions run through the implicit-GEMM kernel (gemm_conv.hip);
+// this file holds the three bandwidth kernels around them and the launch
+// sequence:
+//   stem_repack       fp32 RGB [n,224,224,3] -> zero-padded RGBX [n,230,232,4]
+//                     in the operand dtype, so the 7x7/2 stem (explicit pad 3,
+//                     VALID) becomes an 8-tap x 32-element implicit GEMM
+//                     (tap = ky, 32 elements = 8 pixels x 4 channels)
+//   maxpool_bn_relu   3x3/2 TF-SAME max pool (pad bottom/right only) fused with
+//                     block1/unit_1's `preact` BN + ReLU
+//   bn_relu_avgpool   postnorm BN + ReLU + spatial mean (pool5)
+// Inference BN is folded to y = x*scale + shift on the host
+// (scale = gamma*rsqrt(var+1e-5), shift = beta - mean*scale).
+#include "common.h"
+#include "hmmr_hip.h"
+
+static constexpr int IMG = 224, PADH = 230, PADW = 232;
+
+template <typename T>
+__global__ void stem_repack_kernel(const float* __restrict__ img, T* __restrict__ out, long long npix) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % PADW);
+        const long long t = i / PADW;
+        const int y = (int)(t % PADH);
+        const long long n = t / PADH;
+        float r = 0.f, g = 0.f, b = 0.f;
+        const int sy = y - 3, sx = x - 3;
+        if ((unsigned)sy < (unsigned)IMG && (unsigned)sx < (unsigned)IMG) {
+            const float* p = img + ((n * IMG + sy) * IMG + sx) * 3;
+            r = p[0]; g = p[1]; b = p[2];
+        }
+        T* o = out + i * 4;
+        o[0] = elem_traits<T>::from_f32(r);
+        o[1] = elem_traits<T>::from_f32(g);
+        o[2] = elem_traits<T>::from_f32(b);
+        o[3] = elem_traits<T>::from_f32(0.f);
+    }
+}
+
+// in [n,112,112,64] -> out [n,56,56,64]; window rows 2oy..2oy+2, cols 2ox..2ox+2,
+// out-of-range taps ignored (TF SAME with pad_before = 0).
+template <typename T>
+__global__ void maxpool_bn_relu_kernel(const T* __restrict__ in, T* __restrict__ out,
+                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                       long long nvec) {
+    constexpr int HI = 112, HO = 56, C = 64, CV = C / 8;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        long long t = i / CV;
+        const int ox = (int)(t % HO); t /= HO;
+        const int oy = (int)(t % HO);
+        const long long n = t / HO;
+        float m[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = -3.0e38f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int iy = 2 * oy + dy;
+            if (iy >= HI) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ix = 2 * ox + dx;
+                if (ix >= HI) continue;
+                float v[8];
+                load8(in + ((n * HI + iy) * HI + ix) * C + cv * 8, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], v[j]);
+            }
+        }
+        float s[8], b[8];
+        load8(scale + cv * 8, s); load8(shift + cv * 8, b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j] * s[j] + b[j], 0.f);
+        store8(out + i * 8, m);
+    }
+}
+
+// in [n,hw,c] -> phi [n,c] fp32: mean over hw of relu(x*scale+shift)
+template <typename T>
+__global__ void bn_relu_avgpool_kernel(const T* __restrict__ in, float* __restrict__ phi,
+                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                       int n, int hw, int c) {
+    const int cv = c / 8;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)n * cv) return;
+    const int v8 = (int)(i % cv);
+    const long long img = i / cv;
+    float s[8], b[8], acc[8];
+    load8(scale + v8 * 8, s); load8(shift + v8 * 8, b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int p = 0; p < hw; ++p) {
+        float v[8];
+        load8(in + (img * hw + p) * c + v8 * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += fmaxf(v[j] * s[j] + b[j], 0.f);
+    }
+    const float inv = 1.0f / (float)hw;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] *= inv;
+    store8(phi + img * c + v8 * 8, acc);
+}
+
+// ------------------------------------------------------------------------- //
+struct Prof {
+    float* ms; int slot; hipStream_t s; hipEvent_t ev[HMMR_RESNET_PROF_SLOTS + 1];
+    bool on() const { return ms != nullptr; }
+};
+
+static int prof_begin(Prof& p) {
+    if (!p.on()) return 0;
+    for (int i = 0; i <= HMMR_RESNET_PROF_SLOTS; ++i) HMMR_CHECK_HIP(hipEventCreate(&p.ev[i]));
+    HMMR_CHECK_HIP(hipEventRecord(p.ev[0], p.s));
+    p.slot = 0;
+    return 0;
+}
+static int prof_mark(Prof& p) {
+    if (!p.on() || p.slot >= HMMR_RESNET_PROF_SLOTS) return 0;
+    ++p.slot;
+    HMMR_CHECK_HIP(hipEventRecord(p.ev[p.slot], p.s));
+    return 0;
+}
+static int prof_end(Prof& p) {
+    if (!p.on()) return 0;
+    HMMR_CHECK_HIP(hipStreamSynchronize(p.s));
+    for (int i = 0; i < HMMR_RESNET_PROF_SLOTS; ++i) {
+        p.ms[i] = 0.f;
+        if (i < p.slot) HMMR_CHECK_HIP(hipEventElapsedTime(&p.ms[i], p.ev[i], p.ev[i + 1]));
+    }
+    for (int i = 0; i <= HMMR_RESNET_PROF_SLOTS; ++i) hipEventDestroy(p.ev[i]);
+    return 0;
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct ResnetBufs {
+    size_t xpad, stem, x[2], p[2], t1, t2, total;
+};
+static ResnetBufs resnet_layout(int n, int dtype) {
+    const size_t e = dtype == HMMR_BF16 ? 2 : 4;
+    ResnetBufs b; size_t off = 0;
+    auto take = [&](size_t elems) { size_t o = off; off = align_up(off + elems * e, 256); return o; };
+    b.xpad = take((size_t)n * PADH * PADW * 4);
+    b.stem = take((size_t)n * 112 * 112 * 64);
+    for (int i = 0; i < 2; ++i) b.x[i] = take((size_t)n * 56 * 56 * 256);
+    for (int i = 0; i < 2; ++i) b.p[i] = take((size_t)n * 56 * 56 * 256);
+    b.t1 = take((size_t)n * 56 * 56 * 64);
+    b.t2 = take((size_t)n * 56 * 56 * 64);
+    b.total = off;
+    return b;
+}
+
+extern "C" size_t hmmr_resnet50_workspace_bytes(int n, int dtype) {
+    return n > 0 ? resnet_layout(n, dtype).total : 0;
+}
+
+template <typename T>
+static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int n, float* phi,
+                        char* ws, hipStream_t s, float* prof_ms) {
+    const ResnetBufs L = resnet_layout(n, w->dtype);
+    T* xpad = (T*)(ws + L.xpad);
+    T* stem = (T*)(ws + L.stem);
+    T* X[2] = {(T*)(ws + L.x[0]), (T*)(ws + L.x[1])};
+    T* P[2] = {(T*)(ws + L.p[0]), (T*)(ws + L.p[1])};
+    T* T1 = (T*)(ws + L.t1);
+    T* T2 = (T*)(ws + L.t2);
+    Prof pf; pf.ms = prof_ms; pf.s = s; pf.slot = 0;
+    if (prof_begin(pf)) return -2;
+
+    // ---- stem: repack -> 7x7/2 conv (+bias, no BN/ReLU) -> pool1 + preact of block1/unit_1
+    {
+        const long long npix = (long long)n * PADH * PADW;
+        const int grid = (int)((npix + 255) / 256 < 8192 ? (npix + 255) / 256 : 8192);
+        hipLaunchKernelGGL(stem_repack_kernel<T>, dim3(grid), dim3(256), 0, s, images, xpad, npix);
+        HMMR_CHECK_HIP(hipGetLastError());
+        if (prof_mark(pf)) return -2;
+        hmmr_conv_desc_t d = {};
+        d.in = xpad; d.w = w->stem.w; d.scale = w->stem.scale; d.shift = w->stem.shift;
+        d.out = stem; d.in_dtype = d.out_dtype = w->dtype;
+        d.n_img = n; d.hin = PADH; d.win = 2 * 111 + 1; d.cin = 32;
+        d.in_img_stride = (int64_t)PADH * PADW * 4; d.in_row_stride = PADW * 4; d.in_px_stride = 4;
+        d.kh = 8; d.kw = 1; d.sy = 2; d.sx = 2; d.py = 0; d.px = 0;
+        d.ho = 112; d.wo = 112; d.cout = 64; d.ldo = 64;
+        if (hmmr_conv_gemm(&d, s)) return -2;
+        if (prof_mark(pf)) return -2;
+        const long long nvec = (long long)n * 56 * 56 * 8;
+        const int g2 = (int)((nvec + 255) / 256 < 16384 ? (nvec + 255) / 256 : 16384);
+        hipLaunchKernelGGL(maxpool_bn_relu_kernel<T>, dim3(g2), dim3(256), 0, s, (const T*)stem, P[0],
+                           w->pool_scale, w->pool_shift, nvec);
+        HMMR_CHECK_HIP(hipGetLastError());
+        if (prof_mark(pf)) return -2;
+    }
+
+    int H = 56, cur = 0;
+    const T* xraw = nullptr;     // raw input of the unit (only valid when the shortcut is identity)
+    for (int u = 0; u < HMMR_RESNET_UNITS; ++u) {
+        const hmmr_resnet_unit_t& U = w->unit[u];
+        const int Ho = H / U.stride;
+        const bool last = (u == HMMR_RESNET_UNITS - 1);
+        const bool next_needs_raw = last || (w->unit[u + 1].c_in == w->unit[u + 1].depth);
+        T* xn = X[cur ^ 1];
+        T* pn = P[cur ^ 1];
+        const T* p = P[cur];
+        hmmr_conv_desc_t d;
+        if (U.shortcut.w) {           // 1x1 conv on preact, bias, no BN/ReLU (stride is 1 here)
+            d = hmmr_conv_desc_t{};
+            d.in = p; d.w = U.shortcut.w; d.scale = U.shortcut.scale; d.shift = U.shortcut.shift;
+            d.out = xn; d.in_dtype = d.out_dtype = w->dtype;
+            d.n_img = n; d.hin = H; d.win = H; d.cin = U.c_in;
+            d.in_img_stride = (int64_t)H * H * U.c_in; d.in_row_stride = H * U.c_in; d.in_px_stride = U.c_in;
+            d.kh = d.kw = 1; d.sy = d.sx = U.stride; d.ho = d.wo = Ho; d.cout = U.depth; d.ldo = U.depth;
+            if (hmmr_conv_gemm(&d, s)) return -2;
+            if (prof_mark(pf)) return -2;
+        }
+        // conv1: 1x1, BN + ReLU
+        d = hmmr_conv_desc_t{};
+        d.in = p; d.w = U.conv1.w; d.scale = U.conv1.scale; d.shift = U.conv1.shift; d.relu = 1;
+        d.out = T1; d.in_dtype = d.out_dtype = w->dtype;
+        d.n_img = n; d.hin = H; d.win = H; d.cin = U.c_in;
+        d.in_img_stride = (int64_t)H * H * U.c_in; d.in_row_stride = H * U.c_in; d.in_px_stride = U.c_in;
+        d.kh = d.kw = 1; d.sy = d.sx = 1; d.ho = d.wo = H; d.cout = U.base; d.ldo = U.base;
+        if (hmmr_conv_gemm(&d, s)) return -2;
+        if (prof_mark(pf)) return -2;
+        // conv2: 3x3 conv2d_same(stride): pad 1/1 both for stride 1 (SAME) and stride 2 (explicit pad + VALID)
+        d = hmmr_conv_desc_t{};
+        d.in = T1; d.w = U.conv2.w; d.scale = U.conv2.scale; d.shift = U.conv2.shift; d.relu = 1;
+        d.out = T2; d.in_dtype = d.out_dtype = w->dtype;
+        d.n_img = n; d.hin = H; d.win = H; d.cin = U.base;
+        d.in_img_stride = (int64_t)H * H * U.base; d.in_row_stride = H * U.base; d.in_px_stride = U.base;
+        d.kh = d.kw = 3; d.sy = d.sx = U.stride; d.py = d.px = 1; d.ho = d.wo = Ho; d.cout = U.base; d.ldo = U.base;
+        if (hmmr_conv_gemm(&d, s)) return -2;
+        if (prof_mark(pf)) return -2;
+        // conv3: 1x1 + bias, + shortcut; second output = next unit's preact
+        d = hmmr_conv_desc_t{};
+        d.in = T2; d.w = U.conv3.w; d.scale = U.conv3.scale; d.shift = U.conv3.shift;
+        d.in_dtype = d.out_dtype = w->dtype;
+        d.n_img = n; d.hin = Ho; d.win = Ho; d.cin = U.base;
+        d.in_img_stride = (int64_t)Ho * Ho * U.base; d.in_row_stride = Ho * U.base; d.in_px_stride = U.base;
+        d.kh = d.kw = 1; d.sy = d.sx = 1; d.ho = d.wo = Ho; d.cout = U.depth; d.ldo = U.depth;
+        if (U.shortcut.w) { d.res = xn; d.ldr = U.depth; }
+        else if (U.stride == 1) { d.res = xraw; d.ldr = U.depth; }
+        else {                        // max_pool2d(x, [1,1], stride) = x[:, ::s, ::s]
+            d.res = xraw; d.res_strided = 1;
+            d.res_img_stride = (int64_t)H * H * U.depth; d.res_row_stride = U.stride * H * U.depth;
+            d.res_px_stride = U.stride * U.depth;
+        }
+        HMMR_REQUIRE(d.res != nullptr, "resnet: unit %d has no shortcut source", u);
+        d.out = next_needs_raw ? xn : nullptr;
+        if (!last) { d.out2 = pn; d.scale2 = U.next_scale; d.shift2 = U.next_shift; }
+        if (hmmr_conv_gemm(&d, s)) return -2;
+        if (prof_mark(pf)) return -2;
+        xraw = next_needs_raw ? xn : nullptr;
+        cur ^= 1; H = Ho;
+    }
+    // ---- postnorm BN + ReLU + mean over 7x7
+    {
+        const long long nth = (long long)n * (2048 / 8);
+        hipLaunchKernelGGL(bn_relu_avgpool_kernel<T>, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, s,
+                           (const T*)xraw, phi, w->post_scale, w->post_shift, n, H * H, 2048);
+        HMMR_CHECK_HIP(hipGetLastError());
+        if (prof_mark(pf)) return -2;
+    }
+    return prof_end(pf);
+}
+
+extern "C" int hmmr_resnet50_fwd(const hmmr_resnet_weights_t* w, const float* images, int n, float* phi,
+                                 void* ws, size_t ws_bytes, void* stream, float* prof_ms) {
+    HMMR_REQUIRE(w && images && phi && ws, "hmmr_resnet50_fwd: null argument");
+    HMMR_REQUIRE(n > 0, "hmmr_resnet50_fwd: n must be positive");
+    HMMR_REQUIRE(ws_bytes >= hmmr_resnet50_workspace_bytes(n, w->dtype),
+                 "hmmr_resnet50_fwd: workspace too small (%zu < %zu)", ws_bytes,
+                 hmmr_resnet50_workspace_bytes(n, w->dtype));
+    HMMR_REQUIRE(w->unit[0].c_in == 64 && w->unit[15].depth == 2048, "hmmr_resnet50_fwd: bad unit table");
+    if (w->dtype == HMMR_BF16) return resnet_fwd_t<bf16_t>(w, images, n, phi, (char*)ws, (hipStream_t)stream, prof_ms);
+    if (w->dtype == HMMR_F32) return resnet_fwd_t<float>(w, images, n, phi, (char*)ws, (hipStream_t)stream, prof_ms);
+    hmmr_set_error("hmmr_resnet50_fwd: bad dtype %d", w->dtype);
+    return -1;
+}

@@ -1,0 +1,265 @@
+// SMPL forward for gfx950: SMPL.__call__ (src/tf_smpl/batch_smpl.py:89-162),
+// batch_rodrigues / batch_global_rigid_transformation
+// (src/tf_smpl/batch_lbs.py:42-60, 133-194) and batch_orth_proj_idrot
+// (src/tf_smpl/projection.py:16-29).  Always fp32.
+//
+// Three launches per call, nothing but the outputs and a 2 KB/instance
+// scratch record ever touches HBM (the reference materialises the tiled
+// skinning weights [m,6890,24] and T [m,6890,4,4]):
+//   smpl_pose_kernel   per instance: Rodrigues (24 joints), shape-dependent
+//                      joints, forward kinematics in the reference's
+//                      multiplication order, relative transforms A, and the
+//                      blend feature row [1, beta, (R_1..23 - I)]
+//   smpl_verts_kernel  per (256-vertex tile, 8 instances): blend shapes as a
+//                      218-deep FMA chain whose per-instance coefficients are
+//                      wave-uniform (scalar registers), then linear-blend
+//                      skinning over the vertex's non-zero weights (ELL) with
+//                      A staged in LDS; T and W are never materialised
+//   smpl_joints_kernel per instance: keypoints = sparse regressor x verts
+//                      (CSR), then kps = s * (xy + t)
+// Layout note: `dirs` is the tf_smpl basis re-packed on the host as
+// [218][3][VPAD] (planar x/y/z, VPAD = 6912) so that a wave's 64 lanes read
+// 256 contiguous bytes per coordinate.
+#include "common.h"
+#include "hmmr_hip.h"
+
+static constexpr int NJ = 24;
+static constexpr int NFEAT = 218;        // 1 + 10 + 207
+static constexpr int LDF = 224;          // feature row stride (floats)
+static constexpr int LDA = NJ * 12;      // A record: 24 x (3x4) floats
+static constexpr int VT = 256;           // vertices per workgroup
+static constexpr int IB = 8;             // instances per workgroup
+
+// ---- kernel 1 ------------------------------------------------------------ //
+__global__ __launch_bounds__(256) void smpl_pose_kernel(
+    const float* __restrict__ theta, int ld_theta, const float* __restrict__ beta, int ld_beta,
+    const float* __restrict__ j_template, const float* __restrict__ j_shapedirs,
+    const int* __restrict__ parents, int m, float* __restrict__ feat, float* __restrict__ Aout,
+    float* __restrict__ rs) {
+    // per instance slot: local transform (R 9, t 3) and global (R 9, t 3) per joint
+    __shared__ float sLoc[8][NJ][12];
+    __shared__ float sGlb[8][NJ][12];
+    __shared__ float sJ[8][NJ][3];
+    const int slot = threadIdx.x >> 5, j = threadIdx.x & 31;
+    const int inst = blockIdx.x * 8 + slot;
+    const bool live = inst < m && j < NJ;
+    float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (live) {
+        const float* th = theta + (long long)inst * ld_theta + 3 * j;
+        const float x = th[0], y = th[1], z = th[2];
+        // batch_lbs.py:48-50: angle = ||theta + 1e-8||, r = theta / angle
+        const float ex = x + 1e-8f, ey = y + 1e-8f, ez = z + 1e-8f;
+        const float angle = sqrtf(ex * ex + ey * ey + ez * ez);
+        const float rx = x / angle, ry = y / angle, rz = z / angle;
+        const float c = cosf(angle), s = sinf(angle), oc = 1.0f - c;
+        // R = cos*I + (1-cos)*r r^T + sin*skew(r)      (batch_lbs.py:56-59, :24-36)
+        R[0] = c + oc * rx * rx;      R[1] = oc * rx * ry - s * rz; R[2] = oc * rx * rz + s * ry;
+        R[3] = oc * ry * rx + s * rz; R[4] = c + oc * ry * ry;      R[5] = oc * ry * rz - s * rx;
+        R[6] = oc * rz * rx - s * ry; R[7] = oc * rz * ry + s * rx; R[8] = c + oc * rz * rz;
+        if (rs) {
+            float* o = rs + ((long long)inst * NJ + j) * 9;
+#pragma unroll
+            for (int e = 0; e < 9; ++e) o[e] = R[e];
+        }
+        float* f = feat + (long long)inst * LDF;
+        if (j >= 1) {
+#pragma unroll
+            for (int e = 0; e < 9; ++e) f[11 + (j - 1) * 9 + e] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f);
+        }
+        const float* bt = beta + (long long)inst * ld_beta;
+        if (j < 10) f[1 + j] = bt[j];
+        if (j == 0) f[0] = 1.0f;
+        if (j < LDF - NFEAT) f[NFEAT + j] = 0.0f;
+        // joints of the shaped template: J = J_regressor^T (v_template + S beta), folded on the host
+        float J[3];
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3) {
+            float acc = j_template[j * 3 + c3];
+#pragma unroll
+            for (int b = 0; b < 10; ++b) acc += bt[b] * j_shapedirs[b * (NJ * 3) + j * 3 + c3];
+            J[c3] = acc;
+            sJ[slot][j][c3] = acc;
+        }
+#pragma unroll
+        for (int e = 0; e < 9; ++e) sLoc[slot][j][e] = R[e];
+        (void)J;
+    }
+    __syncthreads();
+    if (live) {
+        // local translation: J_i - J_parent(i); root keeps J_0   (batch_lbs.py:163-173)
+        const int p = j == 0 ? -1 : parents[j];
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3)
+            sLoc[slot][j][9 + c3] = sJ[slot][j][c3] - (p >= 0 ? sJ[slot][p][c3] : 0.0f);
+        if (j == 0) {
+#pragma unroll
+            for (int e = 0; e < 12; ++e) sGlb[slot][0][e] = sLoc[slot][0][e];
+        }
+    }
+    __syncthreads();
+    // G_i = G_parent(i) . [R_i | t_i], in index order like the reference loop (parents[i] < i)
+    for (int i = 1; i < NJ; ++i) {
+        if (live && j == i) {
+            const int p = parents[i];
+            const float* G = sGlb[slot][p];
+            const float* Lc = sLoc[slot][i];
+            float o[12];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc)
+                    o[r * 3 + cc] = G[r * 3 + 0] * Lc[0 * 3 + cc] + G[r * 3 + 1] * Lc[1 * 3 + cc] + G[r * 3 + 2] * Lc[2 * 3 + cc];
+                o[9 + r] = G[r * 3 + 0] * Lc[9] + G[r * 3 + 1] * Lc[10] + G[r * 3 + 2] * Lc[11] + G[9 + r];
+            }
+#pragma unroll
+            for (int e = 0; e < 12; ++e) sGlb[slot][i][e] = o[e];
+        }
+        __syncthreads();
+    }
+    if (live) {
+        // A = G - [0 | G . [J; 0]]  ->  rows [R_g | t_g - R_g J]   (batch_lbs.py:188-192)
+        const float* G = sGlb[slot][j];
+        float* o = Aout + (long long)inst * LDA + j * 12;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float bone = G[r * 3 + 0] * sJ[slot][j][0] + G[r * 3 + 1] * sJ[slot][j][1] + G[r * 3 + 2] * sJ[slot][j][2];
+            o[r * 4 + 0] = G[r * 3 + 0]; o[r * 4 + 1] = G[r * 3 + 1]; o[r * 4 + 2] = G[r * 3 + 2];
+            o[r * 4 + 3] = G[9 + r] - bone;
+        }
+    }
+}
+
+// ---- kernel 2 ------------------------------------------------------------ //
+__global__ __launch_bounds__(256) void smpl_verts_kernel(
+    const float* __restrict__ dirs, int vpad, const float* __restrict__ feat, const float* __restrict__ A,
+    const int* __restrict__ lbs_idx, const float* __restrict__ lbs_w, int nnz, int nv, int m,
+    float* __restrict__ verts) {
+    __shared__ __attribute__((aligned(16))) float sA[IB][LDA];
+    const int v = blockIdx.x * VT + threadIdx.x;
+    const int i0 = blockIdx.y * IB;
+    for (int e = threadIdx.x; e < IB * LDA; e += 256) {
+        const int ii = e / LDA;
+        sA[ii][e % LDA] = (i0 + ii < m) ? A[(long long)(i0 + ii) * LDA + (e % LDA)] : 0.f;
+    }
+    float acc[IB][3];
+#pragma unroll
+    for (int ii = 0; ii < IB; ++ii) acc[ii][0] = acc[ii][1] = acc[ii][2] = 0.f;
+    // feature rows of the 8 instances are wave-uniform: clamp so tail blocks read valid memory
+    const float* f[IB];
+#pragma unroll
+    for (int ii = 0; ii < IB; ++ii) f[ii] = feat + (long long)min(i0 + ii, m - 1) * LDF;
+    // v_posed = v_template + beta.S + pose_feature.P   (batch_smpl.py:110-112, 131-133)
+    const float* d = dirs + v;             // v < vpad always (grid covers vpad exactly)
+#pragma unroll 2
+    for (int k = 0; k < NFEAT; ++k) {
+        const float dx = d[(long long)(k * 3 + 0) * vpad];
+        const float dy = d[(long long)(k * 3 + 1) * vpad];
+        const float dz = d[(long long)(k * 3 + 2) * vpad];
+#pragma unroll
+        for (int ii = 0; ii < IB; ++ii) {
+            const float c = f[ii][k];
+            acc[ii][0] = fmaf(c, dx, acc[ii][0]);
+            acc[ii][1] = fmaf(c, dy, acc[ii][1]);
+            acc[ii][2] = fmaf(c, dz, acc[ii][2]);
+        }
+    }
+    __syncthreads();
+    if (v >= nv) return;
+    // skinning: T = sum_j W[v,j] A_j over the non-zero weights; v' = T [v_posed; 1]   (batch_smpl.py:141-151)
+    float T[IB][12];
+#pragma unroll
+    for (int ii = 0; ii < IB; ++ii)
+#pragma unroll
+        for (int e = 0; e < 12; ++e) T[ii][e] = 0.f;
+    for (int z = 0; z < nnz; ++z) {
+        const int jj = lbs_idx[(long long)v * nnz + z];
+        const float wv = lbs_w[(long long)v * nnz + z];
+#pragma unroll
+        for (int ii = 0; ii < IB; ++ii) {
+            const f32x4* a4 = (const f32x4*)&sA[ii][jj * 12];
+            const f32x4 r0 = a4[0], r1 = a4[1], r2 = a4[2];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                T[ii][e] = fmaf(wv, r0[e], T[ii][e]);
+                T[ii][4 + e] = fmaf(wv, r1[e], T[ii][4 + e]);
+                T[ii][8 + e] = fmaf(wv, r2[e], T[ii][8 + e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int ii = 0; ii < IB; ++ii) {
+        if (i0 + ii >= m) break;
+        const float x = acc[ii][0], y = acc[ii][1], z = acc[ii][2];
+        float* o = verts + ((long long)(i0 + ii) * nv + v) * 3;
+        o[0] = T[ii][0] * x + T[ii][1] * y + T[ii][2] * z + T[ii][3];
+        o[1] = T[ii][4] * x + T[ii][5] * y + T[ii][6] * z + T[ii][7];
+        o[2] = T[ii][8] * x + T[ii][9] * y + T[ii][10] * z + T[ii][11];
+    }
+}
+
+// ---- kernel 3 ------------------------------------------------------------ //
+// joints = cocoplus_regressor^T verts (batch_smpl.py:154-157); kps = s*(xy + t) (projection.py:25-29)
+__global__ __launch_bounds__(256) void smpl_joints_kernel(
+    const float* __restrict__ verts, const int* __restrict__ kptr, const int* __restrict__ kidx,
+    const float* __restrict__ kval, const float* __restrict__ cams, int ld_cam, int nv, int nk,
+    float* __restrict__ joints, float* __restrict__ kps) {
+    const int inst = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float* vb = verts + (long long)inst * nv * 3;
+    for (int k = wave; k < nk; k += 4) {
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int e = kptr[k] + lane; e < kptr[k + 1]; e += 64) {
+            const float w = kval[e];
+            const float* p = vb + (long long)kidx[e] * 3;
+            sx = fmaf(w, p[0], sx); sy = fmaf(w, p[1], sy); sz = fmaf(w, p[2], sz);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o); sz += __shfl_xor(sz, o);
+        }
+        if (lane == 0) {
+            float* jo = joints + ((long long)inst * nk + k) * 3;
+            jo[0] = sx; jo[1] = sy; jo[2] = sz;
+            if (kps && cams) {
+                const float* cm = cams + (long long)inst * ld_cam;
+                float* ko = kps + ((long long)inst * nk + k) * 2;
+                ko[0] = cm[0] * (sx + cm[1]);
+                ko[1] = cm[0] * (sy + cm[2]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------- //
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+extern "C" size_t hmmr_smpl_workspace_bytes(int m) {
+    if (m <= 0) return 0;
+    return align_up((size_t)m * LDF * 4, 256) + align_up((size_t)m * LDA * 4, 256);
+}
+
+extern "C" int hmmr_smpl_fwd(const hmmr_smpl_consts_t* c, const float* theta, int ld_theta,
+                             const float* beta, int ld_beta, const float* cams, int ld_cam, int m,
+                             float* verts, float* joints, float* kps, float* rs,
+                             void* ws, size_t ws_bytes, void* stream) {
+    HMMR_REQUIRE(c && theta && beta && verts && joints && ws, "hmmr_smpl_fwd: null argument");
+    HMMR_REQUIRE(m > 0, "hmmr_smpl_fwd: m must be positive");
+    HMMR_REQUIRE(c->lbs_nnz >= 1 && c->lbs_nnz <= NJ, "hmmr_smpl_fwd: lbs_nnz=%d out of range", c->lbs_nnz);
+    HMMR_REQUIRE(ws_bytes >= hmmr_smpl_workspace_bytes(m), "hmmr_smpl_fwd: workspace too small");
+    HMMR_REQUIRE(!kps || cams, "hmmr_smpl_fwd: kps requested without cams");
+    hipStream_t s = (hipStream_t)stream;
+    float* feat = (float*)ws;
+    float* A = (float*)((char*)ws + align_up((size_t)m * LDF * 4, 256));
+    const int vtiles = (c->num_verts + VT - 1) / VT;
+    hipLaunchKernelGGL(smpl_pose_kernel, dim3((m + 7) / 8), dim3(256), 0, s, theta, ld_theta, beta, ld_beta,
+                       c->j_template, c->j_shapedirs, c->parents, m, feat, A, rs);
+    HMMR_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(smpl_verts_kernel, dim3(vtiles, (m + IB - 1) / IB), dim3(256), 0, s, c->dirs,
+                       vtiles * VT, (const float*)feat, (const float*)A, c->lbs_idx, c->lbs_w, c->lbs_nnz,
+                       c->num_verts, m, verts);
+    HMMR_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(smpl_joints_kernel, dim3(m), dim3(256), 0, s, (const float*)verts, c->kreg_ptr,
+                       c->kreg_idx, c->kreg_val, cams, ld_cam, c->num_verts, c->num_kps, joints, kps);
+    HMMR_CHECK_HIP(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,113 @@
+// f_movie temporal encoder for gfx950: az_fc2_groupnorm / az_fc_block2
+// (src/models.py:121-228).  Per residual block, on a [b, t, 1, 2048] tensor:
+//   GN(32 groups, stats over time x 64 channels, eps 1e-6) -> ReLU ->
+//   conv [3,1] SAME + bias -> GN -> ReLU -> conv [3,1] SAME + bias -> + input
+// The two convolutions run through the implicit-GEMM kernel (M = b*t,
+// K = 3*2048, N = 2048; zero rows outside the window come from its bounds
+// check); the residual trunk and the GN statistics stay fp32 in every mode,
+// only the GEMM operands take the struct's dtype.
+#include "common.h"
+#include "hmmr_hip.h"
+
+#define GN_EPS 1e-6f
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();                       // protect `red` from the previous use
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// One workgroup per (window b, group g).  tf.contrib.layers.group_norm with
+// reduction_axes=(-3,-2) on [b,t,1,c]: mean and POPULATION variance over
+// (t, c/groups); gain = rsqrt(var+eps)*gamma; offset = -mean*gain + beta.
+template <typename TO>
+__global__ __launch_bounds__(256) void groupnorm_relu_kernel(const float* __restrict__ x,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             TO* __restrict__ out, int t, int c, int groups) {
+    __shared__ float red[4];
+    const int cpg = c / groups;
+    const int b = blockIdx.x / groups, g = blockIdx.x % groups;
+    const int cnt = t * cpg;
+    const float* xb = x + (long long)b * t * c + g * cpg;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < cnt; i += 256) s += xb[(i / cpg) * c + (i % cpg)];
+    const float mean = block_sum_256(s, red) / (float)cnt;
+    float q = 0.f;
+    for (int i = threadIdx.x; i < cnt; i += 256) {
+        const float d = xb[(i / cpg) * c + (i % cpg)] - mean;
+        q += d * d;
+    }
+    const float var = block_sum_256(q, red) / (float)cnt;
+    const float rstd = rsqrtf(var + GN_EPS);
+    TO* ob = out + (long long)b * t * c + g * cpg;
+    for (int i = threadIdx.x; i < cnt; i += 256) {
+        const int tt = i / cpg, j = i % cpg;
+        const float gain = rstd * gamma[g * cpg + j];
+        const float offset = -mean * gain + beta[g * cpg + j];
+        ob[tt * c + j] = elem_traits<TO>::from_f32(fmaxf(xb[tt * c + j] * gain + offset, 0.f));
+    }
+}
+
+extern "C" int hmmr_groupnorm_relu(const float* x, const float* gamma, const float* beta, int b, int t,
+                                   int c, int groups, void* out, int out_dtype, void* stream) {
+    HMMR_REQUIRE(x && gamma && beta && out, "hmmr_groupnorm_relu: null argument");
+    HMMR_REQUIRE(b > 0 && t > 0 && groups > 0 && c % groups == 0, "hmmr_groupnorm_relu: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    if (out_dtype == HMMR_BF16)
+        hipLaunchKernelGGL(groupnorm_relu_kernel<bf16_t>, dim3(b * groups), dim3(256), 0, s, x, gamma, beta,
+                           (bf16_t*)out, t, c, groups);
+    else if (out_dtype == HMMR_F32)
+        hipLaunchKernelGGL(groupnorm_relu_kernel<float>, dim3(b * groups), dim3(256), 0, s, x, gamma, beta,
+                           (float*)out, t, c, groups);
+    else { hmmr_set_error("hmmr_groupnorm_relu: bad dtype %d", out_dtype); return -1; }
+    HMMR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+extern "C" size_t hmmr_temporal_workspace_bytes(int b, int t, int dtype) {
+    if (b <= 0 || t <= 0) return 0;
+    const size_t m = (size_t)b * t, e = dtype == HMMR_BF16 ? 2 : 4;
+    // h (operand dtype) + h1 (fp32) + two fp32 trunk buffers
+    return align_up(m * 2048 * e, 256) + 3 * align_up(m * 2048 * 4, 256);
+}
+
+extern "C" int hmmr_temporal_fwd(const hmmr_temporal_weights_t* w, const float* phi, int b, int t,
+                                 float* strips, void* ws, size_t ws_bytes, void* stream) {
+    HMMR_REQUIRE(w && phi && strips && ws, "hmmr_temporal_fwd: null argument");
+    HMMR_REQUIRE(b > 0 && t > 0, "hmmr_temporal_fwd: bad shape");
+    HMMR_REQUIRE(w->num_blocks >= 1 && w->num_blocks <= HMMR_MAX_TEMPORAL_BLOCKS, "hmmr_temporal_fwd: bad num_blocks");
+    HMMR_REQUIRE(ws_bytes >= hmmr_temporal_workspace_bytes(b, t, w->dtype), "hmmr_temporal_fwd: workspace too small");
+    const int C = 2048;
+    const size_t m = (size_t)b * t, e = w->dtype == HMMR_BF16 ? 2 : 4;
+    char* p = (char*)ws;
+    void* h = p;              p += align_up(m * C * e, 256);
+    float* h1 = (float*)p;    p += align_up(m * C * 4, 256);
+    float* net[2];
+    net[0] = (float*)p;       p += align_up(m * C * 4, 256);
+    net[1] = (float*)p;
+    const float* cur = phi;
+    for (int i = 0; i < w->num_blocks; ++i) {
+        const hmmr_temporal_block_t& B = w->block[i];
+        float* dst = (i == w->num_blocks - 1) ? strips : net[i & 1];
+        if (hmmr_groupnorm_relu(cur, B.gn1_gamma, B.gn1_beta, b, t, C, 32, h, w->dtype, stream)) return -2;
+        hmmr_conv_desc_t d = {};
+        d.in = h; d.w = B.conv1.w; d.scale = B.conv1.scale; d.shift = B.conv1.shift;
+        d.out = h1; d.in_dtype = w->dtype; d.out_dtype = HMMR_F32;
+        d.n_img = b; d.hin = t; d.win = 1; d.cin = C;
+        d.in_img_stride = (int64_t)t * C; d.in_row_stride = C; d.in_px_stride = C;
+        d.kh = 3; d.kw = 1; d.sy = d.sx = 1; d.py = 1; d.px = 0; d.ho = t; d.wo = 1; d.cout = C; d.ldo = C;
+        if (hmmr_conv_gemm(&d, stream)) return -2;
+        if (hmmr_groupnorm_relu(h1, B.gn2_gamma, B.gn2_beta, b, t, C, 32, h, w->dtype, stream)) return -2;
+        d.w = B.conv2.w; d.scale = B.conv2.scale; d.shift = B.conv2.shift;
+        d.res = cur; d.ldr = C; d.out = dst;            // residual adds the BLOCK INPUT (models.py:226)
+        if (hmmr_conv_gemm(&d, stream)) return -2;
+        cur = dst;
+    }
+    return 0;
+}

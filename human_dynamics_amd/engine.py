@@ -1,0 +1,209 @@
+"""Device engine: owns the packed weights, the HBM workspaces and the four
+stage calls of libhmmr_hip.so.  Everything above it (models.py, omega.py,
+evaluation/tester.py) mirrors the reference's Python interface and only
+shuffles tensors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import assets, packing
+
+DTYPES = {"f32": L.HMMR_F32, "fp32": L.HMMR_F32, "float32": L.HMMR_F32,
+          "bf16": L.HMMR_BF16, "bfloat16": L.HMMR_BF16}
+
+
+def _dt(d):
+    if isinstance(d, str):
+        return DTYPES[d]
+    return int(d)
+
+
+class _Workspace(object):
+    """Grow-only HBM scratch buffer."""
+
+    def __init__(self, device):
+        self.device, self.buf = device, None
+
+    def get(self, nbytes):
+        if self.buf is None or self.buf.numel() < nbytes:
+            self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self.buf
+
+
+class HmmrEngine(object):
+    """weights: dict of checkpoint-named arrays (assets.py); smpl: dict in the
+    src/tf_smpl layout.  dtype: GEMM operand type of ResNet / temporal / IEF
+    ('bf16' or 'f32'); SMPL is always fp32."""
+
+    def __init__(self, weights, smpl, dtype="bf16", device="cuda:0", num_conv_layers=3,
+                 delta_t_values=(-5, 5), joint_type="cocoplus", resnet_chunk=0,
+                 temporal_dtype=None, ief_dtype=None):
+        self.lib = L.load()
+        if not torch.cuda.is_available():
+            raise L.HmmrError("HmmrEngine needs a HIP device (torch.cuda.is_available() is False)")
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.dtype = _dt(dtype)
+        self.temporal_dtype = self.dtype if temporal_dtype is None else _dt(temporal_dtype)
+        self.ief_dtype = self.dtype if ief_dtype is None else _dt(ief_dtype)
+        self.resnet_chunk = int(resnet_chunk)
+        self.store = packing.DeviceStore(self.device)
+        self.num_conv_layers = num_conv_layers
+        self.delta_keys = sorted(int(d) for d in delta_t_values)
+        self.rw = packing.pack_resnet(weights, self.dtype, self.store) if weights is not None else None
+        self.tw = (packing.pack_temporal(weights, self.temporal_dtype, self.store, num_conv_layers)
+                   if weights is not None else None)
+        if weights is not None:
+            self.iw, self.reg_keys = packing.pack_ief(weights, self.ief_dtype, self.store, self.delta_keys)
+        else:
+            self.iw, self.reg_keys = None, [0]
+        self.sc = packing.pack_smpl(smpl, self.store, joint_type) if smpl is not None else None
+        self.num_kps = self.sc.num_kps if self.sc is not None else assets.NUM_KPS
+        self.num_verts = self.sc.num_verts if self.sc is not None else assets.NUM_VERTS
+        self._ws = {k: _Workspace(self.device) for k in ("resnet", "temporal", "ief", "smpl")}
+
+    # -- helpers ---------------------------------------------------------------
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def to_device(self, a, dtype=torch.float32):
+        if isinstance(a, torch.Tensor):
+            return a.to(self.device, dtype).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(a)).to(self.device).to(dtype).contiguous()
+
+    # -- stages ----------------------------------------------------------------
+    def resnet(self, images, prof=False):
+        """images [n,224,224,3] fp32 (device) -> phi [n,2048] fp32.
+        encoder_resnet, src/models.py:50-77."""
+        images = self.to_device(images)
+        n = images.shape[0]
+        assert tuple(images.shape[1:]) == (224, 224, 3), images.shape
+        phi = torch.empty((n, 2048), dtype=torch.float32, device=self.device)
+        chunk = self.resnet_chunk if self.resnet_chunk > 0 else n
+        prof_tot = np.zeros(L.RESNET_PROF_SLOTS, np.float64) if prof else None
+        for i in range(0, n, chunk):
+            c = min(chunk, n - i)
+            nbytes = self.lib.hmmr_resnet50_workspace_bytes(c, self.dtype)
+            ws = self._ws["resnet"].get(nbytes)
+            pm = (C.c_float * L.RESNET_PROF_SLOTS)() if prof else None
+            L.check(self.lib.hmmr_resnet50_fwd(C.byref(self.rw), images[i:i + c].data_ptr(), c,
+                                               phi[i:i + c].data_ptr(), ws.data_ptr(), nbytes,
+                                               self._stream(), pm), "hmmr_resnet50_fwd")
+            if prof:
+                prof_tot += np.frombuffer(pm, dtype=np.float32)
+        return (phi, prof_tot) if prof else phi
+
+    def temporal(self, phi):
+        """phi [b,t,2048] fp32 -> movie strips [b,t,2048].  az_fc2_groupnorm, src/models.py:121-141."""
+        phi = self.to_device(phi)
+        b, t, c = phi.shape
+        assert c == 2048
+        out = torch.empty_like(phi)
+        nbytes = self.lib.hmmr_temporal_workspace_bytes(b, t, self.temporal_dtype)
+        ws = self._ws["temporal"].get(nbytes)
+        L.check(self.lib.hmmr_temporal_fwd(C.byref(self.tw), phi.data_ptr(), b, t, out.data_ptr(),
+                                           ws.data_ptr(), nbytes, self._stream()), "hmmr_temporal_fwd")
+        return out
+
+    def ief(self, strips):
+        """strips [m,2048] -> omegas [R,m,85]; R = 1 + len(delta_t_values), deltas in sorted order.
+        batch_pred_omega, src/models.py:233-267."""
+        strips = self.to_device(strips)
+        m = strips.shape[0]
+        R = self.iw.num_regressors
+        out = torch.empty((R, m, 85), dtype=torch.float32, device=self.device)
+        nbytes = self.lib.hmmr_ief_workspace_bytes(m, R, self.ief_dtype)
+        ws = self._ws["ief"].get(nbytes)
+        L.check(self.lib.hmmr_ief_fwd(C.byref(self.iw), strips.data_ptr(), m, out.data_ptr(),
+                                      ws.data_ptr(), nbytes, self._stream()), "hmmr_ief_fwd")
+        return out
+
+    def smpl(self, theta, beta, cams=None, want_rs=True):
+        """theta [m,72], beta [m,10], cams [m,3] or None (row-major views with a
+        unit inner stride are used in place).  Returns verts [m,V,3], joints
+        [m,K,3], kps [m,K,2] or None, Rs [m,24,3,3] or None.
+        SMPL.__call__, src/tf_smpl/batch_smpl.py:89-162."""
+        def prep(x, width):
+            if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32
+                    and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == width):
+                x = self.to_device(x).reshape(-1, width)
+            return x
+        theta, beta = prep(theta, 72), prep(beta, 10)
+        m = theta.shape[0]
+        cams = prep(cams, 3) if cams is not None else None
+        V, K = self.num_verts, self.num_kps
+        verts = torch.empty((m, V, 3), dtype=torch.float32, device=self.device)
+        joints = torch.empty((m, K, 3), dtype=torch.float32, device=self.device)
+        kps = torch.empty((m, K, 2), dtype=torch.float32, device=self.device) if cams is not None else None
+        rs = torch.empty((m, 24, 3, 3), dtype=torch.float32, device=self.device) if want_rs else None
+        nbytes = self.lib.hmmr_smpl_workspace_bytes(m)
+        ws = self._ws["smpl"].get(nbytes)
+        L.check(self.lib.hmmr_smpl_fwd(C.byref(self.sc), theta.data_ptr(), theta.stride(0),
+                                       beta.data_ptr(), beta.stride(0),
+                                       L.ptr(cams), cams.stride(0) if cams is not None else 0, m,
+                                       verts.data_ptr(), joints.data_ptr(), L.ptr(kps), L.ptr(rs),
+                                       ws.data_ptr(), nbytes, self._stream()), "hmmr_smpl_fwd")
+        return verts, joints, kps, rs
+
+    def groupnorm_relu(self, x, gamma, beta, groups=32, out_dtype=L.HMMR_F32):
+        x = self.to_device(x)
+        b, t, c = x.shape
+        g, be = self.to_device(gamma), self.to_device(beta)
+        out = torch.empty((b, t, c), dtype=packing.TORCH_DT[out_dtype], device=self.device)
+        L.check(self.lib.hmmr_groupnorm_relu(x.data_ptr(), g.data_ptr(), be.data_ptr(), b, t, c, groups,
+                                             out.data_ptr(), out_dtype, self._stream()), "hmmr_groupnorm_relu")
+        return out
+
+
+def conv_gemm(x, w_hwio, stride=1, pad=0, scale=None, shift=None, res=None, relu=False,
+              scale2=None, shift2=None, in_dtype=L.HMMR_F32, out_dtype=L.HMMR_F32, tile=0,
+              device="cuda:0", res_stride=1):
+    """Test/utility entry: run one NHWC convolution through hmmr_conv_gemm.
+    x [n,h,w,cin] (numpy/torch), w_hwio [kh,kw,cin,cout].  Returns (out, out2)."""
+    lib = L.load()
+    dev = torch.device(device)
+    store = packing.DeviceStore(dev)
+    xt = store.put(np.asarray(x, np.float32), packing.TORCH_DT[in_dtype])
+    n, h, w_, cin = xt.shape
+    kh, kw, _, cout = w_hwio.shape
+    py, px = (pad, pad) if isinstance(pad, int) else pad
+    ho = (h + 2 * py - kh) // stride + 1
+    wo = (w_ + 2 * px - kw) // stride + 1
+    wt = store.put(packing.pack_conv_weight(np.asarray(w_hwio, np.float32)), packing.TORCH_DT[in_dtype])
+    ldo = (cout + 7) // 8 * 8
+    out = torch.zeros((n, ho, wo, ldo), dtype=packing.TORCH_DT[out_dtype], device=dev)
+    d = L.ConvDesc()
+    d.in_, d.w, d.out = xt.data_ptr(), wt.data_ptr(), out.data_ptr()
+    d.scale = store.vec(scale).data_ptr() if scale is not None else None
+    d.shift = store.vec(shift).data_ptr() if shift is not None else None
+    out2 = None
+    if scale2 is not None:
+        out2 = torch.zeros_like(out)
+        d.out2, d.scale2, d.shift2 = out2.data_ptr(), store.vec(scale2).data_ptr(), store.vec(shift2).data_ptr()
+    if res is not None:
+        rt = store.put(np.asarray(res, np.float32), packing.TORCH_DT[out_dtype])
+        d.res = rt.data_ptr()
+        if res_stride == 1:
+            assert tuple(rt.shape) == (n, ho, wo, cout) and cout % 8 == 0
+            d.ldr = cout
+        else:
+            d.res_strided = 1
+            d.res_img_stride = rt.shape[1] * rt.shape[2] * cout
+            d.res_row_stride = res_stride * rt.shape[2] * cout
+            d.res_px_stride = res_stride * cout
+    d.in_dtype, d.out_dtype = in_dtype, out_dtype
+    d.n_img, d.hin, d.win, d.cin = n, h, w_, cin
+    d.in_img_stride, d.in_row_stride, d.in_px_stride = h * w_ * cin, w_ * cin, cin
+    d.kh, d.kw, d.sy, d.sx, d.py, d.px = kh, kw, stride, stride, py, px
+    d.ho, d.wo, d.cout, d.ldo = ho, wo, cout, ldo
+    d.relu, d.tile = int(relu), tile
+    L.check(lib.hmmr_conv_gemm(C.byref(d), torch.cuda.current_stream(dev).cuda_stream), "hmmr_conv_gemm")
+    torch.cuda.synchronize(dev)
+    o = out[..., :cout].float().cpu().numpy()
+    o2 = out2[..., :cout].float().cpu().numpy() if out2 is not None else None
+    return o, o2

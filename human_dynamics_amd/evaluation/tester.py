@@ -1,0 +1,251 @@
+"""Drop-in for src/evaluation/tester.py's ``Tester`` on MI355X.
+
+Same constructor, attributes and methods as the reference:
+
+    Tester(config, pretrained_resnet_path='', sequence_length=None)
+    .predict(images[B,T,224,224,3]) -> dict of float32 ndarrays   (tester.py:229-258)
+    .predict_all_images(all_images[N,224,224,3]) -> dict[N,...]   (tester.py:260-312)
+    .fov .batch_size .sequence_length .img_size .num_output
+
+``config`` is duck-typed (load_path, batch_size, sequence_length, pred_mode,
+num_conv_layers, delta_t_values, smpl_model_path, num_kps).  Differences, all
+deliberate: errors raise instead of dropping into ipdb; weights come from an
+``.npz`` with the checkpoint's variable names (or ``synthetic[:seed]``) because
+TF checkpoints cannot be read without TF yet;
+``predict_all_images`` pushes every frame through the ResNet once instead of
+T/g = 2.5 times (inference-mode ResNet is per-frame independent, so the
+result is identical; pass ``dedup=False`` for the literal schedule).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+from .. import assets
+from ..engine import HmmrEngine
+from ..models import (batch_pred_omega, get_hallucinator_model, get_image_encoder,
+                      get_temporal_encoder)
+from ..omega import OmegasPred
+from ..tf_smpl.batch_smpl import SMPL, load_smpl_constants
+
+OUTPUT_KEYS = ("cams", "joints", "kps", "poses", "shapes", "verts", "omegas")
+
+
+def load_weights(load_path, resnet_path=""):
+    """'synthetic[:seed]' or .npz files holding the checkpoint variable names of
+    SURVEY App. B.  ResNet variables come from `resnet_path` when given
+    (tester.py:99-112)."""
+    def one(path):
+        if str(path).startswith("synthetic"):
+            seed = int(str(path).split(":")[1]) if ":" in str(path) else 0
+            return assets.make_synthetic_weights(seed)
+        if os.path.exists(path) and path.endswith(".npz"):
+            return {k: v for k, v in np.load(path).items()}
+        if os.path.exists(str(path) + ".index"):
+            raise NotImplementedError(
+                "%s is a TF checkpoint; convert it to .npz with the variable names of SURVEY App. B "
+                "(a native TF-checkpoint-V2 reader is a later row, SURVEY 8 f-1)" % path)
+        raise FileNotFoundError("{} doesnt exist..".format(path))
+    w = dict(one(load_path))
+    if resnet_path:
+        for k, v in one(resnet_path).items():
+            if "resnet" in k:
+                w[k] = v
+    return w
+
+
+def window_plan(n_frames, batch_size, sequence_length, fov):
+    """Index arithmetic of predict_all_images (tester.py:281-289)."""
+    margin = (fov - 1) // 2
+    g = sequence_length - 2 * margin
+    count = int(np.ceil(n_frames / float(g * batch_size)))
+    num_fill = count * batch_size * g + sequence_length - n_frames
+    return margin, g, count, num_fill
+
+
+class Tester(object):
+
+    def __init__(self, config, pretrained_resnet_path="", sequence_length=None,
+                 weights=None, smpl=None, dtype=None, device=None, dedup=True):
+        self.config = config
+        self.load_path = config.load_path
+        if not config.load_path and weights is None:
+            raise Exception("[!] You need to specify `load_path` to load a pretrained model")
+        # Model parameters (tester.py:41-50).
+        self.batch_size = config.batch_size
+        self.sequence_length = sequence_length if sequence_length else config.sequence_length
+        self.pred_mode = config.pred_mode
+        self.num_conv_layers = config.num_conv_layers
+        self.fov = self.num_conv_layers * 4 + 1
+        self.delta_t_values = [int(dt) for dt in config.delta_t_values]
+        self.img_size = 224
+        self.num_output = 85
+        self.smpl_model_path = config.smpl_model_path
+        self.dedup = dedup
+        if self.pred_mode not in ("pred", "hal"):
+            raise Exception("Pred mode {} not recognized".format(self.pred_mode))
+        if self.pred_mode == "hal":
+            raise NotImplementedError("pred_mode 'hal' is a later hot-path row (SURVEY.md section 8 f-4)")
+
+        if weights is None:
+            weights = load_weights(config.load_path, pretrained_resnet_path)
+        if smpl is None:
+            smpl = load_smpl_constants(self.smpl_model_path)
+        dtype = dtype or getattr(config, "dtype", "bf16")
+        device = device or getattr(config, "device", "cuda:0")
+        self.engine = HmmrEngine(weights, smpl, dtype=dtype, device=device,
+                                 num_conv_layers=self.num_conv_layers,
+                                 delta_t_values=self.delta_t_values,
+                                 resnet_chunk=getattr(config, "resnet_chunk", 0))
+        self.smpl = SMPL(smpl, engine=self.engine)
+        if self.engine.num_kps != config.num_kps:
+            raise ValueError("config.num_kps=%d but the SMPL regressor has %d keypoints"
+                             % (config.num_kps, self.engine.num_kps))
+        self.f_hal = get_hallucinator_model()
+        self.f_image_enc = get_image_encoder()
+        self.f_temporal_enc = get_temporal_encoder()
+        self.theta_mean = np.asarray(weights["mean_param"], np.float32).reshape(1, 85)
+
+    # ------------------------------------------------------------------------
+    def make_omega_pred(self, registry, use_optcam=False, batch_size=None):
+        return OmegasPred(config=self.config, smpl_engine=self.engine, use_optcam=use_optcam,
+                          vis_max_batch=batch_size or self.batch_size, batch_size=batch_size,
+                          is_training=False, registry=registry)
+
+    def _regress(self, movie_strips, B, T):
+        """movie strips [B,T,2048] -> {0, -5, +5: OmegasPred} with SMPL computed
+        (the tail of build_test_model, tester.py:196-214)."""
+        registry = []
+        omegas_pred = {0: self.make_omega_pred(registry, use_optcam=False, batch_size=B)}
+        for dt in self.delta_t_values:
+            omegas_pred[dt] = self.make_omega_pred(registry, use_optcam=True, batch_size=B)
+        omegas_raw, deltas_pred = batch_pred_omega(
+            input_features=movie_strips, batch_size=B, sequence_length=T,
+            num_output=self.num_output, is_training=False, omega_mean=None,
+            scope="single_view_ief", engine=self.engine,
+            predict_delta_keys=omegas_pred.keys(), use_optcam=True, use_delta_from_pred=True)
+        omegas_pred[0].append_batched(omegas_raw)
+        for k in deltas_pred.keys():
+            omegas_pred[k].append_batched(deltas_pred[k])
+            omegas_pred[k].set_cams(omegas_pred[0].get_cams())
+        OmegasPred.compute_all_smpl(registry)
+        return omegas_pred
+
+    @staticmethod
+    def make_fetch_dict(omegas, suffix=""):
+        return {
+            "cams" + suffix: omegas.get_cams(),
+            "joints" + suffix: omegas.get_joints(),
+            "kps" + suffix: omegas.get_kps(),
+            "poses" + suffix: omegas.get_poses_rot(),
+            "shapes" + suffix: omegas.get_shapes(),
+            "verts" + suffix: omegas.get_verts(),
+            "omegas" + suffix: omegas.get_raw(),
+        }
+
+    def _fetch(self, omegas_pred, to_numpy=True):
+        fetch = self.make_fetch_dict(omegas_pred[0])
+        deltas = {}
+        for delta_t, omega_delta in sorted(omegas_pred.items()):
+            if delta_t == 0:
+                continue
+            for k, v in self.make_fetch_dict(omega_delta, suffix="_delta").items():
+                deltas.setdefault(k, []).append(v)
+        for k, v in deltas.items():                  # DxBxTx... --> BxTxDx...
+            fetch[k] = torch.stack(v, dim=2)
+        if not to_numpy:
+            return fetch
+        torch.cuda.synchronize(self.engine.device)
+        return {k: v.float().cpu().numpy() for k, v in fetch.items()}
+
+    # ------------------------------------------------------------------------
+    def predict_device(self, images):
+        """Forward pass on device tensors: images [B,T,224,224,3] -> dict of device tensors."""
+        B, T = images.shape[0], images.shape[1]
+        I_t = self.engine.to_device(images).reshape(B * T, self.img_size, self.img_size, 3)
+        img_feat, _ = self.f_image_enc(I_t, engine=self.engine, is_training=False, reuse=False)
+        img_feat_full = img_feat.reshape(B, T, -1)
+        movie_strips = self.f_temporal_enc(is_training=False, net=img_feat_full,
+                                           num_conv_layers=self.num_conv_layers, engine=self.engine)
+        return self._fetch(self._regress(movie_strips, B, T), to_numpy=False)
+
+    def predict(self, images):
+        """Runs forward pass of model.  images (BxTxHxWx3) -> dict of float32 ndarrays."""
+        out = self.predict_device(images)
+        torch.cuda.synchronize(self.engine.device)
+        return {k: v.float().cpu().numpy() for k, v in out.items()}
+
+    # ------------------------------------------------------------------------
+    def features(self, frames, chunk=256):
+        """frames [N,224,224,3] (host or device) -> phi [N,2048] on device."""
+        if isinstance(frames, torch.Tensor) and frames.is_cuda:
+            return self.engine.resnet(frames)
+        outs = []
+        for i in range(0, len(frames), chunk):
+            outs.append(self.engine.resnet(np.asarray(frames[i:i + chunk], np.float32)))
+        return torch.cat(outs, dim=0)
+
+    def predict_windows_device(self, phi, phi_zero, n_out=None, window_range=None):
+        """The part of predict_all_images after the ResNet, on features.
+
+        phi [N,2048]: features of the N real frames; phi_zero [1,2048]: feature of
+        the all-zero padding image (tester.py:285-289 pads with zero IMAGES).
+        window_range = (w0, w1) restricts the work to global windows [w0, w1)
+        (multi-GPU sharding); returns outputs for the frames those windows keep.
+        """
+        B, T = self.batch_size, self.sequence_length
+        N = phi.shape[0]
+        margin, g, count, num_fill = window_plan(N, B, T, self.fov)
+        nwin = count * B
+        w0, w1 = (0, nwin) if window_range is None else window_range
+        padded = torch.cat([phi_zero.expand(margin, -1), phi, phi_zero.expand(num_fill, -1)], dim=0)
+        idx = (torch.arange(w0, w1, device=phi.device)[:, None] * g +
+               torch.arange(T, device=phi.device)[None, :])          # window i = padded[i*g : i*g+T]
+        windows = padded[idx]                                         # [W,T,2048]
+        strips = self.engine.temporal(windows)
+        kept = strips[:, margin:T - margin].reshape(-1, strips.shape[-1])   # keep [:, margin:-margin]
+        first = w0 * g
+        n_keep = min(kept.shape[0], max(0, N - first))
+        kept = kept[:n_keep].contiguous()
+        if n_keep == 0:
+            return {}, first, 0
+        omegas_pred = self._regress(kept.reshape(n_keep, 1, -1), n_keep, 1)
+        out = self._fetch(omegas_pred, to_numpy=False)
+        out = {k: v[:, 0] for k, v in out.items()}                   # drop the T=1 axis -> [n, (2,) ...]
+        return out, first, n_keep
+
+    def predict_all_images(self, all_images):
+        """Wrapper to predict an entire sequence with the sliding-window scheme of
+        tester.py:260-312: windows of T frames every g = T - (fov-1) frames over
+        the zero-image-padded video, keeping the centre g predictions of each."""
+        N = len(all_images)
+        if not self.dedup:
+            return self._predict_all_images_literal(all_images)
+        phi = self.features(all_images)
+        phi_zero = self.engine.resnet(torch.zeros((1, self.img_size, self.img_size, 3),
+                                                  dtype=torch.float32, device=self.engine.device))
+        out, first, n = self.predict_windows_device(phi, phi_zero)
+        assert first == 0 and n == N
+        torch.cuda.synchronize(self.engine.device)
+        return {k: v.float().cpu().numpy() for k, v in out.items()}
+
+    def _predict_all_images_literal(self, all_images):
+        B, T = self.batch_size, self.sequence_length
+        N = len(all_images)
+        H = W = self.img_size
+        margin, g, count, num_fill = window_plan(N, B, T, self.fov)
+        images_padded = np.concatenate((np.zeros((margin, H, W, 3), np.float32),
+                                        np.asarray(all_images, np.float32),
+                                        np.zeros((num_fill, H, W, 3), np.float32)), axis=0)
+        results = {}
+        for c in range(count):
+            batch = np.stack([images_padded[i * g:i * g + T] for i in range(c * B, (c + 1) * B)])
+            for k, v in self.predict(batch).items():
+                results.setdefault(k, []).append(v)
+        new_results = {}
+        for k, v in results.items():
+            v = np.array(v)[:, :, margin:-margin]
+            new_results[k] = v.reshape((-1,) + v.shape[3:])[:N]
+        return new_results

@@ -1,0 +1,75 @@
+"""Mirror of src/models.py's model-fn registry (the reference's only plugin
+API): three string-keyed factories returning callables, plus
+``batch_pred_omega``.  The callables take/return device tensors and run the
+HIP stages of an ``HmmrEngine`` instead of building TF ops; TF-only arguments
+(`is_training`, `reuse`, `weight_decay`) are accepted and must describe
+inference.
+"""
+from __future__ import annotations
+
+
+def get_image_encoder(model_type="resnet"):
+    """src/models.py:12-23."""
+    models = {"resnet": encoder_resnet}
+    if model_type in models:
+        return models[model_type]
+    raise ValueError("Unknown image encoder: %s" % model_type)
+
+
+def get_hallucinator_model(model_type="fc2_res"):
+    """src/models.py:26-34."""
+    models = {"fc2_res": fc2_res}
+    if model_type in models:
+        return models[model_type]
+    raise ValueError("Unknown predict hal model: %s" % model_type)
+
+
+def get_temporal_encoder(model_type="AZ_FC2GN"):
+    """src/models.py:37-45."""
+    models = {"AZ_FC2GN": az_fc2_groupnorm}
+    if model_type in models:
+        return models[model_type]
+    raise ValueError("Unknown temporal encoder: %s" % model_type)
+
+
+def _inference_only(is_training):
+    if is_training:
+        raise NotImplementedError("the MI355X path implements inference only (is_training must be False)")
+
+
+def encoder_resnet(x, engine, is_training=False, weight_decay=0.001, reuse=False):
+    """x [N,224,224,3] -> (phi [N,2048], 'resnet_v2_50')  (src/models.py:50-77)."""
+    _inference_only(is_training)
+    return engine.resnet(x), "resnet_v2_50"
+
+
+def az_fc2_groupnorm(is_training, net, num_conv_layers, engine):
+    """net [B,T,2048] -> movie strips [B,T,2048]  (src/models.py:121-141)."""
+    _inference_only(is_training)
+    if num_conv_layers != engine.num_conv_layers:
+        raise ValueError("engine was packed with num_conv_layers=%d" % engine.num_conv_layers)
+    return engine.temporal(net)
+
+
+def fc2_res(phi, engine, name="fc2_res"):
+    """Hallucinator (src/models.py:270-296, pred_mode == 'hal')."""
+    raise NotImplementedError("pred_mode 'hal' is a later hot-path row (SURVEY.md section 8 f-4)")
+
+
+def batch_pred_omega(input_features, batch_size, is_training, num_output, omega_mean,
+                     sequence_length, scope, engine, predict_delta_keys=(),
+                     use_delta_from_pred=False, use_optcam=False):
+    """[B,T,2048] -> (omega [B,T,85], {delta_t: [B,T,85]})  (src/models.py:233-267).
+
+    The engine's IEF weights carry the mean theta and the regressor set, so
+    `omega_mean`/`scope` are only validated."""
+    _inference_only(is_training)
+    if num_output != 85 or not use_delta_from_pred or not use_optcam or scope != "single_view_ief":
+        raise NotImplementedError("only the Tester configuration of batch_pred_omega is implemented "
+                                  "(tester.py:196-207)")
+    keys = [k for k in sorted(predict_delta_keys) if k != 0]
+    if keys != [k for k in engine.reg_keys if k != 0]:
+        raise ValueError("engine was packed for delta keys %s" % engine.reg_keys)
+    om = engine.ief(input_features.reshape(batch_size * sequence_length, -1))
+    om = om.reshape(om.shape[0], batch_size, sequence_length, 85)
+    return om[0], {k: om[i] for i, k in enumerate(engine.reg_keys) if k != 0}

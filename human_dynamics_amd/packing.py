@@ -1,0 +1,193 @@
+"""Host-side packing of checkpoint-named arrays (assets.py / SURVEY App. B) into
+the device layouts libhmmr_hip.so consumes (include/hmmr_hip.h).
+
+All folds happen here, once, in float64:
+  * inference BN -> (scale, shift):  scale = gamma*rsqrt(var+1e-5),
+    shift = beta - mean*scale                       (slim batch_norm, App. A)
+  * HWIO conv filters -> [cout_pad][kh*kw*cin] (K contiguous per output channel)
+  * 7x7/2 stem -> 8 taps x 32 elements (8 pixels x RGBX) on a padded image
+  * fc1 of the IEF regressors split into its phi rows and theta rows
+  * SMPL: planar blend-shape basis, folded joint regressor, ELL skinning
+    weights, CSR keypoint regressor
+PyTorch is used only as the HBM allocator / H2D copier.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import assets
+
+TORCH_DT = {L.HMMR_F32: torch.float32, L.HMMR_BF16: torch.bfloat16}
+
+
+def _pad_rows(a, mult=128):
+    r = (-a.shape[0]) % mult
+    if r:
+        a = np.concatenate([a, np.zeros((r,) + a.shape[1:], a.dtype)], axis=0)
+    return a
+
+
+def fold_bn(w, prefix, eps=assets.BN_EPS):
+    g = w[prefix + "/gamma"].astype(np.float64)
+    b = w[prefix + "/beta"].astype(np.float64)
+    m = w[prefix + "/moving_mean"].astype(np.float64)
+    v = w[prefix + "/moving_variance"].astype(np.float64)
+    scale = g / np.sqrt(v + eps)
+    return scale.astype(np.float32), (b - m * scale).astype(np.float32)
+
+
+def pack_conv_weight(w_hwio):
+    """[kh,kw,cin,cout] -> [cout_pad][kh*kw*cin] float32."""
+    kh, kw, cin, cout = w_hwio.shape
+    return _pad_rows(np.ascontiguousarray(w_hwio.reshape(kh * kw * cin, cout).T))
+
+
+def pack_stem_weight(w_hwio):
+    """[7,7,3,64] -> [128][8*32]: k = ky*32 + kx*4 + c (kx = 7, c = 3 and ky = 7 are zero)."""
+    out = np.zeros((64, 8, 8, 4), np.float32)
+    out[:, :7, :7, :3] = np.transpose(w_hwio, (3, 0, 1, 2))
+    return _pad_rows(out.reshape(64, 256))
+
+
+class DeviceStore(object):
+    """Keeps every packed tensor alive and hands out device pointers."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.tensors = []
+
+    def put(self, arr, dtype=torch.float32):
+        t = torch.from_numpy(np.ascontiguousarray(arr)).to(self.device)
+        if t.dtype != dtype:
+            t = t.to(dtype)
+        self.tensors.append(t)
+        return t
+
+    def vec(self, arr, mult=128):
+        return self.put(_pad_rows(np.asarray(arr, np.float32), mult))
+
+
+def _layer(store, w_packed, dtype, scale=None, shift=None):
+    lay = L.Layer()
+    lay.w = store.put(w_packed, TORCH_DT[dtype]).data_ptr()
+    lay.scale = store.vec(scale).data_ptr() if scale is not None else None
+    lay.shift = store.vec(shift).data_ptr() if shift is not None else None
+    return lay
+
+
+def pack_resnet(w, dtype, store):
+    rw = L.ResnetWeights()
+    rw.dtype = dtype
+    rw.stem = _layer(store, pack_stem_weight(w["resnet_v2_50/conv1/weights"]), dtype,
+                     shift=w["resnet_v2_50/conv1/biases"])
+    units = list(assets.resnet_units())
+    assert len(units) == L.RESNET_UNITS
+    s0, b0 = fold_bn(w, units[0][0] + "/preact")
+    rw.pool_scale, rw.pool_shift = store.vec(s0).data_ptr(), store.vec(b0).data_ptr()
+    for i, (scope, c_in, base, depth, stride, has_sc) in enumerate(units):
+        u = rw.unit[i]
+        u.c_in, u.base, u.depth, u.stride = c_in, base, depth, stride
+        s, b = fold_bn(w, scope + "/conv1/BatchNorm")
+        u.conv1 = _layer(store, pack_conv_weight(w[scope + "/conv1/weights"]), dtype, s, b)
+        s, b = fold_bn(w, scope + "/conv2/BatchNorm")
+        u.conv2 = _layer(store, pack_conv_weight(w[scope + "/conv2/weights"]), dtype, s, b)
+        u.conv3 = _layer(store, pack_conv_weight(w[scope + "/conv3/weights"]), dtype,
+                         shift=w[scope + "/conv3/biases"])
+        if has_sc:
+            u.shortcut = _layer(store, pack_conv_weight(w[scope + "/shortcut/weights"]), dtype,
+                                shift=w[scope + "/shortcut/biases"])
+        if i + 1 < len(units):
+            s, b = fold_bn(w, units[i + 1][0] + "/preact")
+            u.next_scale, u.next_shift = store.vec(s).data_ptr(), store.vec(b).data_ptr()
+    s, b = fold_bn(w, "resnet_v2_50/postnorm")
+    rw.post_scale, rw.post_shift = store.vec(s).data_ptr(), store.vec(b).data_ptr()
+    return rw
+
+
+def pack_temporal(w, dtype, store, num_conv_layers=3):
+    tw = L.TemporalWeights()
+    tw.dtype, tw.num_blocks = dtype, num_conv_layers
+    for i in range(num_conv_layers):
+        gn1, c1, gn2, c2 = assets.temporal_scopes(i)
+        b = tw.block[i]
+        b.gn1_gamma, b.gn1_beta = store.put(w[gn1 + "/gamma"]).data_ptr(), store.put(w[gn1 + "/beta"]).data_ptr()
+        b.gn2_gamma, b.gn2_beta = store.put(w[gn2 + "/gamma"]).data_ptr(), store.put(w[gn2 + "/beta"]).data_ptr()
+        b.conv1 = _layer(store, pack_conv_weight(w[c1 + "/weights"]), dtype, shift=w[c1 + "/biases"])
+        b.conv2 = _layer(store, pack_conv_weight(w[c2 + "/weights"]), dtype, shift=w[c2 + "/biases"])
+    return tw
+
+
+def pack_ief(w, dtype, store, delta_t_values=(-5, 5), num_stages=3):
+    iw = L.IefWeights()
+    scopes = assets.ief_scopes(delta_t_values)
+    keys = [0] + sorted(k for k in scopes if k != 0)      # deltas in sorted order (tester.py:245)
+    iw.dtype, iw.num_regressors, iw.num_stages = dtype, len(keys), num_stages
+    for r, key in enumerate(keys):
+        scope, nd = scopes[key]
+        p = scope + "/3D_module"
+        W1 = w[p + "/fc1/weights"]
+        assert W1.shape == (assets.FEAT_DIM + nd, 1024)
+        reg = iw.reg[r]
+        reg.nd = nd
+        reg.fc1_phi = _layer(store, _pad_rows(np.ascontiguousarray(W1[:assets.FEAT_DIM].T)), dtype,
+                             shift=w[p + "/fc1/biases"])
+        wt = np.zeros((1024, 128), np.float32)
+        wt[:, :nd] = W1[assets.FEAT_DIM:].T
+        reg.fc1_theta = _layer(store, wt, L.HMMR_F32)            # theta path stays fp32
+        reg.fc2 = _layer(store, _pad_rows(np.ascontiguousarray(w[p + "/fc2/weights"].T)), dtype,
+                         shift=w[p + "/fc2/biases"])
+        reg.fc3 = _layer(store, _pad_rows(np.ascontiguousarray(w[p + "/fc3/weights"].T)), dtype,
+                         shift=w[p + "/fc3/biases"])
+    iw.mean_theta = store.put(np.asarray(w["mean_param"], np.float32).reshape(85)).data_ptr()
+    return iw, keys
+
+
+def pack_smpl(smpl, store, joint_type="cocoplus"):
+    """tf_smpl-layout constants (src/tf_smpl/batch_smpl.py:35-80) -> SmplConsts."""
+    nv = smpl["v_template"].shape[0]
+    vpad = (nv + 255) // 256 * 256
+    v_t = smpl["v_template"].astype(np.float64)
+    S = smpl["shapedirs"].astype(np.float64).reshape(10, nv, 3)
+    P = smpl["posedirs"].astype(np.float64).reshape(207, nv, 3)
+    dirs = np.zeros((218, 3, vpad), np.float32)
+    dirs[0, :, :nv] = v_t.T
+    dirs[1:11, :, :nv] = np.transpose(S, (0, 2, 1))
+    dirs[11:218, :, :nv] = np.transpose(P, (0, 2, 1))
+    Jreg = smpl["J_regressor"].astype(np.float64)              # [nv, 24] (stored transposed)
+    j_template = (Jreg.T @ v_t).reshape(72)
+    j_shapedirs = np.einsum("vj,bvc->bjc", Jreg, S).reshape(10, 72)
+    Wl = np.asarray(smpl["lbs_weights"], np.float32)
+    nz = Wl != 0
+    nnz = max(1, int(nz.sum(axis=1).max()))
+    idx = np.zeros((nv, nnz), np.int32)
+    val = np.zeros((nv, nnz), np.float32)
+    for v in range(nv):
+        js = np.nonzero(nz[v])[0]                               # ascending joint order, like the dense sum
+        idx[v, :len(js)] = js
+        val[v, :len(js)] = Wl[v, js]
+    kreg = np.asarray(smpl["cocoplus_regressor"], np.float32)   # [nv, K]
+    if joint_type == "lsp":
+        kreg = kreg[:, :14]                                     # batch_smpl.py:81-82
+    nk = kreg.shape[1]
+    kptr, kidx, kval = [0], [], []
+    for k in range(nk):
+        rows = np.nonzero(kreg[:, k])[0]
+        kidx.append(rows.astype(np.int32))
+        kval.append(kreg[rows, k])
+        kptr.append(kptr[-1] + len(rows))
+    kidx = np.concatenate(kidx) if kptr[-1] else np.zeros(1, np.int32)
+    kval = np.concatenate(kval) if kptr[-1] else np.zeros(1, np.float32)
+    sc = L.SmplConsts()
+    sc.num_verts, sc.num_kps, sc.lbs_nnz = nv, nk, nnz
+    sc.dirs = store.put(dirs).data_ptr()
+    sc.j_template = store.put(j_template.astype(np.float32)).data_ptr()
+    sc.j_shapedirs = store.put(j_shapedirs.astype(np.float32)).data_ptr()
+    sc.parents = store.put(np.asarray(smpl["parents"]).astype(np.int32), torch.int32).data_ptr()
+    sc.lbs_idx = store.put(idx, torch.int32).data_ptr()
+    sc.lbs_w = store.put(val).data_ptr()
+    sc.kreg_ptr = store.put(np.asarray(kptr, np.int32), torch.int32).data_ptr()
+    sc.kreg_idx = store.put(kidx, torch.int32).data_ptr()
+    sc.kreg_val = store.put(kval.astype(np.float32)).data_ptr()
+    return sc

@@ -1,0 +1,217 @@
+/* libhmmr_hip.so -- C ABI of the MI355X (gfx950) HMMR inference hot path.
+ *
+ * Drop-in boundary for akanazawa/human_dynamics `Tester.predict`
+ * (src/evaluation/tester.py:229-258).  The reference has no FFI of its own:
+ * the path sits behind one `sess.run` of a TF-1.8 graph.  Each entry point
+ * below replaces one op-group of that graph (citations are relative to the
+ * reference tree) and is what a ctypes binding on the reference side would
+ * call.
+ *
+ * Conventions
+ *   - every pointer that carries tensor data is a DEVICE pointer (HBM);
+ *     structs themselves live in host memory;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *     all work is enqueued asynchronously on it, nothing is allocated or
+ *     synchronised inside a call: scratch comes from the caller through
+ *     (`ws`, `ws_bytes`) sized by the matching *_workspace_bytes();
+ *   - return 0 on success, <0 on error; hmmr_last_error() describes the last
+ *     failure of the calling thread;
+ *   - activations are NHWC / row-major, fp32 at every stage boundary.  Inside
+ *     the ResNet / temporal / IEF stages the GEMM operand type is selected by
+ *     `dtype` (HMMR_F32 = exact-fp32 MFMA, HMMR_BF16 = bf16 MFMA with fp32
+ *     accumulate).  The SMPL stage is always fp32.
+ */
+#ifndef HMMR_HIP_H
+#define HMMR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HMMR_ABI_VERSION 1
+
+enum { HMMR_F32 = 0, HMMR_BF16 = 1 };
+
+int hmmr_abi_version(void);
+const char* hmmr_last_error(void);
+
+/* ------------------------------------------------------------------------- *
+ * Generic implicit-GEMM convolution / fully-connected building block.
+ * out[m, n] = epilogue( sum_k A[m, k] * W[n, k] ), m = (img, oy, ox) over an
+ * NHWC input gathered on the fly, k = (ky, kx, ci).  Replaces every
+ * slim.conv2d / tf.contrib.layers.conv2d / slim.fully_connected on the path
+ * (src/models.py:65-74 via slim resnet_v2; :102-113; :173-184; :209-221).
+ * Exposed so each layer shape can be parity-tested in isolation.
+ * ------------------------------------------------------------------------- */
+typedef struct {
+    /* operands */
+    const void* in;        /* activations, dtype in_dtype                        */
+    const void* w;         /* [cout_pad][K], K = kh*kw*cin contiguous, in_dtype;
+                              cout_pad = cout rounded up to 128                   */
+    const float* scale;    /* [cout_pad] or NULL (=1): multiplies the accumulator */
+    const float* shift;    /* [cout_pad] or NULL (=0): bias / folded BN shift     */
+    const void* res;       /* residual added before the ReLU, out_dtype, or NULL  */
+    void* out;             /* [M, ldo] out_dtype, may be NULL if out2 is set      */
+    void* out2;            /* optional second output relu(v*scale2+shift2), or NULL */
+    const float* scale2;
+    const float* shift2;
+    int in_dtype;          /* HMMR_F32 / HMMR_BF16 */
+    int out_dtype;
+    /* input geometry (element strides) */
+    int n_img, hin, win, cin;          /* cin: channels per tap, power of two, >= 32B/elt */
+    int64_t in_img_stride;
+    int in_row_stride, in_px_stride;
+    /* filter geometry */
+    int kh, kw, sy, sx, py, px;
+    int ho, wo;
+    int cout;
+    int ldo;               /* row stride of out / out2 in elements (multiple of 8) */
+    /* residual addressing: flat rows of stride ldr, or strided pixels */
+    int ldr;
+    int res_strided;       /* 1: res[img*res_img_stride + oy*res_row_stride + ox*res_px_stride + n] */
+    int64_t res_img_stride;
+    int res_row_stride, res_px_stride;
+    int relu;              /* ReLU on `out` after the residual add */
+    int tile;              /* 0 = auto; 1 = 128x128; 2 = 128x64; 3 = 64x64 */
+} hmmr_conv_desc_t;
+
+int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * ResNet-v2-50 image encoder: encoder_resnet (src/models.py:50-77) ->
+ * tf.contrib.slim.nets.resnet_v2.resnet_v2_50(num_classes=None,
+ * is_training=False) + squeeze.  images [n,224,224,3] fp32 in [-1,1] -> phi
+ * [n,2048] fp32.
+ * ------------------------------------------------------------------------- */
+typedef struct {
+    const void* w;         /* packed [cout_pad][K] in the struct's dtype */
+    const float* scale;    /* folded BN scale or NULL */
+    const float* shift;    /* folded BN shift or conv bias */
+} hmmr_layer_t;
+
+typedef struct {
+    hmmr_layer_t conv1, conv2, conv3, shortcut;   /* shortcut.w == NULL: identity / subsample */
+    const float* next_scale;   /* folded `preact` BN of the following unit (NULL for the last) */
+    const float* next_shift;
+    int c_in, base, depth, stride;
+} hmmr_resnet_unit_t;
+
+#define HMMR_RESNET_UNITS 16
+
+typedef struct {
+    int dtype;                         /* operand type of convs + activations */
+    hmmr_layer_t stem;                 /* 7x7/2 packed as [128][8 taps x (8 px x 4 ch)] */
+    const float* pool_scale;           /* block1/unit_1 `preact` BN, applied after pool1 */
+    const float* pool_shift;
+    hmmr_resnet_unit_t unit[HMMR_RESNET_UNITS];
+    const float* post_scale;           /* postnorm BN folded */
+    const float* post_shift;
+} hmmr_resnet_weights_t;
+
+size_t hmmr_resnet50_workspace_bytes(int n, int dtype);
+/* prof_ms: NULL, or a host array of HMMR_RESNET_PROF_SLOTS floats that receives
+ * the HIP-event duration (ms) of every launch (forces a stream sync). */
+#define HMMR_RESNET_PROF_SLOTS 64
+int hmmr_resnet50_fwd(const hmmr_resnet_weights_t* w, const float* images, int n,
+                      float* phi, void* ws, size_t ws_bytes, void* stream, float* prof_ms);
+
+/* ------------------------------------------------------------------------- *
+ * f_movie temporal encoder: az_fc2_groupnorm / az_fc_block2
+ * (src/models.py:121-228).  phi [b, t, 2048] fp32 -> strips [b, t, 2048] fp32.
+ * ------------------------------------------------------------------------- */
+typedef struct {
+    const float* gn1_gamma; const float* gn1_beta;
+    hmmr_layer_t conv1;                /* w [2048][3*2048], shift = bias */
+    const float* gn2_gamma; const float* gn2_beta;
+    hmmr_layer_t conv2;
+} hmmr_temporal_block_t;
+
+#define HMMR_MAX_TEMPORAL_BLOCKS 8
+
+typedef struct {
+    int dtype;
+    int num_blocks;
+    hmmr_temporal_block_t block[HMMR_MAX_TEMPORAL_BLOCKS];
+} hmmr_temporal_weights_t;
+
+size_t hmmr_temporal_workspace_bytes(int b, int t, int dtype);
+int hmmr_temporal_fwd(const hmmr_temporal_weights_t* w, const float* phi, int b, int t,
+                      float* strips, void* ws, size_t ws_bytes, void* stream);
+
+/* Standalone GroupNorm(+ReLU) over (time, channels-in-group), exposed for tests:
+ * tf.contrib.layers.group_norm(reduction_axes=(-3,-2)), src/models.py:155-161. */
+int hmmr_groupnorm_relu(const float* x, const float* gamma, const float* beta, int b, int t,
+                        int c, int groups, void* out, int out_dtype, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * IEF regressors: batch_pred_omega / call_hmr_ief / hmr_ief /
+ * encoder_fc3_dropout (src/models.py:80-116, 233-267, 299-415) with
+ * use_optcam=True, use_delta_from_pred=True (tester.py:196-207).
+ * strips [m,2048] fp32 -> omega[r] [m,85] fp32 for r = 0 (present) and each
+ * delta regressor, already in the final layout ([1,0,0 | pose | beta of omega0]
+ * for deltas, models.py:367-371).
+ * ------------------------------------------------------------------------- */
+typedef struct {
+    int nd;                            /* 85 (present) or 72 (delta) */
+    hmmr_layer_t fc1_phi;              /* w [1024][2048], shift = fc1 bias */
+    hmmr_layer_t fc1_theta;            /* w [1024][128]: rows of fc1 for theta, zero padded */
+    hmmr_layer_t fc2;                  /* w [1024][1024], shift = bias */
+    hmmr_layer_t fc3;                  /* w [128][1024] (nd rows used), shift = bias padded */
+} hmmr_ief_regressor_t;
+
+#define HMMR_MAX_REGRESSORS 8
+
+typedef struct {
+    int dtype;
+    int num_regressors;                /* [0] = present, then deltas in sorted delta_t order */
+    int num_stages;                    /* 3 */
+    hmmr_ief_regressor_t reg[HMMR_MAX_REGRESSORS];
+    const float* mean_theta;           /* [85] */
+} hmmr_ief_weights_t;
+
+size_t hmmr_ief_workspace_bytes(int m, int num_regressors, int dtype);
+/* omegas: [num_regressors][m][85] fp32 */
+int hmmr_ief_fwd(const hmmr_ief_weights_t* w, const float* strips, int m, float* omegas,
+                 void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * SMPL forward + keypoint projection: SMPL.__call__ (src/tf_smpl/batch_smpl.py:
+ * 89-162), batch_rodrigues / batch_global_rigid_transformation
+ * (src/tf_smpl/batch_lbs.py:42-60, 133-194), batch_orth_proj_idrot
+ * (src/tf_smpl/projection.py:16-29), as driven by OmegasPred.compute_smpl
+ * (src/omega.py:263-304).
+ * ------------------------------------------------------------------------- */
+typedef struct {
+    int num_verts;                     /* 6890 */
+    int num_kps;                       /* 25 (cocoplus) or 14 (lsp) */
+    int lbs_nnz;                       /* ELL width of the skinning weights (<= 24) */
+    const float* dirs;                 /* [218][3][vpad] planar re-pack of the tf_smpl bases
+                                          (vpad = num_verts rounded up to 256): row 0 v_template,
+                                          1..10 shapedirs, 11..217 posedirs; dirs[k][c][v] =
+                                          basis[k][3*v + c] (src/tf_smpl/batch_smpl.py:45-63) */
+    const float* j_template;           /* [24*3]      J_regressor^T v_template            */
+    const float* j_shapedirs;          /* [10][24*3]  J_regressor^T shapedirs (folded)    */
+    const int32_t* parents;            /* [24], parents[0] ignored                         */
+    const int32_t* lbs_idx;            /* [num_verts][lbs_nnz] joint ids                  */
+    const float* lbs_w;                /* [num_verts][lbs_nnz] weights (0 for padding)    */
+    const int32_t* kreg_ptr;           /* CSR by keypoint of cocoplus_regressor^T: [num_kps+1] */
+    const int32_t* kreg_idx;           /* vertex ids   */
+    const float* kreg_val;
+} hmmr_smpl_consts_t;
+
+size_t hmmr_smpl_workspace_bytes(int m);
+/* theta: m rows of 72 floats with row stride ld_theta; beta: m rows of 10 floats
+ * (stride ld_beta); cams: m rows of 3 floats (stride ld_cam) or NULL (no kps).
+ * verts [m,V,3], joints [m,K,3], kps [m,K,2] (NULL ok), rs [m,24,3,3] (NULL ok). */
+int hmmr_smpl_fwd(const hmmr_smpl_consts_t* c, const float* theta, int ld_theta,
+                  const float* beta, int ld_beta, const float* cams, int ld_cam, int m,
+                  float* verts, float* joints, float* kps, float* rs,
+                  void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HMMR_HIP_H */

@@ -1,0 +1,125 @@
+"""Host-side packing / folding / windowing logic, checked on CPU against the
+unfused forms (every fold re-associates fp32 arithmetic)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from human_dynamics_amd import _lib, assets, packing
+from human_dynamics_amd.evaluation import tester as T
+from oracle import hmmr_oracle as O
+
+
+class _HostStore(packing.DeviceStore):
+    """DeviceStore that keeps everything on the CPU so the packers run without a GPU."""
+    def __init__(self):
+        super().__init__("cpu")
+
+
+def _tensor_at(store, ptr):
+    for t in store.tensors:
+        if t.data_ptr() == ptr:
+            return t
+    raise KeyError(ptr)
+
+
+def test_bn_fold_matches_unfused(weights):
+    scope = "resnet_v2_50/block2/unit_1/bottleneck_v2/preact"
+    s, b = packing.fold_bn(weights, scope)
+    x = np.random.default_rng(0).normal(size=(7, 256))
+    ref = (weights[scope + "/gamma"] * (x - weights[scope + "/moving_mean"])
+           / np.sqrt(weights[scope + "/moving_variance"] + 1e-5) + weights[scope + "/beta"])
+    assert np.allclose(x * s + b, ref, atol=1e-5)
+
+
+def test_conv_weight_pack_is_k_contiguous_per_output_channel():
+    w = np.random.default_rng(0).normal(size=(3, 3, 64, 96)).astype(np.float32)
+    p = packing.pack_conv_weight(w)
+    assert p.shape == (128, 576) and not p[96:].any()
+    # k = (ky*kw + kx)*cin + ci
+    assert p[5, (1 * 3 + 2) * 64 + 17] == w[1, 2, 17, 5]
+
+
+def test_stem_pack_equals_7x7_conv_on_padded_rgbx(weights):
+    """The 8-tap x 32-element GEMM on a zero-padded RGBX image is the slim stem conv."""
+    w = weights["resnet_v2_50/conv1/weights"]
+    img = assets.make_synthetic_frames(1, seed=3)[0, :40, :40]          # small crop, same algebra
+    ref = O._conv(torch.tensor(img[None]).permute(0, 3, 1, 2).double(), w, torch.float64, stride=2, pad=3)[0]
+    pk = packing.pack_stem_weight(w).astype(np.float64)                  # [128][256]
+    H = img.shape[0]
+    xp = np.zeros((H + 6 + 2, H + 6 + 8, 4))
+    xp[3:3 + H, 3:3 + H, :3] = img
+    Ho = ref.shape[1]
+    out = np.zeros((64, Ho, Ho))
+    for oy in range(Ho):
+        for ox in range(Ho):
+            a = np.concatenate([xp[2 * oy + ky, 2 * ox:2 * ox + 8].reshape(32) for ky in range(8)])
+            out[:, oy, ox] = pk[:64] @ a
+    assert np.abs(out - ref.numpy()).max() < 1e-9
+
+
+def test_smpl_pack_joint_fold_and_sparse_forms(smpl_consts):
+    st = _HostStore()
+    sc = packing.pack_smpl(smpl_consts, st)
+    rng = np.random.default_rng(0)
+    beta = rng.normal(size=10)
+    v_shaped = (beta @ smpl_consts["shapedirs"].astype(np.float64)).reshape(-1, 3) + smpl_consts["v_template"]
+    J_ref = smpl_consts["J_regressor"].astype(np.float64).T @ v_shaped
+    jt = _tensor_at(st, sc.j_template).numpy().astype(np.float64)
+    js = _tensor_at(st, sc.j_shapedirs).numpy().astype(np.float64)
+    assert np.abs((jt + beta @ js).reshape(24, 3) - J_ref).max() < 1e-6
+    # planar basis: dirs[k][c][v] = basis[k][3v + c]
+    dirs = _tensor_at(st, sc.dirs).numpy()
+    assert dirs.shape == (218, 3, 6912)
+    assert dirs[0, 1, 100] == smpl_consts["v_template"][100, 1]
+    assert dirs[1 + 4, 2, 77] == smpl_consts["shapedirs"][4, 3 * 77 + 2]
+    assert dirs[11 + 200, 0, 6889] == smpl_consts["posedirs"][200, 3 * 6889]
+    # ELL skinning weights reproduce the dense matrix
+    idx = _tensor_at(st, sc.lbs_idx).numpy(); val = _tensor_at(st, sc.lbs_w).numpy()
+    dense = np.zeros((6890, 24), np.float32)
+    for z in range(sc.lbs_nnz):
+        np.add.at(dense, (np.arange(6890), idx[:, z]), val[:, z])
+    assert np.array_equal(dense, smpl_consts["lbs_weights"])
+    # CSR keypoint regressor reproduces the dense matrix
+    kp = _tensor_at(st, sc.kreg_ptr).numpy(); ki = _tensor_at(st, sc.kreg_idx).numpy(); kv = _tensor_at(st, sc.kreg_val).numpy()
+    dense = np.zeros((6890, 25), np.float32)
+    for k in range(25):
+        dense[ki[kp[k]:kp[k + 1]], k] = kv[kp[k]:kp[k + 1]]
+    assert np.array_equal(dense, smpl_consts["cocoplus_regressor"])
+
+
+def test_ief_pack_splits_fc1_and_orders_regressors(weights):
+    st = _HostStore()
+    iw, keys = packing.pack_ief(weights, _lib.HMMR_F32, st, (5, -5))
+    assert keys == [0, -5, 5] and iw.num_regressors == 3 and iw.num_stages == 3
+    assert [iw.reg[i].nd for i in range(3)] == [85, 72, 72]
+    W1 = weights["single_view_ief_past5/3D_module/fc1/weights"]
+    wphi = _tensor_at(st, iw.reg[1].fc1_phi.w).numpy()
+    wth = _tensor_at(st, iw.reg[1].fc1_theta.w).numpy()
+    assert wphi.shape == (1024, 2048) and wth.shape == (1024, 128)
+    assert np.array_equal(wphi, W1[:2048].T) and np.array_equal(wth[:, :72], W1[2048:].T) and not wth[:, 72:].any()
+    w3 = _tensor_at(st, iw.reg[0].fc3.w).numpy()
+    assert w3.shape == (128, 1024) and not w3[85:].any()
+
+
+def test_resnet_pack_unit_table(weights):
+    st = _HostStore()
+    rw = packing.pack_resnet(weights, _lib.HMMR_F32, st)
+    strides = [rw.unit[i].stride for i in range(16)]
+    assert strides == [1, 1, 2, 1, 1, 1, 2, 1, 1, 1, 1, 1, 2, 1, 1, 1]      # stride on the LAST unit of blocks 1-3
+    assert [bool(rw.unit[i].shortcut.w) for i in range(16)] == [i in (0, 3, 7, 13) for i in range(16)]
+    assert rw.unit[15].next_scale is None and rw.unit[0].next_scale is not None
+    assert (rw.unit[0].c_in, rw.unit[15].depth) == (64, 2048)
+
+
+def test_window_plan_matches_oracle():
+    for n in (1, 8, 24, 64, 65, 256, 4096):
+        for b in (1, 2, 8):
+            assert T.window_plan(n, b, 20, 13) == O.window_plan(n, b, 20, 13)
+
+
+def test_ctypes_struct_sizes_are_plausible():
+    # catches accidental field drift between include/hmmr_hip.h and _lib.py
+    assert C.sizeof(_lib.Layer) == 24
+    assert C.sizeof(_lib.ResnetUnit) == 4 * 24 + 16 + 16
+    assert C.sizeof(_lib.ConvDesc) % 8 == 0
