@@ -297,7 +297,10 @@ extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
     const int K = d->kh * d->kw * d->cin;
     HMMR_REQUIRE(K % (8 * eps) == 0, "hmmr_conv_gemm: K=%d must be a multiple of %d", K, 8 * eps);
     HMMR_REQUIRE(d->ldo % 8 == 0, "hmmr_conv_gemm: ldo=%d must be a multiple of 8", d->ldo);
-    HMMR_REQUIRE(d->in_px_stride % eps == 0 && d->in_row_stride % eps == 0 && d->in_img_stride % eps == 0,
+    // every gathered 16-byte slot must stay aligned: ix = ox*sx + kx - px
+    const bool px_ok = d->in_px_stride % eps == 0 ||
+                       (d->kw == 1 && d->px == 0 && (d->in_px_stride * d->sx) % eps == 0);
+    HMMR_REQUIRE(px_ok && d->in_row_stride % eps == 0 && d->in_img_stride % eps == 0,
                  "hmmr_conv_gemm: input strides must keep 16-byte alignment");
     HMMR_REQUIRE(!d->res || d->res_strided || d->ldr % 8 == 0, "hmmr_conv_gemm: ldr must be a multiple of 8");
     HMMR_REQUIRE(!d->out2 || (d->scale2 && d->shift2), "hmmr_conv_gemm: out2 needs scale2/shift2");

@@ -46,9 +46,10 @@ __global__ __launch_bounds__(256) void groupnorm_relu_kernel(const float* __rest
     TO* ob = out + (long long)b * t * c + g * cpg;
     for (int i = threadIdx.x; i < cnt; i += 256) {
         const int tt = i / cpg, j = i % cpg;
+        // x*gain + (beta - mean*gain) evaluated as (x - mean)*gain + beta: same value,
+        // without the cancellation of two large products when var -> 0
         const float gain = rstd * gamma[g * cpg + j];
-        const float offset = -mean * gain + beta[g * cpg + j];
-        ob[tt * c + j] = elem_traits<TO>::from_f32(fmaxf(xb[tt * c + j] * gain + offset, 0.f));
+        ob[tt * c + j] = elem_traits<TO>::from_f32(fmaxf((xb[tt * c + j] - mean) * gain + beta[g * cpg + j], 0.f));
     }
 }
 
