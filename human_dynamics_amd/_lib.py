@@ -109,6 +109,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise HmmrError("%s not found: build it with `python -m human_dynamics_amd.build` "
                         "(the HIP library is mandatory; there is no CPU fallback)" % LIB_PATH)
+    # PyTorch-ROCm ships its own HIP runtime (torch/lib/libamdhip64.so).  Import
+    # torch FIRST so that libhmmr_hip.so binds to that already-loaded runtime
+    # (same soname) -- two HIP runtimes in one process cannot see each other's
+    # streams, allocations or code objects.
+    import torch  # noqa: F401
+    if torch.cuda.is_available():
+        torch.cuda.init()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError if the .so does not export it

@@ -1,0 +1,126 @@
+"""Multi-GPU sharding of ``predict_all_images`` (one process per GPU, RCCL).
+
+The reference is single-GPU.  Its sliding windows (tester.py:281-295) are
+independent of each other, so a video shards by contiguous WINDOW ranges with
+no data-path communication: rank r recomputes the <= 2*margin halo frames its
+edge windows need, and a single all-gather re-assembles the per-frame outputs.
+Sharding never changes any reduction order, so the N-GPU result is
+bit-identical to the 1-GPU result.
+
+Everything here is device-agnostic (works with the gloo backend on CPU
+tensors), which is how the N>1 plumbing is tested without GPUs.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+# per-frame output record of one container, in make_fetch_dict order (tester.py:217-227)
+FIELDS = (("cams", (3,)), ("joints", (25, 3)), ("kps", (25, 2)), ("poses", (24, 3, 3)),
+          ("shapes", (10,)), ("verts", (6890, 3)), ("omegas", (85,)))
+
+
+def record_layout(num_deltas=2, fields=FIELDS):
+    """[(key, shape, offset, size)] of the packed per-frame record and its length."""
+    out, off = [], 0
+    for suffix, rep in (("", 0), ("_delta", num_deltas)):
+        if suffix and rep == 0:
+            continue
+        for k, shp in fields:
+            full = ((rep,) if suffix else ()) + tuple(shp)
+            size = int(np.prod(full))
+            out.append((k + suffix, full, off, size))
+            off += size
+    return out, off
+
+
+class ShardPlan(object):
+    """Window range, frame range and output range of one rank."""
+
+    def __init__(self, n_frames, batch_size, sequence_length, fov, world_size, rank):
+        self.n_frames = n_frames
+        self.margin = (fov - 1) // 2
+        self.g = sequence_length - 2 * self.margin
+        self.T = sequence_length
+        count = int(np.ceil(n_frames / float(self.g * batch_size)))
+        self.n_windows = count * batch_size
+        self.world_size, self.rank = world_size, rank
+        # equal contiguous window ranges (the last ranks may own empty / padding windows)
+        self.win_per_rank = int(np.ceil(self.n_windows / float(world_size)))
+        self.w0 = min(rank * self.win_per_rank, self.n_windows)
+        self.w1 = min(self.w0 + self.win_per_rank, self.n_windows)
+        # real frames this rank must encode (window span minus the zero-image padding)
+        lo = self.w0 * self.g - self.margin
+        hi = (self.w1 - 1) * self.g + self.T - self.margin if self.w1 > self.w0 else lo
+        self.f0, self.f1 = max(0, min(lo, n_frames)), max(0, min(hi, n_frames))
+        # output frames this rank produces
+        self.o0 = min(self.w0 * self.g, n_frames)
+        self.o1 = min(self.w1 * self.g, n_frames)
+        self.out_per_rank = self.win_per_rank * self.g       # padded, equal on every rank
+
+    def window_frame_index(self):
+        """[W, T] int64: index of every window slot into the rank's local frame
+        array, -1 for zero-image padding slots (front margin / back fill)."""
+        w = np.arange(self.w0, self.w1)[:, None] * self.g + np.arange(self.T)[None, :] - self.margin
+        idx = np.where((w >= 0) & (w < self.n_frames), w - self.f0, -1)
+        return idx.astype(np.int64)
+
+
+def pack_outputs(out, n_rows, layout, rec_len, device=None, dtype=torch.float32):
+    """dict of [n, ...] tensors -> [n_rows, rec_len] (rows >= n are zero)."""
+    n = next(iter(out.values())).shape[0] if out else 0
+    dev = device if device is not None else (next(iter(out.values())).device if out else "cpu")
+    buf = torch.zeros((n_rows, rec_len), dtype=dtype, device=dev)
+    for k, shp, off, size in layout:
+        if n:
+            buf[:n, off:off + size] = out[k].reshape(n, size)
+    return buf
+
+
+def unpack_outputs(buf, layout):
+    n = buf.shape[0]
+    return {k: buf[:, off:off + size].reshape((n,) + shp) for k, shp, off, size in layout}
+
+
+def all_gather_outputs(local_buf, plan, group=None):
+    """ONE all-gather (RCCL over xGMI on GPUs) of the packed per-frame records;
+    returns the [n_frames, rec_len] result on every rank."""
+    world = plan.world_size
+    if world == 1:
+        return local_buf[:plan.n_frames]
+    full = torch.empty((world * plan.out_per_rank, local_buf.shape[1]), dtype=local_buf.dtype,
+                       device=local_buf.device)
+    dist.all_gather_into_tensor(full, local_buf.contiguous(), group=group)
+    return full[:plan.n_frames]
+
+
+def predict_all_images_sharded(tester, frames_fn, n_frames, rank=None, world_size=None, group=None,
+                               gather=True):
+    """Distributed ``Tester.predict_all_images``.
+
+    frames_fn(f0, f1) -> the real frames [f1-f0,224,224,3] of the video (host or
+    device); every rank only ever asks for its own span.  Returns the packed
+    [n_frames, rec_len] device tensor (identical on every rank) and the layout."""
+    if world_size is None:
+        world_size = dist.get_world_size() if dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    plan = ShardPlan(n_frames, tester.batch_size, tester.sequence_length, tester.fov, world_size, rank)
+    layout, rec_len = record_layout(len(tester.delta_t_values))
+    eng = tester.engine
+    zero = torch.zeros((1, tester.img_size, tester.img_size, 3), dtype=torch.float32, device=eng.device)
+    if plan.f1 > plan.f0:
+        frames = eng.to_device(frames_fn(plan.f0, plan.f1))
+        phi_all = eng.resnet(torch.cat([frames, zero], dim=0))      # last row = feature of the zero image
+    else:
+        phi_all = eng.resnet(zero)
+    out = {}
+    if plan.w1 > plan.w0:
+        idx = torch.from_numpy(plan.window_frame_index()).to(eng.device)
+        idx = torch.where(idx < 0, torch.full_like(idx, phi_all.shape[0] - 1), idx)
+        out = tester.predict_strips_device(phi_all[idx], plan.o1 - plan.o0)
+    local = pack_outputs(out, plan.out_per_rank, layout, rec_len, device=eng.device)
+    if not gather:
+        return local, layout, plan
+    return all_gather_outputs(local, plan, group), layout, plan

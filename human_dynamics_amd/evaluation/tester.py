@@ -187,34 +187,32 @@ class Tester(object):
             outs.append(self.engine.resnet(np.asarray(frames[i:i + chunk], np.float32)))
         return torch.cat(outs, dim=0)
 
-    def predict_windows_device(self, phi, phi_zero, n_out=None, window_range=None):
-        """The part of predict_all_images after the ResNet, on features.
+    def predict_strips_device(self, windows, n_keep):
+        """windows [W,T,2048] of frame features (padding slots hold the feature of
+        the zero image) -> outputs of the first n_keep frames the windows keep
+        (the centre g = T - 2*margin of each, tester.py:305-311), as device
+        tensors [n_keep, ...] / [n_keep, 2, ...] for the delta keys."""
+        T = self.sequence_length
+        margin = (self.fov - 1) // 2
+        strips = self.engine.temporal(windows)
+        kept = strips[:, margin:T - margin].reshape(-1, strips.shape[-1])[:n_keep].contiguous()
+        if n_keep == 0:
+            return {}
+        omegas_pred = self._regress(kept.reshape(n_keep, 1, -1), n_keep, 1)
+        out = self._fetch(omegas_pred, to_numpy=False)
+        return {k: v[:, 0] for k, v in out.items()}                  # drop the T=1 axis
 
-        phi [N,2048]: features of the N real frames; phi_zero [1,2048]: feature of
-        the all-zero padding image (tester.py:285-289 pads with zero IMAGES).
-        window_range = (w0, w1) restricts the work to global windows [w0, w1)
-        (multi-GPU sharding); returns outputs for the frames those windows keep.
-        """
+    def predict_windows_device(self, phi, phi_zero):
+        """The part of predict_all_images after the ResNet: phi [N,2048] are the
+        features of the N real frames, phi_zero [1,2048] the feature of the
+        all-zero padding image (tester.py:285-289 pads with zero IMAGES)."""
         B, T = self.batch_size, self.sequence_length
         N = phi.shape[0]
         margin, g, count, num_fill = window_plan(N, B, T, self.fov)
-        nwin = count * B
-        w0, w1 = (0, nwin) if window_range is None else window_range
         padded = torch.cat([phi_zero.expand(margin, -1), phi, phi_zero.expand(num_fill, -1)], dim=0)
-        idx = (torch.arange(w0, w1, device=phi.device)[:, None] * g +
+        idx = (torch.arange(count * B, device=phi.device)[:, None] * g +
                torch.arange(T, device=phi.device)[None, :])          # window i = padded[i*g : i*g+T]
-        windows = padded[idx]                                         # [W,T,2048]
-        strips = self.engine.temporal(windows)
-        kept = strips[:, margin:T - margin].reshape(-1, strips.shape[-1])   # keep [:, margin:-margin]
-        first = w0 * g
-        n_keep = min(kept.shape[0], max(0, N - first))
-        kept = kept[:n_keep].contiguous()
-        if n_keep == 0:
-            return {}, first, 0
-        omegas_pred = self._regress(kept.reshape(n_keep, 1, -1), n_keep, 1)
-        out = self._fetch(omegas_pred, to_numpy=False)
-        out = {k: v[:, 0] for k, v in out.items()}                   # drop the T=1 axis -> [n, (2,) ...]
-        return out, first, n_keep
+        return self.predict_strips_device(padded[idx], N)
 
     def predict_all_images(self, all_images):
         """Wrapper to predict an entire sequence with the sliding-window scheme of
@@ -226,8 +224,7 @@ class Tester(object):
         phi = self.features(all_images)
         phi_zero = self.engine.resnet(torch.zeros((1, self.img_size, self.img_size, 3),
                                                   dtype=torch.float32, device=self.engine.device))
-        out, first, n = self.predict_windows_device(phi, phi_zero)
-        assert first == 0 and n == N
+        out = self.predict_windows_device(phi, phi_zero)
         torch.cuda.synchronize(self.engine.device)
         return {k: v.float().cpu().numpy() for k, v in out.items()}
 
