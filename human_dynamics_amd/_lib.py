@@ -81,7 +81,7 @@ SIGNATURES = {
     "hmmr_last_error": (C.c_char_p, []),
     "hmmr_conv_gemm": (C.c_int, [C.POINTER(ConvDesc), _vp]),
     "hmmr_resnet50_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
-    "hmmr_resnet50_fwd": (C.c_int, [C.POINTER(ResnetWeights), _fp, C.c_int, _fp, _vp, C.c_size_t, _vp,
+    "hmmr_resnet50_fwd": (C.c_int, [C.POINTER(ResnetWeights), _fp, C.c_int, C.c_int, _fp, _vp, C.c_size_t, _vp,
                                     C.POINTER(C.c_float)]),
     "hmmr_temporal_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "hmmr_temporal_fwd": (C.c_int, [C.POINTER(TemporalWeights), _fp, C.c_int, C.c_int, _fp, _vp, C.c_size_t, _vp]),
@@ -91,6 +91,8 @@ SIGNATURES = {
     "hmmr_smpl_workspace_bytes": (C.c_size_t, [C.c_int]),
     "hmmr_smpl_fwd": (C.c_int, [C.POINTER(SmplConsts), _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int,
                                 _fp, _fp, _fp, _fp, _vp, C.c_size_t, _vp]),
+    "hmmr_smpl_fwd_strided": (C.c_int, [C.POINTER(SmplConsts), _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int,
+                                        _fp, _fp, _fp, _fp, C.c_int64, _vp, C.c_size_t, _vp]),
 }
 
 _lib = None
@@ -120,7 +122,7 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError if the .so does not export it
         fn.restype, fn.argtypes = res, args
-    if lib.hmmr_abi_version() != 1:
+    if lib.hmmr_abi_version() != 2:
         raise HmmrError("libhmmr_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -76,3 +76,17 @@ __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
     for (int i = 0; i < 8; ++i) a[i] = (bf16_t)v[i];
     *(bf16x8*)p = a;
 }
+
+// 8 consecutive elements held as raw 16-byte pieces -> 8 floats
+template <typename T> __device__ __forceinline__ void unpack8(const u32x4 (&r)[(int)(8 * sizeof(T) / 16)], float (&v)[8]);
+template <> __device__ __forceinline__ void unpack8<float>(const u32x4 (&r)[2], float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = __uint_as_float(r[0][i]); v[4 + i] = __uint_as_float(r[1][i]); }
+}
+template <> __device__ __forceinline__ void unpack8<bf16_t>(const u32x4 (&r)[1], float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(r[0][i] << 16);            // bf16 -> f32 is a 16-bit shift
+        v[2 * i + 1] = __uint_as_float(r[0][i] & 0xffff0000u);
+    }
+}

@@ -142,6 +142,37 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // ---- epilogue geometry: each lane owns 8 consecutive output channels of NIT rows.
+    // The residual vectors do not depend on the GEMM: issue their loads NOW so their HBM
+    // latency overlaps the operand loads and the K loop instead of serialising after it.
+    constexpr int VPR = BN / 8;                   // 8-channel vectors per row
+    constexpr int NIT = (BM * VPR) / 256;
+    constexpr int RV = (int)(8 * sizeof(TO) / 16); // 16-byte pieces per residual vector
+    const TO* __restrict__ res = (const TO*)a.res;
+    u32x4 rres[NIT][RV];
+    if (res) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = it * 256 + tid;
+            const int m = m0 + idx / VPR, n = n0 + (idx % VPR) * 8;
+#pragma unroll
+            for (int q = 0; q < RV; ++q) rres[it][q] = u32x4{0u, 0u, 0u, 0u};
+            if (m < a.M && n < a.cout) {
+                long long ro;
+                if (a.res_strided) {
+                    const int img = m / a.HoWo, rem = m - img * a.HoWo;
+                    const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+                    ro = (long long)img * a.res_img_stride + (long long)oy * a.res_row_stride +
+                         (long long)ox * a.res_px_stride + n;
+                } else {
+                    ro = (long long)m * a.ldr + n;
+                }
+#pragma unroll
+                for (int q = 0; q < RV; ++q) rres[it][q] = *((const u32x4*)(res + ro) + q);
+            }
+        }
+    }
+
     const int nk = a.K / BKE;
     load_tile(0);
     store_tile(0);
@@ -181,12 +212,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
             }
     __syncthreads();
 
-    constexpr int VPR = BN / 8;                   // 8-channel vectors per row
     TO* __restrict__ out = (TO*)a.out;
     TO* __restrict__ out2 = (TO*)a.out2;
-    const TO* __restrict__ res = (const TO*)a.res;
-#pragma unroll 2
-    for (int it = 0; it < (BM * VPR) / 256; ++it) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
         const int idx = it * 256 + tid;
         const int row = idx / VPR, col = (idx % VPR) * 8;
         const int m = m0 + row, n = n0 + col;
@@ -205,22 +234,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
         }
         const bool full = (n + 8 <= a.cout);
         if (res) {
-            long long ro;
-            if (a.res_strided) {
-                const int img = m / a.HoWo, rem = m - img * a.HoWo;
-                const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-                ro = (long long)img * a.res_img_stride + (long long)oy * a.res_row_stride +
-                     (long long)ox * a.res_px_stride + n;
-            } else {
-                ro = (long long)m * a.ldr + n;
-            }
-            if (full) {
-                float rr[8]; load8(res + ro, rr);
+            float rr[8];
+            unpack8<TO>(rres[it], rr);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += rr[j];
-            } else {
-                for (int j = 0; j < 8 && n + j < a.cout; ++j) v[j] += elem_traits<TO>::to_f32(res[ro + j]);
-            }
+            for (int j = 0; j < 8; ++j) v[j] += rr[j];
         }
         if (a.relu) {
 #pragma unroll
@@ -303,6 +320,9 @@ extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
     HMMR_REQUIRE(px_ok && d->in_row_stride % eps == 0 && d->in_img_stride % eps == 0,
                  "hmmr_conv_gemm: input strides must keep 16-byte alignment");
     HMMR_REQUIRE(!d->res || d->res_strided || d->ldr % 8 == 0, "hmmr_conv_gemm: ldr must be a multiple of 8");
+    // residual rows are read as whole 8-channel vectors: a ragged cout needs the padding to exist
+    HMMR_REQUIRE(!d->res || d->cout % 8 == 0 || (!d->res_strided && d->ldr >= (d->cout + 7) / 8 * 8),
+                 "hmmr_conv_gemm: residual rows must be readable up to cout rounded up to 8");
     HMMR_REQUIRE(!d->out2 || (d->scale2 && d->shift2), "hmmr_conv_gemm: out2 needs scale2/shift2");
     ConvArgs a;
     a.in = d->in; a.w = d->w; a.scale = d->scale; a.shift = d->shift; a.res = d->res;

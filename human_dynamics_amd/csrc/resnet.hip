@@ -20,7 +20,8 @@
 static constexpr int IMG = 224, PADH = 230, PADW = 232;
 
 template <typename T>
-__global__ void stem_repack_kernel(const float* __restrict__ img, T* __restrict__ out, long long npix) {
+__global__ void stem_repack_kernel(const float* __restrict__ img, T* __restrict__ out, long long npix,
+                                   long long n_real) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix;
          i += (long long)gridDim.x * blockDim.x) {
         const int x = (int)(i % PADW);
@@ -29,7 +30,7 @@ __global__ void stem_repack_kernel(const float* __restrict__ img, T* __restrict_
         const long long n = t / PADH;
         float r = 0.f, g = 0.f, b = 0.f;
         const int sy = y - 3, sx = x - 3;
-        if ((unsigned)sy < (unsigned)IMG && (unsigned)sx < (unsigned)IMG) {
+        if (n < n_real && (unsigned)sy < (unsigned)IMG && (unsigned)sx < (unsigned)IMG) {
             const float* p = img + ((n * IMG + sy) * IMG + sx) * 3;
             r = p[0]; g = p[1]; b = p[2];
         }
@@ -160,7 +161,7 @@ extern "C" size_t hmmr_resnet50_workspace_bytes(int n, int dtype) {
 }
 
 template <typename T>
-static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int n, float* phi,
+static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int n_real, int n, float* phi,
                         char* ws, hipStream_t s, float* prof_ms) {
     const ResnetBufs L = resnet_layout(n, w->dtype);
     T* xpad = (T*)(ws + L.xpad);
@@ -176,7 +177,7 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
     {
         const long long npix = (long long)n * PADH * PADW;
         const int grid = (int)((npix + 255) / 256 < 8192 ? (npix + 255) / 256 : 8192);
-        hipLaunchKernelGGL(stem_repack_kernel<T>, dim3(grid), dim3(256), 0, s, images, xpad, npix);
+        hipLaunchKernelGGL(stem_repack_kernel<T>, dim3(grid), dim3(256), 0, s, images, xpad, npix, (long long)n_real);
         HMMR_CHECK_HIP(hipGetLastError());
         if (prof_mark(pf)) return -2;
         hmmr_conv_desc_t d = {};
@@ -268,16 +269,17 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
     return prof_end(pf);
 }
 
-extern "C" int hmmr_resnet50_fwd(const hmmr_resnet_weights_t* w, const float* images, int n, float* phi,
-                                 void* ws, size_t ws_bytes, void* stream, float* prof_ms) {
-    HMMR_REQUIRE(w && images && phi && ws, "hmmr_resnet50_fwd: null argument");
-    HMMR_REQUIRE(n > 0, "hmmr_resnet50_fwd: n must be positive");
-    HMMR_REQUIRE(ws_bytes >= hmmr_resnet50_workspace_bytes(n, w->dtype),
+extern "C" int hmmr_resnet50_fwd(const hmmr_resnet_weights_t* w, const float* images, int n, int n_zero,
+                                 float* phi, void* ws, size_t ws_bytes, void* stream, float* prof_ms) {
+    HMMR_REQUIRE(w && phi && ws && (images || n == 0), "hmmr_resnet50_fwd: null argument");
+    HMMR_REQUIRE(n >= 0 && n_zero >= 0 && n + n_zero > 0, "hmmr_resnet50_fwd: need at least one image");
+    const int nt = n + n_zero;
+    HMMR_REQUIRE(ws_bytes >= hmmr_resnet50_workspace_bytes(nt, w->dtype),
                  "hmmr_resnet50_fwd: workspace too small (%zu < %zu)", ws_bytes,
-                 hmmr_resnet50_workspace_bytes(n, w->dtype));
+                 hmmr_resnet50_workspace_bytes(nt, w->dtype));
     HMMR_REQUIRE(w->unit[0].c_in == 64 && w->unit[15].depth == 2048, "hmmr_resnet50_fwd: bad unit table");
-    if (w->dtype == HMMR_BF16) return resnet_fwd_t<bf16_t>(w, images, n, phi, (char*)ws, (hipStream_t)stream, prof_ms);
-    if (w->dtype == HMMR_F32) return resnet_fwd_t<float>(w, images, n, phi, (char*)ws, (hipStream_t)stream, prof_ms);
+    if (w->dtype == HMMR_BF16) return resnet_fwd_t<bf16_t>(w, images, n, nt, phi, (char*)ws, (hipStream_t)stream, prof_ms);
+    if (w->dtype == HMMR_F32) return resnet_fwd_t<float>(w, images, n, nt, phi, (char*)ws, (hipStream_t)stream, prof_ms);
     hmmr_set_error("hmmr_resnet50_fwd: bad dtype %d", w->dtype);
     return -1;
 }

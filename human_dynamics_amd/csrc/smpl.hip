@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void smpl_pose_kernel(
     const float* __restrict__ theta, int ld_theta, const float* __restrict__ beta, int ld_beta,
     const float* __restrict__ j_template, const float* __restrict__ j_shapedirs,
     const int* __restrict__ parents, int m, float* __restrict__ feat, float* __restrict__ Aout,
-    float* __restrict__ rs) {
+    float* __restrict__ rs, long long ld_rs) {
     // per instance slot: local transform (R 9, t 3) and global (R 9, t 3) per joint
     __shared__ float sLoc[8][NJ][12];
     __shared__ float sGlb[8][NJ][12];
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void smpl_pose_kernel(
         R[3] = oc * ry * rx + s * rz; R[4] = c + oc * ry * ry;      R[5] = oc * ry * rz - s * rx;
         R[6] = oc * rz * rx - s * ry; R[7] = oc * rz * ry + s * rx; R[8] = c + oc * rz * rz;
         if (rs) {
-            float* o = rs + ((long long)inst * NJ + j) * 9;
+            float* o = rs + (long long)inst * ld_rs + j * 9;
 #pragma unroll
             for (int e = 0; e < 9; ++e) o[e] = R[e];
         }
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void smpl_pose_kernel(
 __global__ __launch_bounds__(256) void smpl_verts_kernel(
     const float* __restrict__ dirs, int vpad, const float* __restrict__ feat, const float* __restrict__ A,
     const int* __restrict__ lbs_idx, const float* __restrict__ lbs_w, int nnz, int nv, int m,
-    float* __restrict__ verts) {
+    float* __restrict__ verts, long long ld_verts) {
     __shared__ __attribute__((aligned(16))) float sA[IB][LDA];
     const int v = blockIdx.x * VT + threadIdx.x;
     const int i0 = blockIdx.y * IB;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void smpl_verts_kernel(
     for (int ii = 0; ii < IB; ++ii) {
         if (i0 + ii >= m) break;
         const float x = acc[ii][0], y = acc[ii][1], z = acc[ii][2];
-        float* o = verts + ((long long)(i0 + ii) * nv + v) * 3;
+        float* o = verts + (long long)(i0 + ii) * ld_verts + v * 3;
         o[0] = T[ii][0] * x + T[ii][1] * y + T[ii][2] * z + T[ii][3];
         o[1] = T[ii][4] * x + T[ii][5] * y + T[ii][6] * z + T[ii][7];
         o[2] = T[ii][8] * x + T[ii][9] * y + T[ii][10] * z + T[ii][11];
@@ -202,10 +202,11 @@ __global__ __launch_bounds__(256) void smpl_verts_kernel(
 __global__ __launch_bounds__(256) void smpl_joints_kernel(
     const float* __restrict__ verts, const int* __restrict__ kptr, const int* __restrict__ kidx,
     const float* __restrict__ kval, const float* __restrict__ cams, int ld_cam, int nv, int nk,
-    float* __restrict__ joints, float* __restrict__ kps) {
+    float* __restrict__ joints, float* __restrict__ kps, long long ld_verts, long long ld_joints,
+    long long ld_kps) {
     const int inst = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const float* vb = verts + (long long)inst * nv * 3;
+    const float* vb = verts + (long long)inst * ld_verts;
     for (int k = wave; k < nk; k += 4) {
         float sx = 0.f, sy = 0.f, sz = 0.f;
         for (int e = kptr[k] + lane; e < kptr[k + 1]; e += 64) {
@@ -218,11 +219,11 @@ __global__ __launch_bounds__(256) void smpl_joints_kernel(
             sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o); sz += __shfl_xor(sz, o);
         }
         if (lane == 0) {
-            float* jo = joints + ((long long)inst * nk + k) * 3;
+            float* jo = joints + (long long)inst * ld_joints + k * 3;
             jo[0] = sx; jo[1] = sy; jo[2] = sz;
             if (kps && cams) {
                 const float* cm = cams + (long long)inst * ld_cam;
-                float* ko = kps + ((long long)inst * nk + k) * 2;
+                float* ko = kps + (long long)inst * ld_kps + k * 2;
                 ko[0] = cm[0] * (sx + cm[1]);
                 ko[1] = cm[0] * (sy + cm[2]);
             }
@@ -238,10 +239,10 @@ extern "C" size_t hmmr_smpl_workspace_bytes(int m) {
     return align_up((size_t)m * LDF * 4, 256) + align_up((size_t)m * LDA * 4, 256);
 }
 
-extern "C" int hmmr_smpl_fwd(const hmmr_smpl_consts_t* c, const float* theta, int ld_theta,
-                             const float* beta, int ld_beta, const float* cams, int ld_cam, int m,
-                             float* verts, float* joints, float* kps, float* rs,
-                             void* ws, size_t ws_bytes, void* stream) {
+static int smpl_launch(const hmmr_smpl_consts_t* c, const float* theta, int ld_theta, const float* beta,
+                       int ld_beta, const float* cams, int ld_cam, int m, float* verts, float* joints,
+                       float* kps, float* rs, long long ld_verts, long long ld_joints, long long ld_kps,
+                       long long ld_rs, void* ws, size_t ws_bytes, void* stream) {
     HMMR_REQUIRE(c && theta && beta && verts && joints && ws, "hmmr_smpl_fwd: null argument");
     HMMR_REQUIRE(m > 0, "hmmr_smpl_fwd: m must be positive");
     HMMR_REQUIRE(c->lbs_nnz >= 1 && c->lbs_nnz <= NJ, "hmmr_smpl_fwd: lbs_nnz=%d out of range", c->lbs_nnz);
@@ -252,14 +253,33 @@ extern "C" int hmmr_smpl_fwd(const hmmr_smpl_consts_t* c, const float* theta, in
     float* A = (float*)((char*)ws + align_up((size_t)m * LDF * 4, 256));
     const int vtiles = (c->num_verts + VT - 1) / VT;
     hipLaunchKernelGGL(smpl_pose_kernel, dim3((m + 7) / 8), dim3(256), 0, s, theta, ld_theta, beta, ld_beta,
-                       c->j_template, c->j_shapedirs, c->parents, m, feat, A, rs);
+                       c->j_template, c->j_shapedirs, c->parents, m, feat, A, rs, ld_rs);
     HMMR_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(smpl_verts_kernel, dim3(vtiles, (m + IB - 1) / IB), dim3(256), 0, s, c->dirs,
                        vtiles * VT, (const float*)feat, (const float*)A, c->lbs_idx, c->lbs_w, c->lbs_nnz,
-                       c->num_verts, m, verts);
+                       c->num_verts, m, verts, ld_verts);
     HMMR_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(smpl_joints_kernel, dim3(m), dim3(256), 0, s, (const float*)verts, c->kreg_ptr,
-                       c->kreg_idx, c->kreg_val, cams, ld_cam, c->num_verts, c->num_kps, joints, kps);
+                       c->kreg_idx, c->kreg_val, cams, ld_cam, c->num_verts, c->num_kps, joints, kps,
+                       ld_verts, ld_joints, ld_kps);
     HMMR_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+extern "C" int hmmr_smpl_fwd(const hmmr_smpl_consts_t* c, const float* theta, int ld_theta,
+                             const float* beta, int ld_beta, const float* cams, int ld_cam, int m,
+                             float* verts, float* joints, float* kps, float* rs,
+                             void* ws, size_t ws_bytes, void* stream) {
+    HMMR_REQUIRE(c, "hmmr_smpl_fwd: null argument");
+    return smpl_launch(c, theta, ld_theta, beta, ld_beta, cams, ld_cam, m, verts, joints, kps, rs,
+                       (long long)c->num_verts * 3, (long long)c->num_kps * 3, (long long)c->num_kps * 2,
+                       NJ * 9, ws, ws_bytes, stream);
+}
+
+extern "C" int hmmr_smpl_fwd_strided(const hmmr_smpl_consts_t* c, const float* theta, int ld_theta,
+                                     const float* beta, int ld_beta, const float* cams, int ld_cam, int m,
+                                     float* verts, float* joints, float* kps, float* rs, int64_t ld_out,
+                                     void* ws, size_t ws_bytes, void* stream) {
+    return smpl_launch(c, theta, ld_theta, beta, ld_beta, cams, ld_cam, m, verts, joints, kps, rs,
+                       ld_out, ld_out, ld_out, ld_out, ws, ws_bytes, stream);
 }

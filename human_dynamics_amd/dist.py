@@ -107,20 +107,19 @@ def predict_all_images_sharded(tester, frames_fn, n_frames, rank=None, world_siz
     if rank is None:
         rank = dist.get_rank() if dist.is_initialized() else 0
     plan = ShardPlan(n_frames, tester.batch_size, tester.sequence_length, tester.fov, world_size, rank)
-    layout, rec_len = record_layout(len(tester.delta_t_values))
+    layout, rec_len = tester.record_layout()
     eng = tester.engine
-    zero = torch.zeros((1, tester.img_size, tester.img_size, 3), dtype=torch.float32, device=eng.device)
-    if plan.f1 > plan.f0:
-        frames = eng.to_device(frames_fn(plan.f0, plan.f1))
-        phi_all = eng.resnet(torch.cat([frames, zero], dim=0))      # last row = feature of the zero image
-    else:
-        phi_all = eng.resnet(zero)
-    out = {}
-    if plan.w1 > plan.w0:
+    frames = frames_fn(plan.f0, plan.f1) if plan.f1 > plan.f0 else None
+    if frames is None:
+        frames = torch.empty((0, tester.img_size, tester.img_size, 3), dtype=torch.float32, device=eng.device)
+    phi_all = tester.features(frames, n_zero=1)                 # last row = feature of the zero image
+    local = torch.zeros((plan.out_per_rank, rec_len), dtype=torch.float32, device=eng.device) \
+        if plan.o1 - plan.o0 < plan.out_per_rank else \
+        torch.empty((plan.out_per_rank, rec_len), dtype=torch.float32, device=eng.device)
+    if plan.w1 > plan.w0 and plan.o1 > plan.o0:
         idx = torch.from_numpy(plan.window_frame_index()).to(eng.device)
         idx = torch.where(idx < 0, torch.full_like(idx, phi_all.shape[0] - 1), idx)
-        out = tester.predict_strips_device(phi_all[idx], plan.o1 - plan.o0)
-    local = pack_outputs(out, plan.out_per_rank, layout, rec_len, device=eng.device)
+        tester.predict_strips_records(phi_all[idx], plan.o1 - plan.o0, out=local)
     if not gather:
         return local, layout, plan
     return all_gather_outputs(local, plan, group), layout, plan

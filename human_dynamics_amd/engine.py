@@ -77,25 +77,32 @@ class HmmrEngine(object):
         return torch.from_numpy(np.ascontiguousarray(a)).to(self.device).to(dtype).contiguous()
 
     # -- stages ----------------------------------------------------------------
-    def resnet(self, images, prof=False):
-        """images [n,224,224,3] fp32 (device) -> phi [n,2048] fp32.
-        encoder_resnet, src/models.py:50-77."""
+    def resnet(self, images, prof=False, n_zero=0):
+        """images [n,224,224,3] fp32 (device) -> phi [n + n_zero,2048] fp32; the last
+        n_zero rows are the features of all-zero images (the padding frames of
+        predict_all_images), encoded in the same pass.  encoder_resnet, src/models.py:50-77."""
         images = self.to_device(images)
         n = images.shape[0]
-        assert tuple(images.shape[1:]) == (224, 224, 3), images.shape
-        phi = torch.empty((n, 2048), dtype=torch.float32, device=self.device)
-        chunk = self.resnet_chunk if self.resnet_chunk > 0 else n
+        assert n == 0 or tuple(images.shape[1:]) == (224, 224, 3), images.shape
+        nt = n + n_zero
+        phi = torch.empty((nt, 2048), dtype=torch.float32, device=self.device)
+        chunk = self.resnet_chunk if self.resnet_chunk > 0 else max(nt, 1)
         prof_tot = np.zeros(L.RESNET_PROF_SLOTS, np.float64) if prof else None
-        for i in range(0, n, chunk):
-            c = min(chunk, n - i)
+        i = 0
+        while i < nt:
+            c_real = max(0, min(chunk, n - i))
+            c_zero = min(chunk - c_real, nt - i - c_real) if i + c_real >= n else 0
+            c = c_real + c_zero
             nbytes = self.lib.hmmr_resnet50_workspace_bytes(c, self.dtype)
             ws = self._ws["resnet"].get(nbytes)
             pm = (C.c_float * L.RESNET_PROF_SLOTS)() if prof else None
-            L.check(self.lib.hmmr_resnet50_fwd(C.byref(self.rw), images[i:i + c].data_ptr(), c,
+            src = images[i:i + c_real].data_ptr() if c_real else None
+            L.check(self.lib.hmmr_resnet50_fwd(C.byref(self.rw), src, c_real, c_zero,
                                                phi[i:i + c].data_ptr(), ws.data_ptr(), nbytes,
                                                self._stream(), pm), "hmmr_resnet50_fwd")
             if prof:
                 prof_tot += np.frombuffer(pm, dtype=np.float32)
+            i += c
         return (phi, prof_tot) if prof else phi
 
     def temporal(self, phi):
@@ -149,6 +156,23 @@ class HmmrEngine(object):
                                        verts.data_ptr(), joints.data_ptr(), L.ptr(kps), L.ptr(rs),
                                        ws.data_ptr(), nbytes, self._stream()), "hmmr_smpl_fwd")
         return verts, joints, kps, rs
+
+    def smpl_into(self, theta, beta, cams, rec, off_verts, off_joints, off_kps, off_rs):
+        """SMPL forward that writes instance i's verts/joints/kps/Rs straight into row i of
+        the packed record tensor `rec` [m, rec_len] at the given float offsets
+        (hmmr_smpl_fwd_strided).  theta/beta/cams: fp32 device views with unit inner stride."""
+        m = theta.shape[0]
+        assert rec.dtype == torch.float32 and rec.stride(1) == 1 and rec.shape[0] >= m
+        for x, wdt in ((theta, 72), (beta, 10), (cams, 3)):
+            assert x.is_cuda and x.dtype == torch.float32 and x.stride(1) == 1 and x.shape == (m, wdt)
+        nbytes = self.lib.hmmr_smpl_workspace_bytes(m)
+        ws = self._ws["smpl"].get(nbytes)
+        base = rec.data_ptr()
+        L.check(self.lib.hmmr_smpl_fwd_strided(
+            C.byref(self.sc), theta.data_ptr(), theta.stride(0), beta.data_ptr(), beta.stride(0),
+            cams.data_ptr(), cams.stride(0), m, base + 4 * off_verts, base + 4 * off_joints,
+            base + 4 * off_kps, base + 4 * off_rs, rec.stride(0), ws.data_ptr(), nbytes, self._stream()),
+            "hmmr_smpl_fwd_strided")
 
     def groupnorm_relu(self, x, gamma, beta, groups=32, out_dtype=L.HMMR_F32):
         x = self.to_device(x)

@@ -68,7 +68,7 @@ def window_plan(n_frames, batch_size, sequence_length, fov):
 class Tester(object):
 
     def __init__(self, config, pretrained_resnet_path="", sequence_length=None,
-                 weights=None, smpl=None, dtype=None, device=None, dedup=True):
+                 weights=None, smpl=None, dtype=None, device=None, dedup=True, use_containers=False):
         self.config = config
         self.load_path = config.load_path
         if not config.load_path and weights is None:
@@ -84,6 +84,7 @@ class Tester(object):
         self.num_output = 85
         self.smpl_model_path = config.smpl_model_path
         self.dedup = dedup
+        self.use_containers = use_containers
         if self.pred_mode not in ("pred", "hal"):
             raise Exception("Pred mode {} not recognized".format(self.pred_mode))
         if self.pred_mode == "hal":
@@ -161,15 +162,58 @@ class Tester(object):
         return {k: v.float().cpu().numpy() for k, v in fetch.items()}
 
     # ------------------------------------------------------------------------
+    def record_layout(self):
+        from ..dist import record_layout
+        K = self.engine.num_kps
+        V = self.engine.num_verts
+        fields = (("cams", (3,)), ("joints", (K, 3)), ("kps", (K, 2)), ("poses", (24, 3, 3)),
+                  ("shapes", (10,)), ("verts", (V, 3)), ("omegas", (85,)))
+        return record_layout(len(self.delta_t_values), fields)
+
+    def predict_records(self, strips, out=None):
+        """movie strips [n,2048] -> packed per-frame records [n, rec_len] (device):
+        IEF for the present and the delta regressors, then one SMPL evaluation per
+        container that writes verts/joints/kps/poses straight into the record
+        (the tail of build_test_model + make_fetch_dict, tester.py:196-227, with the
+        containers' cams = omega_0's cams, tester.py:211-213)."""
+        from ..dist import unpack_outputs  # noqa: F401  (layout owner)
+        eng = self.engine
+        n = strips.shape[0]
+        layout, rec_len = self.record_layout()
+        off = {k: (o, sz) for k, shp, o, sz in layout}
+        if out is None:
+            out = torch.empty((n, rec_len), dtype=torch.float32, device=eng.device)
+        rec = out[:n]
+        om = eng.ief(strips)                                    # [R, n, 85], deltas in sorted order
+        cams0 = om[0][:, :3]
+        for r, key in enumerate(eng.reg_keys):
+            if key == 0:
+                base = {k: off[k][0] for k in OUTPUT_KEYS}
+            else:
+                d = r - 1
+                base = {k: off[k + "_delta"][0] + d * (off[k + "_delta"][1] // len(self.delta_t_values))
+                        for k in OUTPUT_KEYS}
+            eng.smpl_into(om[r][:, 3:75], om[r][:, 75:85], cams0, rec,
+                          base["verts"], base["joints"], base["kps"], base["poses"])
+            rec[:, base["cams"]:base["cams"] + 3] = cams0
+            rec[:, base["shapes"]:base["shapes"] + 10] = om[r][:, 75:85]
+            rec[:, base["omegas"]:base["omegas"] + 85] = om[r]
+        return out
+
     def predict_device(self, images):
         """Forward pass on device tensors: images [B,T,224,224,3] -> dict of device tensors."""
+        from ..dist import unpack_outputs
         B, T = images.shape[0], images.shape[1]
         I_t = self.engine.to_device(images).reshape(B * T, self.img_size, self.img_size, 3)
         img_feat, _ = self.f_image_enc(I_t, engine=self.engine, is_training=False, reuse=False)
         img_feat_full = img_feat.reshape(B, T, -1)
         movie_strips = self.f_temporal_enc(is_training=False, net=img_feat_full,
                                            num_conv_layers=self.num_conv_layers, engine=self.engine)
-        return self._fetch(self._regress(movie_strips, B, T), to_numpy=False)
+        if self.use_containers:      # the reference's OmegasPred route (same numbers, more copies)
+            return self._fetch(self._regress(movie_strips, B, T), to_numpy=False)
+        rec = self.predict_records(movie_strips.reshape(B * T, -1))
+        layout, _ = self.record_layout()
+        return {k: v.reshape((B, T) + v.shape[1:]) for k, v in unpack_outputs(rec, layout).items()}
 
     def predict(self, images):
         """Runs forward pass of model.  images (BxTxHxWx3) -> dict of float32 ndarrays."""
@@ -178,29 +222,33 @@ class Tester(object):
         return {k: v.float().cpu().numpy() for k, v in out.items()}
 
     # ------------------------------------------------------------------------
-    def features(self, frames, chunk=256):
-        """frames [N,224,224,3] (host or device) -> phi [N,2048] on device."""
+    def features(self, frames, chunk=256, n_zero=0):
+        """frames [N,224,224,3] (host or device) -> phi [N + n_zero,2048] on device."""
         if isinstance(frames, torch.Tensor) and frames.is_cuda:
-            return self.engine.resnet(frames)
+            return self.engine.resnet(frames, n_zero=n_zero)
         outs = []
         for i in range(0, len(frames), chunk):
-            outs.append(self.engine.resnet(np.asarray(frames[i:i + chunk], np.float32)))
+            last = i + chunk >= len(frames)
+            outs.append(self.engine.resnet(np.asarray(frames[i:i + chunk], np.float32),
+                                           n_zero=n_zero if last else 0))
         return torch.cat(outs, dim=0)
 
-    def predict_strips_device(self, windows, n_keep):
+    def predict_strips_records(self, windows, n_keep, out=None):
         """windows [W,T,2048] of frame features (padding slots hold the feature of
-        the zero image) -> outputs of the first n_keep frames the windows keep
-        (the centre g = T - 2*margin of each, tester.py:305-311), as device
-        tensors [n_keep, ...] / [n_keep, 2, ...] for the delta keys."""
+        the zero image) -> records of the first n_keep frames the windows keep
+        (the centre g = T - 2*margin of each, tester.py:305-311)."""
         T = self.sequence_length
         margin = (self.fov - 1) // 2
         strips = self.engine.temporal(windows)
-        kept = strips[:, margin:T - margin].reshape(-1, strips.shape[-1])[:n_keep].contiguous()
+        kept = strips[:, margin:T - margin].reshape(-1, strips.shape[-1])[:n_keep]
+        return self.predict_records(kept, out)
+
+    def predict_strips_device(self, windows, n_keep):
+        from ..dist import unpack_outputs
         if n_keep == 0:
             return {}
-        omegas_pred = self._regress(kept.reshape(n_keep, 1, -1), n_keep, 1)
-        out = self._fetch(omegas_pred, to_numpy=False)
-        return {k: v[:, 0] for k, v in out.items()}                  # drop the T=1 axis
+        layout, _ = self.record_layout()
+        return unpack_outputs(self.predict_strips_records(windows, n_keep), layout)
 
     def predict_windows_device(self, phi, phi_zero):
         """The part of predict_all_images after the ResNet: phi [N,2048] are the
@@ -221,10 +269,8 @@ class Tester(object):
         N = len(all_images)
         if not self.dedup:
             return self._predict_all_images_literal(all_images)
-        phi = self.features(all_images)
-        phi_zero = self.engine.resnet(torch.zeros((1, self.img_size, self.img_size, 3),
-                                                  dtype=torch.float32, device=self.engine.device))
-        out = self.predict_windows_device(phi, phi_zero)
+        phi = self.features(all_images, n_zero=1)        # last row: feature of the zero padding image
+        out = self.predict_windows_device(phi[:N], phi[N:])
         torch.cuda.synchronize(self.engine.device)
         return {k: v.float().cpu().numpy() for k, v in out.items()}
 

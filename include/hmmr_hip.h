@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HMMR_ABI_VERSION 1
+#define HMMR_ABI_VERSION 2
 
 enum { HMMR_F32 = 0, HMMR_BF16 = 1 };
 
@@ -115,7 +115,10 @@ size_t hmmr_resnet50_workspace_bytes(int n, int dtype);
 /* prof_ms: NULL, or a host array of HMMR_RESNET_PROF_SLOTS floats that receives
  * the HIP-event duration (ms) of every launch (forces a stream sync). */
 #define HMMR_RESNET_PROF_SLOTS 64
-int hmmr_resnet50_fwd(const hmmr_resnet_weights_t* w, const float* images, int n,
+/* n_zero: that many all-zero images are appended after the n real ones (the padding frames of
+ * predict_all_images, tester.py:285-289, are zero IMAGES that still go through the encoder);
+ * phi has n + n_zero rows, the workspace must be sized for n + n_zero. */
+int hmmr_resnet50_fwd(const hmmr_resnet_weights_t* w, const float* images, int n, int n_zero,
                       float* phi, void* ws, size_t ws_bytes, void* stream, float* prof_ms);
 
 /* ------------------------------------------------------------------------- *
@@ -210,6 +213,13 @@ int hmmr_smpl_fwd(const hmmr_smpl_consts_t* c, const float* theta, int ld_theta,
                   const float* beta, int ld_beta, const float* cams, int ld_cam, int m,
                   float* verts, float* joints, float* kps, float* rs,
                   void* ws, size_t ws_bytes, void* stream);
+/* Same, but instance i's outputs start at verts + i*ld_out, joints + i*ld_out, ... (floats):
+ * the four outputs are fields of one packed per-frame record of ld_out floats, so the
+ * record that the multi-GPU all-gather ships is written in place (no re-packing pass). */
+int hmmr_smpl_fwd_strided(const hmmr_smpl_consts_t* c, const float* theta, int ld_theta,
+                          const float* beta, int ld_beta, const float* cams, int ld_cam, int m,
+                          float* verts, float* joints, float* kps, float* rs, int64_t ld_out,
+                          void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

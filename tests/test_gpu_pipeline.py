@@ -97,3 +97,27 @@ def test_tester_rejects_bad_config(weights, smpl_consts, gpu_device):
         Tester(Config(pred_mode="bogus"), weights=weights, smpl=smpl_consts, device=gpu_device)
     with pytest.raises(FileNotFoundError):
         Tester(Config(load_path="/nonexistent/model.ckpt-1"), smpl=smpl_consts, device=gpu_device)
+
+
+def test_container_route_equals_record_route(weights, smpl_consts, gpu_device):
+    """The reference-shaped OmegasPred route and the in-place record route are the same numbers."""
+    from human_dynamics_amd.evaluation.tester import Tester
+    frames = assets.make_synthetic_frames(20, seed=3).reshape(2, 10, 224, 224, 3)
+    a = Tester(Config(batch_size=2, sequence_length=10), weights=weights, smpl=smpl_consts, dtype="f32",
+               device=gpu_device).predict(frames)
+    b = Tester(Config(batch_size=2, sequence_length=10), weights=weights, smpl=smpl_consts, dtype="f32",
+               device=gpu_device, use_containers=True).predict(frames)
+    assert sorted(a) == sorted(b)
+    for k in a:
+        assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), k
+
+
+def test_resnet_zero_tail_equals_explicit_zero_images(weights, gpu_device):
+    from human_dynamics_amd.engine import HmmrEngine
+    eng = HmmrEngine(weights, None, dtype="bf16", device=gpu_device)
+    frames = assets.make_synthetic_frames(3, seed=4)
+    a = eng.resnet(frames, n_zero=2).cpu().numpy()
+    b = eng.resnet(np.concatenate([frames, np.zeros((2, 224, 224, 3), np.float32)])).cpu().numpy()
+    assert a.shape == (5, 2048) and np.array_equal(a, b)
+    c = eng.resnet(frames[:0], n_zero=1).cpu().numpy()
+    assert np.array_equal(c, a[3:4])

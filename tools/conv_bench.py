@@ -1,0 +1,97 @@
+"""Micro-benchmark of hmmr_conv_gemm on the ResNet-50 / temporal / IEF layer shapes (dev aid).
+
+    python tools/conv_bench.py [batch] [dtype]
+"""
+import ctypes as C
+import json
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from human_dynamics_amd import _lib as L
+from human_dynamics_amd import packing
+
+DT = {"bf16": (L.HMMR_BF16, torch.bfloat16), "f32": (L.HMMR_F32, torch.float32)}
+
+
+def run(lib, name, n, h, cin, cout, k, stride, kind, dt, tile, iters=20):
+    code, tdt = DT[dt]
+    dev = "cuda"
+    pad = 1 if k == 3 else 0
+    ho = (h + 2 * pad - k) // stride + 1
+    x = (torch.randn((n, h, h, cin), device=dev) * 0.5).to(tdt)
+    w = (torch.randn((max(cout, 128) if cout % 128 else cout, k * k * cin), device=dev) / (k * k * cin) ** 0.5).to(tdt)
+    if w.shape[0] % 128:
+        w = torch.cat([w, torch.zeros((128 - w.shape[0] % 128, w.shape[1]), device=dev, dtype=tdt)])
+    sc = torch.rand(w.shape[0], device=dev) + 0.5
+    sh = torch.randn(w.shape[0], device=dev)
+    out = torch.empty((n, ho, ho, cout), device=dev, dtype=tdt)
+    d = L.ConvDesc()
+    d.in_, d.w, d.out = x.data_ptr(), w.data_ptr(), out.data_ptr()
+    d.in_dtype = d.out_dtype = code
+    d.n_img, d.hin, d.win, d.cin = n, h, h, cin
+    d.in_img_stride, d.in_row_stride, d.in_px_stride = h * h * cin, h * cin, cin
+    d.kh = d.kw = k; d.sy = d.sx = stride; d.py = d.px = pad
+    d.ho = d.wo = ho; d.cout = cout; d.ldo = cout; d.tile = tile
+    keep = [x, w, sc, sh, out]
+    nbytes = x.numel() * x.element_size() / (stride * stride if k == 1 else 1) + out.numel() * out.element_size()
+    if kind == "bnrelu":
+        d.scale, d.shift, d.relu = sc.data_ptr(), sh.data_ptr(), 1
+    elif kind == "bias":
+        d.shift = sh.data_ptr()
+    elif kind == "res2":                      # conv3: bias + residual + second output
+        res = torch.randn_like(out)
+        out2 = torch.empty_like(out)
+        d.shift, d.res, d.ldr = sh.data_ptr(), res.data_ptr(), cout
+        d.out2, d.scale2, d.shift2 = out2.data_ptr(), sc.data_ptr(), sh.data_ptr()
+        keep += [res, out2]
+        nbytes += 2 * out.numel() * out.element_size()
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        L.check(lib.hmmr_conv_gemm(C.byref(d), st))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        lib.hmmr_conv_gemm(C.byref(d), st)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * n * ho * ho * cout * k * k * cin
+    return {"layer": name, "tile": tile, "ms": round(ms, 4), "TF": round(flops / ms / 1e9, 1),
+            "GBs": round(nbytes / ms / 1e6, 0)}
+
+
+SHAPES = [  # name, h, cin, cout, k, stride, kind
+    ("b1.conv1(256->64)", 56, 256, 64, 1, 1, "bnrelu"),
+    ("b1.conv2(3x3 64)", 56, 64, 64, 3, 1, "bnrelu"),
+    ("b1.conv3(64->256)", 56, 64, 256, 1, 1, "res2"),
+    ("b1.short(64->256)", 56, 64, 256, 1, 1, "bias"),
+    ("b2.conv1(512->128)", 28, 512, 128, 1, 1, "bnrelu"),
+    ("b2.conv2(3x3 128)", 28, 128, 128, 3, 1, "bnrelu"),
+    ("b2.conv3(128->512)", 28, 128, 512, 1, 1, "res2"),
+    ("b3.conv1(1024->256)", 14, 1024, 256, 1, 1, "bnrelu"),
+    ("b3.conv2(3x3 256)", 14, 256, 256, 3, 1, "bnrelu"),
+    ("b3.conv3(256->1024)", 14, 256, 1024, 1, 1, "res2"),
+    ("b4.conv1(2048->512)", 7, 2048, 512, 1, 1, "bnrelu"),
+    ("b4.conv2(3x3 512)", 7, 512, 512, 3, 1, "bnrelu"),
+    ("b4.conv3(512->2048)", 7, 512, 2048, 1, 1, "res2"),
+]
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    dt = sys.argv[2] if len(sys.argv) > 2 else "bf16"
+    lib = L.load()
+    rows = []
+    for name, h, cin, cout, k, stride, kind in SHAPES:
+        for tile in (1, 2, 3):
+            if tile == 1 and cout % 128:
+                continue
+            rows.append(run(lib, name, n, h, cin, cout, k, stride, kind, dt, tile))
+            print(json.dumps(rows[-1]), flush=True)
+
+
+if __name__ == "__main__":
+    main()
