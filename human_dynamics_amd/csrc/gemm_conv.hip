@@ -27,6 +27,8 @@
 //     as 16-byte coalesced accesses;
 //   * 1-D grid remapped so that each XCD (private 4 MiB L2) walks a contiguous
 //     range of tiles that share A rows.
+#include <stdlib.h>
+
 #include "common.h"
 #include "hmmr_hip.h"
 
@@ -36,7 +38,7 @@ struct ConvArgs {
     int M, K, cout, ldo, ldr;
     int Wo, HoWo, Hin, Win;
     long long in_img_stride; int in_row_stride, in_px_stride;
-    int cin_log2, KW, SY, SX, PY, PX;
+    int cin_log2, KH, KW, SY, SX, PY, PX;
     int res_strided; long long res_img_stride; int res_row_stride, res_px_stride;
     int relu, tiles_n, n_tiles;
 };
@@ -54,7 +56,18 @@ __device__ __forceinline__ f32x16 mma(const bf16x8& a, const bf16x8& b, f32x16 c
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-template <typename TA, typename TO, int BM, int BN, int WGM, int WGN>
+// 64 zero bytes in HBM: out-of-bounds gather slots of the LDS-DMA path read from here
+__device__ const u32x4 g_zero_page[4] = {};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// GLDS = true : operands go HBM -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave
+//               instruction, LDS image lane-linear, swizzle applied to the per-lane SOURCE slot);
+// GLDS = false: HBM -> VGPR -> ds_write_b128 (kept for A/B measurements).
+// UTAP = true : every 128-byte K step lies inside one filter tap (cin*sizeof >= 128), so the
+//               tap decode is wave-uniform scalar arithmetic.
+template <typename TA, typename TO, int BM, int BN, int WGM, int WGN, bool GLDS, bool UTAP>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
     static_assert(WGM * WGN == 4, "4 waves per workgroup");
     constexpr int EPS = elem_traits<TA>::EPS;     // elements per 16-B slot
@@ -68,63 +81,88 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int L = xcd_remap(blockIdx.x, a.n_tiles);
     const int m0 = (L / a.tiles_n) * BM;
     const int n0 = (L % a.tiles_n) * BN;
 
-    // ---- staging geometry: 8 lanes per row (one 128-B line), 32 rows per pass
-    const int slot = tid & 7, r0 = tid >> 3;
-    const int wslot = (slot ^ ((r0 >> 1) & 7)) << 4;           // swizzled byte offset in the row
+    // ---- staging geometry: 8 lanes per row (one 128-B line), 32 rows per pass.
+    // Lane (r0, pslot) fills PHYSICAL slot pslot of row r0 with LOGICAL slot lslot.
+    const int pslot = tid & 7, r0 = tid >> 3;
+    const int lslot = pslot ^ ((r0 >> 1) & 7);
     const TA* __restrict__ in = (const TA*)a.in;
     const TA* __restrict__ wt = (const TA*)a.w;
 
-    long long abase[PA]; int aiy[PA], aix[PA];
+    const TA* aptr[PA]; unsigned amask[PA];
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
         const int m = m0 + r0 + 32 * p;
+        aptr[p] = in; amask[p] = 0u;
         if (m < a.M) {
             const int img = m / a.HoWo, rem = m - img * a.HoWo;
             const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-            abase[p] = (long long)img * a.in_img_stride;
-            aiy[p] = oy * a.SY - a.PY;
-            aix[p] = ox * a.SX - a.PX;
-        } else {
-            abase[p] = 0; aiy[p] = -(1 << 28); aix[p] = 0;       // always out of bounds -> zeros
+            const int iy0 = oy * a.SY - a.PY, ix0 = ox * a.SX - a.PX;
+            aptr[p] = in + (long long)img * a.in_img_stride + (long long)iy0 * a.in_row_stride +
+                      (long long)ix0 * a.in_px_stride + lslot * EPS;
+            unsigned mk = 0u;
+            for (int t = 0; t < a.KH * a.KW; ++t) {       // <= 32 taps (host-checked)
+                const int ky = t / a.KW, kx = t - ky * a.KW;
+                if ((unsigned)(iy0 + ky) < (unsigned)a.Hin && (unsigned)(ix0 + kx) < (unsigned)a.Win) mk |= 1u << t;
+            }
+            amask[p] = mk;
         }
     }
-    const TA* wrow = wt + (long long)(n0 + r0) * a.K + slot * EPS;
-
-    u32x4 ra[PA], rb[PB];
+    const TA* wptr = wt + (long long)(n0 + r0) * a.K + lslot * EPS;
     const int cin_mask = (1 << a.cin_log2) - 1;
 
-    auto load_tile = [&](int kt) {
-        const int k = kt * BKE + slot * EPS;
-        const int tap = k >> a.cin_log2, ci = k & cin_mask;
+    // element offset of K step kt inside the gathered row + its tap index
+    auto tap_of = [&](int k, int& tap) -> int {
+        tap = k >> a.cin_log2;
+        const int ci = k & cin_mask;
         int ky, kx;
         if (a.KW == 1) { ky = tap; kx = 0; }
         else if (a.KW == 3) { ky = (int)(((unsigned)tap * 43691u) >> 17); kx = tap - 3 * ky; }
         else { ky = tap / a.KW; kx = tap - ky * a.KW; }
+        return ky * a.in_row_stride + kx * a.in_px_stride + ci;
+    };
+
+    u32x4 ra[GLDS ? 1 : PA], rb[GLDS ? 1 : PB];
+    auto load_tile = [&](int kt, int buf) {
+        int tap;
+        const int koff = UTAP ? tap_of(kt * BKE, tap) : tap_of(kt * BKE + lslot * EPS, tap) - lslot * EPS;
+        if constexpr (GLDS) {
+            char* sa = smem + buf * STAGE + wave * 1024;
 #pragma unroll
-        for (int p = 0; p < PA; ++p) {
-            const int iy = aiy[p] + ky, ix = aix[p] + kx;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if ((unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win)
-                v = *(const u32x4*)(in + abase[p] + (long long)iy * a.in_row_stride +
-                                    (long long)ix * a.in_px_stride + ci);
-            ra[p] = v;
+            for (int p = 0; p < PA; ++p) {
+                const bool ok = (amask[p] >> tap) & 1u;
+                const void* src = ok ? (const void*)(aptr[p] + koff) : (const void*)g_zero_page;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + p * 4096), 16, 0, 0);
+            }
+#pragma unroll
+            for (int p = 0; p < PB; ++p)
+                __builtin_amdgcn_global_load_lds((gptr_t)(wptr + (long long)(32 * p) * a.K + kt * BKE),
+                                                 (lptr_t)(sa + A_BYTES + p * 4096), 16, 0, 0);
+        } else {
+#pragma unroll
+            for (int p = 0; p < PA; ++p) {
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if ((amask[p] >> tap) & 1u) v = *(const u32x4*)(aptr[p] + koff);
+                ra[p] = v;
+            }
+#pragma unroll
+            for (int p = 0; p < PB; ++p)
+                rb[p] = *(const u32x4*)(wptr + (long long)(32 * p) * a.K + kt * BKE);
         }
-#pragma unroll
-        for (int p = 0; p < PB; ++p)
-            rb[p] = *(const u32x4*)(wrow + (long long)(32 * p) * a.K + kt * BKE);
     };
     auto store_tile = [&](int buf) {
-        char* sa = smem + buf * STAGE;
-        char* sb = sa + A_BYTES;
+        if constexpr (!GLDS) {
+            char* sa = smem + buf * STAGE + r0 * 128 + pslot * 16;
 #pragma unroll
-        for (int p = 0; p < PA; ++p) *(u32x4*)(sa + (r0 + 32 * p) * 128 + wslot) = ra[p];
+            for (int p = 0; p < PA; ++p) *(u32x4*)(sa + p * 4096) = ra[p];
 #pragma unroll
-        for (int p = 0; p < PB; ++p) *(u32x4*)(sb + (r0 + 32 * p) * 128 + wslot) = rb[p];
+            for (int p = 0; p < PB; ++p) *(u32x4*)(sa + A_BYTES + p * 4096) = rb[p];
+        }
     };
 
     // ---- fragment geometry
@@ -174,12 +212,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
     }
 
     const int nk = a.K / BKE;
-    load_tile(0);
+    load_tile(0, 0);
     store_tile(0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
+        if (kt + 1 < nk) load_tile(kt + 1, cur ^ 1);
         const char* sbuf = smem + cur * STAGE;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -262,7 +300,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
 // ------------------------------------------------------------------------- //
 // Host side
 // ------------------------------------------------------------------------- //
-template <typename TA, typename TO, int BM, int BN, int WGM, int WGN>
+template <typename TA, typename TO, int BM, int BN, int WGM, int WGN, bool GLDS, bool UTAP>
 static int launch_cfg(const ConvArgs& base, hipStream_t stream) {
     ConvArgs a = base;
     const int tiles_m = (a.M + BM - 1) / BM;
@@ -270,7 +308,7 @@ static int launch_cfg(const ConvArgs& base, hipStream_t stream) {
     a.n_tiles = tiles_m * a.tiles_n;
     constexpr int kloop = 2 * (BM + BN) * 128, epi = BM * BN * 4;
     constexpr int lds = kloop > epi ? kloop : epi;
-    auto kern = conv_gemm_kernel<TA, TO, BM, BN, WGM, WGN>;
+    auto kern = conv_gemm_kernel<TA, TO, BM, BN, WGM, WGN, GLDS, UTAP>;
     static bool attr_set = false;
     if (!attr_set) {
         HMMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -281,22 +319,36 @@ static int launch_cfg(const ConvArgs& base, hipStream_t stream) {
     return 0;
 }
 
-template <typename TA, typename TO>
-static int launch_typed(const ConvArgs& a, int tile, hipStream_t stream) {
-    if (tile == 0) {
-        // pick the largest tile that still gives every CU (256) >= ~2 workgroups
-        const long long t128 = (long long)((a.M + 127) / 128) * ((a.cout + 127) / 128);
-        const long long t12864 = (long long)((a.M + 127) / 128) * ((a.cout + 63) / 64);
-        if (a.cout >= 128 && a.cout % 128 == 0 && t128 >= 512) tile = 1;
-        else if (t12864 >= 512) tile = 2;
-        else tile = 3;
-    }
+template <typename TA, typename TO, bool GLDS, bool UTAP>
+static int launch_tiled(const ConvArgs& a, int tile, hipStream_t stream) {
     switch (tile) {
-        case 1: return launch_cfg<TA, TO, 128, 128, 2, 2>(a, stream);
-        case 2: return launch_cfg<TA, TO, 128, 64, 2, 2>(a, stream);
-        case 3: return launch_cfg<TA, TO, 64, 64, 2, 2>(a, stream);
+        case 1: return launch_cfg<TA, TO, 128, 128, 2, 2, GLDS, UTAP>(a, stream);
+        case 2: return launch_cfg<TA, TO, 128, 64, 2, 2, GLDS, UTAP>(a, stream);
+        case 3: return launch_cfg<TA, TO, 64, 64, 2, 2, GLDS, UTAP>(a, stream);
         default: hmmr_set_error("hmmr_conv_gemm: bad tile %d", tile); return -1;
     }
+}
+
+template <typename TA, typename TO>
+static int launch_typed(const ConvArgs& a, int tile, hipStream_t stream) {
+    // A/B switch for development: HMMR_CONV_STAGING=reg selects the register-staged variant
+    static const bool env_reg = [] { const char* e = getenv("HMMR_CONV_STAGING"); return e && e[0] == 'r'; }();
+    bool glds = !env_reg;
+    if (tile >= 10) { glds = false; tile -= 10; }          // 11..13: register-staged variant (A/B only)
+    if (tile == 0) {
+        // largest tile that still gives most of the 256 CUs a workgroup (measured on the
+        // ResNet shapes at batch 256: 392 tiles of 128x128 beat 784 of 128x64 by 1.5x)
+        const long long t128 = (long long)((a.M + 127) / 128) * ((a.cout + 127) / 128);
+        const long long t12864 = (long long)((a.M + 127) / 128) * ((a.cout + 63) / 64);
+        if (a.cout >= 128 && a.cout % 128 == 0 && t128 >= 192) tile = 1;
+        else if (t12864 >= 192) tile = 2;
+        else tile = 3;
+    }
+    const bool utap = ((size_t)1 << a.cin_log2) * sizeof(TA) >= 128;
+    if (glds) return utap ? launch_tiled<TA, TO, true, true>(a, tile, stream)
+                          : launch_tiled<TA, TO, true, false>(a, tile, stream);
+    return utap ? launch_tiled<TA, TO, false, true>(a, tile, stream)
+                : launch_tiled<TA, TO, false, false>(a, tile, stream);
 }
 
 static int ilog2_exact(int v) {
@@ -312,6 +364,7 @@ extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
     const int cl2 = ilog2_exact(d->cin);
     HMMR_REQUIRE(cl2 >= 0 && d->cin % eps == 0, "hmmr_conv_gemm: cin=%d must be a power of two >= %d", d->cin, eps);
     const int K = d->kh * d->kw * d->cin;
+    HMMR_REQUIRE(d->kh * d->kw <= 32, "hmmr_conv_gemm: at most 32 filter taps");
     HMMR_REQUIRE(K % (8 * eps) == 0, "hmmr_conv_gemm: K=%d must be a multiple of %d", K, 8 * eps);
     HMMR_REQUIRE(d->ldo % 8 == 0, "hmmr_conv_gemm: ldo=%d must be a multiple of 8", d->ldo);
     // every gathered 16-byte slot must stay aligned: ix = ox*sx + kx - px
@@ -330,7 +383,7 @@ extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
     a.M = d->n_img * d->ho * d->wo; a.K = K; a.cout = d->cout; a.ldo = d->ldo; a.ldr = d->ldr;
     a.Wo = d->wo; a.HoWo = d->ho * d->wo; a.Hin = d->hin; a.Win = d->win;
     a.in_img_stride = d->in_img_stride; a.in_row_stride = d->in_row_stride; a.in_px_stride = d->in_px_stride;
-    a.cin_log2 = cl2; a.KW = d->kw; a.SY = d->sy; a.SX = d->sx; a.PY = d->py; a.PX = d->px;
+    a.cin_log2 = cl2; a.KH = d->kh; a.KW = d->kw; a.SY = d->sy; a.SX = d->sx; a.PY = d->py; a.PX = d->px;
     a.res_strided = d->res_strided; a.res_img_stride = d->res_img_stride;
     a.res_row_stride = d->res_row_stride; a.res_px_stride = d->res_px_stride;
     a.relu = d->relu; a.tiles_n = 0; a.n_tiles = 0;
