@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libhmmr_hip.so")
+# HMMR_LIB_PATH lets a development run A/B two builds of the library; the default is the in-tree build
+LIB_PATH = os.environ.get("HMMR_LIB_PATH") or os.path.join(HERE, "libhmmr_hip.so")
 
 HMMR_F32, HMMR_BF16 = 0, 1
 RESNET_UNITS = 16

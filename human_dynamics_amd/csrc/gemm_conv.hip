@@ -28,6 +28,7 @@
 //   * 1-D grid remapped so that each XCD (private 4 MiB L2) walks a contiguous
 //     range of tiles that share A rows.
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 #include "hmmr_hip.h"
@@ -67,14 +68,19 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // GLDS = false: HBM -> VGPR -> ds_write_b128 (kept for A/B measurements).
 // UTAP = true : every 128-byte K step lies inside one filter tap (cin*sizeof >= 128), so the
 //               tap decode is wave-uniform scalar arithmetic.
-template <typename TA, typename TO, int BM, int BN, int WGM, int WGN, bool GLDS, bool UTAP>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
-    static_assert(WGM * WGN == 4, "4 waves per workgroup");
+// NSTAGE = 3 : three LDS stages, tiles prefetched TWO K steps ahead with counted vmcnt waits and a raw
+//               s_barrier (LDS-DMA only); NSTAGE = 2: one step ahead, plain __syncthreads().
+template <typename TA, typename TO, int BM, int BN, int WGM, int WGN, bool GLDS, bool UTAP, int NSTAGE>
+__global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const ConvArgs a) {
+    static_assert(NSTAGE == 2 || (NSTAGE == 3 && GLDS), "3 stages need the LDS-DMA path");
+    constexpr int NT = WGM * WGN * 64;            // threads per workgroup (4 or 8 waves)
+    constexpr int RPP = NT / 8;                   // tile rows staged per pass (8 lanes per row)
     constexpr int EPS = elem_traits<TA>::EPS;     // elements per 16-B slot
     constexpr int BKE = 8 * EPS;                  // elements per 128-B K step
     constexpr int TM = BM / WGM, TN = BN / WGN;   // wave tile
     constexpr int FM = TM / 32, FN = TN / 32;     // 32x32 fragments per wave
-    constexpr int PA = BM / 32, PB = BN / 32;     // staging passes (32 rows per pass)
+    constexpr int PA = BM / RPP, PB = BN / RPP;   // staging passes
+    static_assert(PA >= 1 && PB >= 1, "tile smaller than one staging pass");
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
     typedef typename Frag<TA>::type frag_t;
 
@@ -97,7 +103,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
     const TA* aptr[PA]; unsigned amask[PA];
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
-        const int m = m0 + r0 + 32 * p;
+        const int m = m0 + r0 + RPP * p;
         aptr[p] = in; amask[p] = 0u;
         if (m < a.M) {
             const int img = m / a.HoWo, rem = m - img * a.HoWo;
@@ -137,12 +143,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
             for (int p = 0; p < PA; ++p) {
                 const bool ok = (amask[p] >> tap) & 1u;
                 const void* src = ok ? (const void*)(aptr[p] + koff) : (const void*)g_zero_page;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + p * 4096), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + p * (RPP * 128)), 16, 0, 0);
             }
 #pragma unroll
             for (int p = 0; p < PB; ++p)
-                __builtin_amdgcn_global_load_lds((gptr_t)(wptr + (long long)(32 * p) * a.K + kt * BKE),
-                                                 (lptr_t)(sa + A_BYTES + p * 4096), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(wptr + (long long)(RPP * p) * a.K + kt * BKE),
+                                                 (lptr_t)(sa + A_BYTES + p * (RPP * 128)), 16, 0, 0);
         } else {
 #pragma unroll
             for (int p = 0; p < PA; ++p) {
@@ -152,16 +158,16 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
             }
 #pragma unroll
             for (int p = 0; p < PB; ++p)
-                rb[p] = *(const u32x4*)(wptr + (long long)(32 * p) * a.K + kt * BKE);
+                rb[p] = *(const u32x4*)(wptr + (long long)(RPP * p) * a.K + kt * BKE);
         }
     };
     auto store_tile = [&](int buf) {
         if constexpr (!GLDS) {
             char* sa = smem + buf * STAGE + r0 * 128 + pslot * 16;
 #pragma unroll
-            for (int p = 0; p < PA; ++p) *(u32x4*)(sa + p * 4096) = ra[p];
+            for (int p = 0; p < PA; ++p) *(u32x4*)(sa + p * (RPP * 128)) = ra[p];
 #pragma unroll
-            for (int p = 0; p < PB; ++p) *(u32x4*)(sa + A_BYTES + p * 4096) = rb[p];
+            for (int p = 0; p < PB; ++p) *(u32x4*)(sa + A_BYTES + p * (RPP * 128)) = rb[p];
         }
     };
 
@@ -184,14 +190,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
     // The residual vectors do not depend on the GEMM: issue their loads NOW so their HBM
     // latency overlaps the operand loads and the K loop instead of serialising after it.
     constexpr int VPR = BN / 8;                   // 8-channel vectors per row
-    constexpr int NIT = (BM * VPR) / 256;
+    constexpr int NIT = (BM * VPR) / NT;
     constexpr int RV = (int)(8 * sizeof(TO) / 16); // 16-byte pieces per residual vector
     const TO* __restrict__ res = (const TO*)a.res;
     u32x4 rres[NIT][RV];
     if (res) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int idx = it * 256 + tid;
+            const int idx = it * NT + tid;
             const int m = m0 + idx / VPR, n = n0 + (idx % VPR) * 8;
 #pragma unroll
             for (int q = 0; q < RV; ++q) rres[it][q] = u32x4{0u, 0u, 0u, 0u};
@@ -212,28 +218,55 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
     }
 
     const int nk = a.K / BKE;
-    load_tile(0, 0);
-    store_tile(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1, cur ^ 1);
-        const char* sbuf = smem + cur * STAGE;
+    // one K step of MFMAs out of LDS stage `sbuf`; fragments of 32-B chunk c+1 are fetched before
+    // the MFMAs of chunk c issue
+    auto compute_stage = [&](const char* sbuf) {
+        frag_t fa[2][FM], fb[2][FN];
+        auto read_frags = [&](int c, int slot_) {
+            const int so = (((2 * c + lh) ^ fsw) << 4);
+#pragma unroll
+            for (int i = 0; i < FM; ++i) fa[slot_][i] = *(const frag_t*)(sbuf + a_row_off + i * 32 * 128 + so);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) fb[slot_][j] = *(const frag_t*)(sbuf + b_row_off + j * 32 * 128 + so);
+        };
+        read_frags(0, 0);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const int so = (((2 * c + lh) ^ fsw) << 4);
-            frag_t fa[FM], fb[FN];
-#pragma unroll
-            for (int i = 0; i < FM; ++i) fa[i] = *(const frag_t*)(sbuf + a_row_off + i * 32 * 128 + so);
-#pragma unroll
-            for (int j = 0; j < FN; ++j) fb[j] = *(const frag_t*)(sbuf + b_row_off + j * 32 * 128 + so);
+            if (c + 1 < 4) read_frags(c + 1, (c + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of this chunk's MFMAs
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
-                for (int j = 0; j < FN; ++j) acc[i][j] = mma(fa[i], fb[j], acc[i][j]);
+                for (int j = 0; j < FN; ++j) acc[i][j] = mma(fa[c & 1][i], fb[c & 1][j], acc[i][j]);
         }
-        if (kt + 1 < nk) store_tile(cur ^ 1);
+    };
+    if constexpr (NSTAGE == 3) {
+        constexpr int NL = PA + PB;               // LDS-DMA instructions per wave per tile
+        load_tile(0, 0);
+        if (nk > 1) load_tile(1, 1);
+        int st = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            // tile kt has landed once at most the NL loads of tile kt+1 are still outstanding
+            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // all waves: their slices of tile kt are visible, and nobody still reads stage (kt-1)%3
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < nk) load_tile(kt + 2, st == 0 ? 2 : st - 1);
+            compute_stage(smem + st * STAGE);
+            st = st == 2 ? 0 : st + 1;
+        }
         __syncthreads();
+    } else {
+        load_tile(0, 0);
+        store_tile(0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) load_tile(kt + 1, cur ^ 1);
+            compute_stage(smem + cur * STAGE);
+            if (kt + 1 < nk) store_tile(cur ^ 1);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: accumulators -> LDS as fp32 [BM][BN]
@@ -254,7 +287,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
     TO* __restrict__ out2 = (TO*)a.out2;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        const int idx = it * 256 + tid;
+        const int idx = it * NT + tid;
         const int row = idx / VPR, col = (idx % VPR) * 8;
         const int m = m0 + row, n = n0 + col;
         if (m >= a.M || n >= a.cout) continue;
@@ -300,55 +333,51 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a) {
 // ------------------------------------------------------------------------- //
 // Host side
 // ------------------------------------------------------------------------- //
-template <typename TA, typename TO, int BM, int BN, int WGM, int WGN, bool GLDS, bool UTAP>
+template <typename TA, typename TO, int BM, int BN, int WGM, int WGN, bool GLDS, bool UTAP, int NSTAGE>
 static int launch_cfg(const ConvArgs& base, hipStream_t stream) {
     ConvArgs a = base;
     const int tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.cout + BN - 1) / BN;
     a.n_tiles = tiles_m * a.tiles_n;
-    constexpr int kloop = 2 * (BM + BN) * 128, epi = BM * BN * 4;
+    constexpr int kloop = NSTAGE * (BM + BN) * 128, epi = BM * BN * 4;
     constexpr int lds = kloop > epi ? kloop : epi;
-    auto kern = conv_gemm_kernel<TA, TO, BM, BN, WGM, WGN, GLDS, UTAP>;
+    auto kern = conv_gemm_kernel<TA, TO, BM, BN, WGM, WGN, GLDS, UTAP, NSTAGE>;
     static bool attr_set = false;
     if (!attr_set) {
         HMMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(a.n_tiles), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(a.n_tiles), dim3(WGM * WGN * 64), lds, stream, a);
     HMMR_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
-template <typename TA, typename TO, bool GLDS, bool UTAP>
+template <typename TA, typename TO, bool UTAP>
 static int launch_tiled(const ConvArgs& a, int tile, hipStream_t stream) {
-    switch (tile) {
-        case 1: return launch_cfg<TA, TO, 128, 128, 2, 2, GLDS, UTAP>(a, stream);
-        case 2: return launch_cfg<TA, TO, 128, 64, 2, 2, GLDS, UTAP>(a, stream);
-        case 3: return launch_cfg<TA, TO, 64, 64, 2, 2, GLDS, UTAP>(a, stream);
+    switch (tile) {   // BM, BN, waves along M, waves along N
+        case 1: return launch_cfg<TA, TO, 128, 128, 2, 2, true, UTAP, 2>(a, stream);   // 4 waves, 64x64 each
+        case 2: return launch_cfg<TA, TO, 128, 64, 2, 2, true, UTAP, 2>(a, stream);    // 4 waves, 64x32 each
+        case 3: return launch_cfg<TA, TO, 64, 64, 2, 2, true, UTAP, 2>(a, stream);     // 4 waves, 32x32 each
+        case 5: return launch_cfg<TA, TO, 128, 128, 4, 2, true, UTAP, 2>(a, stream);   // 8 waves, 32x64 each
+        case 6: return launch_cfg<TA, TO, 128, 64, 4, 2, true, UTAP, 2>(a, stream);    // 8 waves, 32x32 each
         default: hmmr_set_error("hmmr_conv_gemm: bad tile %d", tile); return -1;
     }
 }
 
 template <typename TA, typename TO>
 static int launch_typed(const ConvArgs& a, int tile, hipStream_t stream) {
-    // A/B switch for development: HMMR_CONV_STAGING=reg selects the register-staged variant
-    static const bool env_reg = [] { const char* e = getenv("HMMR_CONV_STAGING"); return e && e[0] == 'r'; }();
-    bool glds = !env_reg;
-    if (tile >= 10) { glds = false; tile -= 10; }          // 11..13: register-staged variant (A/B only)
     if (tile == 0) {
-        // largest tile that still gives most of the 256 CUs a workgroup (measured on the
-        // ResNet shapes at batch 256: 392 tiles of 128x128 beat 784 of 128x64 by 1.5x)
+        // Measured on the ResNet-50 shapes at batch 256 (tools/conv_bench.py): 8-wave workgroups
+        // (4 waves per SIMD at 2 workgroups per CU) beat 4-wave ones by 5-20 %, and a tile count of
+        // ~1.5x the CU count with 128x128 tiles beats twice as many 128x64 tiles.
         const long long t128 = (long long)((a.M + 127) / 128) * ((a.cout + 127) / 128);
         const long long t12864 = (long long)((a.M + 127) / 128) * ((a.cout + 63) / 64);
-        if (a.cout >= 128 && a.cout % 128 == 0 && t128 >= 192) tile = 1;
-        else if (t12864 >= 192) tile = 2;
+        if (a.cout >= 128 && a.cout % 128 == 0 && t128 >= 192) tile = 5;
+        else if (t12864 >= 192) tile = 6;
         else tile = 3;
     }
     const bool utap = ((size_t)1 << a.cin_log2) * sizeof(TA) >= 128;
-    if (glds) return utap ? launch_tiled<TA, TO, true, true>(a, tile, stream)
-                          : launch_tiled<TA, TO, true, false>(a, tile, stream);
-    return utap ? launch_tiled<TA, TO, false, true>(a, tile, stream)
-                : launch_tiled<TA, TO, false, false>(a, tile, stream);
+    return utap ? launch_tiled<TA, TO, true>(a, tile, stream) : launch_tiled<TA, TO, false>(a, tile, stream);
 }
 
 static int ilog2_exact(int v) {

@@ -75,7 +75,8 @@ typedef struct {
     int64_t res_img_stride;
     int res_row_stride, res_px_stride;
     int relu;              /* ReLU on `out` after the residual add */
-    int tile;              /* 0 = auto; 1 = 128x128; 2 = 128x64; 3 = 64x64; +10 = register-staged variant */
+    int tile;              /* 0 = auto; 4-wave tiles: 1 = 128x128, 2 = 128x64, 3 = 64x64;
+                              8-wave tiles: 5 = 128x128, 6 = 128x64 */
 } hmmr_conv_desc_t;
 
 int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream);

@@ -86,8 +86,8 @@ def main():
     lib = L.load()
     rows = []
     for name, h, cin, cout, k, stride, kind in SHAPES:
-        for tile in (1, 11, 2, 12, 3, 13):
-            if tile % 10 == 1 and cout % 128:
+        for tile in (1, 5, 2, 6, 3):
+            if tile in (1, 5) and cout % 128:
                 continue
             rows.append(run(lib, name, n, h, cin, cout, k, stride, kind, dt, tile))
             print(json.dumps(rows[-1]), flush=True)
