@@ -34,6 +34,7 @@ class ConvDesc(C.Structure):
         ("ldr", C.c_int), ("res_strided", C.c_int), ("res_img_stride", C.c_int64),
         ("res_row_stride", C.c_int), ("res_px_stride", C.c_int),
         ("relu", C.c_int), ("tile", C.c_int),
+        ("split_k", C.c_int), ("ws", _vp), ("ws_bytes", C.c_size_t),
     ]
 
 
@@ -81,6 +82,7 @@ SIGNATURES = {
     "hmmr_abi_version": (C.c_int, []),
     "hmmr_last_error": (C.c_char_p, []),
     "hmmr_conv_gemm": (C.c_int, [C.POINTER(ConvDesc), _vp]),
+    "hmmr_conv_splitk_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "hmmr_resnet50_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "hmmr_resnet50_fwd": (C.c_int, [C.POINTER(ResnetWeights), _fp, C.c_int, C.c_int, _fp, _vp, C.c_size_t, _vp,
                                     C.POINTER(C.c_float)]),

@@ -42,6 +42,8 @@ struct ConvArgs {
     int cin_log2, KH, KW, SY, SX, PY, PX;
     int res_strided; long long res_img_stride; int res_row_stride, res_px_stride;
     int relu, tiles_n, n_tiles;
+    int kt_per_slice;                 // K steps per split-K slice (blockIdx.y); == all of them without split-K
+    long long out_slice_stride;       // elements between the partial-sum planes of consecutive slices
 };
 
 template <typename TA> struct Frag;
@@ -68,11 +70,13 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // GLDS = false: HBM -> VGPR -> ds_write_b128 (kept for A/B measurements).
 // UTAP = true : every 128-byte K step lies inside one filter tap (cin*sizeof >= 128), so the
 //               tap decode is wave-uniform scalar arithmetic.
-// NSTAGE = 3 : three LDS stages, tiles prefetched TWO K steps ahead with counted vmcnt waits and a raw
-//               s_barrier (LDS-DMA only); NSTAGE = 2: one step ahead, plain __syncthreads().
+// NSTAGE: LDS stages (2 = next tile in flight while the current one is consumed).  A 3-stage ring
+//         (two tiles ahead, counted vmcnt + raw s_barrier) was measured 15-40 % SLOWER on every
+//         ResNet shape: it halves the resident workgroups per CU, and occupancy is what hides
+//         latency here.
 template <typename TA, typename TO, int BM, int BN, int WGM, int WGN, bool GLDS, bool UTAP, int NSTAGE>
 __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const ConvArgs a) {
-    static_assert(NSTAGE == 2 || (NSTAGE == 3 && GLDS), "3 stages need the LDS-DMA path");
+    static_assert(NSTAGE == 2, "only the 2-stage pipeline is kept");
     constexpr int NT = WGM * WGN * 64;            // threads per workgroup (4 or 8 waves)
     constexpr int RPP = NT / 8;                   // tile rows staged per pass (8 lanes per row)
     constexpr int EPS = elem_traits<TA>::EPS;     // elements per 16-B slot
@@ -240,33 +244,18 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const ConvArg
                 for (int j = 0; j < FN; ++j) acc[i][j] = mma(fa[c & 1][i], fb[c & 1][j], acc[i][j]);
         }
     };
-    if constexpr (NSTAGE == 3) {
-        constexpr int NL = PA + PB;               // LDS-DMA instructions per wave per tile
-        load_tile(0, 0);
-        if (nk > 1) load_tile(1, 1);
-        int st = 0;
-        for (int kt = 0; kt < nk; ++kt) {
-            // tile kt has landed once at most the NL loads of tile kt+1 are still outstanding
-            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            // all waves: their slices of tile kt are visible, and nobody still reads stage (kt-1)%3
-            __builtin_amdgcn_s_barrier();
-            if (kt + 2 < nk) load_tile(kt + 2, st == 0 ? 2 : st - 1);
-            compute_stage(smem + st * STAGE);
-            st = st == 2 ? 0 : st + 1;
-        }
+    // split-K: slice blockIdx.y owns K steps [kt0, kt1) and writes a raw fp32 partial plane
+    const int kt0 = blockIdx.y * a.kt_per_slice;
+    const int kt1 = min(nk, kt0 + a.kt_per_slice);
+    load_tile(kt0, 0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        if (kt + 1 < kt1) load_tile(kt + 1, cur ^ 1);
+        compute_stage(smem + cur * STAGE);
+        if (kt + 1 < kt1) store_tile(cur ^ 1);
         __syncthreads();
-    } else {
-        load_tile(0, 0);
-        store_tile(0);
-        __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            if (kt + 1 < nk) load_tile(kt + 1, cur ^ 1);
-            compute_stage(smem + cur * STAGE);
-            if (kt + 1 < nk) store_tile(cur ^ 1);
-            __syncthreads();
-        }
     }
 
     // ---- epilogue: accumulators -> LDS as fp32 [BM][BN]
@@ -283,7 +272,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const ConvArg
             }
     __syncthreads();
 
-    TO* __restrict__ out = (TO*)a.out;
+    TO* __restrict__ out = a.out ? (TO*)a.out + (long long)blockIdx.y * a.out_slice_stride : nullptr;
     TO* __restrict__ out2 = (TO*)a.out2;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -334,7 +323,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const ConvArg
 // Host side
 // ------------------------------------------------------------------------- //
 template <typename TA, typename TO, int BM, int BN, int WGM, int WGN, bool GLDS, bool UTAP, int NSTAGE>
-static int launch_cfg(const ConvArgs& base, hipStream_t stream) {
+static int launch_cfg(const ConvArgs& base, int slices, hipStream_t stream) {
     ConvArgs a = base;
     const int tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.cout + BN - 1) / BN;
@@ -347,37 +336,109 @@ static int launch_cfg(const ConvArgs& base, hipStream_t stream) {
         HMMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(a.n_tiles), dim3(WGM * WGN * 64), lds, stream, a);
+    constexpr int BKE_ = 8 * elem_traits<TA>::EPS;
+    const int nk = a.K / BKE_;
+    a.kt_per_slice = (nk + slices - 1) / slices;
+    hipLaunchKernelGGL(kern, dim3(a.n_tiles, slices), dim3(WGM * WGN * 64), lds, stream, a);
     HMMR_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 template <typename TA, typename TO, bool UTAP>
-static int launch_tiled(const ConvArgs& a, int tile, hipStream_t stream) {
+static int launch_tiled(const ConvArgs& a, int tile, int slices, hipStream_t stream) {
     switch (tile) {   // BM, BN, waves along M, waves along N
-        case 1: return launch_cfg<TA, TO, 128, 128, 2, 2, true, UTAP, 2>(a, stream);   // 4 waves, 64x64 each
-        case 2: return launch_cfg<TA, TO, 128, 64, 2, 2, true, UTAP, 2>(a, stream);    // 4 waves, 64x32 each
-        case 3: return launch_cfg<TA, TO, 64, 64, 2, 2, true, UTAP, 2>(a, stream);     // 4 waves, 32x32 each
-        case 5: return launch_cfg<TA, TO, 128, 128, 4, 2, true, UTAP, 2>(a, stream);   // 8 waves, 32x64 each
-        case 6: return launch_cfg<TA, TO, 128, 64, 4, 2, true, UTAP, 2>(a, stream);    // 8 waves, 32x32 each
+        case 1: return launch_cfg<TA, TO, 128, 128, 2, 2, true, UTAP, 2>(a, slices, stream);   // 4 waves, 64x64 each
+        case 2: return launch_cfg<TA, TO, 128, 64, 2, 2, true, UTAP, 2>(a, slices, stream);    // 4 waves, 64x32 each
+        case 3: return launch_cfg<TA, TO, 64, 64, 2, 2, true, UTAP, 2>(a, slices, stream);     // 4 waves, 32x32 each
+        case 5: return launch_cfg<TA, TO, 128, 128, 4, 2, true, UTAP, 2>(a, slices, stream);   // 8 waves, 32x64 each
+        case 6: return launch_cfg<TA, TO, 128, 64, 4, 2, true, UTAP, 2>(a, slices, stream);    // 8 waves, 32x32 each
         default: hmmr_set_error("hmmr_conv_gemm: bad tile %d", tile); return -1;
     }
 }
 
 template <typename TA, typename TO>
-static int launch_typed(const ConvArgs& a, int tile, hipStream_t stream) {
+static int launch_typed(const ConvArgs& a, int tile, int slices, hipStream_t stream) {
     if (tile == 0) {
         // Measured on the ResNet-50 shapes at batch 256 (tools/conv_bench.py): 8-wave workgroups
         // (4 waves per SIMD at 2 workgroups per CU) beat 4-wave ones by 5-20 %, and a tile count of
         // ~1.5x the CU count with 128x128 tiles beats twice as many 128x64 tiles.
         const long long t128 = (long long)((a.M + 127) / 128) * ((a.cout + 127) / 128);
         const long long t12864 = (long long)((a.M + 127) / 128) * ((a.cout + 63) / 64);
-        if (a.cout >= 128 && a.cout % 128 == 0 && t128 >= 192) tile = 5;
-        else if (t12864 >= 192) tile = 6;
+        if (a.cout >= 128 && a.cout % 128 == 0 && t128 * slices >= 192) tile = 5;
+        else if (t12864 * slices >= 192) tile = 6;
         else tile = 3;
     }
     const bool utap = ((size_t)1 << a.cin_log2) * sizeof(TA) >= 128;
-    return utap ? launch_tiled<TA, TO, true>(a, tile, stream) : launch_tiled<TA, TO, false>(a, tile, stream);
+    return utap ? launch_tiled<TA, TO, true>(a, tile, slices, stream) : launch_tiled<TA, TO, false>(a, tile, slices, stream);
+}
+
+// Split-K second pass: sum the S fp32 partial planes in slice order, then the same epilogue as
+// the GEMM kernel (scale/shift, residual, ReLU, optional second output).
+template <typename TO>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a, const float* __restrict__ part,
+                                                            int slices, int ldw, long long plane) {
+    const int vpr = (a.cout + 7) / 8;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)a.M * vpr) return;
+    const int m = (int)(i / vpr), n = (int)(i % vpr) * 8;
+    float v[8];
+    load8(part + (long long)m * ldw + n, v);
+    for (int s = 1; s < slices; ++s) {
+        float p[8];
+        load8(part + s * plane + (long long)m * ldw + n, p);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += p[j];
+    }
+    if (a.scale) {
+        float s[8]; load8(a.scale + n, s);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= s[j];
+    }
+    if (a.shift) {
+        float s[8]; load8(a.shift + n, s);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += s[j];
+    }
+    const bool full = (n + 8 <= a.cout);
+    const TO* __restrict__ res = (const TO*)a.res;
+    if (res) {
+        long long ro;
+        if (a.res_strided) {
+            const int img = m / a.HoWo, rem = m - img * a.HoWo;
+            const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+            ro = (long long)img * a.res_img_stride + (long long)oy * a.res_row_stride + (long long)ox * a.res_px_stride + n;
+        } else {
+            ro = (long long)m * a.ldr + n;
+        }
+        float rr[8];
+        load8(res + ro, rr);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += rr[j];
+    }
+    if (a.relu) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+    }
+    TO* __restrict__ out = (TO*)a.out;
+    TO* __restrict__ out2 = (TO*)a.out2;
+    const long long oo = (long long)m * a.ldo + n;
+    if (out) {
+        if (full) store8(out + oo, v);
+        else for (int j = 0; j < 8 && n + j < a.cout; ++j) out[oo + j] = elem_traits<TO>::from_f32(v[j]);
+    }
+    if (out2) {
+        float s2[8], b2[8], u[8];
+        load8(a.scale2 + n, s2); load8(a.shift2 + n, b2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) u[j] = fmaxf(v[j] * s2[j] + b2[j], 0.f);
+        if (full) store8(out2 + oo, u);
+        else for (int j = 0; j < 8 && n + j < a.cout; ++j) out2[oo + j] = elem_traits<TO>::from_f32(u[j]);
+    }
+}
+
+extern "C" size_t hmmr_conv_splitk_workspace_bytes(int m, int cout, int split_k) {
+    if (split_k <= 1 || m <= 0) return 0;
+    return (size_t)split_k * (size_t)m * (size_t)((cout + 127) / 128 * 128) * sizeof(float);
 }
 
 static int ilog2_exact(int v) {
@@ -416,12 +477,38 @@ extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
     a.res_strided = d->res_strided; a.res_img_stride = d->res_img_stride;
     a.res_row_stride = d->res_row_stride; a.res_px_stride = d->res_px_stride;
     a.relu = d->relu; a.tiles_n = 0; a.n_tiles = 0;
+    a.kt_per_slice = 0; a.out_slice_stride = 0;
     if (a.M <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    if (d->in_dtype == HMMR_BF16 && d->out_dtype == HMMR_BF16) return launch_typed<bf16_t, bf16_t>(a, d->tile, s);
-    if (d->in_dtype == HMMR_BF16 && d->out_dtype == HMMR_F32) return launch_typed<bf16_t, float>(a, d->tile, s);
-    if (d->in_dtype == HMMR_F32 && d->out_dtype == HMMR_F32) return launch_typed<float, float>(a, d->tile, s);
-    if (d->in_dtype == HMMR_F32 && d->out_dtype == HMMR_BF16) return launch_typed<float, bf16_t>(a, d->tile, s);
+    const bool in16 = d->in_dtype == HMMR_BF16, in32 = d->in_dtype == HMMR_F32;
+    const bool out16 = d->out_dtype == HMMR_BF16, out32 = d->out_dtype == HMMR_F32;
+    HMMR_REQUIRE((in16 || in32) && (out16 || out32), "hmmr_conv_gemm: unsupported dtypes %d -> %d", d->in_dtype, d->out_dtype);
+    const int nk = K / (8 * eps);
+    int slices = d->split_k > 1 ? d->split_k : 1;
+    if (slices > nk) slices = nk;
+    slices = (nk + ((nk + slices - 1) / slices) - 1) / ((nk + slices - 1) / slices);   // no empty slice
+    if (slices > 1) {
+        // pass 1: raw fp32 partial planes [slice][M][ldw]; pass 2: ordered sum + epilogue
+        const int ldw = (d->cout + 127) / 128 * 128;
+        const long long plane = (long long)a.M * ldw;
+        HMMR_REQUIRE(d->ws && d->ws_bytes >= hmmr_conv_splitk_workspace_bytes(a.M, d->cout, slices),
+                     "hmmr_conv_gemm: split-K workspace missing or too small");
+        ConvArgs p = a;
+        p.scale = p.shift = nullptr; p.res = nullptr; p.out2 = nullptr; p.scale2 = p.shift2 = nullptr;
+        p.relu = 0; p.out = d->ws; p.ldo = ldw; p.out_slice_stride = plane;
+        const int rc = in16 ? launch_typed<bf16_t, float>(p, d->tile, slices, s) : launch_typed<float, float>(p, d->tile, slices, s);
+        if (rc) return rc;
+        const long long nvec = (long long)a.M * ((a.cout + 7) / 8);
+        const unsigned grid = (unsigned)((nvec + 255) / 256);
+        if (out16) hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, a, (const float*)d->ws, slices, ldw, plane);
+        else hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(grid), dim3(256), 0, s, a, (const float*)d->ws, slices, ldw, plane);
+        HMMR_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
+    if (in16 && out16) return launch_typed<bf16_t, bf16_t>(a, d->tile, 1, s);
+    if (in16 && out32) return launch_typed<bf16_t, float>(a, d->tile, 1, s);
+    if (in32 && out32) return launch_typed<float, float>(a, d->tile, 1, s);
+    if (in32 && out16) return launch_typed<float, bf16_t>(a, d->tile, 1, s);
     hmmr_set_error("hmmr_conv_gemm: unsupported dtypes %d -> %d", d->in_dtype, d->out_dtype);
     return -1;
 }

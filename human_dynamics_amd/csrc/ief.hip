@@ -13,6 +13,9 @@
 #include "hmmr_hip.h"
 
 static constexpr int LDT = 128;      // row stride of the zero-padded theta state
+// The K = 2048 / 1024 GEMMs have at most m/64 x 16 output tiles (m = kept frames of a step, a few
+// hundred): 4 K-slices fill the chip.  Fixed per layer so a row's result is batch-independent.
+static constexpr int IEF_SPLIT_K = 4;
 
 template <typename TO>
 __global__ void cast_rows_kernel(const float* __restrict__ in, TO* __restrict__ out, long long n8) {
@@ -50,7 +53,7 @@ __global__ void ief_finalize_kernel(const float* __restrict__ theta, const float
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-struct IefBufs { size_t xin, pre, h1, h2, th[2], total; };
+struct IefBufs { size_t xin, pre, h1, h2, th[2], sk, skbytes, total; };
 static IefBufs ief_layout(int m, int dtype) {
     const size_t e = dtype == HMMR_BF16 ? 2 : 4;
     IefBufs b; size_t off = 0;
@@ -61,6 +64,8 @@ static IefBufs ief_layout(int m, int dtype) {
     b.h2 = take((size_t)m * 1024 * e);
     b.th[0] = take((size_t)m * LDT * 4);
     b.th[1] = take((size_t)m * LDT * 4);
+    b.skbytes = hmmr_conv_splitk_workspace_bytes(m, 1024, IEF_SPLIT_K);
+    b.sk = take(b.skbytes);
     b.total = off;
     return b;
 }
@@ -71,13 +76,15 @@ extern "C" size_t hmmr_ief_workspace_bytes(int m, int num_regressors, int dtype)
 }
 
 static hmmr_conv_desc_t fc_desc(const void* in, int in_dtype, int m, int k, const hmmr_layer_t& l,
-                                void* out, int out_dtype, int cout, int ldo) {
+                                void* out, int out_dtype, int cout, int ldo, void* sk = nullptr,
+                                size_t skbytes = 0) {
     hmmr_conv_desc_t d = {};
     d.in = in; d.w = l.w; d.scale = l.scale; d.shift = l.shift; d.out = out;
     d.in_dtype = in_dtype; d.out_dtype = out_dtype;
     d.n_img = m; d.hin = d.win = 1; d.cin = k;
     d.in_img_stride = k; d.in_row_stride = k; d.in_px_stride = k;
     d.kh = d.kw = 1; d.sy = d.sx = 1; d.ho = d.wo = 1; d.cout = cout; d.ldo = ldo;
+    if (sk) { d.split_k = IEF_SPLIT_K; d.ws = sk; d.ws_bytes = skbytes; }
     return d;
 }
 
@@ -115,7 +122,7 @@ extern "C" int hmmr_ief_fwd(const hmmr_ief_weights_t* w, const float* strips, in
         HMMR_CHECK_HIP(hipGetLastError());
         HMMR_CHECK_HIP(hipMemsetAsync(th[1], 0, (size_t)m * LDT * 4, s));
         // pre = phi . W1[:2048] + b1
-        hmmr_conv_desc_t d = fc_desc(xin, w->dtype, m, 2048, R.fc1_phi, pre, w->dtype, 1024, 1024);
+        hmmr_conv_desc_t d = fc_desc(xin, w->dtype, m, 2048, R.fc1_phi, pre, w->dtype, 1024, 1024, base + L.sk, L.skbytes);
         if (hmmr_conv_gemm(&d, s)) return -2;
         int cur = 0;
         for (int st = 0; st < w->num_stages; ++st) {
@@ -124,11 +131,11 @@ extern "C" int hmmr_ief_fwd(const hmmr_ief_weights_t* w, const float* strips, in
             d.res = pre; d.ldr = 1024; d.relu = 1;
             if (hmmr_conv_gemm(&d, s)) return -2;
             // h2 = relu(h1 . W2 + b2)
-            d = fc_desc(h1, w->dtype, m, 1024, R.fc2, h2, w->dtype, 1024, 1024);
+            d = fc_desc(h1, w->dtype, m, 1024, R.fc2, h2, w->dtype, 1024, 1024, base + L.sk, L.skbytes);
             d.relu = 1;
             if (hmmr_conv_gemm(&d, s)) return -2;
             // theta' = theta + h2 . W3 + b3
-            d = fc_desc(h2, w->dtype, m, 1024, R.fc3, th[cur ^ 1], HMMR_F32, R.nd, LDT);
+            d = fc_desc(h2, w->dtype, m, 1024, R.fc3, th[cur ^ 1], HMMR_F32, R.nd, LDT, base + L.sk, L.skbytes);
             d.res = th[cur]; d.ldr = LDT;
             if (hmmr_conv_gemm(&d, s)) return -2;
             cur ^= 1;

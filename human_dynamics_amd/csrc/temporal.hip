@@ -10,6 +10,10 @@
 #include "hmmr_hip.h"
 
 #define GN_EPS 1e-6f
+// K = 3*2048 is long and M = b*t is short (640 rows for 32 windows): 4 K-slices quadruple the
+// number of workgroups.  Fixed per layer, never derived from b, so a window's result does not
+// depend on how many windows share the launch.
+#define TEMPORAL_SPLIT_K 4
 
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
 #pragma unroll
@@ -74,8 +78,9 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 extern "C" size_t hmmr_temporal_workspace_bytes(int b, int t, int dtype) {
     if (b <= 0 || t <= 0) return 0;
     const size_t m = (size_t)b * t, e = dtype == HMMR_BF16 ? 2 : 4;
-    // h (operand dtype) + h1 (fp32) + two fp32 trunk buffers
-    return align_up(m * 2048 * e, 256) + 3 * align_up(m * 2048 * 4, 256);
+    // h (operand dtype) + h1 (fp32) + two fp32 trunk buffers + split-K partial planes
+    return align_up(m * 2048 * e, 256) + 3 * align_up(m * 2048 * 4, 256) +
+           align_up(hmmr_conv_splitk_workspace_bytes((int)m, 2048, TEMPORAL_SPLIT_K), 256);
 }
 
 extern "C" int hmmr_temporal_fwd(const hmmr_temporal_weights_t* w, const float* phi, int b, int t,
@@ -91,7 +96,9 @@ extern "C" int hmmr_temporal_fwd(const hmmr_temporal_weights_t* w, const float* 
     float* h1 = (float*)p;    p += align_up(m * C * 4, 256);
     float* net[2];
     net[0] = (float*)p;       p += align_up(m * C * 4, 256);
-    net[1] = (float*)p;
+    net[1] = (float*)p;       p += align_up(m * C * 4, 256);
+    void* skws = p;
+    const size_t skbytes = hmmr_conv_splitk_workspace_bytes((int)m, C, TEMPORAL_SPLIT_K);
     const float* cur = phi;
     for (int i = 0; i < w->num_blocks; ++i) {
         const hmmr_temporal_block_t& B = w->block[i];
@@ -103,6 +110,7 @@ extern "C" int hmmr_temporal_fwd(const hmmr_temporal_weights_t* w, const float* 
         d.n_img = b; d.hin = t; d.win = 1; d.cin = C;
         d.in_img_stride = (int64_t)t * C; d.in_row_stride = C; d.in_px_stride = C;
         d.kh = 3; d.kw = 1; d.sy = d.sx = 1; d.py = 1; d.px = 0; d.ho = t; d.wo = 1; d.cout = C; d.ldo = C;
+        d.split_k = TEMPORAL_SPLIT_K; d.ws = skws; d.ws_bytes = skbytes;
         if (hmmr_conv_gemm(&d, stream)) return -2;
         if (hmmr_groupnorm_relu(h1, B.gn2_gamma, B.gn2_beta, b, t, C, 32, h, w->dtype, stream)) return -2;
         d.w = B.conv2.w; d.scale = B.conv2.scale; d.shift = B.conv2.shift;

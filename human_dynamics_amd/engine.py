@@ -186,7 +186,7 @@ class HmmrEngine(object):
 
 def conv_gemm(x, w_hwio, stride=1, pad=0, scale=None, shift=None, res=None, relu=False,
               scale2=None, shift2=None, in_dtype=L.HMMR_F32, out_dtype=L.HMMR_F32, tile=0,
-              device="cuda:0", res_stride=1):
+              device="cuda:0", res_stride=1, split_k=0):
     """Test/utility entry: run one NHWC convolution through hmmr_conv_gemm.
     x [n,h,w,cin] (numpy/torch), w_hwio [kh,kw,cin,cout].  Returns (out, out2)."""
     lib = L.load()
@@ -226,6 +226,10 @@ def conv_gemm(x, w_hwio, stride=1, pad=0, scale=None, shift=None, res=None, relu
     d.kh, d.kw, d.sy, d.sx, d.py, d.px = kh, kw, stride, stride, py, px
     d.ho, d.wo, d.cout, d.ldo = ho, wo, cout, ldo
     d.relu, d.tile = int(relu), tile
+    if split_k > 1:
+        nb = lib.hmmr_conv_splitk_workspace_bytes(n * ho * wo, cout, split_k)
+        skws = torch.empty(int(nb), dtype=torch.uint8, device=dev)
+        d.split_k, d.ws, d.ws_bytes = split_k, skws.data_ptr(), nb
     L.check(lib.hmmr_conv_gemm(C.byref(d), torch.cuda.current_stream(dev).cuda_stream), "hmmr_conv_gemm")
     torch.cuda.synchronize(dev)
     o = out[..., :cout].float().cpu().numpy()

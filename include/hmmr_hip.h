@@ -77,9 +77,17 @@ typedef struct {
     int relu;              /* ReLU on `out` after the residual add */
     int tile;              /* 0 = auto; 4-wave tiles: 1 = 128x128, 2 = 128x64, 3 = 64x64;
                               8-wave tiles: 5 = 128x128, 6 = 128x64 */
+    /* split-K (for GEMMs with few output tiles and a long K): split_k > 1 slices K into that many
+     * contiguous ranges, each range leaves an fp32 partial plane in `ws`, and a second launch adds the
+     * planes IN SLICE ORDER and applies the epilogue.  The caller fixes split_k per layer (never from
+     * the batch size), so results stay independent of batch composition.  0/1 = off. */
+    int split_k;
+    void* ws;              /* >= hmmr_conv_splitk_workspace_bytes(M, cout, split_k) */
+    size_t ws_bytes;
 } hmmr_conv_desc_t;
 
 int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream);
+size_t hmmr_conv_splitk_workspace_bytes(int m, int cout, int split_k);
 
 /* ------------------------------------------------------------------------- *
  * ResNet-v2-50 image encoder: encoder_resnet (src/models.py:50-77) ->
