@@ -10,7 +10,7 @@
 //                      joints, forward kinematics in the reference's
 //                      multiplication order, relative transforms A, and the
 //                      blend feature row [1, beta, (R_1..23 - I)]
-//   smpl_verts_kernel  per (256-vertex tile, 8 instances): blend shapes as a
+//   smpl_verts_kernel  per (128-vertex tile, 16 instances): blend shapes as a
 //                      218-deep FMA chain whose per-instance coefficients are
 //                      wave-uniform (scalar registers), then linear-blend
 //                      skinning over the vertex's non-zero weights (ELL) with
@@ -18,7 +18,7 @@
 //   smpl_joints_kernel per instance: keypoints = sparse regressor x verts
 //                      (CSR), then kps = s * (xy + t)
 // Layout note: `dirs` is the tf_smpl basis re-packed on the host as
-// [218][3][VPAD] (planar x/y/z, VPAD = 6912) so that a wave's 64 lanes read
+// [224][3][VPAD] (planar x/y/z, VPAD = 6912, rows >= 218 zero) so that a wave's 64 lanes read
 // 256 contiguous bytes per coordinate.
 #include "common.h"
 #include "hmmr_hip.h"
@@ -27,8 +27,9 @@ static constexpr int NJ = 24;
 static constexpr int NFEAT = 218;        // 1 + 10 + 207
 static constexpr int LDF = 224;          // feature row stride (floats)
 static constexpr int LDA = NJ * 12;      // A record: 24 x (3x4) floats
-static constexpr int VT = 256;           // vertices per workgroup
-static constexpr int IB = 8;             // instances per workgroup
+static constexpr int NFEAT_PAD = 220;    // blend loop length (multiple of 4; rows >= 218 of `dirs` are zero)
+static constexpr int VT = 128;           // vertices per workgroup
+static constexpr int IB = 16;            // instances per workgroup
 
 // ---- kernel 1 ------------------------------------------------------------ //
 __global__ __launch_bounds__(256) void smpl_pose_kernel(
@@ -130,70 +131,83 @@ __global__ __launch_bounds__(256) void smpl_pose_kernel(
 }
 
 // ---- kernel 2 ------------------------------------------------------------ //
-__global__ __launch_bounds__(256) void smpl_verts_kernel(
+// 128 vertices x 16 instances per workgroup.  The blend loop walks k four at a time: the 16
+// instances' coefficients are wave-uniform (four s_load_dwordx4-able floats each), every basis
+// value fetched from L2 feeds 16 FMAs, and the basis rows beyond 218 are zero (host-padded to 224).
+__global__ __launch_bounds__(VT) void smpl_verts_kernel(
     const float* __restrict__ dirs, int vpad, const float* __restrict__ feat, const float* __restrict__ A,
     const int* __restrict__ lbs_idx, const float* __restrict__ lbs_w, int nnz, int nv, int m,
     float* __restrict__ verts, long long ld_verts) {
     __shared__ __attribute__((aligned(16))) float sA[IB][LDA];
     const int v = blockIdx.x * VT + threadIdx.x;
     const int i0 = blockIdx.y * IB;
-    for (int e = threadIdx.x; e < IB * LDA; e += 256) {
+    for (int e = threadIdx.x; e < IB * LDA; e += VT) {
         const int ii = e / LDA;
         sA[ii][e % LDA] = (i0 + ii < m) ? A[(long long)(i0 + ii) * LDA + (e % LDA)] : 0.f;
     }
     float acc[IB][3];
 #pragma unroll
     for (int ii = 0; ii < IB; ++ii) acc[ii][0] = acc[ii][1] = acc[ii][2] = 0.f;
-    // feature rows of the 8 instances are wave-uniform: clamp so tail blocks read valid memory
-    const float* f[IB];
-#pragma unroll
-    for (int ii = 0; ii < IB; ++ii) f[ii] = feat + (long long)min(i0 + ii, m - 1) * LDF;
+    // feature rows of the 16 instances are wave-uniform (scalar loads); the scratch buffer is
+    // sized for m rounded up to IB, so tail blocks read (and ignore) valid memory
+    const float* fb = feat + (long long)i0 * LDF;
     // v_posed = v_template + beta.S + pose_feature.P   (batch_smpl.py:110-112, 131-133)
     const float* d = dirs + v;             // v < vpad always (grid covers vpad exactly)
-#pragma unroll 2
-    for (int k = 0; k < NFEAT; ++k) {
-        const float dx = d[(long long)(k * 3 + 0) * vpad];
-        const float dy = d[(long long)(k * 3 + 1) * vpad];
-        const float dz = d[(long long)(k * 3 + 2) * vpad];
+    for (int k = 0; k < NFEAT_PAD; k += 4) {
+        float dv[4][3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dv[q][c] = d[(long long)((k + q) * 3 + c) * vpad];
 #pragma unroll
         for (int ii = 0; ii < IB; ++ii) {
-            const float c = f[ii][k];
-            acc[ii][0] = fmaf(c, dx, acc[ii][0]);
-            acc[ii][1] = fmaf(c, dy, acc[ii][1]);
-            acc[ii][2] = fmaf(c, dz, acc[ii][2]);
+            const f32x4 c4 = *(const f32x4*)(fb + ii * LDF + k);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc[ii][0] = fmaf(c4[q], dv[q][0], acc[ii][0]);
+                acc[ii][1] = fmaf(c4[q], dv[q][1], acc[ii][1]);
+                acc[ii][2] = fmaf(c4[q], dv[q][2], acc[ii][2]);
+            }
         }
     }
     __syncthreads();
     if (v >= nv) return;
     // skinning: T = sum_j W[v,j] A_j over the non-zero weights; v' = T [v_posed; 1]   (batch_smpl.py:141-151)
-    float T[IB][12];
+    const int* vidx = lbs_idx + (long long)v * nnz;
+    const float* vw = lbs_w + (long long)v * nnz;
 #pragma unroll
-    for (int ii = 0; ii < IB; ++ii)
+    for (int g = 0; g < IB; g += 4) {               // 4 instances at a time: T stays in registers
+        if (i0 + g >= m) continue;
+        float T[4][12];
 #pragma unroll
-        for (int e = 0; e < 12; ++e) T[ii][e] = 0.f;
-    for (int z = 0; z < nnz; ++z) {
-        const int jj = lbs_idx[(long long)v * nnz + z];
-        const float wv = lbs_w[(long long)v * nnz + z];
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int ii = 0; ii < IB; ++ii) {
-            const f32x4* a4 = (const f32x4*)&sA[ii][jj * 12];
-            const f32x4 r0 = a4[0], r1 = a4[1], r2 = a4[2];
+            for (int e = 0; e < 12; ++e) T[q][e] = 0.f;
+        for (int z = 0; z < nnz; ++z) {
+            const int jj = vidx[z] * 12;
+            const float wv = vw[z];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                T[ii][e] = fmaf(wv, r0[e], T[ii][e]);
-                T[ii][4 + e] = fmaf(wv, r1[e], T[ii][4 + e]);
-                T[ii][8 + e] = fmaf(wv, r2[e], T[ii][8 + e]);
+            for (int q = 0; q < 4; ++q) {
+                const f32x4* a4 = (const f32x4*)&sA[g + q][jj];
+                const f32x4 r0 = a4[0], r1 = a4[1], r2 = a4[2];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    T[q][e] = fmaf(wv, r0[e], T[q][e]);
+                    T[q][4 + e] = fmaf(wv, r1[e], T[q][4 + e]);
+                    T[q][8 + e] = fmaf(wv, r2[e], T[q][8 + e]);
+                }
             }
         }
-    }
 #pragma unroll
-    for (int ii = 0; ii < IB; ++ii) {
-        if (i0 + ii >= m) break;
-        const float x = acc[ii][0], y = acc[ii][1], z = acc[ii][2];
-        float* o = verts + (long long)(i0 + ii) * ld_verts + v * 3;
-        o[0] = T[ii][0] * x + T[ii][1] * y + T[ii][2] * z + T[ii][3];
-        o[1] = T[ii][4] * x + T[ii][5] * y + T[ii][6] * z + T[ii][7];
-        o[2] = T[ii][8] * x + T[ii][9] * y + T[ii][10] * z + T[ii][11];
+        for (int q = 0; q < 4; ++q) {
+            if (i0 + g + q < m) {
+                const float x = acc[g + q][0], y = acc[g + q][1], z = acc[g + q][2];
+                float* o = verts + (long long)(i0 + g + q) * ld_verts + v * 3;
+                o[0] = T[q][0] * x + T[q][1] * y + T[q][2] * z + T[q][3];
+                o[1] = T[q][4] * x + T[q][5] * y + T[q][6] * z + T[q][7];
+                o[2] = T[q][8] * x + T[q][9] * y + T[q][10] * z + T[q][11];
+            }
+        }
     }
 }
 
@@ -236,7 +250,8 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 extern "C" size_t hmmr_smpl_workspace_bytes(int m) {
     if (m <= 0) return 0;
-    return align_up((size_t)m * LDF * 4, 256) + align_up((size_t)m * LDA * 4, 256);
+    const size_t mp = ((size_t)m + IB - 1) / IB * IB;          // the verts kernel reads whole instance groups
+    return align_up(mp * LDF * 4, 256) + align_up(mp * LDA * 4, 256);
 }
 
 static int smpl_launch(const hmmr_smpl_consts_t* c, const float* theta, int ld_theta, const float* beta,
@@ -250,12 +265,12 @@ static int smpl_launch(const hmmr_smpl_consts_t* c, const float* theta, int ld_t
     HMMR_REQUIRE(!kps || cams, "hmmr_smpl_fwd: kps requested without cams");
     hipStream_t s = (hipStream_t)stream;
     float* feat = (float*)ws;
-    float* A = (float*)((char*)ws + align_up((size_t)m * LDF * 4, 256));
+    float* A = (float*)((char*)ws + align_up(((size_t)m + IB - 1) / IB * IB * LDF * 4, 256));
     const int vtiles = (c->num_verts + VT - 1) / VT;
     hipLaunchKernelGGL(smpl_pose_kernel, dim3((m + 7) / 8), dim3(256), 0, s, theta, ld_theta, beta, ld_beta,
                        c->j_template, c->j_shapedirs, c->parents, m, feat, A, rs, ld_rs);
     HMMR_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(smpl_verts_kernel, dim3(vtiles, (m + IB - 1) / IB), dim3(256), 0, s, c->dirs,
+    hipLaunchKernelGGL(smpl_verts_kernel, dim3(vtiles, (m + IB - 1) / IB), dim3(VT), 0, s, c->dirs,
                        vtiles * VT, (const float*)feat, (const float*)A, c->lbs_idx, c->lbs_w, c->lbs_nnz,
                        c->num_verts, m, verts, ld_verts);
     HMMR_CHECK_HIP(hipGetLastError());

@@ -151,7 +151,7 @@ def pack_smpl(smpl, store, joint_type="cocoplus"):
     v_t = smpl["v_template"].astype(np.float64)
     S = smpl["shapedirs"].astype(np.float64).reshape(10, nv, 3)
     P = smpl["posedirs"].astype(np.float64).reshape(207, nv, 3)
-    dirs = np.zeros((218, 3, vpad), np.float32)
+    dirs = np.zeros((224, 3, vpad), np.float32)      # rows >= 218 stay zero (kernel walks k in fours)
     dirs[0, :, :nv] = v_t.T
     dirs[1:11, :, :nv] = np.transpose(S, (0, 2, 1))
     dirs[11:218, :, :nv] = np.transpose(P, (0, 2, 1))

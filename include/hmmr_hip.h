@@ -200,7 +200,7 @@ typedef struct {
     int num_verts;                     /* 6890 */
     int num_kps;                       /* 25 (cocoplus) or 14 (lsp) */
     int lbs_nnz;                       /* ELL width of the skinning weights (<= 24) */
-    const float* dirs;                 /* [218][3][vpad] planar re-pack of the tf_smpl bases
+    const float* dirs;                 /* [224][3][vpad] planar re-pack of the tf_smpl bases (rows >= 218 zero)
                                           (vpad = num_verts rounded up to 256): row 0 v_template,
                                           1..10 shapedirs, 11..217 posedirs; dirs[k][c][v] =
                                           basis[k][3*v + c] (src/tf_smpl/batch_smpl.py:45-63) */

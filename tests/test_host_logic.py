@@ -70,7 +70,7 @@ def test_smpl_pack_joint_fold_and_sparse_forms(smpl_consts):
     assert np.abs((jt + beta @ js).reshape(24, 3) - J_ref).max() < 1e-6
     # planar basis: dirs[k][c][v] = basis[k][3v + c]
     dirs = _tensor_at(st, sc.dirs).numpy()
-    assert dirs.shape == (218, 3, 6912)
+    assert dirs.shape == (224, 3, 6912) and not dirs[218:].any()
     assert dirs[0, 1, 100] == smpl_consts["v_template"][100, 1]
     assert dirs[1 + 4, 2, 77] == smpl_consts["shapedirs"][4, 3 * 77 + 2]
     assert dirs[11 + 200, 0, 6889] == smpl_consts["posedirs"][200, 3 * 6889]
