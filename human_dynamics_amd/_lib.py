@@ -35,6 +35,7 @@ class ConvDesc(C.Structure):
         ("res_row_stride", C.c_int), ("res_px_stride", C.c_int),
         ("relu", C.c_int), ("tile", C.c_int),
         ("split_k", C.c_int), ("ws", _vp), ("ws_bytes", C.c_size_t),
+        ("pro_scale", _fp), ("pro_shift", _fp),
     ]
 
 
@@ -44,12 +45,13 @@ class Layer(C.Structure):
 
 class ResnetUnit(C.Structure):
     _fields_ = [("conv1", Layer), ("conv2", Layer), ("conv3", Layer), ("shortcut", Layer),
-                ("next_scale", _fp), ("next_shift", _fp),
-                ("c_in", C.c_int), ("base", C.c_int), ("depth", C.c_int), ("stride", C.c_int)]
+                ("pre_scale", _fp), ("pre_shift", _fp),
+                ("c_in", C.c_int), ("base", C.c_int), ("depth", C.c_int), ("stride", C.c_int),
+                ("fuse_preact", C.c_int)]
 
 
 class ResnetWeights(C.Structure):
-    _fields_ = [("dtype", C.c_int), ("stem", Layer), ("pool_scale", _fp), ("pool_shift", _fp),
+    _fields_ = [("dtype", C.c_int), ("stem", Layer),
                 ("unit", ResnetUnit * RESNET_UNITS), ("post_scale", _fp), ("post_shift", _fp)]
 
 
@@ -125,7 +127,7 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError if the .so does not export it
         fn.restype, fn.argtypes = res, args
-    if lib.hmmr_abi_version() != 2:
+    if lib.hmmr_abi_version() != 3:
         raise HmmrError("libhmmr_hip.so ABI version mismatch")
     _lib = lib
     return lib

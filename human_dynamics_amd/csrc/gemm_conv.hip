@@ -36,6 +36,7 @@
 struct ConvArgs {
     const void* in; const void* w; const float* scale; const float* shift;
     const void* res; void* out; void* out2; const float* scale2; const float* shift2;
+    const float* pro_scale; const float* pro_shift;     // fused pre-activation of the A operand (PRO)
     int M, K, cout, ldo, ldr;
     int Wo, HoWo, Hin, Win;
     long long in_img_stride; int in_row_stride, in_px_stride;
@@ -65,18 +66,46 @@ __device__ const u32x4 g_zero_page[4] = {};
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-// GLDS = true : operands go HBM -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave
-//               instruction, LDS image lane-linear, swizzle applied to the per-lane SOURCE slot);
-// GLDS = false: HBM -> VGPR -> ds_write_b128 (kept for A/B measurements).
+// pre-activation of one 16-byte slot: relu(x * scale + shift) per element, back to the operand type
+template <typename TA> __device__ __forceinline__ u32x4 preact_slot(const u32x4& v, const f32x4* sc, const f32x4* sh);
+template <> __device__ __forceinline__ u32x4 preact_slot<float>(const u32x4& v, const f32x4* sc, const f32x4* sh) {
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = __float_as_uint(fmaxf(fmaf(__uint_as_float(v[i]), sc[0][i], sh[0][i]), 0.f));
+    return o;
+}
+template <> __device__ __forceinline__ u32x4 preact_slot<bf16_t>(const u32x4& v, const f32x4* sc, const f32x4* sh) {
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float lo = __uint_as_float(v[i] << 16), hi = __uint_as_float(v[i] & 0xffff0000u);
+        const int e = 2 * i;
+        const float a = fmaxf(fmaf(lo, sc[e >> 2][e & 3], sh[e >> 2][e & 3]), 0.f);
+        const float b = fmaxf(fmaf(hi, sc[(e + 1) >> 2][(e + 1) & 3], sh[(e + 1) >> 2][(e + 1) & 3]), 0.f);
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+        bf16x2 pk = {(bf16_t)a, (bf16_t)b};
+        o[i] = __builtin_bit_cast(unsigned, pk);
+    }
+    return o;
+}
+
+// Operands go HBM -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave instruction, LDS image
+// lane-linear, swizzle applied to the per-lane SOURCE slot).
+// PRO  = true : the A operand instead takes the register route HBM -> VGPR -> (x*scale[ci] +
+//               shift[ci], ReLU) -> ds_write_b128: the consumer-side fusion of the pre-activation
+//               BN + ReLU of a ResNet-v2 unit (`preact`), so that tensor never exists in HBM.
+//               Each element is transformed once per workgroup, while the MFMAs of the previous
+//               K step run.  Only for un-padded gathers (1x1 convs): padding must stay zero.
 // UTAP = true : every 128-byte K step lies inside one filter tap (cin*sizeof >= 128), so the
 //               tap decode is wave-uniform scalar arithmetic.
 // NSTAGE: LDS stages (2 = next tile in flight while the current one is consumed).  A 3-stage ring
 //         (two tiles ahead, counted vmcnt + raw s_barrier) was measured 15-40 % SLOWER on every
 //         ResNet shape: it halves the resident workgroups per CU, and occupancy is what hides
 //         latency here.
-template <typename TA, typename TO, int BM, int BN, int WGM, int WGN, bool GLDS, bool UTAP, int NSTAGE>
+template <typename TA, typename TO, int BM, int BN, int WGM, int WGN, bool PRO, bool UTAP, int NSTAGE>
 __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const ConvArgs a) {
     static_assert(NSTAGE == 2, "only the 2-stage pipeline is kept");
+    static_assert(!PRO || UTAP, "the fused pre-activation needs one tap per K step");
     constexpr int NT = WGM * WGN * 64;            // threads per workgroup (4 or 8 waves)
     constexpr int RPP = NT / 8;                   // tile rows staged per pass (8 lanes per row)
     constexpr int EPS = elem_traits<TA>::EPS;     // elements per 16-B slot
@@ -137,41 +166,49 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const ConvArg
         return ky * a.in_row_stride + kx * a.in_px_stride + ci;
     };
 
-    u32x4 ra[GLDS ? 1 : PA], rb[GLDS ? 1 : PB];
+    u32x4 ra[PRO ? PA : 1];
+    f32x4 psc[PRO ? EPS / 4 : 1], psh[PRO ? EPS / 4 : 1];     // scale/shift of this lane's EPS channels
+    unsigned ra_ok = 0u;
     auto load_tile = [&](int kt, int buf) {
         int tap;
         const int koff = UTAP ? tap_of(kt * BKE, tap) : tap_of(kt * BKE + lslot * EPS, tap) - lslot * EPS;
-        if constexpr (GLDS) {
-            char* sa = smem + buf * STAGE + wave * 1024;
+        char* sa = smem + buf * STAGE + wave * 1024;
+        if constexpr (PRO) {
+            const int ci = ((kt * BKE) & cin_mask) + lslot * EPS;
+#pragma unroll
+            for (int q = 0; q < EPS / 4; ++q) {
+                psc[q] = *(const f32x4*)(a.pro_scale + ci + 4 * q);
+                psh[q] = *(const f32x4*)(a.pro_shift + ci + 4 * q);
+            }
+            ra_ok = 0u;
+#pragma unroll
+            for (int p = 0; p < PA; ++p) {
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if ((amask[p] >> tap) & 1u) { v = *(const u32x4*)(aptr[p] + koff); ra_ok |= 1u << p; }
+                ra[p] = v;
+            }
+        } else {
 #pragma unroll
             for (int p = 0; p < PA; ++p) {
                 const bool ok = (amask[p] >> tap) & 1u;
                 const void* src = ok ? (const void*)(aptr[p] + koff) : (const void*)g_zero_page;
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + p * (RPP * 128)), 16, 0, 0);
             }
-#pragma unroll
-            for (int p = 0; p < PB; ++p)
-                __builtin_amdgcn_global_load_lds((gptr_t)(wptr + (long long)(RPP * p) * a.K + kt * BKE),
-                                                 (lptr_t)(sa + A_BYTES + p * (RPP * 128)), 16, 0, 0);
-        } else {
-#pragma unroll
-            for (int p = 0; p < PA; ++p) {
-                u32x4 v = {0u, 0u, 0u, 0u};
-                if ((amask[p] >> tap) & 1u) v = *(const u32x4*)(aptr[p] + koff);
-                ra[p] = v;
-            }
-#pragma unroll
-            for (int p = 0; p < PB; ++p)
-                rb[p] = *(const u32x4*)(wptr + (long long)(RPP * p) * a.K + kt * BKE);
         }
+#pragma unroll
+        for (int p = 0; p < PB; ++p)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wptr + (long long)(RPP * p) * a.K + kt * BKE),
+                                             (lptr_t)(sa + A_BYTES + p * (RPP * 128)), 16, 0, 0);
     };
     auto store_tile = [&](int buf) {
-        if constexpr (!GLDS) {
+        if constexpr (PRO) {
             char* sa = smem + buf * STAGE + r0 * 128 + pslot * 16;
 #pragma unroll
-            for (int p = 0; p < PA; ++p) *(u32x4*)(sa + p * (RPP * 128)) = ra[p];
-#pragma unroll
-            for (int p = 0; p < PB; ++p) *(u32x4*)(sa + A_BYTES + p * (RPP * 128)) = rb[p];
+            for (int p = 0; p < PA; ++p) {
+                u32x4 v = ra[p];
+                if ((ra_ok >> p) & 1u) v = preact_slot<TA>(v, psc, psh);
+                *(u32x4*)(sa + p * (RPP * 128)) = v;
+            }
         }
     };
 
@@ -322,7 +359,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const ConvArg
 // ------------------------------------------------------------------------- //
 // Host side
 // ------------------------------------------------------------------------- //
-template <typename TA, typename TO, int BM, int BN, int WGM, int WGN, bool GLDS, bool UTAP, int NSTAGE>
+template <typename TA, typename TO, int BM, int BN, int WGM, int WGN, bool PRO, bool UTAP, int NSTAGE>
 static int launch_cfg(const ConvArgs& base, int slices, hipStream_t stream) {
     ConvArgs a = base;
     const int tiles_m = (a.M + BM - 1) / BM;
@@ -330,7 +367,7 @@ static int launch_cfg(const ConvArgs& base, int slices, hipStream_t stream) {
     a.n_tiles = tiles_m * a.tiles_n;
     constexpr int kloop = NSTAGE * (BM + BN) * 128, epi = BM * BN * 4;
     constexpr int lds = kloop > epi ? kloop : epi;
-    auto kern = conv_gemm_kernel<TA, TO, BM, BN, WGM, WGN, GLDS, UTAP, NSTAGE>;
+    auto kern = conv_gemm_kernel<TA, TO, BM, BN, WGM, WGN, PRO, UTAP, NSTAGE>;
     static bool attr_set = false;
     if (!attr_set) {
         HMMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -344,14 +381,14 @@ static int launch_cfg(const ConvArgs& base, int slices, hipStream_t stream) {
     return 0;
 }
 
-template <typename TA, typename TO, bool UTAP>
+template <typename TA, typename TO, bool PRO, bool UTAP>
 static int launch_tiled(const ConvArgs& a, int tile, int slices, hipStream_t stream) {
     switch (tile) {   // BM, BN, waves along M, waves along N
-        case 1: return launch_cfg<TA, TO, 128, 128, 2, 2, true, UTAP, 2>(a, slices, stream);   // 4 waves, 64x64 each
-        case 2: return launch_cfg<TA, TO, 128, 64, 2, 2, true, UTAP, 2>(a, slices, stream);    // 4 waves, 64x32 each
-        case 3: return launch_cfg<TA, TO, 64, 64, 2, 2, true, UTAP, 2>(a, slices, stream);     // 4 waves, 32x32 each
-        case 5: return launch_cfg<TA, TO, 128, 128, 4, 2, true, UTAP, 2>(a, slices, stream);   // 8 waves, 32x64 each
-        case 6: return launch_cfg<TA, TO, 128, 64, 4, 2, true, UTAP, 2>(a, slices, stream);    // 8 waves, 32x32 each
+        case 1: return launch_cfg<TA, TO, 128, 128, 2, 2, PRO, UTAP, 2>(a, slices, stream);   // 4 waves, 64x64 each
+        case 2: return launch_cfg<TA, TO, 128, 64, 2, 2, PRO, UTAP, 2>(a, slices, stream);    // 4 waves, 64x32 each
+        case 3: return launch_cfg<TA, TO, 64, 64, 2, 2, PRO, UTAP, 2>(a, slices, stream);     // 4 waves, 32x32 each
+        case 5: return launch_cfg<TA, TO, 128, 128, 4, 2, PRO, UTAP, 2>(a, slices, stream);   // 8 waves, 32x64 each
+        case 6: return launch_cfg<TA, TO, 128, 64, 4, 2, PRO, UTAP, 2>(a, slices, stream);    // 8 waves, 32x32 each
         default: hmmr_set_error("hmmr_conv_gemm: bad tile %d", tile); return -1;
     }
 }
@@ -369,7 +406,12 @@ static int launch_typed(const ConvArgs& a, int tile, int slices, hipStream_t str
         else tile = 3;
     }
     const bool utap = ((size_t)1 << a.cin_log2) * sizeof(TA) >= 128;
-    return utap ? launch_tiled<TA, TO, true>(a, tile, slices, stream) : launch_tiled<TA, TO, false>(a, tile, slices, stream);
+    if (a.pro_scale) {
+        if (!utap) { hmmr_set_error("hmmr_conv_gemm: fused pre-activation needs cin*sizeof >= 128"); return -1; }
+        return launch_tiled<TA, TO, true, true>(a, tile, slices, stream);
+    }
+    return utap ? launch_tiled<TA, TO, false, true>(a, tile, slices, stream)
+                : launch_tiled<TA, TO, false, false>(a, tile, slices, stream);
 }
 
 // Split-K second pass: sum the S fp32 partial planes in slice order, then the same epilogue as
@@ -467,9 +509,13 @@ extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
     HMMR_REQUIRE(!d->res || d->cout % 8 == 0 || (!d->res_strided && d->ldr >= (d->cout + 7) / 8 * 8),
                  "hmmr_conv_gemm: residual rows must be readable up to cout rounded up to 8");
     HMMR_REQUIRE(!d->out2 || (d->scale2 && d->shift2), "hmmr_conv_gemm: out2 needs scale2/shift2");
+    HMMR_REQUIRE(!d->pro_scale == !d->pro_shift, "hmmr_conv_gemm: pro_scale and pro_shift go together");
+    HMMR_REQUIRE(!d->pro_scale || (d->py == 0 && d->px == 0 && d->kh == 1 && d->kw == 1),
+                 "hmmr_conv_gemm: the fused pre-activation is for un-padded 1x1 gathers (padding must stay zero)");
     ConvArgs a;
     a.in = d->in; a.w = d->w; a.scale = d->scale; a.shift = d->shift; a.res = d->res;
     a.out = d->out; a.out2 = d->out2; a.scale2 = d->scale2; a.shift2 = d->shift2;
+    a.pro_scale = d->pro_scale; a.pro_shift = d->pro_shift;
     a.M = d->n_img * d->ho * d->wo; a.K = K; a.cout = d->cout; a.ldo = d->ldo; a.ldr = d->ldr;
     a.Wo = d->wo; a.HoWo = d->ho * d->wo; a.Hin = d->hin; a.Win = d->win;
     a.in_img_stride = d->in_img_stride; a.in_row_stride = d->in_row_stride; a.in_px_stride = d->in_px_stride;
@@ -495,6 +541,7 @@ extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
                      "hmmr_conv_gemm: split-K workspace missing or too small");
         ConvArgs p = a;
         p.scale = p.shift = nullptr; p.res = nullptr; p.out2 = nullptr; p.scale2 = p.shift2 = nullptr;
+        // (a fused pre-activation, if any, stays: it acts on the A operand)
         p.relu = 0; p.out = d->ws; p.ldo = ldw; p.out_slice_stride = plane;
         const int rc = in16 ? launch_typed<bf16_t, float>(p, d->tile, slices, s) : launch_typed<float, float>(p, d->tile, slices, s);
         if (rc) return rc;

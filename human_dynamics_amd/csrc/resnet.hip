@@ -10,7 +10,8 @@
 //                     VALID) becomes an 8-tap x 32-element implicit GEMM
 //                     (tap = ky, 32 elements = 8 pixels x 4 channels)
 //   maxpool_bn_relu   3x3/2 TF-SAME max pool (pad bottom/right only) fused with
-//                     block1/unit_1's `preact` BN + ReLU
+//                     block1/unit_1's `preact` BN + ReLU (every later unit's preact is fused
+//                     into the operand staging of its conv1 / shortcut GEMMs)
 //   bn_relu_avgpool   postnorm BN + ReLU + spatial mean (pool5)
 // Inference BN is folded to y = x*scale + shift on the host
 // (scale = gamma*rsqrt(var+1e-5), shift = beta - mean*scale).
@@ -192,25 +193,43 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
         const long long nvec = (long long)n * 56 * 56 * 8;
         const int g2 = (int)((nvec + 255) / 256 < 16384 ? (nvec + 255) / 256 : 16384);
         hipLaunchKernelGGL(maxpool_bn_relu_kernel<T>, dim3(g2), dim3(256), 0, s, (const T*)stem, P[0],
-                           w->pool_scale, w->pool_shift, nvec);
+                           w->unit[0].pre_scale, w->unit[0].pre_shift, nvec);
         HMMR_CHECK_HIP(hipGetLastError());
         if (prof_mark(pf)) return -2;
     }
 
-    int H = 56, cur = 0;
-    const T* xraw = nullptr;     // raw input of the unit (only valid when the shortcut is identity)
+    // Units.  A unit's pre-activation BN + ReLU (`preact`) reaches its 1x1 consumers (conv1 and the
+    // conv shortcut) in one of two ways, chosen per unit by `fuse_preact`:
+    //   1: the consumers read the RAW trunk and apply the preact while staging their A operand
+    //      (the tensor never exists in HBM; pays in the HBM-bound early blocks);
+    //   0: the previous unit's conv3 epilogue writes it as a second output (the consumers keep the
+    //      pure LDS-DMA operand path; better for the MFMA-bound late blocks).
+    // Measured per block at batch 256: fusing wins in block1, is neutral in block2, loses after.
+    int H = 56, cur = 0, pcur = 0;
+    bool have_raw = false;            // X[cur] holds the raw input of the unit
     for (int u = 0; u < HMMR_RESNET_UNITS; ++u) {
         const hmmr_resnet_unit_t& U = w->unit[u];
         const int Ho = H / U.stride;
         const bool last = (u == HMMR_RESNET_UNITS - 1);
-        const bool next_needs_raw = last || (w->unit[u + 1].c_in == w->unit[u + 1].depth);
+        const bool fused = u > 0 && U.fuse_preact;
+        const T* xin = fused ? (const T*)X[cur] : (const T*)P[pcur];
+        const float* ps = fused ? U.pre_scale : nullptr;
+        const float* pb = fused ? U.pre_shift : nullptr;
+        HMMR_REQUIRE(!fused || (ps && pb && have_raw), "resnet: unit %d cannot fuse its preact", u);
+        const bool identity = !U.shortcut.w;
+        HMMR_REQUIRE(!identity || have_raw, "resnet: unit %d has no raw input for its identity shortcut", u);
+        // what the NEXT unit needs from this one
+        const bool next_fused = !last && w->unit[u + 1].fuse_preact;
+        const bool next_identity = !last && !w->unit[u + 1].shortcut.w;
+        const bool write_raw = last || next_fused || next_identity;
+        const bool write_pre = !last && !next_fused;
         T* xn = X[cur ^ 1];
-        T* pn = P[cur ^ 1];
-        const T* p = P[cur];
+        T* pn = P[pcur ^ 1];
         hmmr_conv_desc_t d;
         if (U.shortcut.w) {           // 1x1 conv on preact, bias, no BN/ReLU (stride is 1 here)
             d = hmmr_conv_desc_t{};
-            d.in = p; d.w = U.shortcut.w; d.scale = U.shortcut.scale; d.shift = U.shortcut.shift;
+            d.in = xin; d.pro_scale = ps; d.pro_shift = pb;
+            d.w = U.shortcut.w; d.scale = U.shortcut.scale; d.shift = U.shortcut.shift;
             d.out = xn; d.in_dtype = d.out_dtype = w->dtype;
             d.n_img = n; d.hin = H; d.win = H; d.cin = U.c_in;
             d.in_img_stride = (int64_t)H * H * U.c_in; d.in_row_stride = H * U.c_in; d.in_px_stride = U.c_in;
@@ -218,9 +237,10 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
             if (hmmr_conv_gemm(&d, s)) return -2;
             if (prof_mark(pf)) return -2;
         }
-        // conv1: 1x1, BN + ReLU
+        // conv1: 1x1 on preact, BN + ReLU
         d = hmmr_conv_desc_t{};
-        d.in = p; d.w = U.conv1.w; d.scale = U.conv1.scale; d.shift = U.conv1.shift; d.relu = 1;
+        d.in = xin; d.pro_scale = ps; d.pro_shift = pb;
+        d.w = U.conv1.w; d.scale = U.conv1.scale; d.shift = U.conv1.shift; d.relu = 1;
         d.out = T1; d.in_dtype = d.out_dtype = w->dtype;
         d.n_img = n; d.hin = H; d.win = H; d.cin = U.c_in;
         d.in_img_stride = (int64_t)H * H * U.c_in; d.in_row_stride = H * U.c_in; d.in_px_stride = U.c_in;
@@ -236,7 +256,7 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
         d.kh = d.kw = 3; d.sy = d.sx = U.stride; d.py = d.px = 1; d.ho = d.wo = Ho; d.cout = U.base; d.ldo = U.base;
         if (hmmr_conv_gemm(&d, s)) return -2;
         if (prof_mark(pf)) return -2;
-        // conv3: 1x1 + bias, + shortcut; second output = next unit's preact
+        // conv3: 1x1 + bias, + shortcut (no ReLU after the add)
         d = hmmr_conv_desc_t{};
         d.in = T2; d.w = U.conv3.w; d.scale = U.conv3.scale; d.shift = U.conv3.shift;
         d.in_dtype = d.out_dtype = w->dtype;
@@ -244,20 +264,23 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
         d.in_img_stride = (int64_t)Ho * Ho * U.base; d.in_row_stride = Ho * U.base; d.in_px_stride = U.base;
         d.kh = d.kw = 1; d.sy = d.sx = 1; d.ho = d.wo = Ho; d.cout = U.depth; d.ldo = U.depth;
         if (U.shortcut.w) { d.res = xn; d.ldr = U.depth; }
-        else if (U.stride == 1) { d.res = xraw; d.ldr = U.depth; }
-        else {                        // max_pool2d(x, [1,1], stride) = x[:, ::s, ::s]
-            d.res = xraw; d.res_strided = 1;
+        else if (U.stride == 1) { d.res = X[cur]; d.ldr = U.depth; }
+        else {                        // max_pool2d(x, [1,1], stride) = x[:, ::s, ::s] of the RAW input
+            d.res = X[cur]; d.res_strided = 1;
             d.res_img_stride = (int64_t)H * H * U.depth; d.res_row_stride = U.stride * H * U.depth;
             d.res_px_stride = U.stride * U.depth;
         }
-        HMMR_REQUIRE(d.res != nullptr, "resnet: unit %d has no shortcut source", u);
-        d.out = next_needs_raw ? xn : nullptr;
-        if (!last) { d.out2 = pn; d.scale2 = U.next_scale; d.shift2 = U.next_shift; }
+        d.out = write_raw ? xn : nullptr;
+        if (write_pre) {
+            d.out2 = pn; d.scale2 = w->unit[u + 1].pre_scale; d.shift2 = w->unit[u + 1].pre_shift;
+            HMMR_REQUIRE(d.scale2 && d.shift2, "resnet: unit %d lacks its preact BN", u + 1);
+        }
         if (hmmr_conv_gemm(&d, s)) return -2;
         if (prof_mark(pf)) return -2;
-        xraw = next_needs_raw ? xn : nullptr;
-        cur ^= 1; H = Ho;
+        have_raw = write_raw;
+        cur ^= 1; pcur ^= 1; H = Ho;
     }
+    const T* xraw = X[cur];
     // ---- postnorm BN + ReLU + mean over 7x7
     {
         const long long nth = (long long)n * (2048 / 8);

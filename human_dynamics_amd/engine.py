@@ -6,6 +6,7 @@ shuffles tensors.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -55,7 +56,9 @@ class HmmrEngine(object):
         self.store = packing.DeviceStore(self.device)
         self.num_conv_layers = num_conv_layers
         self.delta_keys = sorted(int(d) for d in delta_t_values)
-        self.rw = packing.pack_resnet(weights, self.dtype, self.store) if weights is not None else None
+        fuse = tuple(b for b in os.environ.get("HMMR_FUSE_PREACT", "block1").split(",") if b)   # dev A/B switch
+        self.rw = (packing.pack_resnet(weights, self.dtype, self.store, fuse_preact_blocks=fuse)
+                   if weights is not None else None)
         self.tw = (packing.pack_temporal(weights, self.temporal_dtype, self.store, num_conv_layers)
                    if weights is not None else None)
         if weights is not None:
@@ -186,7 +189,7 @@ class HmmrEngine(object):
 
 def conv_gemm(x, w_hwio, stride=1, pad=0, scale=None, shift=None, res=None, relu=False,
               scale2=None, shift2=None, in_dtype=L.HMMR_F32, out_dtype=L.HMMR_F32, tile=0,
-              device="cuda:0", res_stride=1, split_k=0):
+              device="cuda:0", res_stride=1, split_k=0, pro=None):
     """Test/utility entry: run one NHWC convolution through hmmr_conv_gemm.
     x [n,h,w,cin] (numpy/torch), w_hwio [kh,kw,cin,cout].  Returns (out, out2)."""
     lib = L.load()
@@ -226,6 +229,8 @@ def conv_gemm(x, w_hwio, stride=1, pad=0, scale=None, shift=None, res=None, relu
     d.kh, d.kw, d.sy, d.sx, d.py, d.px = kh, kw, stride, stride, py, px
     d.ho, d.wo, d.cout, d.ldo = ho, wo, cout, ldo
     d.relu, d.tile = int(relu), tile
+    if pro is not None:
+        d.pro_scale, d.pro_shift = store.put(pro[0]).data_ptr(), store.put(pro[1]).data_ptr()
     if split_k > 1:
         nb = lib.hmmr_conv_splitk_workspace_bytes(n * ho * wo, cout, split_k)
         skws = torch.empty(int(nb), dtype=torch.uint8, device=dev)

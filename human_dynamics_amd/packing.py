@@ -77,18 +77,19 @@ def _layer(store, w_packed, dtype, scale=None, shift=None):
     return lay
 
 
-def pack_resnet(w, dtype, store):
+def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1",)):
+    """fuse_preact_blocks: blocks whose units apply their `preact` BN+ReLU inside the operand
+    staging of conv1/shortcut (measured win in the HBM-bound block1; see csrc/resnet.hip)."""
     rw = L.ResnetWeights()
     rw.dtype = dtype
     rw.stem = _layer(store, pack_stem_weight(w["resnet_v2_50/conv1/weights"]), dtype,
                      shift=w["resnet_v2_50/conv1/biases"])
     units = list(assets.resnet_units())
     assert len(units) == L.RESNET_UNITS
-    s0, b0 = fold_bn(w, units[0][0] + "/preact")
-    rw.pool_scale, rw.pool_shift = store.vec(s0).data_ptr(), store.vec(b0).data_ptr()
     for i, (scope, c_in, base, depth, stride, has_sc) in enumerate(units):
         u = rw.unit[i]
         u.c_in, u.base, u.depth, u.stride = c_in, base, depth, stride
+        u.fuse_preact = int(i > 0 and scope.split("/")[1] in fuse_preact_blocks)
         s, b = fold_bn(w, scope + "/conv1/BatchNorm")
         u.conv1 = _layer(store, pack_conv_weight(w[scope + "/conv1/weights"]), dtype, s, b)
         s, b = fold_bn(w, scope + "/conv2/BatchNorm")
@@ -98,9 +99,8 @@ def pack_resnet(w, dtype, store):
         if has_sc:
             u.shortcut = _layer(store, pack_conv_weight(w[scope + "/shortcut/weights"]), dtype,
                                 shift=w[scope + "/shortcut/biases"])
-        if i + 1 < len(units):
-            s, b = fold_bn(w, units[i + 1][0] + "/preact")
-            u.next_scale, u.next_shift = store.vec(s).data_ptr(), store.vec(b).data_ptr()
+        s, b = fold_bn(w, scope + "/preact")
+        u.pre_scale, u.pre_shift = store.vec(s).data_ptr(), store.vec(b).data_ptr()
     s, b = fold_bn(w, "resnet_v2_50/postnorm")
     rw.post_scale, rw.post_shift = store.vec(s).data_ptr(), store.vec(b).data_ptr()
     return rw

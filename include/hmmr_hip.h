@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HMMR_ABI_VERSION 2
+#define HMMR_ABI_VERSION 3
 
 enum { HMMR_F32 = 0, HMMR_BF16 = 1 };
 
@@ -84,6 +84,11 @@ typedef struct {
     int split_k;
     void* ws;              /* >= hmmr_conv_splitk_workspace_bytes(M, cout, split_k) */
     size_t ws_bytes;
+    /* fused pre-activation of the INPUT: A[m, k] = relu(in * pro_scale[ci] + pro_shift[ci]) applied
+     * while the operand is staged (slim bottleneck_v2 `preact` BN + ReLU, consumer side).  [cin]
+     * floats each, or both NULL.  Only for 1x1, un-padded convolutions. */
+    const float* pro_scale;
+    const float* pro_shift;
 } hmmr_conv_desc_t;
 
 int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream);
@@ -103,9 +108,11 @@ typedef struct {
 
 typedef struct {
     hmmr_layer_t conv1, conv2, conv3, shortcut;   /* shortcut.w == NULL: identity / subsample */
-    const float* next_scale;   /* folded `preact` BN of the following unit (NULL for the last) */
-    const float* next_shift;
+    const float* pre_scale;    /* this unit's folded `preact` BN, [c_in] */
+    const float* pre_shift;
     int c_in, base, depth, stride;
+    int fuse_preact;           /* 1: conv1/shortcut apply the preact while staging their operand;
+                                  0: the previous unit's conv3 writes the preact tensor */
 } hmmr_resnet_unit_t;
 
 #define HMMR_RESNET_UNITS 16
@@ -113,8 +120,6 @@ typedef struct {
 typedef struct {
     int dtype;                         /* operand type of convs + activations */
     hmmr_layer_t stem;                 /* 7x7/2 packed as [128][8 taps x (8 px x 4 ch)] */
-    const float* pool_scale;           /* block1/unit_1 `preact` BN, applied after pool1 */
-    const float* pool_shift;
     hmmr_resnet_unit_t unit[HMMR_RESNET_UNITS];
     const float* post_scale;           /* postnorm BN folded */
     const float* post_shift;

@@ -276,3 +276,26 @@ def test_conv_gemm_split_k(split_k, dt, gpu_device):
     res2 = np.concatenate([res, rng.normal(size=(5, 20, 1, 200)).astype(np.float32)])
     out2, _ = conv_gemm(x2, w, 1, (1, 0), None, b, res2, True, in_dtype=in_dt, device=gpu_device, split_k=split_k)
     assert np.array_equal(out2[:3], out)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("tile", [0, 3, 5, 6])
+def test_conv_gemm_fused_preactivation(tile, dt, gpu_device):
+    """A[m,k] = relu(x*scale[ci]+shift[ci]) applied while staging (slim `preact`, consumer side)."""
+    from human_dynamics_amd.engine import conv_gemm
+    rng = np.random.default_rng(7)
+    x = rng.normal(size=(2, 14, 14, 256)).astype(np.float32)
+    w = (rng.normal(size=(1, 1, 256, 128)) / 16).astype(np.float32)
+    ps = rng.uniform(0.5, 1.5, 256).astype(np.float32)
+    pb = rng.normal(size=256).astype(np.float32)
+    s = rng.uniform(0.5, 1.5, 128).astype(np.float32)
+    b = rng.normal(size=128).astype(np.float32)
+    in_dt = L.HMMR_BF16 if dt == "bf16" else L.HMMR_F32
+    out, _ = conv_gemm(x, w, 1, 0, s, b, None, True, in_dtype=in_dt, tile=tile, device=gpu_device, pro=(ps, pb))
+    if dt == "f32":
+        xa, wr = np.maximum(x.astype(np.float64) * ps + pb, 0), w
+    else:   # the operand is rounded to bf16 before AND after the pre-activation
+        xa = _bf16_round(np.maximum(_bf16_round(x) * ps + pb, 0).astype(np.float32))
+        wr = _bf16_round(w)
+    ref, _ = _ref_conv(xa, wr, 1, 0, s, b, None, True, None, None)
+    assert np.abs(out - ref).max() < 3e-5 * max(1.0, np.abs(ref).max())

@@ -108,7 +108,7 @@ def test_resnet_pack_unit_table(weights):
     strides = [rw.unit[i].stride for i in range(16)]
     assert strides == [1, 1, 2, 1, 1, 1, 2, 1, 1, 1, 1, 1, 2, 1, 1, 1]      # stride on the LAST unit of blocks 1-3
     assert [bool(rw.unit[i].shortcut.w) for i in range(16)] == [i in (0, 3, 7, 13) for i in range(16)]
-    assert rw.unit[15].next_scale is None and rw.unit[0].next_scale is not None
+    assert all(rw.unit[i].pre_scale and rw.unit[i].pre_shift for i in range(16))
     assert (rw.unit[0].c_in, rw.unit[15].depth) == (64, 2048)
 
 
@@ -121,5 +121,5 @@ def test_window_plan_matches_oracle():
 def test_ctypes_struct_sizes_are_plausible():
     # catches accidental field drift between include/hmmr_hip.h and _lib.py
     assert C.sizeof(_lib.Layer) == 24
-    assert C.sizeof(_lib.ResnetUnit) == 4 * 24 + 16 + 16
+    assert C.sizeof(_lib.ResnetUnit) == 4 * 24 + 16 + 16 + 8
     assert C.sizeof(_lib.ConvDesc) % 8 == 0

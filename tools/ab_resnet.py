@@ -21,11 +21,15 @@ torch.cuda.synchronize(); tms = (time.perf_counter() - t) / 10 * 1e3
 print(json.dumps({"resnet_ms": round(ms, 3), "temporal_ms": round(tms, 3)}))
 '''
 n = sys.argv[1] if len(sys.argv) > 1 else "256"
-libs = sys.argv[2:] or ["human_dynamics_amd/libhmmr_hip.so"]
-for rep in range(3):
+var = sys.argv[2] if len(sys.argv) > 2 else "HMMR_LIB_PATH"
+vals = sys.argv[3:] or [""]
+for rep in range(2):
     for dt in ("bf16", "f32"):
-        for lib in libs:
-            env = dict(os.environ, HMMR_LIB_PATH=os.path.abspath(lib))
+        for v in vals:
+            env = dict(os.environ)
+            env[var] = os.path.abspath(v) if var == "HMMR_LIB_PATH" and v else v
+            if var == "HMMR_LIB_PATH" and not v:
+                env.pop(var)
             out = subprocess.run([sys.executable, "-c", code, n, dt], env=env, capture_output=True, text=True)
             line = [l for l in out.stdout.splitlines() if l.startswith("{")]
-            print(rep, dt, os.path.basename(lib), line[-1] if line else out.stderr[-300:], flush=True)
+            print(rep, dt, "%s=%s" % (var, v), line[-1] if line else out.stderr[-300:], flush=True)
