@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--frames", type=int, default=256, help="output frames per GPU per step")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive leg (used for PMC passes)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -169,15 +170,25 @@ def main():
         avg_launch_s = conv_ms * 1e-3 / n_conv
         achieved = flops_per_launch / avg_launch_s
         peak = PEAK_BF16 if args.dtype == "bf16" else PEAK_F32
+        # HBM traffic per launch comes from separate rocprofv3 --pmc passes of this same command
+        # (FETCH_SIZE x2, WRITE_SIZE x1, KiB; tools/pmc_summary.py) committed under profiles/
+        traffic, traffic_src, mfma_util = None, None, None
+        import glob
+        pm = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_summary.json")))
+        if pm and args.dtype == "bf16" and args.frames == 256:
+            rc = json.load(open(pm[-1])).get("resnet_conv_gemm", {})
+            traffic, mfma_util = rc.get("hbm_bytes_per_launch"), rc.get("mfma_util")
+            traffic_src = "profiles/" + os.path.basename(pm[-1])
         roofline = {"bound": "mfma", "kernel": "conv_gemm_kernel (ResNet-v2-50, %d launches/pass)" % n_conv,
                     "achieved": round(achieved / 1e12, 2), "peak": round(peak / 1e12, 1), "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": None,
+                    "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "B/launch",
+                    "traffic_source": traffic_src, "mfma_util_pmc": mfma_util,
                     "avg_launch_us": round(avg_launch_s * 1e6, 2),
                     "flops_per_launch": flops_per_launch,
                     "resnet_pass_ms": round(all_ms, 3), "conv_ms": round(conv_ms, 3), "frames_encoded": n_enc}
         # ---- PCIe-inclusive rate (host frames in, host dict out), 1 GPU only, untimed extra
         pcie_fps = None
-        if world == 1:
+        if world == 1 and not args.no_pcie:
             host_frames = span.cpu().numpy()
             tester.predict_all_images(host_frames[:64])
             t1 = time.perf_counter()
