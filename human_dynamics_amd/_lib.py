@@ -64,6 +64,10 @@ class TemporalWeights(C.Structure):
     _fields_ = [("dtype", C.c_int), ("num_blocks", C.c_int), ("block", TemporalBlock * MAX_TEMPORAL_BLOCKS)]
 
 
+class HallucinatorWeights(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("fc1", Layer), ("fc2", Layer), ("fc3", Layer)]
+
+
 class IefRegressor(C.Structure):
     _fields_ = [("nd", C.c_int), ("fc1_phi", Layer), ("fc1_theta", Layer), ("fc2", Layer), ("fc3", Layer)]
 
@@ -90,6 +94,8 @@ SIGNATURES = {
                                     C.POINTER(C.c_float)]),
     "hmmr_temporal_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "hmmr_temporal_fwd": (C.c_int, [C.POINTER(TemporalWeights), _fp, C.c_int, C.c_int, _fp, _vp, C.c_size_t, _vp]),
+    "hmmr_hallucinator_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "hmmr_hallucinator_fwd": (C.c_int, [C.POINTER(HallucinatorWeights), _fp, C.c_int, _fp, _vp, C.c_size_t, _vp]),
     "hmmr_groupnorm_relu": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp]),
     "hmmr_ief_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "hmmr_ief_fwd": (C.c_int, [C.POINTER(IefWeights), _fp, C.c_int, _fp, _vp, C.c_size_t, _vp]),

@@ -120,3 +120,60 @@ extern "C" int hmmr_temporal_fwd(const hmmr_temporal_weights_t* w, const float* 
     }
     return 0;
 }
+
+// ------------------------------------------------------------------------- //
+// Hallucinator fc2_res (src/models.py:270-296, pred_mode == 'hal'):
+//   phi + fc3(relu(fc2(relu(fc1(phi)))))     three 2048x2048 fully-connected layers.
+extern "C" size_t hmmr_hallucinator_workspace_bytes(int m, int dtype) {
+    if (m <= 0) return 0;
+    const size_t e = dtype == HMMR_BF16 ? 2 : 4;
+    return 3 * align_up((size_t)m * 2048 * e, 256) +
+           align_up(hmmr_conv_splitk_workspace_bytes(m, 2048, TEMPORAL_SPLIT_K), 256);
+}
+
+template <typename TO>
+__global__ void hal_cast_kernel(const float* __restrict__ in, TO* __restrict__ out, long long n8) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    float v[8];
+    load8(in + i * 8, v);
+    store8(out + i * 8, v);
+}
+
+extern "C" int hmmr_hallucinator_fwd(const hmmr_hallucinator_weights_t* w, const float* phi, int m,
+                                     float* out, void* ws, size_t ws_bytes, void* stream) {
+    HMMR_REQUIRE(w && phi && out && ws, "hmmr_hallucinator_fwd: null argument");
+    HMMR_REQUIRE(m > 0, "hmmr_hallucinator_fwd: m must be positive");
+    HMMR_REQUIRE(ws_bytes >= hmmr_hallucinator_workspace_bytes(m, w->dtype), "hmmr_hallucinator_fwd: workspace too small");
+    const int C = 2048;
+    const size_t e = w->dtype == HMMR_BF16 ? 2 : 4;
+    char* p = (char*)ws;
+    void* x = p;  p += align_up((size_t)m * C * e, 256);
+    void* h1 = p; p += align_up((size_t)m * C * e, 256);
+    void* h2 = p; p += align_up((size_t)m * C * e, 256);
+    void* sk = p;
+    const size_t skb = hmmr_conv_splitk_workspace_bytes(m, C, TEMPORAL_SPLIT_K);
+    hipStream_t s = (hipStream_t)stream;
+    const void* xin = phi;
+    if (w->dtype == HMMR_BF16) {
+        const long long n8 = (long long)m * C / 8;
+        hipLaunchKernelGGL(hal_cast_kernel<bf16_t>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, phi, (bf16_t*)x, n8);
+        HMMR_CHECK_HIP(hipGetLastError());
+        xin = x;
+    }
+    auto fc = [&](const void* in, const hmmr_layer_t& l, void* o, int odt, int relu, const float* res) {
+        hmmr_conv_desc_t d = {};
+        d.in = in; d.w = l.w; d.scale = l.scale; d.shift = l.shift; d.out = o;
+        d.in_dtype = w->dtype; d.out_dtype = odt;
+        d.n_img = m; d.hin = d.win = 1; d.cin = C;
+        d.in_img_stride = C; d.in_row_stride = C; d.in_px_stride = C;
+        d.kh = d.kw = 1; d.sy = d.sx = 1; d.ho = d.wo = 1; d.cout = C; d.ldo = C;
+        d.relu = relu; d.res = res; d.ldr = C;
+        d.split_k = TEMPORAL_SPLIT_K; d.ws = sk; d.ws_bytes = skb;
+        return hmmr_conv_gemm(&d, s);
+    };
+    if (fc(xin, w->fc1, h1, w->dtype, 1, nullptr)) return -2;
+    if (fc(h1, w->fc2, h2, w->dtype, 1, nullptr)) return -2;
+    if (fc(h2, w->fc3, out, HMMR_F32, 0, phi)) return -2;      // + phi (models.py:295)
+    return 0;
+}

@@ -61,6 +61,7 @@ class HmmrEngine(object):
                    if weights is not None else None)
         self.tw = (packing.pack_temporal(weights, self.temporal_dtype, self.store, num_conv_layers)
                    if weights is not None else None)
+        self.hw = packing.pack_hallucinator(weights, self.temporal_dtype, self.store) if weights is not None else None
         if weights is not None:
             self.iw, self.reg_keys = packing.pack_ief(weights, self.ief_dtype, self.store, self.delta_keys)
         else:
@@ -68,7 +69,7 @@ class HmmrEngine(object):
         self.sc = packing.pack_smpl(smpl, self.store, joint_type) if smpl is not None else None
         self.num_kps = self.sc.num_kps if self.sc is not None else assets.NUM_KPS
         self.num_verts = self.sc.num_verts if self.sc is not None else assets.NUM_VERTS
-        self._ws = {k: _Workspace(self.device) for k in ("resnet", "temporal", "ief", "smpl")}
+        self._ws = {k: _Workspace(self.device) for k in ("resnet", "temporal", "ief", "smpl", "hal")}
 
     # -- helpers ---------------------------------------------------------------
     def _stream(self):
@@ -119,6 +120,20 @@ class HmmrEngine(object):
         L.check(self.lib.hmmr_temporal_fwd(C.byref(self.tw), phi.data_ptr(), b, t, out.data_ptr(),
                                            ws.data_ptr(), nbytes, self._stream()), "hmmr_temporal_fwd")
         return out
+
+    def hallucinate(self, phi):
+        """phi [..., 2048] -> hallucinated movie strips, same shape.  fc2_res, src/models.py:270-296."""
+        if self.hw is None:
+            raise L.HmmrError("the loaded weights have no fc2_res/* variables (pred_mode 'hal')")
+        phi = self.to_device(phi)
+        flat = phi.reshape(-1, 2048)
+        m = flat.shape[0]
+        out = torch.empty_like(flat)
+        nbytes = self.lib.hmmr_hallucinator_workspace_bytes(m, self.temporal_dtype)
+        ws = self._ws["hal"].get(nbytes)
+        L.check(self.lib.hmmr_hallucinator_fwd(C.byref(self.hw), flat.data_ptr(), m, out.data_ptr(),
+                                               ws.data_ptr(), nbytes, self._stream()), "hmmr_hallucinator_fwd")
+        return out.reshape(phi.shape)
 
     def ief(self, strips):
         """strips [m,2048] -> omegas [R,m,85]; R = 1 + len(delta_t_values), deltas in sorted order.

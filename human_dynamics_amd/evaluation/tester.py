@@ -9,9 +9,9 @@ Same constructor, attributes and methods as the reference:
 
 ``config`` is duck-typed (load_path, batch_size, sequence_length, pred_mode,
 num_conv_layers, delta_t_values, smpl_model_path, num_kps).  Differences, all
-deliberate: errors raise instead of dropping into ipdb; weights come from an
-``.npz`` with the checkpoint's variable names (or ``synthetic[:seed]``) because
-TF checkpoints cannot be read without TF yet (SURVEY section 8 f-1);
+deliberate: errors raise instead of dropping into ipdb; weights are read from the
+TF checkpoint-V2 files natively (no TensorFlow; or an ``.npz`` with the same
+variable names, or ``synthetic[:seed]``);
 ``predict_all_images`` pushes every frame through the ResNet once instead of
 T/g = 2.5 times (inference-mode ResNet is per-frame independent, so the
 result is identical; pass ``dedup=False`` for the literal schedule).
@@ -34,19 +34,20 @@ OUTPUT_KEYS = ("cams", "joints", "kps", "poses", "shapes", "verts", "omegas")
 
 
 def load_weights(load_path, resnet_path=""):
-    """'synthetic[:seed]' or .npz files holding the checkpoint variable names of
-    SURVEY App. B.  ResNet variables come from `resnet_path` when given
-    (tester.py:99-112)."""
+    """Checkpoint variables by name: a TensorFlow checkpoint-V2 prefix such as
+    'models/hmmr_model.ckpt-1119816' (read natively, human_dynamics_amd/tf_checkpoint.py), an
+    .npz with the same names, or 'synthetic[:seed]'.  ResNet variables come from `resnet_path`
+    when given (tester.py:99-112)."""
+    from .. import tf_checkpoint
+
     def one(path):
         if str(path).startswith("synthetic"):
             seed = int(str(path).split(":")[1]) if ":" in str(path) else 0
             return assets.make_synthetic_weights(seed)
-        if os.path.exists(path) and path.endswith(".npz"):
+        if os.path.exists(path) and str(path).endswith(".npz"):
             return {k: v for k, v in np.load(path).items()}
-        if os.path.exists(str(path) + ".index"):
-            raise NotImplementedError(
-                "%s is a TF checkpoint; convert it to .npz with the variable names of SURVEY App. B "
-                "(a native TF-checkpoint-V2 reader is a later row, SURVEY 8 f-1)" % path)
+        if tf_checkpoint.is_checkpoint(path):
+            return tf_checkpoint.read_checkpoint(path)
         raise FileNotFoundError("{} doesnt exist..".format(path))
     w = dict(one(load_path))
     if resnet_path:
@@ -87,13 +88,11 @@ class Tester(object):
         self.use_containers = use_containers
         if self.pred_mode not in ("pred", "hal"):
             raise Exception("Pred mode {} not recognized".format(self.pred_mode))
-        if self.pred_mode == "hal":
-            raise NotImplementedError("pred_mode 'hal' is a later hot-path row (SURVEY.md section 8 f-4)")
 
         if weights is None:
             weights = load_weights(config.load_path, pretrained_resnet_path)
         if smpl is None:
-            smpl = load_smpl_constants(self.smpl_model_path)
+            smpl = load_smpl_constants(self.smpl_model_path, checkpoint_vars=weights)
         dtype = dtype or getattr(config, "dtype", "bf16")
         device = device or getattr(config, "device", "cuda:0")
         self.engine = HmmrEngine(weights, smpl, dtype=dtype, device=device,
@@ -200,6 +199,13 @@ class Tester(object):
             rec[:, base["omegas"]:base["omegas"] + 85] = om[r]
         return out
 
+    def _movie_strips(self, img_feat_full):
+        """tester.py:183-194: temporal encoder ('pred') or hallucinator ('hal')."""
+        if self.pred_mode == "pred":
+            return self.f_temporal_enc(is_training=False, net=img_feat_full,
+                                       num_conv_layers=self.num_conv_layers, engine=self.engine)
+        return self.f_hal(img_feat_full, engine=self.engine)
+
     def predict_device(self, images):
         """Forward pass on device tensors: images [B,T,224,224,3] -> dict of device tensors."""
         from ..dist import unpack_outputs
@@ -207,8 +213,7 @@ class Tester(object):
         I_t = self.engine.to_device(images).reshape(B * T, self.img_size, self.img_size, 3)
         img_feat, _ = self.f_image_enc(I_t, engine=self.engine, is_training=False, reuse=False)
         img_feat_full = img_feat.reshape(B, T, -1)
-        movie_strips = self.f_temporal_enc(is_training=False, net=img_feat_full,
-                                           num_conv_layers=self.num_conv_layers, engine=self.engine)
+        movie_strips = self._movie_strips(img_feat_full)
         if self.use_containers:      # the reference's OmegasPred route (same numbers, more copies)
             return self._fetch(self._regress(movie_strips, B, T), to_numpy=False)
         rec = self.predict_records(movie_strips.reshape(B * T, -1))
@@ -239,7 +244,7 @@ class Tester(object):
         (the centre g = T - 2*margin of each, tester.py:305-311)."""
         T = self.sequence_length
         margin = (self.fov - 1) // 2
-        strips = self.engine.temporal(windows)
+        strips = self._movie_strips(windows)
         kept = strips[:, margin:T - margin].reshape(-1, strips.shape[-1])[:n_keep]
         return self.predict_records(kept, out)
 

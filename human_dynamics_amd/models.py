@@ -52,8 +52,9 @@ def az_fc2_groupnorm(is_training, net, num_conv_layers, engine):
 
 
 def fc2_res(phi, engine, name="fc2_res"):
-    """Hallucinator (src/models.py:270-296, pred_mode == 'hal')."""
-    raise NotImplementedError("pred_mode 'hal' is a later hot-path row (SURVEY.md section 8 f-4)")
+    """phi [B,T,2048] -> hallucinated movie strip [B,T,2048]: phi + fc3(relu(fc2(relu(fc1 phi))))
+    (src/models.py:270-296, pred_mode == 'hal')."""
+    return engine.hallucinate(phi)
 
 
 def batch_pred_omega(input_features, batch_size, is_training, num_output, omega_mean,

@@ -119,6 +119,19 @@ def pack_temporal(w, dtype, store, num_conv_layers=3):
     return tw
 
 
+def pack_hallucinator(w, dtype, store):
+    """fc2_res/fc{1,2,3} (src/models.py:283-294); None when the checkpoint has no hallucinator."""
+    if "fc2_res/fc1/weights" not in w:
+        return None
+    hw = L.HallucinatorWeights()
+    hw.dtype = dtype
+    for k in ("fc1", "fc2", "fc3"):
+        lay = _layer(store, _pad_rows(np.ascontiguousarray(w["fc2_res/%s/weights" % k].T)), dtype,
+                     shift=w["fc2_res/%s/biases" % k])
+        setattr(hw, k, lay)
+    return hw
+
+
 def pack_ief(w, dtype, store, delta_t_values=(-5, 5), num_stages=3):
     iw = L.IefWeights()
     scopes = assets.ief_scopes(delta_t_values)

@@ -22,27 +22,58 @@ def _undo_chumpy(x):
     return x if isinstance(x, np.ndarray) else np.asarray(x.r)
 
 
-def load_smpl_constants(path):
-    """'synthetic[:seed]' | .npz in the tf_smpl layout | SMPL .pkl (needs chumpy
-    importable for the official pickles, like the reference)."""
-    if path is None or str(path).startswith("synthetic"):
-        seed = int(str(path).split(":")[1]) if path and ":" in str(path) else 2
+class _ChStub(object):
+    """Stand-in for chumpy.Ch while unpickling: the SMPL pickles store leaf arrays as chumpy
+    objects whose state holds the ndarray under 'x'; `.r` is all the reference uses
+    (batch_smpl.py:22-23)."""
+    def __setstate__(self, state):
+        self.__dict__.update(state if isinstance(state, dict) else {})
+
+    @property
+    def r(self):
+        return np.asarray(self.__dict__["x"])
+
+
+class _SmplUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        if module.split(".")[0] == "chumpy":
+            return _ChStub
+        return super().find_class(module, name)
+
+
+_CKPT_SMPL_VARS = ("v_template", "shapedirs", "J_regressor", "posedirs", "lbs_weights", "cocoplus_regressor")
+
+
+def load_smpl_constants(path, checkpoint_vars=None):
+    """'synthetic[:seed]' | .npz in the tf_smpl layout | SMPL .pkl (chumpy NOT required) |
+    the SMPL variables the reference saves inside its checkpoint (non-trainable tf.Variables,
+    batch_smpl.py:35-80), when `path` does not exist but `checkpoint_vars` has them."""
+    if path is not None and str(path).startswith("synthetic"):
+        seed = int(str(path).split(":")[1]) if ":" in str(path) else 2
         return assets.make_synthetic_smpl(seed)
-    if not os.path.exists(path):
+    if path is None or not os.path.exists(path):
+        if checkpoint_vars is not None and all(k in checkpoint_vars for k in _CKPT_SMPL_VARS):
+            out = {k: np.asarray(checkpoint_vars[k], np.float32) for k in _CKPT_SMPL_VARS}
+            out["parents"] = assets.SMPL_PARENTS.copy()      # kintree_table[0] of every SMPL model
+            return out
         raise FileNotFoundError("SMPL model %s does not exist" % path)
-    if path.endswith(".npz"):
+    if str(path).endswith(".npz"):
         return {k: v for k, v in np.load(path).items()}
     with open(path, "rb") as f:
-        dd = pickle.load(f, encoding="latin1")
-    nb = dd["shapedirs"].shape[-1]
+        dd = _SmplUnpickler(f, encoding="latin1").load()
+    nb = _undo_chumpy(dd["shapedirs"]).shape[-1]
+    posedirs = _undo_chumpy(dd["posedirs"])
+
+    def dense_t(m):
+        return np.asarray(m.T.todense() if hasattr(m, "todense") else np.asarray(m).T, np.float32)
     out = {
         "v_template": _undo_chumpy(dd["v_template"]).astype(np.float32),
         "shapedirs": np.reshape(_undo_chumpy(dd["shapedirs"]), [-1, nb]).T.astype(np.float32),
-        "J_regressor": np.asarray(dd["J_regressor"].T.todense(), np.float32),
-        "posedirs": np.reshape(_undo_chumpy(dd["posedirs"]), [-1, dd["posedirs"].shape[-1]]).T.astype(np.float32),
-        "parents": dd["kintree_table"][0].astype(np.int32),
+        "J_regressor": dense_t(dd["J_regressor"]),
+        "posedirs": np.reshape(posedirs, [-1, posedirs.shape[-1]]).T.astype(np.float32),
+        "parents": np.asarray(dd["kintree_table"])[0].astype(np.int64).astype(np.int32),
         "lbs_weights": _undo_chumpy(dd["weights"]).astype(np.float32),
-        "cocoplus_regressor": np.asarray(dd["cocoplus_regressor"].T.todense(), np.float32),
+        "cocoplus_regressor": dense_t(dd["cocoplus_regressor"]),
     }
     return out
 

@@ -158,6 +158,17 @@ size_t hmmr_temporal_workspace_bytes(int b, int t, int dtype);
 int hmmr_temporal_fwd(const hmmr_temporal_weights_t* w, const float* phi, int b, int t,
                       float* strips, void* ws, size_t ws_bytes, void* stream);
 
+/* Hallucinator fc2_res (src/models.py:270-296, pred_mode == 'hal'): phi [m,2048] fp32 ->
+ * phi + fc3(relu(fc2(relu(fc1 phi)))) [m,2048] fp32; each w is [2048][2048], shift = bias. */
+typedef struct {
+    int dtype;
+    hmmr_layer_t fc1, fc2, fc3;
+} hmmr_hallucinator_weights_t;
+
+size_t hmmr_hallucinator_workspace_bytes(int m, int dtype);
+int hmmr_hallucinator_fwd(const hmmr_hallucinator_weights_t* w, const float* phi, int m,
+                          float* out, void* ws, size_t ws_bytes, void* stream);
+
 /* Standalone GroupNorm(+ReLU) over (time, channels-in-group), exposed for tests:
  * tf.contrib.layers.group_norm(reduction_axes=(-3,-2)), src/models.py:155-161. */
 int hmmr_groupnorm_relu(const float* x, const float* gamma, const float* beta, int b, int t,

@@ -121,3 +121,24 @@ def test_resnet_zero_tail_equals_explicit_zero_images(weights, gpu_device):
     assert a.shape == (5, 2048) and np.array_equal(a, b)
     c = eng.resnet(frames[:0], n_zero=1).cpu().numpy()
     assert np.array_equal(c, a[3:4])
+
+
+def test_hal_mode_matches_oracle(smpl_consts, gpu_device):
+    """pred_mode 'hal' (tester.py:189-190): the hallucinator fc2_res replaces the temporal encoder."""
+    import torch
+    from human_dynamics_amd.evaluation.tester import Tester
+    from oracle import hmmr_oracle as O
+    w = assets.make_synthetic_weights(0, with_hallucinator=True)
+    frames = assets.make_synthetic_frames(8, seed=21).reshape(2, 4, 224, 224, 3)
+    t = Tester(Config(batch_size=2, sequence_length=4, pred_mode="hal"), weights=w, smpl=smpl_consts,
+               dtype="f32", device=gpu_device)
+    got = t.predict(frames)
+    ref = O.OracleTester(w, smpl_consts, batch_size=2, sequence_length=4, pred_mode="hal",
+                         dtype=torch.float64).predict(frames)
+    for k in ("omegas", "verts", "joints", "verts_delta", "kps"):
+        assert np.abs(got[k] - ref[k]).max() < 1e-4, k
+    # and the stage alone
+    phi = np.random.default_rng(0).normal(size=(3, 5, 2048)).astype(np.float32)
+    out = t.engine.hallucinate(phi).cpu().numpy()
+    ref = O.fc2_res(phi, w, torch.float64).numpy()
+    assert np.abs(out - ref).max() < 1e-4
