@@ -79,7 +79,7 @@ def test_smpl_pickle_loads_without_chumpy(tmp_path, smpl_consts):
     class Ch(object):
         def __init__(self, x):
             self.x = np.asarray(x)
-    Ch.__module__ = "chumpy.ch"
+    Ch.__module__, Ch.__qualname__ = "chumpy.ch", "Ch"
     sub.Ch = Ch; mod.ch = sub
     sys.modules["chumpy"], sys.modules["chumpy.ch"] = mod, sub
     try:
