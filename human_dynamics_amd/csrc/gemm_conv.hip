@@ -169,11 +169,31 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const ConvArg
     u32x4 ra[PRO ? PA : 1];
     f32x4 psc[PRO ? EPS / 4 : 1], psh[PRO ? EPS / 4 : 1];     // scale/shift of this lane's EPS channels
     unsigned ra_ok = 0u;
-    auto load_tile = [&](int kt, int buf) {
+    // A operand of K step kt, LDS-DMA route (non-PRO)
+    auto glds_a = [&](int kt, int buf) {
         int tap;
         const int koff = UTAP ? tap_of(kt * BKE, tap) : tap_of(kt * BKE + lslot * EPS, tap) - lslot * EPS;
         char* sa = smem + buf * STAGE + wave * 1024;
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const bool ok = (amask[p] >> tap) & 1u;
+            const void* src = ok ? (const void*)(aptr[p] + koff) : (const void*)g_zero_page;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + p * (RPP * 128)), 16, 0, 0);
+        }
+    };
+    // B operand of K step kt, always LDS-DMA
+    auto glds_b = [&](int kt, int buf) {
+        char* sb = smem + buf * STAGE + A_BYTES + wave * 1024;
+#pragma unroll
+        for (int p = 0; p < PB; ++p)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wptr + (long long)(RPP * p) * a.K + kt * BKE),
+                                             (lptr_t)(sb + p * (RPP * 128)), 16, 0, 0);
+    };
+    // PRO: raw A slots of K step kt (and the pre-activation constants of their channels) -> VGPRs
+    auto load_a_regs = [&](int kt) {
         if constexpr (PRO) {
+            int tap;
+            const int koff = tap_of(kt * BKE, tap);
             const int ci = ((kt * BKE) & cin_mask) + lslot * EPS;
 #pragma unroll
             for (int q = 0; q < EPS / 4; ++q) {
@@ -187,20 +207,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const ConvArg
                 if ((amask[p] >> tap) & 1u) { v = *(const u32x4*)(aptr[p] + koff); ra_ok |= 1u << p; }
                 ra[p] = v;
             }
-        } else {
-#pragma unroll
-            for (int p = 0; p < PA; ++p) {
-                const bool ok = (amask[p] >> tap) & 1u;
-                const void* src = ok ? (const void*)(aptr[p] + koff) : (const void*)g_zero_page;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + p * (RPP * 128)), 16, 0, 0);
-            }
         }
-#pragma unroll
-        for (int p = 0; p < PB; ++p)
-            __builtin_amdgcn_global_load_lds((gptr_t)(wptr + (long long)(RPP * p) * a.K + kt * BKE),
-                                             (lptr_t)(sa + A_BYTES + p * (RPP * 128)), 16, 0, 0);
     };
-    auto store_tile = [&](int buf) {
+    // PRO: pre-activate the slots held in VGPRs and write them to LDS stage `buf`
+    auto store_a_regs = [&](int buf) {
         if constexpr (PRO) {
             char* sa = smem + buf * STAGE + r0 * 128 + pslot * 16;
 #pragma unroll
@@ -284,15 +294,31 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const ConvArg
     // split-K: slice blockIdx.y owns K steps [kt0, kt1) and writes a raw fp32 partial plane
     const int kt0 = blockIdx.y * a.kt_per_slice;
     const int kt1 = min(nk, kt0 + a.kt_per_slice);
-    load_tile(kt0, 0);
-    store_tile(0);
-    __syncthreads();
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int cur = (kt - kt0) & 1;
-        if (kt + 1 < kt1) load_tile(kt + 1, cur ^ 1);
-        compute_stage(smem + cur * STAGE);
-        if (kt + 1 < kt1) store_tile(cur ^ 1);
+    if constexpr (PRO) {
+        // A(kt+1) was fetched into VGPRs a whole K step earlier, so pre-activating and writing it at
+        // the TOP of step kt never waits for HBM; its registers are then free for A(kt+2).
+        load_a_regs(kt0);
+        glds_b(kt0, 0);
+        store_a_regs(0);
+        if (kt0 + 1 < kt1) load_a_regs(kt0 + 1);
         __syncthreads();
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const int cur = (kt - kt0) & 1;
+            if (kt + 1 < kt1) { store_a_regs(cur ^ 1); glds_b(kt + 1, cur ^ 1); }
+            if (kt + 2 < kt1) load_a_regs(kt + 2);
+            compute_stage(smem + cur * STAGE);
+            __syncthreads();
+        }
+    } else {
+        glds_a(kt0, 0);
+        glds_b(kt0, 0);
+        __syncthreads();
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const int cur = (kt - kt0) & 1;
+            if (kt + 1 < kt1) { glds_a(kt + 1, cur ^ 1); glds_b(kt + 1, cur ^ 1); }
+            compute_stage(smem + cur * STAGE);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: accumulators -> LDS as fp32 [BM][BN]

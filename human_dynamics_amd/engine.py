@@ -52,11 +52,11 @@ class HmmrEngine(object):
         self.dtype = _dt(dtype)
         self.temporal_dtype = self.dtype if temporal_dtype is None else _dt(temporal_dtype)
         self.ief_dtype = self.dtype if ief_dtype is None else _dt(ief_dtype)
-        self.resnet_chunk = int(resnet_chunk)
+        self.resnet_chunk = int(os.environ.get("HMMR_RESNET_CHUNK", resnet_chunk))   # env: dev A/B switch
         self.store = packing.DeviceStore(self.device)
         self.num_conv_layers = num_conv_layers
         self.delta_keys = sorted(int(d) for d in delta_t_values)
-        fuse = tuple(b for b in os.environ.get("HMMR_FUSE_PREACT", "block1").split(",") if b)   # dev A/B switch
+        fuse = tuple(b for b in os.environ.get("HMMR_FUSE_PREACT", "block1,block2,block3,block4").split(",") if b)   # dev A/B switch
         self.rw = (packing.pack_resnet(weights, self.dtype, self.store, fuse_preact_blocks=fuse)
                    if weights is not None else None)
         self.tw = (packing.pack_temporal(weights, self.temporal_dtype, self.store, num_conv_layers)
