@@ -2,9 +2,10 @@
 // -> tf.contrib.slim.nets.resnet_v2.resnet_v2_50(num_classes=None,
 // is_training=False).  Layer semantics restated in SURVEY.md App. A.
 //
-// All 53 convolutions run through the implicit-GEMM kernel (gemm_conv.hip);
-// this file holds the three bandwidth kernels around them and the launch
-// sequence:
+// The 52 convolutions after the stem run through the implicit-GEMM kernel
+// (gemm_conv.hip); the stem + pool1 + first preact is one fused kernel
+// (stem.hip).  This file holds the launch sequence, pool5, and the unfused stem
+// route kept for A/B measurements:
 //   stem_repack       fp32 RGB [n,224,224,3] -> zero-padded RGBX [n,230,232,4]
 //                     in the operand dtype, so the 7x7/2 stem (explicit pad 3,
 //                     VALID) becomes an 8-tap x 32-element implicit GEMM
@@ -15,8 +16,14 @@
 //   bn_relu_avgpool   postnorm BN + ReLU + spatial mean (pool5)
 // Inference BN is folded to y = x*scale + shift on the host
 // (scale = gamma*rsqrt(var+1e-5), shift = beta - mean*scale).
+#include <stdlib.h>
+
 #include "common.h"
 #include "hmmr_hip.h"
+
+// csrc/stem.hip
+int hmmr_stem_fused(const float* images, int n_real, int n, const void* wts, const float* bias,
+                    const float* pscale, const float* pshift, void* out, int dtype, hipStream_t s);
 
 static constexpr int IMG = 224, PADH = 230, PADW = 232;
 
@@ -174,8 +181,20 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
     Prof pf; pf.ms = prof_ms; pf.s = s; pf.slot = 0;
     if (prof_begin(pf)) return -2;
 
-    // ---- stem: repack -> 7x7/2 conv (+bias, no BN/ReLU) -> pool1 + preact of block1/unit_1
-    {
+    // ---- stem: 7x7/2 conv (+bias, no BN/ReLU) -> pool1 -> preact of block1/unit_1.
+    // Default: ONE fused kernel (csrc/stem.hip).  HMMR_STEM=unfused keeps the three-kernel route
+    // (re-pack, implicit GEMM, pool) for A/B measurements.
+    // In fp32-operand mode the fused kernel needs 104 KB of LDS (one workgroup per CU) and measures
+    // ~1 % slower than the three-kernel route, which therefore stays the fp32 default.
+    static const int stem_env = [] { const char* e = getenv("HMMR_STEM"); return !e ? 0 : (e[0] == 'u' ? 1 : 2); }();
+    const bool unfused = stem_env == 1 || (stem_env == 0 && w->dtype == HMMR_F32);
+    if (!unfused) {
+        if (hmmr_stem_fused(images, n_real, n, w->stem.w, w->stem.shift, w->unit[0].pre_scale,
+                            w->unit[0].pre_shift, P[0], w->dtype, s)) return -2;
+        if (prof_mark(pf)) return -2;
+        if (prof_mark(pf)) return -2;     // (keeps the profile slot numbering of the 3-kernel route)
+        if (prof_mark(pf)) return -2;
+    } else {
         const long long npix = (long long)n * PADH * PADW;
         const int grid = (int)((npix + 255) / 256 < 8192 ? (npix + 255) / 256 : 8192);
         hipLaunchKernelGGL(stem_repack_kernel<T>, dim3(grid), dim3(256), 0, s, images, xpad, npix, (long long)n_real);

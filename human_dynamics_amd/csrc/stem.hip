@@ -1,0 +1,219 @@
+// Fused ResNet-v2-50 stem for gfx950: slim `conv2d_same(x, 64, 7, stride=2)` (explicit zero pad 3,
+// VALID, + bias, no BN/ReLU) -> `max_pool2d([3,3], stride=2, padding=SAME)` (pad bottom/right only)
+// -> block1/unit_1 `preact` BN + ReLU, in ONE kernel.  fp32 RGB images in, the
+// pooled pre-activated [n,56,56,64] tensor out: the 112x112x64 conv map (1.6 MB/frame in bf16) and
+// the re-packed RGBX image never touch HBM.
+//
+// One workgroup (4 waves) per 8x8 tile of POOLED pixels of one image:
+//   1. the 39x39 input patch it needs is read from the fp32 image (zeros outside the image = the
+//      explicit padding), converted to the operand type and stored in LDS as RGBX (8/16 B per pixel);
+//   2. the 64 filters, packed [64][tap ky][8 px x RGBX] (kx = 7 and X are zero), go to LDS with
+//      16-B-padded rows (conflict-free ds_read_b128 across 16 filters);
+//   3. the 17x17 conv pixels of the tile are the rows of an implicit GEMM whose A fragments are read
+//      STRAIGHT out of the patch: 8 consecutive k of tap ky = 2 neighbouring RGBX pixels = one
+//      aligned 16-byte LDS read -- no im2col buffer.  M = 289 (10 MFMA tiles of 32), N = 64, K = 7x32;
+//   4. conv + bias is staged in LDS in the activation type (the rounding point of the unfused path),
+//      then each lane max-pools 3x3/2 windows of 8 channels, applies scale/shift + ReLU, and writes
+//      16 B (bf16) / 32 B (fp32) of a 128/256-B pixel row.
+#include "common.h"
+#include "hmmr_hip.h"
+
+namespace {
+constexpr int IMG = 224, CONV = 112, POOL = 56, CO = 64;
+constexpr int PT = 8;                 // pooled tile edge
+constexpr int CT = 2 * PT + 1;        // conv tile edge (17)
+constexpr int IP = 2 * CT + 5;        // input patch edge (39)
+constexpr int IPW = 40;               // patch row stride in pixels
+constexpr int NPIX = CT * CT;         // 289 conv pixels per tile
+constexpr int MT = (NPIX + 31) / 32;  // 10 MFMA row tiles
+constexpr int TAPK = 32;              // K elements per tap: 8 pixels x RGBX
+constexpr int WK = 256;               // packed filter row in HBM: 8 taps x 32 (tap 7 is zero, unused here)
+
+template <typename T> struct StemLds {
+    static constexpr int PXB = 4 * (int)sizeof(T);                 // bytes per RGBX pixel
+    static constexpr int PATCH = IP * IPW * PXB;
+    static constexpr int WROW = 7 * TAPK * (int)sizeof(T) + 16;    // padded filter row
+    static constexpr int WTS = CO * WROW;
+    static constexpr int CST = MT * 32 * CO * (int)sizeof(T);      // conv staging (overlaps the filters)
+    static constexpr int TOTAL = PATCH + (WTS > CST ? WTS : CST);
+};
+
+template <typename T> struct StemFrag;
+template <> struct StemFrag<float> { typedef f32x4 type; };
+template <> struct StemFrag<bf16_t> { typedef bf16x8 type; };
+
+__device__ __forceinline__ f32x16 stem_mma(const f32x4& a, const f32x4& b, f32x16 c) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], c, 0, 0, 0);
+    return c;
+}
+__device__ __forceinline__ f32x16 stem_mma(const bf16x8& a, const bf16x8& b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void store_rgbx(float* o, float r, float g, float b) {
+    *(f32x4*)o = f32x4{r, g, b, 0.f};
+}
+__device__ __forceinline__ void store_rgbx(bf16_t* o, float r, float g, float b) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    *(bf16x4*)o = bf16x4{(bf16_t)r, (bf16_t)g, (bf16_t)b, (bf16_t)0.f};
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void stem_fused_kernel(const float* __restrict__ img, const T* __restrict__ wts,
+                                                         const float* __restrict__ bias,
+                                                         const float* __restrict__ pscale,
+                                                         const float* __restrict__ pshift, T* __restrict__ out,
+                                                         int n_real) {
+    typedef StemLds<T> LD;
+    typedef typename StemFrag<T>::type frag_t;
+    constexpr int CPT = (int)sizeof(T);           // 32-byte MFMA chunks per tap: 2 (bf16) / 4 (fp32)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_patch = smem;
+    char* s_w = smem + LD::PATCH;
+    T* s_c = (T*)(smem + LD::PATCH);              // reuses the filter region after the MFMAs
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ty = blockIdx.x / (POOL / PT), tx = blockIdx.x % (POOL / PT);
+    const int n = blockIdx.y;
+    const int cy0 = 2 * PT * ty, cx0 = 2 * PT * tx;          // first conv row/col of the tile
+    const int iy0 = 2 * cy0 - 3, ix0 = 2 * cx0 - 3;          // first input row/col of the patch
+
+    // ---- 1. input patch -> LDS (RGBX, operand type); zeros outside the image and for zero-tail images.
+    // Work item = 4 pixels starting at a global column that is a multiple of 4: 12 floats = three
+    // aligned 16-byte loads (image rows are 2688 B, a multiple of 16).  The patch starts at column
+    // ix0 = 32*tx - 3, so groups 32*tx - 4 + 4*q (q = 0..10) cover it; a group is entirely inside or
+    // outside the image (224 is a multiple of 4).
+    const float* im = img + (long long)n * IMG * IMG * 3;
+    for (int i = tid; i < IP * 11; i += 256) {
+        const int py = i / 11, q = i - py * 11;
+        const int gy = iy0 + py, gx = ix0 - 1 + 4 * q;
+        float f[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) f[e] = 0.f;
+        if (n < n_real && (unsigned)gy < (unsigned)IMG && (unsigned)gx < (unsigned)IMG) {
+            const f32x4* p = (const f32x4*)(im + (gy * IMG + gx) * 3);
+            const f32x4 v0 = p[0], v1 = p[1], v2 = p[2];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { f[e] = v0[e]; f[4 + e] = v1[e]; f[8 + e] = v2[e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int px = 4 * q - 1 + e;                     // patch column of this pixel
+            if ((unsigned)px < (unsigned)IPW) {
+                T* o = (T*)(s_patch + (py * IPW + px) * LD::PXB);
+                store_rgbx(o, f[3 * e], f[3 * e + 1], f[3 * e + 2]);
+            }
+        }
+    }
+    // ---- 2. filters -> LDS, rows padded by 16 B
+    constexpr int SLOTS_PER_ROW = 7 * TAPK * (int)sizeof(T) / 16;
+    for (int i = tid; i < CO * SLOTS_PER_ROW; i += 256) {
+        const int row = i / SLOTS_PER_ROW, sl = i - row * SLOTS_PER_ROW;
+        *(u32x4*)(s_w + row * LD::WROW + sl * 16) = *(const u32x4*)((const char*)(wts + (long long)row * WK) + sl * 16);
+    }
+    __syncthreads();
+
+    // ---- 3. implicit GEMM: wave w owns row tiles w, w+4, w+8 (all 64 output channels)
+    const int lr = lane & 31, lh = lane >> 5;
+    constexpr int MPW = (MT + 3) / 4;             // row tiles per wave (3)
+    f32x16 acc[MPW][2];
+#pragma unroll
+    for (int i = 0; i < MPW; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    int abase[MPW];
+#pragma unroll
+    for (int i = 0; i < MPW; ++i) {
+        int p = (wave + 4 * i) * 32 + lr;
+        if (p >= NPIX) p = 0;                     // padding rows of the last tile: computed, never used
+        const int cy = p / CT, cx = p - cy * CT;
+        abase[i] = ((2 * cy) * IPW + 2 * cx) * LD::PXB + lh * 16;
+    }
+    const int bbase = lr * LD::WROW + lh * 16;
+#pragma unroll 1
+    for (int ky = 0; ky < 7; ++ky) {
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            const frag_t b0 = *(const frag_t*)(s_w + bbase + ky * TAPK * (int)sizeof(T) + c * 32);
+            const frag_t b1 = *(const frag_t*)(s_w + bbase + 32 * LD::WROW + ky * TAPK * (int)sizeof(T) + c * 32);
+#pragma unroll
+            for (int i = 0; i < MPW; ++i) {
+                if (wave + 4 * i < MT) {
+                    const frag_t a = *(const frag_t*)(s_patch + abase[i] + ky * IPW * LD::PXB + c * 32);
+                    acc[i][0] = stem_mma(a, b0, acc[i][0]);
+                    acc[i][1] = stem_mma(a, b1, acc[i][1]);
+                }
+            }
+        }
+    }
+    __syncthreads();                              // every wave is done with the filters: reuse as staging
+
+    // ---- 4a. conv + bias -> LDS [pixel][64] in the activation type
+#pragma unroll
+    for (int i = 0; i < MPW; ++i) {
+        if (wave + 4 * i < MT) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int ch = j * 32 + lr;
+                const float bch = bias[ch];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int p = (wave + 4 * i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    s_c[p * CO + ch] = elem_traits<T>::from_f32(acc[i][j][r] + bch);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 4b. 3x3/2 max pool (TF SAME: rows/cols past 111 do not exist) + preact BN + ReLU
+    for (int it = tid; it < PT * PT * (CO / 8); it += 256) {
+        const int v8 = it & 7, pp = it >> 3;
+        const int py = pp / PT, px = pp - py * PT;
+        float m[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = -3.0e38f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            if (cy0 + 2 * py + dy >= CONV) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                if (cx0 + 2 * px + dx >= CONV) continue;
+                float v[8];
+                load8(s_c + ((2 * py + dy) * CT + 2 * px + dx) * CO + v8 * 8, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], v[j]);
+            }
+        }
+        float sc[8], sh[8];
+        load8(pscale + v8 * 8, sc); load8(pshift + v8 * 8, sh);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j] * sc[j] + sh[j], 0.f);
+        store8(out + (((long long)n * POOL + PT * ty + py) * POOL + PT * tx + px) * CO + v8 * 8, m);
+    }
+}
+}  // namespace
+
+// images [n_real,224,224,3] fp32 (+ n - n_real implicit zero images) -> out [n,56,56,64] (dtype)
+int hmmr_stem_fused(const float* images, int n_real, int n, const void* wts, const float* bias,
+                    const float* pscale, const float* pshift, void* out, int dtype, hipStream_t s) {
+    if (dtype == HMMR_BF16) {
+        auto kern = stem_fused_kernel<bf16_t>;
+        static bool set16 = false;
+        if (!set16) { HMMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, StemLds<bf16_t>::TOTAL)); set16 = true; }
+        hipLaunchKernelGGL(kern, dim3((POOL / PT) * (POOL / PT), n), dim3(256), StemLds<bf16_t>::TOTAL, s, images,
+                           (const bf16_t*)wts, bias, pscale, pshift, (bf16_t*)out, n_real);
+    } else {
+        auto kern = stem_fused_kernel<float>;
+        static bool set32 = false;
+        if (!set32) { HMMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, StemLds<float>::TOTAL)); set32 = true; }
+        hipLaunchKernelGGL(kern, dim3((POOL / PT) * (POOL / PT), n), dim3(256), StemLds<float>::TOTAL, s, images,
+                           (const float*)wts, bias, pscale, pshift, (float*)out, n_real);
+    }
+    HMMR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
