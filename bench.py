@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive leg (used for PMC passes)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the local pass as one hipGraph per step (measured equal to eager launches: "
+                         "the step is GPU-bound, the host keeps 150 launches ahead)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -130,10 +133,11 @@ def main():
     gen = torch.Generator(device=device)
     gen.manual_seed(1234 + rank)
     span = torch.rand((plan.f1 - plan.f0, 224, 224, 3), generator=gen, device=device) * 2 - 1
-    frames_fn = lambda f0, f1: span
+
+    predictor = hd.ShardedPredictor(tester, n_total, rank, world, use_graph=args.graph)
 
     def step():
-        return hd.predict_all_images_sharded(tester, frames_fn, n_total, rank, world)[0]
+        return predictor.run(span)
 
     def barrier():
         if world > 1:
@@ -218,7 +222,8 @@ def main():
                        "frames_per_gpu_per_step": args.frames, "windows_per_gpu": plan.w1 - plan.w0,
                        "resnet_frames_encoded_per_gpu": plan.f1 - plan.f0 + 1,
                        "resnet_schedule": "de-duplicated (1x per frame + halo; reference-literal is 2.5x)",
-                       "smpl_calls_per_frame": 3, "weights": "synthetic (seed 0), random-init, reference shapes",
+                       "smpl_calls_per_frame": 3, "launch": "hipGraph replay of the local pass" if args.graph else "eager",
+                       "weights": "synthetic (seed 0), random-init, reference shapes",
                        "parallelism": "window-sharded x%d, one RCCL all-gather" % world if world > 1 else "single GPU"},
             "per_gpu_fps": round(value / world, 1),
             "roofline": roofline,

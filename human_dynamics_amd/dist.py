@@ -95,31 +95,84 @@ def all_gather_outputs(local_buf, plan, group=None):
     return full[:plan.n_frames]
 
 
+class ShardedPredictor(object):
+    """One rank's share of ``Tester.predict_all_images`` for a video of `n_frames` frames,
+    re-usable across calls (the shard plan and the window index live on the device).
+
+    use_graph=True captures the local pass -- every launch from the ResNet to the three SMPL
+    evaluations, ~150 kernels -- into ONE hipGraph the first time it runs on a device-resident
+    input and replays it afterwards (no host launch work left in the step).  The input must then
+    be passed as the same device tensor each time (`static_frames`)."""
+
+    def __init__(self, tester, n_frames, rank=None, world_size=None, group=None, use_graph=False):
+        if world_size is None:
+            world_size = dist.get_world_size() if dist.is_initialized() else 1
+        if rank is None:
+            rank = dist.get_rank() if dist.is_initialized() else 0
+        self.tester, self.group, self.use_graph = tester, group, use_graph
+        self.plan = ShardPlan(n_frames, tester.batch_size, tester.sequence_length, tester.fov, world_size, rank)
+        self.layout, self.rec_len = tester.record_layout()
+        eng = tester.engine
+        p = self.plan
+        n_local = p.f1 - p.f0
+        if p.w1 > p.w0 and p.o1 > p.o0:
+            idx = torch.from_numpy(p.window_frame_index())
+            idx = torch.where(idx < 0, torch.full_like(idx, n_local), idx)     # row n_local = zero image
+            self.idx = idx.to(eng.device)
+        else:
+            self.idx = None
+        self.local = torch.zeros((p.out_per_rank, self.rec_len), dtype=torch.float32, device=eng.device)
+        self.graph, self.static_frames, self._warm = None, None, 0
+
+    def _local_pass(self, frames):
+        """frames [f1-f0,224,224,3] on the device -> self.local (packed records of this rank)."""
+        phi_all = self.tester.features(frames, n_zero=1)            # last row = feature of the zero image
+        if self.idx is not None:
+            self.tester.predict_strips_records(phi_all[self.idx], self.plan.o1 - self.plan.o0, out=self.local)
+        return self.local
+
+    def run_local(self, frames):
+        eng = self.tester.engine
+        if not (isinstance(frames, torch.Tensor) and frames.is_cuda):
+            frames = eng.to_device(frames)
+        if not self.use_graph:
+            return self._local_pass(frames)
+        if self.graph is not None:
+            if frames.data_ptr() != self.static_frames.data_ptr():
+                self.static_frames.copy_(frames)
+            self.graph.replay()
+            return self.local
+        if self._warm < 2:                                     # eager warm-up: sizes the workspaces
+            self._warm += 1
+            return self._local_pass(frames)
+        self.static_frames = frames
+        torch.cuda.synchronize(eng.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._local_pass(self.static_frames)
+        self.graph = g
+        g.replay()
+        return self.local
+
+    def run(self, frames, gather=True):
+        local = self.run_local(frames)
+        if not gather:
+            return local
+        return all_gather_outputs(local, self.plan, self.group)
+
+
 def predict_all_images_sharded(tester, frames_fn, n_frames, rank=None, world_size=None, group=None,
                                gather=True):
     """Distributed ``Tester.predict_all_images``.
 
     frames_fn(f0, f1) -> the real frames [f1-f0,224,224,3] of the video (host or
     device); every rank only ever asks for its own span.  Returns the packed
-    [n_frames, rec_len] device tensor (identical on every rank) and the layout."""
-    if world_size is None:
-        world_size = dist.get_world_size() if dist.is_initialized() else 1
-    if rank is None:
-        rank = dist.get_rank() if dist.is_initialized() else 0
-    plan = ShardPlan(n_frames, tester.batch_size, tester.sequence_length, tester.fov, world_size, rank)
-    layout, rec_len = tester.record_layout()
-    eng = tester.engine
-    frames = frames_fn(plan.f0, plan.f1) if plan.f1 > plan.f0 else None
-    if frames is None:
-        frames = torch.empty((0, tester.img_size, tester.img_size, 3), dtype=torch.float32, device=eng.device)
-    phi_all = tester.features(frames, n_zero=1)                 # last row = feature of the zero image
-    local = torch.zeros((plan.out_per_rank, rec_len), dtype=torch.float32, device=eng.device) \
-        if plan.o1 - plan.o0 < plan.out_per_rank else \
-        torch.empty((plan.out_per_rank, rec_len), dtype=torch.float32, device=eng.device)
-    if plan.w1 > plan.w0 and plan.o1 > plan.o0:
-        idx = torch.from_numpy(plan.window_frame_index()).to(eng.device)
-        idx = torch.where(idx < 0, torch.full_like(idx, phi_all.shape[0] - 1), idx)
-        tester.predict_strips_records(phi_all[idx], plan.o1 - plan.o0, out=local)
-    if not gather:
-        return local, layout, plan
-    return all_gather_outputs(local, plan, group), layout, plan
+    [n_frames, rec_len] device tensor (identical on every rank), the layout and the plan."""
+    sp = ShardedPredictor(tester, n_frames, rank, world_size, group)
+    p = sp.plan
+    if p.f1 > p.f0:
+        frames = frames_fn(p.f0, p.f1)
+    else:
+        frames = torch.empty((0, tester.img_size, tester.img_size, 3), dtype=torch.float32,
+                             device=tester.engine.device)
+    return sp.run(frames, gather), sp.layout, p
