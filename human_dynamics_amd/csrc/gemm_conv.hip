@@ -99,9 +99,10 @@ template <> __device__ __forceinline__ u32x4 preact_slot<bf16_t>(const u32x4& v,
 // UTAP = true : every 128-byte K step lies inside one filter tap (cin*sizeof >= 128), so the
 //               tap decode is wave-uniform scalar arithmetic.
 // NSTAGE: LDS stages (2 = next tile in flight while the current one is consumed).  A 3-stage ring
-//         (two tiles ahead, counted vmcnt + raw s_barrier) was measured 15-40 % SLOWER on every
-//         ResNet shape: it halves the resident workgroups per CU, and occupancy is what hides
-//         latency here.
+//         (two tiles ahead, counted vmcnt + raw s_barrier) was measured 10-40 % SLOWER on every
+//         ResNet shape, with 4-wave 128x128, 8-wave 128x128 and 8-wave 256x128 tiles alike: it
+//         halves the resident workgroups per CU, and resident waves are what hides latency in this
+//         structure.
 template <typename TA, typename TO, int BM, int BN, int WGM, int WGN, bool PRO, bool UTAP, int NSTAGE>
 __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const ConvArgs a) {
     static_assert(NSTAGE == 2, "only the 2-stage pipeline is kept");
