@@ -1,13 +1,21 @@
 """CPU oracle for HMMR's inference hot path -- TEST INFRASTRUCTURE ONLY.
 
-*** PARITY UNPINNED ***  The reference (akanazawa/human_dynamics) has no tests,
-no golden vectors and cannot run here (TensorFlow 1.8 / tf-slim / chumpy are
-not installable in this image).  This file is a
-literal restatement of the reference graph in PyTorch-CPU (float64 or
-float32), written from the reference sources and the TF-1.8 semantics of the
-un-vendored ops it calls.  It is pinned only by the
-algebraic known-answer tests in tests/test_oracle.py and by the committed
-fixtures in tests/golden/ that it generated itself.
+*** PARITY: PARTLY PINNED ***  The reference (akanazawa/human_dynamics) has no tests and no
+golden vectors, and TensorFlow 1.8 / tf-slim cannot be installed in this image (SURVEY.md
+section 8c).  This file is a literal restatement of the reference graph in PyTorch-CPU (float64 or
+float32), written from the reference sources and the TF-1.8 semantics of the un-vendored ops it
+calls.
+
+  * PINNED to the reference's own source: smpl_forward / batch_rodrigues /
+    batch_global_rigid_transformation / batch_orth_proj_idrot, the OmegasPred container semantics
+    (smpl_outputs) and the sliding-window arithmetic.  tests/golden/make_reference_golden.py imports
+    src/tf_smpl/*, src/omega.py and Tester.predict_all_images from the reference tree and EXECUTES
+    them on a NumPy stand-in for the elementary TF ops they call (oracle/tf_shim.py); this oracle
+    agrees with those outputs to 1e-12 (tests/test_reference_golden.py).
+  * UNPINNED (restatement only): resnet_v2_50, az_fc2_groupnorm (group_norm / conv2d), hmr_ief.
+    These depend on tf.contrib.slim / tf.contrib.layers code that is not in the reference tree; they
+    are pinned only by the algebraic known-answer tests in tests/test_oracle.py and by the fixtures
+    this file generated itself (tests/golden/window_b1_t20.npz, video_n24_b2_t20.npz).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
 this module.  The product path (human_dynamics_amd) never does.

@@ -1,0 +1,128 @@
+"""Parity against golden vectors produced by EXECUTING THE REFERENCE'S OWN SOURCE
+(tests/golden/make_reference_golden.py: src/tf_smpl/*, src/omega.py, Tester.predict_all_images and
+src/evaluation/eval_util.py imported from the reference tree and run on a NumPy stand-in for the
+elementary TF ops they call).  These fixtures pin (i) the CPU oracle and (ii) the HIP path for the
+SMPL / projection / container / sliding-window rows of the hot path."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, Config
+from human_dynamics_amd import assets
+from human_dynamics_amd import dist as hd
+from oracle import hmmr_oracle as O
+
+VSUB = 8
+F64 = torch.float64
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return dict(np.load(os.path.join(GOLDEN, "reference_smpl.npz")))
+
+
+@pytest.fixture(scope="module")
+def ref_windows():
+    return dict(np.load(os.path.join(GOLDEN, "reference_windows.npz")))
+
+
+# ------------------------------------------------------------------ the oracle vs the reference
+def test_oracle_smpl_equals_reference_code(ref, smpl_consts):
+    v, j, R = O.smpl_forward(ref["beta"], ref["theta"], smpl_consts, F64)
+    k = O.batch_orth_proj_idrot(j, torch.tensor(ref["cams"]))
+    assert np.abs(v.numpy()[:, ::VSUB] - ref["verts"]).max() < 1e-12
+    assert np.abs(j.numpy() - ref["joints"]).max() < 1e-12
+    assert np.abs(R.numpy() - ref["Rs"]).max() < 1e-13
+    assert np.abs(k.numpy() - ref["kps"]).max() < 1e-12
+
+
+def test_oracle_containers_equal_reference_omegaspred(ref, weights, smpl_consts):
+    """OmegasPred as driven by build_test_model: delta containers project with omega_0's camera,
+    keep [1,0,0] in their raw omega (tester.py:208-213, omega.py:263-304)."""
+    t = O.OracleTester(weights, smpl_consts, dtype=F64)
+    om0 = torch.tensor(ref["omg_omega0"]).reshape(-1, 85)
+    main = t.smpl_outputs(om0, om0[:, :3])
+    for k in ("cams", "joints", "kps", "poses", "shapes", "omegas"):
+        assert np.abs(main[k].numpy().reshape(ref["omg_" + k].shape) - ref["omg_" + k]).max() < 1e-12, k
+    assert np.abs(main["verts"].numpy()[:, ::VSUB].reshape(ref["omg_verts"].shape) - ref["omg_verts"]).max() < 1e-12
+    for tag, key in (("-5", "omg_delta_m5"), ("+5", "omg_delta_p5")):
+        d = t.smpl_outputs(torch.tensor(ref[key]).reshape(-1, 85), om0[:, :3])
+        for k in ("cams", "joints", "kps", "poses", "shapes", "omegas"):
+            g = ref["omg_%s_delta_%s" % (k, tag)]
+            assert np.abs(d[k].numpy().reshape(g.shape) - g).max() < 1e-12, (k, tag)
+
+
+def test_window_logic_equals_reference_predict_all_images(ref_windows):
+    """What the reference feeds the network (every window slot) and what it keeps, for several
+    (N, B): ShardPlan / window_plan reproduce both, on one rank and split over ranks."""
+    for key in [k for k in ref_windows if k.startswith("fed_")]:
+        n, B = [int(x[1:]) for x in key.split("_")[1:]]
+        fed = ref_windows[key].astype(np.int64)                  # [count*B, T], 1-based ids, -1 = zero image
+        kept = ref_windows["kept_n%d_b%d" % (n, B)]
+        assert np.array_equal(kept, np.arange(1, n + 1))         # every frame exactly once, in order
+        p = hd.ShardPlan(n, B, 20, 13, 1, 0)
+        idx = p.window_frame_index()
+        assert np.array_equal(np.where(idx >= 0, idx + 1, -1), fed)
+        for world in (2, 3):
+            parts = []
+            for r in range(world):
+                q = hd.ShardPlan(n, B, 20, 13, world, r)
+                ix = q.window_frame_index()
+                parts.append(np.where(ix >= 0, ix + q.f0 + 1, -1))
+            assert np.array_equal(np.concatenate(parts, 0), fed)
+
+
+def test_oracle_predict_all_images_uses_the_reference_windows(ref_windows, weights, smpl_consts):
+    from human_dynamics_amd.evaluation.tester import window_plan
+    for key in [k for k in ref_windows if k.startswith("fed_")]:
+        n, B = [int(x[1:]) for x in key.split("_")[1:]]
+        margin, g, count, num_fill = window_plan(n, B, 20, 13)
+        assert (margin, g) == (6, 8) and count * B == ref_windows[key].shape[0]
+        assert O.window_plan(n, B, 20, 13) == (margin, g, count, num_fill)
+
+
+# ------------------------------------------------------------------ the HIP path vs the reference
+@pytest.mark.gpu
+def test_hip_smpl_equals_reference_code(ref, smpl_consts, gpu_device):
+    """BASELINE metric 'SMPL verts max-abs-err' against the reference's own SMPL source: <= 1e-4."""
+    from human_dynamics_amd.engine import HmmrEngine
+    eng = HmmrEngine(None, smpl_consts, device=gpu_device)
+    verts, joints, kps, rs = eng.smpl(ref["theta"].astype(np.float32), ref["beta"].astype(np.float32),
+                                      ref["cams"].astype(np.float32))
+    errs = {"verts": np.abs(verts.cpu().numpy()[:, ::VSUB] - ref["verts"]).max(),
+            "joints": np.abs(joints.cpu().numpy() - ref["joints"]).max(),
+            "kps": np.abs(kps.cpu().numpy() - ref["kps"]).max(),
+            "Rs": np.abs(rs.cpu().numpy() - ref["Rs"]).max()}
+    print("HIP SMPL vs reference source (float64):", {k: "%.2e" % v for k, v in errs.items()})
+    assert all(e < 1e-4 for e in errs.values()), errs
+    assert errs["verts"] < 1e-5
+
+
+@pytest.mark.gpu
+def test_hip_containers_equal_reference_omegaspred(ref, weights, smpl_consts, gpu_device):
+    from human_dynamics_amd.engine import HmmrEngine
+    from human_dynamics_amd.omega import OmegasPred
+    eng = HmmrEngine(None, smpl_consts, device=gpu_device)
+    B, T = ref["omg_omega0"].shape[:2]
+    cfg = Config(batch_size=B)
+    reg = []
+    preds = {0: OmegasPred(cfg, eng, use_optcam=False, vis_max_batch=B, registry=reg)}
+    for dt in (-5, 5):
+        preds[dt] = OmegasPred(cfg, eng, use_optcam=True, vis_max_batch=B, registry=reg)
+    preds[0].append_batched(eng.to_device(ref["omg_omega0"]))
+    for dt, key in ((-5, "omg_delta_m5"), (5, "omg_delta_p5")):
+        preds[dt].append_batched(eng.to_device(ref[key]))
+        preds[dt].set_cams(preds[0].get_cams())
+    OmegasPred.compute_all_smpl(reg)
+    from human_dynamics_amd.evaluation.tester import Tester
+    for dt in (0, -5, 5):
+        got = Tester.make_fetch_dict(preds[dt], suffix="_delta" if dt else "")
+        for k, v in got.items():
+            g = ref["omg_%s%s" % (k, ("_%+d" % dt) if dt else "")]
+            a = v.float().cpu().numpy()
+            if "verts" in k:
+                a = a[..., ::VSUB, :]
+            assert a.shape == g.shape, (k, a.shape, g.shape)
+            assert np.abs(a - g).max() < 1e-4, (k, dt, np.abs(a - g).max())
