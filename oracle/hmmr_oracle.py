@@ -8,14 +8,17 @@ calls.
 
   * PINNED to the reference's own source: smpl_forward / batch_rodrigues /
     batch_global_rigid_transformation / batch_orth_proj_idrot, the OmegasPred container semantics
-    (smpl_outputs) and the sliding-window arithmetic.  tests/golden/make_reference_golden.py imports
-    src/tf_smpl/*, src/omega.py and Tester.predict_all_images from the reference tree and EXECUTES
-    them on a NumPy stand-in for the elementary TF ops they call (oracle/tf_shim.py); this oracle
-    agrees with those outputs to 1e-12 (tests/test_reference_golden.py).
-  * UNPINNED (restatement only): resnet_v2_50, az_fc2_groupnorm (group_norm / conv2d), hmr_ief.
-    These depend on tf.contrib.slim / tf.contrib.layers code that is not in the reference tree; they
-    are pinned only by the algebraic known-answer tests in tests/test_oracle.py and by the fixtures
-    this file generated itself (tests/golden/window_b1_t20.npz, video_n24_b2_t20.npz).
+    (smpl_outputs), the sliding-window arithmetic, and the WIRING + checkpoint variable names of
+    az_fc2_groupnorm / az_fc_block2 and batch_pred_omega / call_hmr_ief / hmr_ief.
+    tests/golden/make_reference_golden.py imports src/tf_smpl/*, src/omega.py, src/models.py and
+    Tester.predict_all_images from the reference tree and EXECUTES them on a NumPy stand-in for
+    the TF ops they call (oracle/tf_shim.py); this oracle agrees with those outputs to 1e-9 or
+    better (tests/test_reference_golden.py).
+  * UNPINNED (restatement only): resnet_v2_50 (its wiring lives in tf.contrib.slim, outside the
+    reference tree), and the SEMANTICS of the three tf.contrib layers under f_movie / IEF
+    (group_norm, conv2d SAME, fully_connected), which tf_shim.py restates from TF 1.8.  These are
+    pinned only by the algebraic known-answer tests in tests/test_oracle.py and by the fixtures this
+    file generated itself (tests/golden/window_b1_t20.npz, video_n24_b2_t20.npz).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
 this module.  The product path (human_dynamics_amd) never does.

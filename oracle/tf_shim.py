@@ -273,7 +273,104 @@ def name_scope(name=None, default_name=None, values=None):
     yield name or default_name
 
 
-variable_scope = name_scope
+
+# ------------------------------------------------------------------------------------------------
+# Variable scopes + the three tf.contrib layers that src/models.py calls for f_movie and the IEF
+# regressors.  The layer SEMANTICS below restate TF 1.8 (they live in TensorFlow, not in the
+# reference); what running the reference through them pins is the reference's own WIRING: op order,
+# residual connections, IEF recurrence, delta-omega assembly and -- through the scope stack -- the
+# checkpoint variable names of SURVEY.md App. B.
+# ------------------------------------------------------------------------------------------------
+WEIGHTS = {}                # {checkpoint variable name: ndarray}, set by the golden generator
+USED_VARIABLES = []         # names looked up, in order (lets the generator check the name contract)
+_SCOPES = []
+AUTO_REUSE = "AUTO_REUSE"
+
+
+@contextlib.contextmanager
+def variable_scope(name_or_scope=None, default_name=None, values=None, reuse=None, **kw):   # noqa: F811
+    name = name_or_scope if name_or_scope is not None else default_name
+    _SCOPES.append(str(name))
+    try:
+        yield "/".join(_SCOPES)
+    finally:
+        _SCOPES.pop()
+
+
+def _var(scope, leaf):
+    name = "/".join(_SCOPES + [scope, leaf])
+    USED_VARIABLES.append(name)
+    if name not in WEIGHTS:
+        raise KeyError("the reference asked for variable %r which the weight dict lacks" % name)
+    return np.asarray(WEIGHTS[name], DTYPE)
+
+
+def _relu(x, name=None):
+    return Tensor(np.maximum(_a(x), 0))
+
+
+def _fully_connected(inputs, num_outputs, activation_fn=_relu, weights_initializer=None, scope=None, **kw):
+    """slim.fully_connected: activation_fn(inputs @ weights + biases); default activation ReLU."""
+    w, b = _var(scope, "weights"), _var(scope, "biases")
+    assert w.shape[1] == int(num_outputs)
+    y = Tensor(np.matmul(_a(inputs), w) + b)
+    return activation_fn(y) if activation_fn is not None else y
+
+
+def _dropout(inputs, keep_prob=0.5, is_training=True, scope=None, **kw):
+    assert not is_training, "inference only"
+    return inputs
+
+
+def _conv2d(inputs, num_outputs, kernel_size, stride=1, padding="SAME", data_format="NHWC", rate=1,
+            activation_fn=_relu, weights_initializer=None, scope=None, reuse=None, **kw):
+    """tf.contrib.layers.conv2d on NHWC with stride 1 / rate 1: SAME zero padding, + bias."""
+    assert padding == "SAME" and data_format == "NHWC" and stride == 1 and rate == 1
+    w, b = _var(scope, "weights"), _var(scope, "biases")            # HWIO
+    x = _a(inputs)
+    kh, kw_, cin, cout = w.shape
+    assert [kh, kw_] == [int(k) for k in kernel_size] and cout == int(num_outputs)
+    ph, pw = kh - 1, kw_ - 1
+    xp = np.pad(x, ((0, 0), (ph // 2, ph - ph // 2), (pw // 2, pw - pw // 2), (0, 0)))
+    H, W = x.shape[1], x.shape[2]
+    y = np.zeros(x.shape[:3] + (cout,), DTYPE) + b
+    for i in np.arange(kh):
+        for j in np.arange(kw_):
+            y = y + np.matmul(xp[:, i:i + H, j:j + W, :], w[i, j])
+    y = Tensor(y)
+    return activation_fn(y) if activation_fn is not None else y
+
+
+def _group_norm(inputs, groups=32, channels_axis=-1, reduction_axes=(-3, -2), center=True, scale=True,
+                epsilon=1e-6, activation_fn=None, scope=None, reuse=None, **kw):
+    """tf.contrib.layers.group_norm (TF 1.8): moments over reduction_axes and the within-group
+    channel sub-axis, population variance; gain = rsqrt(var+eps)*gamma; offset = -mean*gain+beta."""
+    x = _a(inputs)
+    nd = x.ndim
+    ca = channels_axis % nd
+    assert ca == nd - 1, "channels-last only"
+    C = x.shape[ca]
+    xg = x.reshape(x.shape[:-1] + (groups, C // groups))
+    axes = tuple(a % nd for a in reduction_axes) + (nd,)             # reduction axes + channel sub-axis
+    mean = xg.mean(axis=axes, keepdims=True)
+    var = ((xg - mean) ** 2).mean(axis=axes, keepdims=True)
+    gamma = _var(scope, "gamma").reshape((1,) * (nd - 1) + (groups, C // groups)) if scale else 1.0
+    beta = _var(scope, "beta").reshape((1,) * (nd - 1) + (groups, C // groups)) if center else 0.0
+    gain = gamma / np.sqrt(var + epsilon)
+    offset = beta - mean * gain
+    y = Tensor((xg * gain + offset).reshape(x.shape))
+    return activation_fn(y) if activation_fn is not None else y
+
+
+def add(x, y, name=None):
+    return Tensor(np.add(_a(x), _a(y)))
+
+
+class _NN(object):
+    relu = staticmethod(_relu)
+
+
+nn = _NN()
 
 
 def install(precision=np.float64):
@@ -293,10 +390,15 @@ def install(precision=np.float64):
     contrib = types.ModuleType("tensorflow.contrib")
     put("tensorflow.contrib", contrib)
     for sub in ("tensorflow.contrib.slim", "tensorflow.contrib.layers", "tensorflow.contrib.layers.python",
-                "tensorflow.contrib.layers.python.layers", "tensorflow.contrib.layers.python.layers.initializers"):
+                "tensorflow.contrib.layers.python.layers", "tensorflow.contrib.layers.python.layers.initializers",
+                "tensorflow.contrib.framework"):
         m = types.ModuleType(sub)
         m.variance_scaling_initializer = lambda *a, **k: None
+        m.fully_connected, m.dropout = _fully_connected, _dropout
+        m.conv2d, m.group_norm = _conv2d, _group_norm
+        m.get_variables = lambda *a, **k: []
         put(sub, m)
+        setattr(contrib, sub.split(".")[2], sys.modules[sub]) if sub.count(".") == 2 else None
     me.contrib = contrib
     for stub in ("deepdish", "ipdb", "cv2"):
         put(stub, types.ModuleType(stub))

@@ -15,7 +15,11 @@ code is imported from /root/reference and run unmodified, in float64:
                                 window arithmetic, lines 260-312), driven with a stub `predict`
   * src/evaluation/eval_util.py compute_accel, compute_error_3d, compute_error_verts, ...
 
-Outputs (committed): reference_smpl.npz, reference_windows.npz, reference_metrics.npz.
+  * src/models.py               az_fc2_groupnorm / az_fc_block2, batch_pred_omega / call_hmr_ief /
+                                hmr_ief / encoder_fc3_dropout (on the shim's slim / contrib layers)
+
+Outputs (committed): reference_smpl.npz, reference_windows.npz, reference_metrics.npz,
+reference_temporal_ief.npz.
 The GPU box never runs this script; the tests there only read the fixtures.
 """
 import os
@@ -166,8 +170,35 @@ def main():
                                                                eval_util.align_by_pelvis(gt[0]))
     np.savez_compressed(os.path.join(HERE, "reference_metrics.npz"), **met)
 
+    # ---- (5) f_movie and the IEF regressors: src/models.py run on the shim's contrib layers --------
+    # (pins the reference's wiring and its checkpoint variable names; the layer semantics themselves
+    #  are TF's and are restated in oracle/tf_shim.py)
+    sys.path.insert(0, REF)
+    try:
+        from src import models as ref_models
+    finally:
+        sys.path.remove(REF)
+    w = assets.make_synthetic_weights(0)
+    tf_shim.WEIGHTS = w
+    del tf_shim.USED_VARIABLES[:]
+    phi = np.load(os.path.join(HERE, "window_b1_t20.npz"))["phi"].astype(np.float64).reshape(1, 20, 2048)
+    phi2 = np.concatenate([phi, phi[:, ::-1]], 0)                       # two different windows
+    f_temporal = ref_models.get_temporal_encoder()
+    strips = f_temporal(is_training=False, net=tf.constant(phi2), num_conv_layers=3)
+    B, T = 2, 20
+    omega_mean = np.tile(np.asarray(w["mean_param"], np.float64), (B * T, 1))
+    omega, deltas = ref_models.batch_pred_omega(
+        input_features=strips, batch_size=B, sequence_length=T, num_output=85, is_training=False,
+        omega_mean=tf.constant(omega_mean), scope="single_view_ief", predict_delta_keys=[0, -5, 5],
+        use_optcam=True, use_delta_from_pred=True)
+    used = sorted(set(tf_shim.USED_VARIABLES))
+    np.savez_compressed(os.path.join(HERE, "reference_temporal_ief.npz"), phi=phi2, strips=np.asarray(strips),
+                        omega=np.asarray(omega), delta_m5=np.asarray(deltas[-5]), delta_p5=np.asarray(deltas[5]),
+                        used_variables=np.array(used))
+    print("variables the reference code looked up:", len(used))
+
     tf_shim.uninstall(added)
-    for f in ("reference_smpl.npz", "reference_windows.npz", "reference_metrics.npz"):
+    for f in ("reference_smpl.npz", "reference_windows.npz", "reference_metrics.npz", "reference_temporal_ief.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)))
 
 

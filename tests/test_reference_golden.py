@@ -126,3 +126,42 @@ def test_hip_containers_equal_reference_omegaspred(ref, weights, smpl_consts, gp
                 a = a[..., ::VSUB, :]
             assert a.shape == g.shape, (k, a.shape, g.shape)
             assert np.abs(a - g).max() < 1e-4, (k, dt, np.abs(a - g).max())
+
+
+# ------------------------------------------------------------------ f_movie + IEF wiring (src/models.py)
+@pytest.fixture(scope="module")
+def ref_ti():
+    return dict(np.load(os.path.join(GOLDEN, "reference_temporal_ief.npz")))
+
+
+def test_checkpoint_variable_names_are_the_ones_the_reference_asks_for(ref_ti, weights):
+    """The reference's own variable scopes (models.py run under the shim) resolve inside the
+    weight dict contract of assets.py / SURVEY App. B."""
+    used = [str(u) for u in ref_ti["used_variables"]]
+    assert len(used) == 42 and all(u in weights for u in used)
+    assert "AZ_FC_block_preact_gn1block_0/gamma" in used and "AZ_FC_block2_conv2block_2/weights" in used
+    assert "single_view_ief/3D_module/fc1/weights" in used
+    assert "single_view_ief_past5/3D_module/fc3/biases" in used and "single_view_ief_future5/3D_module/fc2/weights" in used
+
+
+def test_oracle_temporal_and_ief_equal_reference_wiring(ref_ti, weights):
+    strips = O.az_fc2_groupnorm(ref_ti["phi"], weights, 3, F64)
+    assert np.abs(strips.numpy() - ref_ti["strips"]).max() < 1e-9
+    mean = torch.tensor(weights["mean_param"], dtype=F64).reshape(1, 85).expand(40, 85)
+    om, deltas = O.call_hmr_ief(torch.tensor(ref_ti["strips"]).reshape(40, -1), mean, weights, (-5, 5), F64)
+    assert np.abs(om.numpy().reshape(2, 20, 85) - ref_ti["omega"]).max() < 1e-9
+    assert np.abs(deltas[-5].numpy().reshape(2, 20, 85) - ref_ti["delta_m5"]).max() < 1e-9
+    assert np.abs(deltas[5].numpy().reshape(2, 20, 85) - ref_ti["delta_p5"]).max() < 1e-9
+
+
+@pytest.mark.gpu
+def test_hip_temporal_and_ief_equal_reference_wiring(ref_ti, weights, smpl_consts, gpu_device):
+    from human_dynamics_amd.engine import HmmrEngine
+    eng = HmmrEngine(weights, smpl_consts, dtype="f32", device=gpu_device)
+    strips = eng.temporal(ref_ti["phi"].astype(np.float32)).cpu().numpy()
+    e1 = np.abs(strips - ref_ti["strips"]).max()
+    om = eng.ief(ref_ti["strips"].astype(np.float32).reshape(40, -1)).cpu().numpy().reshape(3, 2, 20, 85)
+    e2 = max(np.abs(om[0] - ref_ti["omega"]).max(), np.abs(om[1] - ref_ti["delta_m5"]).max(),
+             np.abs(om[2] - ref_ti["delta_p5"]).max())
+    print("HIP (fp32 operands) vs reference models.py wiring: strips %.2e  omegas %.2e" % (e1, e2))
+    assert e1 < 1e-4 and e2 < 1e-4
