@@ -246,6 +246,20 @@ int hmmr_smpl_fwd_strided(const hmmr_smpl_consts_t* c, const float* theta, int l
                           float* verts, float* joints, float* kps, float* rs, int64_t ld_out,
                           void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * Evaluation metrics on device (src/evaluation/eval_util.py): per-frame MPJPE after pelvis alignment
+ * and after Procrustes alignment (compute_error_3d :30-60 with align_by_pelvis :158 and
+ * compute_similarity_transform :177), acceleration (compute_accel :14) and acceleration error
+ * (compute_error_accel :63, before its visibility filter), vertex error (compute_error_verts :140).
+ * gt / pred: [n, k, 3] fp32 (k <= 32); outputs [n] / [n-2] fp32; any output pointer may be NULL.
+ * ------------------------------------------------------------------------- */
+int hmmr_eval_joints(const float* gt, const float* pred, int n, int k, int left_id, int right_id,
+                     float* mpjpe, float* pa_mpjpe, float* accel_pred, float* accel_err, void* stream);
+/* err[i] = mean_v || gt[i, v] - pred[i, v] ||; row strides in floats (pred may be a field of the
+ * packed per-frame record). */
+int hmmr_eval_verts(const float* gt, int64_t ld_gt, const float* pred, int64_t ld_pred, int n, int nv,
+                    float* err, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
