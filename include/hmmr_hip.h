@@ -247,6 +247,16 @@ int hmmr_smpl_fwd_strided(const hmmr_smpl_consts_t* c, const float* theta, int l
                           void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * Crop before the path (process_image, src/evaluation/run_video.py:56-107; resize_img,
+ * src/util/common.py:7-14): frames [n,h,w,3] uint8 -> out [n,224,224,3] fp32 in [-1,1].
+ * geom [n][4] int32 = {scaled height, scaled width, u0, v0}: floor(h*scale), floor(w*scale) and the
+ * scaled-image coordinates of crop pixel (0,0) (round(centre*factors) - 112, may be negative: the
+ * edge padding).  The host mirror (evaluation/run_video.py) computes geom in float64.
+ * ------------------------------------------------------------------------- */
+int hmmr_crop_frames(const unsigned char* frames, const int32_t* geom, int n, int h, int w,
+                     float* out, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Evaluation metrics on device (src/evaluation/eval_util.py): per-frame MPJPE after pelvis alignment
  * and after Procrustes alignment (compute_error_3d :30-60 with align_by_pelvis :158 and
  * compute_similarity_transform :177), acceleration (compute_accel :14) and acceleration error

@@ -18,7 +18,9 @@ code is imported from /root/reference and run unmodified, in float64:
   * src/models.py               az_fc2_groupnorm / az_fc_block2, batch_pred_omega / call_hmr_ief /
                                 hmr_ief / encoder_fc3_dropout (on the shim's slim / contrib layers)
 
-Outputs (committed): reference_smpl.npz, reference_windows.npz, reference_metrics.npz,
+  * src/evaluation/run_video.py process_image (crop before the path; cv2.resize restated, see (6))
+
+Outputs (committed): reference_crops.npz, reference_smpl.npz, reference_windows.npz, reference_metrics.npz,
 reference_temporal_ief.npz.
 The GPU box never runs this script; the tests there only read the fixtures.
 """
@@ -197,8 +199,45 @@ def main():
                         used_variables=np.array(used))
     print("variables the reference code looked up:", len(used))
 
+    # ---- (6) the crop before the path: process_image (src/evaluation/run_video.py:56-107) ----------
+    # executed from the reference with stubs for what cannot be installed: skimage.io.imread returns
+    # our synthetic frame, cv2.resize is the restated bilinear of oracle/preprocess_oracle.py, the NMR
+    # renderer module is an empty stand-in, and np.int (removed in NumPy 2) is int.
+    import types
+    from oracle import preprocess_oracle as PO
+    if not hasattr(np, "int"):
+        np.int = int
+    cv2 = sys.modules["cv2"]
+    cv2.resize = lambda img, dsize: PO.cv2_resize_linear(img, dsize)
+    frames = {}
+    skio = types.ModuleType("skimage.io"); skio.imread = lambda path: frames[path]
+    sk = types.ModuleType("skimage"); sk.io = skio
+    nmr = types.ModuleType("src.util.render.nmr_renderer")
+    nmr.VisRenderer = nmr.visualize_img = nmr.visualize_img_orig = None
+    for name, mod in (("skimage", sk), ("skimage.io", skio), ("src.util.render.nmr_renderer", nmr)):
+        if name not in sys.modules:
+            sys.modules[name] = mod
+            added.append(name)
+    sys.path.insert(0, REF)
+    try:
+        from src.evaluation import run_video as ref_rv
+    finally:
+        sys.path.remove(REF)
+    rng = np.random.default_rng(9)
+    crops, params, srcs = [], [], []
+    H, W = 96, 128
+    for i, (cx, cy, sc) in enumerate([(64.3, 40.2, 1.7), (5.0, 90.0, 2.3), (120.0, 3.0, 0.9), (70.0, 50.0, 3.1)]):
+        fr = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+        frames["f%d" % i] = fr
+        out = ref_rv.process_image("f%d" % i, np.array([cx, cy, sc]))
+        assert out["image"].shape == (224, 224, 3), out["image"].shape
+        crops.append(out["image"]); srcs.append(fr)
+        params.append([cx, cy, sc, out["center"][0], out["center"][1], out["start_pt"][0], out["start_pt"][1]])
+    np.savez_compressed(os.path.join(HERE, "reference_crops.npz"), frames=np.stack(srcs),
+                        crops=np.stack(crops).astype(np.float32), params=np.array(params, np.float64))
+
     tf_shim.uninstall(added)
-    for f in ("reference_smpl.npz", "reference_windows.npz", "reference_metrics.npz", "reference_temporal_ief.npz"):
+    for f in ("reference_crops.npz", "reference_smpl.npz", "reference_windows.npz", "reference_metrics.npz", "reference_temporal_ief.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)))
 
 
