@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive leg (used for PMC passes)")
+    ap.add_argument("--serial-gather", action="store_true",
+                    help="N > 1: wait for each all-gather instead of overlapping it with the next step")
     ap.add_argument("--graph", action="store_true",
                     help="replay the local pass as one hipGraph per step (measured equal to eager launches: "
                          "the step is GPU-bound, the host keeps 150 launches ahead)")
@@ -134,7 +136,8 @@ def main():
     gen.manual_seed(1234 + rank)
     span = torch.rand((plan.f1 - plan.f0, 224, 224, 3), generator=gen, device=device) * 2 - 1
 
-    predictor = hd.ShardedPredictor(tester, n_total, rank, world, use_graph=args.graph)
+    predictor = hd.ShardedPredictor(tester, n_total, rank, world, use_graph=args.graph,
+                                     overlap_gather=not args.serial_gather)
 
     def step():
         return predictor.run(span)
@@ -146,10 +149,12 @@ def main():
 
     for _ in range(args.warmup):
         out = step()
+    predictor.finish()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    predictor.finish()                       # outstanding (overlapped) all-gathers complete inside the timed region
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -224,7 +229,9 @@ def main():
                        "resnet_schedule": "de-duplicated (1x per frame + halo; reference-literal is 2.5x)",
                        "smpl_calls_per_frame": 3, "launch": "hipGraph replay of the local pass" if args.graph else "eager",
                        "weights": "synthetic (seed 0), random-init, reference shapes",
-                       "parallelism": "window-sharded x%d, one RCCL all-gather" % world if world > 1 else "single GPU"},
+                       "parallelism": ("window-sharded x%d, one RCCL all-gather per step%s" % (
+                           world, "" if args.serial_gather else ", overlapped with the compute of the next step"))
+                       if world > 1 else "single GPU"},
             "per_gpu_fps": round(value / world, 1),
             "roofline": roofline,
             "pcie_inclusive_fps": pcie_fps,

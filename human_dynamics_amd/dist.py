@@ -99,18 +99,26 @@ class ShardedPredictor(object):
     """One rank's share of ``Tester.predict_all_images`` for a video of `n_frames` frames,
     re-usable across calls (the shard plan and the window index live on the device).
 
+    overlap_gather=True double-buffers the record tensors and issues the all-gather of call k
+    asynchronously (RCCL runs it on its own stream), so it overlaps the compute of call k+1; call
+    `ready(t)` (or `finish()`) before reading a returned tensor, and read it before the second-next
+    `run()`, which re-uses its buffer.
+    With 8 ranks the gather moves 0.5 GB per call -- about a quarter of a step if left serial.
+
     use_graph=True captures the local pass -- every launch from the ResNet to the three SMPL
     evaluations, ~150 kernels -- into ONE hipGraph the first time it runs on a device-resident
-    input and replays it afterwards (no host launch work left in the step).  The input must then
-    be passed as the same device tensor each time (`static_frames`)."""
+    input and replays it afterwards.  (Measured equal to eager launches: the step is GPU-bound.)"""
 
-    def __init__(self, tester, n_frames, rank=None, world_size=None, group=None, use_graph=False):
+    def __init__(self, tester, n_frames, rank=None, world_size=None, group=None, use_graph=False,
+                 overlap_gather=False):
         if world_size is None:
             world_size = dist.get_world_size() if dist.is_initialized() else 1
         if rank is None:
             rank = dist.get_rank() if dist.is_initialized() else 0
-        self.tester, self.group, self.use_graph = tester, group, use_graph
+        self.tester, self.group = tester, group
         self.plan = ShardPlan(n_frames, tester.batch_size, tester.sequence_length, tester.fov, world_size, rank)
+        self.overlap = bool(overlap_gather) and world_size > 1
+        self.use_graph = bool(use_graph) and not self.overlap
         self.layout, self.rec_len = tester.record_layout()
         eng = tester.engine
         p = self.plan
@@ -121,44 +129,82 @@ class ShardedPredictor(object):
             self.idx = idx.to(eng.device)
         else:
             self.idx = None
-        self.local = torch.zeros((p.out_per_rank, self.rec_len), dtype=torch.float32, device=eng.device)
+        nbuf = 2 if self.overlap else 1
+        self.locals = [torch.zeros((p.out_per_rank, self.rec_len), dtype=torch.float32, device=eng.device)
+                       for _ in range(nbuf)]
+        self.fulls = [None] * nbuf
+        self.pending = [None] * nbuf
+        self.calls = 0
         self.graph, self.static_frames, self._warm = None, None, 0
 
-    def _local_pass(self, frames):
-        """frames [f1-f0,224,224,3] on the device -> self.local (packed records of this rank)."""
+    @property
+    def local(self):
+        return self.locals[0]
+
+    def _local_pass(self, frames, out):
+        """frames [f1-f0,224,224,3] on the device -> out (packed records of this rank)."""
         phi_all = self.tester.features(frames, n_zero=1)            # last row = feature of the zero image
         if self.idx is not None:
-            self.tester.predict_strips_records(phi_all[self.idx], self.plan.o1 - self.plan.o0, out=self.local)
-        return self.local
+            self.tester.predict_strips_records(phi_all[self.idx], self.plan.o1 - self.plan.o0, out=out)
+        return out
 
-    def run_local(self, frames):
+    def run_local(self, frames, out=None):
         eng = self.tester.engine
-        if not (isinstance(frames, torch.Tensor) and frames.is_cuda):
+        out = self.locals[0] if out is None else out
+        if not (isinstance(frames, torch.Tensor) and frames.device.type == eng.device.type):
             frames = eng.to_device(frames)
         if not self.use_graph:
-            return self._local_pass(frames)
+            return self._local_pass(frames, out)
         if self.graph is not None:
             if frames.data_ptr() != self.static_frames.data_ptr():
                 self.static_frames.copy_(frames)
             self.graph.replay()
-            return self.local
+            return self.locals[0]
         if self._warm < 2:                                     # eager warm-up: sizes the workspaces
             self._warm += 1
-            return self._local_pass(frames)
+            return self._local_pass(frames, out)
         self.static_frames = frames
         torch.cuda.synchronize(eng.device)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self._local_pass(self.static_frames)
+            self._local_pass(self.static_frames, self.locals[0])
         self.graph = g
         g.replay()
-        return self.local
+        return self.locals[0]
 
     def run(self, frames, gather=True):
-        local = self.run_local(frames)
+        p = self.plan
+        slot = self.calls % len(self.locals)
+        self.calls += 1
+        if self.pending[slot] is not None:                     # the gather that last read this buffer
+            self.pending[slot].wait()
+            self.pending[slot] = None
+        local = self.run_local(frames, self.locals[slot])
         if not gather:
             return local
-        return all_gather_outputs(local, self.plan, self.group)
+        if not self.overlap:
+            return all_gather_outputs(local, p, self.group)
+        if self.fulls[slot] is None:
+            self.fulls[slot] = torch.empty((p.world_size * p.out_per_rank, self.rec_len), dtype=local.dtype,
+                                           device=local.device)
+        self.pending[slot] = dist.all_gather_into_tensor(self.fulls[slot], local, group=self.group, async_op=True)
+        return self.fulls[slot][:p.n_frames]
+
+    def ready(self, result):
+        """Block until the asynchronous gather that fills `result` (a tensor returned by `run`) is
+        complete.  The tensor stays valid until the second-next `run()`, which re-uses its buffer."""
+        for i, full in enumerate(self.fulls):
+            if full is not None and result.data_ptr() == full.data_ptr() and self.pending[i] is not None:
+                self.pending[i].wait()
+                self.pending[i] = None
+        return result
+
+    def finish(self):
+        """Complete every outstanding asynchronous gather."""
+        for i, w in enumerate(self.pending):
+            if w is not None:
+                w.wait()
+                self.pending[i] = None
 
 
 def predict_all_images_sharded(tester, frames_fn, n_frames, rank=None, world_size=None, group=None,

@@ -88,3 +88,59 @@ def test_all_gather_reassembles_the_sequence_world2(n_frames):
     results = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), n_frames, results), nprocs=world, join=True)
     assert dict(results) == {0: True, 1: True}
+
+
+class _FakeEngine(object):
+    device = torch.device("cpu")
+
+
+class _FakeTester(object):
+    """Stands in for Tester in the plumbing test: per-frame records are a function of the frame id."""
+    batch_size, sequence_length, fov, img_size, delta_t_values = 8, 20, 13, 4, [-5, 5]
+    engine = _FakeEngine()
+
+    def record_layout(self):
+        return hd.record_layout(2, (("cams", (3,)), ("omegas", (85,))))
+
+    def features(self, frames, n_zero=0):
+        return torch.cat([frames[:, 0, 0, :1].repeat(1, 4), torch.zeros((n_zero, 4))], 0)   # id in every column
+
+    def predict_strips_records(self, windows, n_keep, out=None):
+        kept = windows[:, 6:14, 0].reshape(-1)[:n_keep]              # the centre 8 slots of each window
+        out[:n_keep] = kept[:, None] + torch.arange(out.shape[1])[None, :] * 1e-3
+        return out
+
+
+def _expected(n, k, width):
+    return ((torch.arange(n) + 1000.0 * k)[:, None] + torch.arange(width)[None, :] * 1e-3).float()
+
+
+def _overlap_worker(rank, world, port, results):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 200
+        sp = hd.ShardedPredictor(_FakeTester(), n, rank, world, overlap_gather=True)
+        ok = sp.overlap and len(sp.locals) == 2
+        outs = []
+        for step in range(4):                                        # pipelined: gather k overlaps compute k+1
+            frames = torch.zeros((sp.plan.f1 - sp.plan.f0, 4, 4, 3))
+            frames[:, 0, 0, 0] = torch.arange(sp.plan.f0, sp.plan.f1) + 1000.0 * step
+            outs.append(sp.run(frames))                              # issues gather(step) asynchronously
+            if step >= 1:                                            # gather(step-1) overlapped this compute
+                t = sp.ready(outs[step - 1])
+                ok = ok and bool(torch.allclose(t, _expected(n, step - 1, t.shape[1])))
+        sp.finish()
+        ok = ok and bool(torch.allclose(outs[3], _expected(n, 3, outs[3].shape[1])))
+        results[rank] = ok and all(w is None for w in sp.pending)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_gather_pipeline_world2():
+    """ShardedPredictor(overlap_gather=True): double-buffered records, async all-gather per call."""
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_overlap_worker, args=(2, _free_port(), results), nprocs=2, join=True)
+    assert dict(results) == {0: True, 1: True}
