@@ -10,21 +10,26 @@
 // fully-connected layers (reference: src/models.py:65-74, 102-113, 173-184).
 //
 // gfx950 mapping
-//   * 256 threads = 4 waves (64 lanes each) per workgroup; block tile BM x BN,
-//     K advanced 128 BYTES per step (64 bf16 or 32 fp32 per row);
-//   * operands are staged HBM -> VGPR -> LDS in 16-byte slots, one full 128-B
-//     line per tile row (8 lanes per row => every wave-load covers 8 complete
-//     lines); next tile's loads are issued before the MFMAs of the current
-//     tile and written to the other LDS buffer after them (one barrier/step);
+//   * workgroups of 8 waves (512 threads; 128x128 or 128x64 block tile, wave tile
+//     32x64 / 32x32) or 4 waves (64x64 for short-M GEMMs); K advances 128 BYTES
+//     per row per step (64 bf16 or 32 fp32);
+//   * operands go HBM -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave
+//     instruction, two LDS stages): the LDS image is lane-linear per wave and the
+//     bank swizzle is applied to each lane's SOURCE slot; zero-padding taps and
+//     M tails read a 64-byte zero page.  With a fused pre-activation (PRO) the A
+//     operand takes the register route instead (HBM -> VGPR -> relu(x*s+b) ->
+//     ds_write_b128), one K step ahead of its use;
 //   * LDS rows are 128 B, slot index XOR-swizzled with (row>>1)&7 so that the
 //     16 lanes serviced together by ds_read_b128 hit 16 distinct 16-B slots of
 //     the 256-B bank row (conflict-free fragment reads);
 //   * MFMA 32x32 tiles: v_mfma_f32_32x32x16_bf16 (bf16 in, fp32 accumulate) or
 //     v_mfma_f32_32x32x2_f32 (exact fp32: bitwise an fmaf chain);
 //   * epilogue: accumulators -> LDS (fp32) -> each lane owns 8 consecutive
-//     output channels of one row: folded-BN scale/shift, residual add, ReLU,
-//     optional second output relu(bn_next(v)) (the next unit's `preact`), all
-//     as 16-byte coalesced accesses;
+//     output channels of one row: folded-BN scale/shift, residual add (vectors
+//     prefetched before the K loop), ReLU, optional second output
+//     relu(bn_next(v)), all as 16-byte coalesced accesses;
+//   * split-K over blockIdx.y: fixed slice count per layer, fp32 partial planes,
+//     ordered reduction in splitk_reduce_kernel (no atomics => batch-independent);
 //   * 1-D grid remapped so that each XCD (private 4 MiB L2) walks a contiguous
 //     range of tiles that share A rows.
 #include <stdlib.h>

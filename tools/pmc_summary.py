@@ -39,7 +39,7 @@ def main():
                                    "hbm_write_MB_per_launch": round(w / 1e6, 1),
                                    "mfma_util": None if util is None else round(util, 4)}
     # the ResNet convolutions are the bf16->bf16 instantiations of conv_gemm_kernel
-    rn = [k for k in fe if "conv_gemm_kernelIDF16bDF16b" in k]
+    rn = [k for k in fe if "conv_gemm_kernelIDF16bDF16b" in k or "stem_fused_kernel" in k]
     n = sum(fe[k][0] for k in rn)
     rd = sum(2 * 1024 * fe[k][1] for k in rn)
     w = sum(1024 * wr[k][1] for k in rn if k in wr)
@@ -48,8 +48,8 @@ def main():
     res["resnet_conv_gemm"] = {"launches": n, "hbm_bytes_per_launch": round((rd + w) / n),
                                "hbm_read_bytes_per_launch": round(rd / n), "hbm_write_bytes_per_launch": round(w / n),
                                "mfma_util": round(busy / (g / 8.0 * 1024.0), 4),
-                               "note": "averaged over every ResNet pass of the bench run (6 passes of 257 frames "
-                                       "+ one of 65 in the PCIe leg: multiply by 7*257/(6*257+65) = 1.12 for a 257-frame pass)"}
+                               "note": "averaged over the ResNet passes of `bench.py --steps 2 --warmup 1 "
+                                       "--no-cpu-baseline --no-pcie` (every pass encodes 257 frames)"}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res["resnet_conv_gemm"], indent=1))
 
