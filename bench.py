@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive leg (used for PMC passes)")
     ap.add_argument("--serial-gather", action="store_true",
                     help="N > 1: wait for each all-gather instead of overlapping it with the next step")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="run the per-window tail on the ResNet's stream instead of a second stream "
+                         "(default: tail of step k overlaps the ResNet of step k+1)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the local pass as one hipGraph per step (measured equal to eager launches: "
                          "the step is GPU-bound, the host keeps 150 launches ahead)")
@@ -136,8 +139,9 @@ def main():
     gen.manual_seed(1234 + rank)
     span = torch.rand((plan.f1 - plan.f0, 224, 224, 3), generator=gen, device=device) * 2 - 1
 
+    pipeline = not (args.no_pipeline or args.graph)
     predictor = hd.ShardedPredictor(tester, n_total, rank, world, use_graph=args.graph,
-                                     overlap_gather=not args.serial_gather)
+                                     overlap_gather=not args.serial_gather, pipeline=pipeline)
 
     def step():
         return predictor.run(span)
@@ -227,7 +231,9 @@ def main():
                        "frames_per_gpu_per_step": args.frames, "windows_per_gpu": plan.w1 - plan.w0,
                        "resnet_frames_encoded_per_gpu": plan.f1 - plan.f0 + 1,
                        "resnet_schedule": "de-duplicated (1x per frame + halo; reference-literal is 2.5x)",
-                       "smpl_calls_per_frame": 3, "launch": "hipGraph replay of the local pass" if args.graph else "eager",
+                       "smpl_calls_per_frame": 3, "launch": ("hipGraph replay of the local pass" if args.graph else
+                                  "eager, two streams: the f_movie/IEF/SMPL tail of step k runs under the ResNet of step k+1"
+                                  if pipeline else "eager, one stream"),
                        "weights": "synthetic (seed 0), random-init, reference shapes",
                        "parallelism": ("window-sharded x%d, one RCCL all-gather per step%s" % (
                            world, "" if args.serial_gather else ", overlapped with the compute of the next step"))

@@ -105,12 +105,19 @@ class ShardedPredictor(object):
     `run()`, which re-uses its buffer.
     With 8 ranks the gather moves 0.5 GB per call -- about a quarter of a step if left serial.
 
+    pipeline=True runs the per-window tail (f_movie, IEF, 3x SMPL: ~150 small, latency-bound
+    launches that leave most CUs idle) on a second HIP stream, so the tail of call k executes
+    underneath the ResNet of call k+1, which has the CUs busy but is not short of queue slots.
+    Results are bit-identical (same kernels, same order per stream); the hand-off is one event,
+    the feature tensor is pinned to the tail stream with `record_stream`.  Same contract as
+    overlap_gather: `ready(t)` / `finish()` before reading, buffers are re-used two calls later.
+
     use_graph=True captures the local pass -- every launch from the ResNet to the three SMPL
     evaluations, ~150 kernels -- into ONE hipGraph the first time it runs on a device-resident
     input and replays it afterwards.  (Measured equal to eager launches: the step is GPU-bound.)"""
 
     def __init__(self, tester, n_frames, rank=None, world_size=None, group=None, use_graph=False,
-                 overlap_gather=False):
+                 overlap_gather=False, pipeline=False):
         if world_size is None:
             world_size = dist.get_world_size() if dist.is_initialized() else 1
         if rank is None:
@@ -118,7 +125,8 @@ class ShardedPredictor(object):
         self.tester, self.group = tester, group
         self.plan = ShardPlan(n_frames, tester.batch_size, tester.sequence_length, tester.fov, world_size, rank)
         self.overlap = bool(overlap_gather) and world_size > 1
-        self.use_graph = bool(use_graph) and not self.overlap
+        self.pipeline = bool(pipeline) and tester.engine.device.type == "cuda"
+        self.use_graph = bool(use_graph) and not self.overlap and not self.pipeline
         self.layout, self.rec_len = tester.record_layout()
         eng = tester.engine
         p = self.plan
@@ -129,7 +137,9 @@ class ShardedPredictor(object):
             self.idx = idx.to(eng.device)
         else:
             self.idx = None
-        nbuf = 2 if self.overlap else 1
+        nbuf = 2 if (self.overlap or self.pipeline) else 1
+        self.s_tail = torch.cuda.Stream(device=eng.device, priority=-1) if self.pipeline else None
+        self.done = [None] * nbuf
         self.locals = [torch.zeros((p.out_per_rank, self.rec_len), dtype=torch.float32, device=eng.device)
                        for _ in range(nbuf)]
         self.fulls = [None] * nbuf
@@ -172,10 +182,43 @@ class ShardedPredictor(object):
         g.replay()
         return self.locals[0]
 
+    def _run_pipelined(self, frames, slot, gather):
+        """ResNet on the caller's stream, everything after it on `s_tail`."""
+        eng, p = self.tester.engine, self.plan
+        enc = torch.cuda.current_stream(eng.device)
+        if not (isinstance(frames, torch.Tensor) and frames.device.type == eng.device.type):
+            frames = eng.to_device(frames)
+        phi_all = self.tester.features(frames, n_zero=1)
+        handoff = torch.cuda.Event()
+        handoff.record(enc)
+        out = self.locals[slot]
+        with torch.cuda.stream(self.s_tail):
+            self.s_tail.wait_event(handoff)
+            phi_all.record_stream(self.s_tail)
+            if self.pending[slot] is not None:                 # the gather that last read this buffer
+                self.pending[slot].wait()
+                self.pending[slot] = None
+            if self.idx is not None:
+                self.tester.predict_strips_records(phi_all[self.idx], p.o1 - p.o0, out=out)
+            if gather and p.world_size > 1:
+                if self.fulls[slot] is None:
+                    self.fulls[slot] = torch.empty((p.world_size * p.out_per_rank, self.rec_len), dtype=out.dtype,
+                                                   device=out.device)
+                self.pending[slot] = dist.all_gather_into_tensor(self.fulls[slot], out, group=self.group,
+                                                                 async_op=True)
+                out = self.fulls[slot][:p.n_frames]
+            elif gather:
+                out = out[:p.n_frames]
+            self.done[slot] = torch.cuda.Event()
+            self.done[slot].record(self.s_tail)
+        return out
+
     def run(self, frames, gather=True):
         p = self.plan
         slot = self.calls % len(self.locals)
         self.calls += 1
+        if self.pipeline:
+            return self._run_pipelined(frames, slot, gather)
         if self.pending[slot] is not None:                     # the gather that last read this buffer
             self.pending[slot].wait()
             self.pending[slot] = None
@@ -194,13 +237,21 @@ class ShardedPredictor(object):
         """Block until the asynchronous gather that fills `result` (a tensor returned by `run`) is
         complete.  The tensor stays valid until the second-next `run()`, which re-uses its buffer."""
         for i, full in enumerate(self.fulls):
-            if full is not None and result.data_ptr() == full.data_ptr() and self.pending[i] is not None:
+            mine = (full is not None and result.data_ptr() == full.data_ptr()) or \
+                   (self.pipeline and result.data_ptr() == self.locals[i].data_ptr())
+            if not mine:
+                continue
+            if self.pipeline and self.done[i] is not None:
+                torch.cuda.current_stream(result.device).wait_event(self.done[i])
+            if self.pending[i] is not None:
                 self.pending[i].wait()
                 self.pending[i] = None
         return result
 
     def finish(self):
         """Complete every outstanding asynchronous gather."""
+        if self.pipeline:
+            torch.cuda.current_stream(self.tester.engine.device).wait_stream(self.s_tail)
         for i, w in enumerate(self.pending):
             if w is not None:
                 w.wait()

@@ -170,3 +170,27 @@ def test_sharded_predictor_graph_replay_equals_eager(weights, smpl_consts, gpu_d
         loc = p.run(dev[p.plan.f0:p.plan.f1], gather=False)
         parts.append(loc[:p.plan.o1 - p.plan.o0])
     assert torch.equal(torch.cat(parts, 0), eager)
+
+
+def test_sharded_predictor_two_stream_pipeline_equals_serial(weights, smpl_consts, gpu_device):
+    """pipeline=True (the tail of call k on a second stream under the ResNet of call k+1)
+    returns bit-identical records for a stream of different inputs."""
+    import torch
+    from human_dynamics_amd import dist as hd
+    from human_dynamics_amd.evaluation.tester import Tester
+    t = Tester(Config(batch_size=2), weights=weights, smpl=smpl_consts, dtype="bf16", device=gpu_device)
+    clips = [torch.from_numpy(assets.make_synthetic_frames(24, seed=20 + i)).to(gpu_device) for i in range(5)]
+    serial = hd.ShardedPredictor(t, 24, 0, 1)
+    want = [serial.run(c).clone() for c in clips]
+    pipe = hd.ShardedPredictor(t, 24, 0, 1, pipeline=True)
+    got, prev = [], None
+    for c in clips:                          # read result k only after call k+1 has been queued
+        cur = pipe.run(c)
+        if prev is not None:
+            got.append(pipe.ready(prev).clone())
+        prev = cur
+    got.append(pipe.ready(prev).clone())
+    pipe.finish()
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert torch.equal(a, b), i

@@ -37,10 +37,20 @@ def run(lib, name, n, h, cin, cout, k, stride, kind, dt, tile, iters=20):
     d.ho = d.wo = ho; d.cout = cout; d.ldo = cout; d.tile = tile
     keep = [x, w, sc, sh, out]
     nbytes = x.numel() * x.element_size() / (stride * stride if k == 1 else 1) + out.numel() * out.element_size()
-    if kind == "bnrelu":
+    if kind in ("bnrelu", "pro"):
         d.scale, d.shift, d.relu = sc.data_ptr(), sh.data_ptr(), 1
+        if kind == "pro":                     # conv1 / shortcut: fused pre-activation of the A operand
+            ps = torch.rand(cin, device=dev) + 0.5
+            pb = torch.randn(cin, device=dev)
+            d.pro_scale, d.pro_shift = ps.data_ptr(), pb.data_ptr()
+            keep += [ps, pb]
     elif kind == "bias":
         d.shift = sh.data_ptr()
+    elif kind == "res":                       # conv3: bias + residual
+        res = torch.randn_like(out)
+        d.shift, d.res, d.ldr = sh.data_ptr(), res.data_ptr(), cout
+        keep += [res]
+        nbytes += out.numel() * out.element_size()
     elif kind == "res2":                      # conv3: bias + residual + second output
         res = torch.randn_like(out)
         out2 = torch.empty_like(out)
@@ -64,29 +74,35 @@ def run(lib, name, n, h, cin, cout, k, stride, kind, dt, tile, iters=20):
 
 
 SHAPES = [  # name, h, cin, cout, k, stride, kind
-    ("b1.conv1(256->64)", 56, 256, 64, 1, 1, "bnrelu"),
+    ("b1.conv1(256->64)", 56, 256, 64, 1, 1, "pro"),
     ("b1.conv2(3x3 64)", 56, 64, 64, 3, 1, "bnrelu"),
-    ("b1.conv3(64->256)", 56, 64, 256, 1, 1, "res2"),
+    ("b1.conv3(64->256)", 56, 64, 256, 1, 1, "res"),
     ("b1.short(64->256)", 56, 64, 256, 1, 1, "bias"),
-    ("b2.conv1(512->128)", 28, 512, 128, 1, 1, "bnrelu"),
+    ("b2.conv1(512->128)", 28, 512, 128, 1, 1, "pro"),
     ("b2.conv2(3x3 128)", 28, 128, 128, 3, 1, "bnrelu"),
-    ("b2.conv3(128->512)", 28, 128, 512, 1, 1, "res2"),
-    ("b3.conv1(1024->256)", 14, 1024, 256, 1, 1, "bnrelu"),
+    ("b2.conv3(128->512)", 28, 128, 512, 1, 1, "res"),
+    ("b3.conv1(1024->256)", 14, 1024, 256, 1, 1, "pro"),
     ("b3.conv2(3x3 256)", 14, 256, 256, 3, 1, "bnrelu"),
-    ("b3.conv3(256->1024)", 14, 256, 1024, 1, 1, "res2"),
-    ("b4.conv1(2048->512)", 7, 2048, 512, 1, 1, "bnrelu"),
+    ("b3.conv3(256->1024)", 14, 256, 1024, 1, 1, "res"),
+    ("b4.conv1(2048->512)", 7, 2048, 512, 1, 1, "pro"),
     ("b4.conv2(3x3 512)", 7, 512, 512, 3, 1, "bnrelu"),
-    ("b4.conv3(512->2048)", 7, 512, 2048, 1, 1, "res2"),
+    ("b4.conv3(512->2048)", 7, 512, 2048, 1, 1, "res"),
 ]
 
 
+TILES = (1, 5, 2, 6, 3)
+
+
 def main():
+    global TILES
+    if len(sys.argv) > 3:
+        TILES = tuple(int(t) for t in sys.argv[3].split(','))
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     dt = sys.argv[2] if len(sys.argv) > 2 else "bf16"
     lib = L.load()
     rows = []
     for name, h, cin, cout, k, stride, kind in SHAPES:
-        for tile in (1, 5, 2, 6, 3):
+        for tile in TILES:
             if tile in (1, 5) and cout % 128:
                 continue
             rows.append(run(lib, name, n, h, cin, cout, k, stride, kind, dt, tile))
