@@ -109,7 +109,7 @@ template <> __device__ __forceinline__ u32x4 preact_slot<bf16_t>(const u32x4& v,
 //         halves the resident workgroups per CU, and resident waves are what hides latency in this
 //         structure.
 template <typename TA, typename TO, int BM, int BN, int WGM, int WGN, bool PRO, bool UTAP, int NSTAGE>
-__global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 1) void conv_gemm_kernel(const ConvArgs a) {
     static_assert(NSTAGE == 2, "only the 2-stage pipeline is kept");
     static_assert(!PRO || UTAP, "the fused pre-activation needs one tap per K step");
     constexpr int NT = WGM * WGN * 64;            // threads per workgroup (4 or 8 waves)
@@ -174,7 +174,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const ConvArg
 
     u32x4 ra[PRO ? PA : 1];
     f32x4 psc[PRO ? EPS / 4 : 1], psh[PRO ? EPS / 4 : 1];     // scale/shift of this lane's EPS channels
-    unsigned ra_ok = 0u;
     // A operand of K step kt, LDS-DMA route (non-PRO)
     auto glds_a = [&](int kt, int buf) {
         int tap;
@@ -195,8 +194,14 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const ConvArg
             __builtin_amdgcn_global_load_lds((gptr_t)(wptr + (long long)(RPP * p) * a.K + kt * BKE),
                                              (lptr_t)(sb + p * (RPP * 128)), 16, 0, 0);
     };
-    // PRO: raw A slots of K step kt (and the pre-activation constants of their channels) -> VGPRs
-    auto load_a_regs = [&](int kt) {
+    // PRO: raw A slots and B slots of K step kt (and the pre-activation constants of the A
+    // channels) -> VGPRs.  BOTH operands take the register route here: with an LDS-DMA in flight
+    // hipcc waits vmcnt(0) before every ordinary load's use and at every barrier, which serialised
+    // the B fetch against the A prefetch; an all-register pipeline gets counted waits and a bare
+    // s_barrier.  PRO gathers are un-padded 1x1 taps, so the only invalid rows are the M tail:
+    // their pointer is clamped to row 0 (aptr = in) and their outputs are never stored.
+    u32x4 rb[PRO ? PB : 1];
+    auto load_regs = [&](int kt) {
         if constexpr (PRO) {
             int tap;
             const int koff = tap_of(kt * BKE, tap);
@@ -206,25 +211,20 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const ConvArg
                 psc[q] = *(const f32x4*)(a.pro_scale + ci + 4 * q);
                 psh[q] = *(const f32x4*)(a.pro_shift + ci + 4 * q);
             }
-            ra_ok = 0u;
 #pragma unroll
-            for (int p = 0; p < PA; ++p) {
-                u32x4 v = {0u, 0u, 0u, 0u};
-                if ((amask[p] >> tap) & 1u) { v = *(const u32x4*)(aptr[p] + koff); ra_ok |= 1u << p; }
-                ra[p] = v;
-            }
+            for (int p = 0; p < PA; ++p) ra[p] = *(const u32x4*)(aptr[p] + koff);
+#pragma unroll
+            for (int p = 0; p < PB; ++p) rb[p] = *(const u32x4*)(wptr + (long long)(RPP * p) * a.K + kt * BKE);
         }
     };
-    // PRO: pre-activate the slots held in VGPRs and write them to LDS stage `buf`
-    auto store_a_regs = [&](int buf) {
+    // PRO: pre-activate the A slots held in VGPRs and write both operands to LDS stage `buf`
+    auto store_regs = [&](int buf) {
         if constexpr (PRO) {
             char* sa = smem + buf * STAGE + r0 * 128 + pslot * 16;
 #pragma unroll
-            for (int p = 0; p < PA; ++p) {
-                u32x4 v = ra[p];
-                if ((ra_ok >> p) & 1u) v = preact_slot<TA>(v, psc, psh);
-                *(u32x4*)(sa + p * (RPP * 128)) = v;
-            }
+            for (int p = 0; p < PA; ++p) *(u32x4*)(sa + p * (RPP * 128)) = preact_slot<TA>(ra[p], psc, psh);
+#pragma unroll
+            for (int p = 0; p < PB; ++p) *(u32x4*)(sa + A_BYTES + p * (RPP * 128)) = rb[p];
         }
     };
 
@@ -249,9 +249,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const ConvArg
     constexpr int VPR = BN / 8;                   // 8-channel vectors per row
     constexpr int NIT = (BM * VPR) / NT;
     constexpr int RV = (int)(8 * sizeof(TO) / 16); // 16-byte pieces per residual vector
-    const TO* __restrict__ res = (const TO*)a.res;
-    u32x4 rres[NIT][RV];
-    if (res) {
+    // (a PRO launch never carries a residual -- host-checked -- which keeps its A/B register
+    //  pipeline inside the 128-VGPR budget of two 8-wave workgroups per CU)
+    const TO* __restrict__ res = PRO ? nullptr : (const TO*)a.res;
+    u32x4 rres[PRO ? 1 : NIT][RV];
+    if (!PRO && res) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = it * NT + tid;
@@ -301,17 +303,16 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const ConvArg
     const int kt0 = blockIdx.y * a.kt_per_slice;
     const int kt1 = min(nk, kt0 + a.kt_per_slice);
     if constexpr (PRO) {
-        // A(kt+1) was fetched into VGPRs a whole K step earlier, so pre-activating and writing it at
-        // the TOP of step kt never waits for HBM; its registers are then free for A(kt+2).
-        load_a_regs(kt0);
-        glds_b(kt0, 0);
-        store_a_regs(0);
-        if (kt0 + 1 < kt1) load_a_regs(kt0 + 1);
+        // tile kt+1 was fetched into VGPRs a whole K step earlier, so pre-activating and writing it
+        // at the TOP of step kt never waits for HBM; its registers are then free for tile kt+2.
+        load_regs(kt0);
+        store_regs(0);
+        if (kt0 + 1 < kt1) load_regs(kt0 + 1);
         __syncthreads();
         for (int kt = kt0; kt < kt1; ++kt) {
             const int cur = (kt - kt0) & 1;
-            if (kt + 1 < kt1) { store_a_regs(cur ^ 1); glds_b(kt + 1, cur ^ 1); }
-            if (kt + 2 < kt1) load_a_regs(kt + 2);
+            if (kt + 1 < kt1) store_regs(cur ^ 1);
+            if (kt + 2 < kt1) load_regs(kt + 2);
             compute_stage(smem + cur * STAGE);
             __syncthreads();
         }
@@ -362,9 +363,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const ConvArg
             for (int j = 0; j < 8; ++j) v[j] += s[j];
         }
         const bool full = (n + 8 <= a.cout);
-        if (res) {
+        if (!PRO && res) {
             float rr[8];
-            unpack8<TO>(rres[it], rr);
+            unpack8<TO>(rres[PRO ? 0 : it], rr);
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] += rr[j];
         }
@@ -542,6 +543,7 @@ extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
                  "hmmr_conv_gemm: residual rows must be readable up to cout rounded up to 8");
     HMMR_REQUIRE(!d->out2 || (d->scale2 && d->shift2), "hmmr_conv_gemm: out2 needs scale2/shift2");
     HMMR_REQUIRE(!d->pro_scale == !d->pro_shift, "hmmr_conv_gemm: pro_scale and pro_shift go together");
+    HMMR_REQUIRE(!d->pro_scale || !d->res, "hmmr_conv_gemm: a fused pre-activation (pro_*) cannot be combined with a residual");
     HMMR_REQUIRE(!d->pro_scale || (d->py == 0 && d->px == 0 && d->kh == 1 && d->kw == 1),
                  "hmmr_conv_gemm: the fused pre-activation is for un-padded 1x1 gathers (padding must stay zero)");
     ConvArgs a;

@@ -1,0 +1,53 @@
+"""Summarise tools/pmc_conv_study.sh: one row per conv_bench configuration (runs of consecutive
+dispatches of the same kernel with the same grid), counters averaged per dispatch."""
+import csv
+import glob
+import sys
+import collections
+
+root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
+runs = collections.OrderedDict()
+for d in sorted(glob.glob(root + "/cs_*")):
+    fs = sorted(glob.glob(d + "/*/*counter_collection.csv"))
+    if not fs:
+        continue
+    rows = list(csv.DictReader(open(fs[-1])))
+    # dispatch id -> counters
+    disp = collections.OrderedDict()
+    for r in rows:
+        k = int(r["Dispatch_Id"])
+        e = disp.setdefault(k, {"name": r["Kernel_Name"], "grid": r["Grid_Size"], "c": {}})
+        e["c"][r["Counter_Name"]] = e["c"].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    seq, prev = [], None
+    for k, e in disp.items():
+        if "conv_gemm_kernel" not in e["name"]:
+            continue
+        key = (e["name"], e["grid"])
+        if key != prev:
+            seq.append({"key": key, "n": 0, "c": collections.defaultdict(float)})
+            prev = key
+        seq[-1]["n"] += 1
+        for cn, v in e["c"].items():
+            seq[-1]["c"][cn] += v
+    for i, s in enumerate(seq):
+        r = runs.setdefault(i, {"grid": s["key"][1], "c": {}})
+        for cn, v in s["c"].items():
+            r["c"][cn] = v / s["n"]
+names = [l.split('"')[3] for l in open(root + "/cs_1.log") if l.startswith("{")]
+ms = [float(l.split('"ms": ')[1].split(",")[0]) for l in open(root + "/cs_1.log") if l.startswith("{")]
+print("%-22s %7s %6s %6s %6s %6s %6s %6s %6s" % ("layer", "grid", "mfma%", "lds%", "bankc%", "valu%", "vmem%", "waitL%", "waves/cu"))
+for i, r in runs.items():
+    c = r["c"]
+    cyc = c.get("GRBM_GUI_ACTIVE", 0) / 8.0            # per-XCD clock count
+    simd = 1024.0
+    mf = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (cyc * simd) if cyc else 0
+    lds = c.get("SQ_LDS_IDX_ACTIVE", 0) / (cyc * 256) if cyc else 0
+    bank = c.get("SQ_LDS_BANK_CONFLICT", 0) / c["SQ_LDS_IDX_ACTIVE"] if c.get("SQ_LDS_IDX_ACTIVE") else 0
+    wc = c.get("SQ_WAVE_CYCLES", 0)
+    valu = c.get("SQ_ACTIVE_INST_VALU", 0) / wc if wc else 0
+    vm = c.get("SQ_ACTIVE_INST_VMEM", 0) / wc if wc else 0
+    wl = c.get("SQ_WAIT_INST_LDS", 0) / wc if wc else 0
+    occ = wc / (c.get("SQ_BUSY_CYCLES", 1)) if c.get("SQ_BUSY_CYCLES") else 0
+    nm = names[i] if i < len(names) else "?"
+    print("%-22s %7s %6.1f %6.1f %6.1f %6.1f %6.1f %6.1f %6.2f" % (nm, int(r["grid"]) // 512 if r["grid"].isdigit() else r["grid"], 100 * mf, 100 * lds, 100 * bank, 100 * valu, 100 * vm, 100 * wl, occ))
+print({k: round(v) for k, v in runs[0]["c"].items()} if runs else "")
