@@ -40,7 +40,7 @@ class ConvDesc(C.Structure):
 
 
 class Layer(C.Structure):
-    _fields_ = [("w", _vp), ("scale", _fp), ("shift", _fp)]
+    _fields_ = [("w", _vp), ("scale", _fp), ("shift", _fp), ("tile", C.c_int)]
 
 
 class ResnetUnit(C.Structure):
@@ -136,7 +136,7 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError if the .so does not export it
         fn.restype, fn.argtypes = res, args
-    if lib.hmmr_abi_version() != 3:
+    if lib.hmmr_abi_version() != 4:
         raise HmmrError("libhmmr_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -249,7 +249,7 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
         if (U.shortcut.w) {           // 1x1 conv on preact, bias, no BN/ReLU (stride is 1 here)
             d = hmmr_conv_desc_t{};
             d.in = xin; d.pro_scale = ps; d.pro_shift = pb;
-            d.w = U.shortcut.w; d.scale = U.shortcut.scale; d.shift = U.shortcut.shift;
+            d.w = U.shortcut.w; d.scale = U.shortcut.scale; d.shift = U.shortcut.shift; d.tile = U.shortcut.tile;
             d.out = xn; d.in_dtype = d.out_dtype = w->dtype;
             d.n_img = n; d.hin = H; d.win = H; d.cin = U.c_in;
             d.in_img_stride = (int64_t)H * H * U.c_in; d.in_row_stride = H * U.c_in; d.in_px_stride = U.c_in;
@@ -260,7 +260,7 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
         // conv1: 1x1 on preact, BN + ReLU
         d = hmmr_conv_desc_t{};
         d.in = xin; d.pro_scale = ps; d.pro_shift = pb;
-        d.w = U.conv1.w; d.scale = U.conv1.scale; d.shift = U.conv1.shift; d.relu = 1;
+        d.w = U.conv1.w; d.scale = U.conv1.scale; d.shift = U.conv1.shift; d.relu = 1; d.tile = U.conv1.tile;
         d.out = T1; d.in_dtype = d.out_dtype = w->dtype;
         d.n_img = n; d.hin = H; d.win = H; d.cin = U.c_in;
         d.in_img_stride = (int64_t)H * H * U.c_in; d.in_row_stride = H * U.c_in; d.in_px_stride = U.c_in;
@@ -269,7 +269,7 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
         if (prof_mark(pf)) return -2;
         // conv2: 3x3 conv2d_same(stride): pad 1/1 both for stride 1 (SAME) and stride 2 (explicit pad + VALID)
         d = hmmr_conv_desc_t{};
-        d.in = T1; d.w = U.conv2.w; d.scale = U.conv2.scale; d.shift = U.conv2.shift; d.relu = 1;
+        d.in = T1; d.w = U.conv2.w; d.scale = U.conv2.scale; d.shift = U.conv2.shift; d.relu = 1; d.tile = U.conv2.tile;
         d.out = T2; d.in_dtype = d.out_dtype = w->dtype;
         d.n_img = n; d.hin = H; d.win = H; d.cin = U.base;
         d.in_img_stride = (int64_t)H * H * U.base; d.in_row_stride = H * U.base; d.in_px_stride = U.base;
@@ -278,7 +278,7 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
         if (prof_mark(pf)) return -2;
         // conv3: 1x1 + bias, + shortcut (no ReLU after the add)
         d = hmmr_conv_desc_t{};
-        d.in = T2; d.w = U.conv3.w; d.scale = U.conv3.scale; d.shift = U.conv3.shift;
+        d.in = T2; d.w = U.conv3.w; d.scale = U.conv3.scale; d.shift = U.conv3.shift; d.tile = U.conv3.tile;
         d.in_dtype = d.out_dtype = w->dtype;
         d.n_img = n; d.hin = Ho; d.win = Ho; d.cin = U.base;
         d.in_img_stride = (int64_t)Ho * Ho * U.base; d.in_row_stride = Ho * U.base; d.in_px_stride = U.base;

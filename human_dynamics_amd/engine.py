@@ -43,7 +43,7 @@ class HmmrEngine(object):
 
     def __init__(self, weights, smpl, dtype="bf16", device="cuda:0", num_conv_layers=3,
                  delta_t_values=(-5, 5), joint_type="cocoplus", resnet_chunk=0,
-                 temporal_dtype=None, ief_dtype=None):
+                 temporal_dtype=None, ief_dtype=None, autotune=True):
         self.lib = L.load()
         if not torch.cuda.is_available():
             raise L.HmmrError("HmmrEngine needs a HIP device (torch.cuda.is_available() is False)")
@@ -70,6 +70,9 @@ class HmmrEngine(object):
         self.num_kps = self.sc.num_kps if self.sc is not None else assets.NUM_KPS
         self.num_verts = self.sc.num_verts if self.sc is not None else assets.NUM_VERTS
         self._ws = {k: _Workspace(self.device) for k in ("resnet", "temporal", "ief", "smpl", "hal")}
+        # per-layer conv tiles of the ResNet, tuned per batch size on first use (see _tune_resnet)
+        self.autotune = bool(autotune) and os.environ.get("HMMR_AUTOTUNE", "1") != "0"
+        self._tiles = {}
 
     # -- helpers ---------------------------------------------------------------
     def _stream(self):
@@ -80,6 +83,55 @@ class HmmrEngine(object):
             return a.to(self.device, dtype).contiguous()
         return torch.from_numpy(np.ascontiguousarray(a)).to(self.device).to(dtype).contiguous()
 
+    # -- ResNet launch tuning ----------------------------------------------------
+    _TUNE_TILES = (5, 6, 3)        # 8-wave 128x128, 8-wave 128x64, 4-wave 64x64 (hmmr_conv_desc_t.tile)
+    _TUNE_MIN_FRAMES = 32
+
+    def _resnet_layers(self):
+        """[(profile slot, unit index, layer name)] in launch order (csrc/resnet.hip)."""
+        out, slot = [], 3
+        for u in range(L.RESNET_UNITS):
+            names = (["shortcut"] if self.rw.unit[u].shortcut.w else []) + ["conv1", "conv2", "conv3"]
+            for nm in names:
+                out.append((slot, u, nm))
+                slot += 1
+        return out
+
+    def _set_tiles(self, table):
+        for (u, nm), t in table.items():
+            getattr(self.rw.unit[u], nm).tile = int(t)
+
+    def _tune_resnet(self, images, n, n_zero):
+        """Pick hmmr_layer_t.tile for every ResNet conv at this batch size: one instrumented pass per
+        candidate tile (every layer timed in place, behind its real producer), fastest wins per layer.
+        The tile never changes a result bit (each output element is one fixed-order K reduction), it
+        only moves the balance between tile-count quantisation, occupancy and operand reuse, which
+        flips between layers as the batch grows.  ~60 ms once per batch size."""
+        layers = self._resnet_layers()
+        nt = n + n_zero
+        nbytes = self.lib.hmmr_resnet50_workspace_bytes(nt, self.dtype)
+        ws = self._ws["resnet"].get(nbytes)
+        phi = torch.empty((nt, 2048), dtype=torch.float32, device=self.device)
+        src = images.data_ptr() if n else None
+        best = {}
+        for cand in (0,) + self._TUNE_TILES:
+            for slot, u, nm in layers:
+                lay = getattr(self.rw.unit[u], nm)
+                cout = self.rw.unit[u].base if nm in ("conv1", "conv2") else self.rw.unit[u].depth
+                lay.tile = cand if (cand not in (1, 5) or cout % 128 == 0) else 0
+            t = None
+            for rep in range(3):
+                pm = (C.c_float * L.RESNET_PROF_SLOTS)()
+                L.check(self.lib.hmmr_resnet50_fwd(C.byref(self.rw), src, n, n_zero, phi.data_ptr(), ws.data_ptr(),
+                                                   nbytes, self._stream(), pm), "hmmr_resnet50_fwd")
+                cur = np.frombuffer(pm, dtype=np.float32).copy()
+                t = cur if (t is None or rep == 0) else np.minimum(t, cur)      # rep 0 is the warm-up
+            for slot, u, nm in layers:
+                tile = getattr(self.rw.unit[u], nm).tile
+                if (u, nm) not in best or t[slot] < best[(u, nm)][0] * 0.98:    # 2 % hysteresis towards the heuristic
+                    best[(u, nm)] = (float(t[slot]), tile)
+        return {k: v[1] for k, v in best.items()}
+
     # -- stages ----------------------------------------------------------------
     def resnet(self, images, prof=False, n_zero=0):
         """images [n,224,224,3] fp32 (device) -> phi [n + n_zero,2048] fp32; the last
@@ -89,6 +141,16 @@ class HmmrEngine(object):
         n = images.shape[0]
         assert n == 0 or tuple(images.shape[1:]) == (224, 224, 3), images.shape
         nt = n + n_zero
+        table = None
+        if self.autotune and self.resnet_chunk <= 0 and nt >= self._TUNE_MIN_FRAMES:
+            if nt not in self._tiles and len(self._tiles) < 8 and not torch.cuda.is_current_stream_capturing():
+                self._tiles[nt] = self._tune_resnet(images, n, n_zero)
+            if self._tiles:                                  # an untuned size borrows the nearest tuned one
+                table = self._tiles[min(self._tiles, key=lambda k: abs(k - nt))]
+        if table is not None:
+            self._set_tiles(table)
+        elif self._tiles:
+            self._set_tiles({k: 0 for k in next(iter(self._tiles.values()))})
         phi = torch.empty((nt, 2048), dtype=torch.float32, device=self.device)
         chunk = self.resnet_chunk if self.resnet_chunk > 0 else max(nt, 1)
         prof_tot = np.zeros(L.RESNET_PROF_SLOTS, np.float64) if prof else None

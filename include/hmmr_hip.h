@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HMMR_ABI_VERSION 3
+#define HMMR_ABI_VERSION 4
 
 enum { HMMR_F32 = 0, HMMR_BF16 = 1 };
 
@@ -104,6 +104,9 @@ typedef struct {
     const void* w;         /* packed [cout_pad][K] in the struct's dtype */
     const float* scale;    /* folded BN scale or NULL */
     const float* shift;    /* folded BN shift or conv bias */
+    int tile;              /* hmmr_conv_desc_t.tile for this layer's launch; 0 = library heuristic.
+                              Results do not depend on it (same K order per output element);
+                              the host may tune it per layer and batch size. */
 } hmmr_layer_t;
 
 typedef struct {

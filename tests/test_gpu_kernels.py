@@ -299,3 +299,26 @@ def test_conv_gemm_fused_preactivation(tile, dt, gpu_device):
         wr = _bf16_round(w)
     ref, _ = _ref_conv(xa, wr, 1, 0, s, b, None, True, None, None)
     assert np.abs(out - ref).max() < 3e-5 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+def test_resnet_tile_choice_never_changes_a_bit(dt, weights, gpu_device):
+    """hmmr_layer_t.tile (and therefore the per-batch-size autotuner) only moves work between
+    workgroup shapes: every output element stays one fixed-order K reduction."""
+    import torch
+    from human_dynamics_amd.engine import HmmrEngine
+    eng = HmmrEngine(weights, None, dtype=dt, device=gpu_device, autotune=False)
+    x = torch.from_numpy(assets.make_synthetic_frames(40, seed=3)).to(gpu_device)
+    ref = eng.resnet(x, n_zero=1).clone()
+    layers = eng._resnet_layers()
+    for tile in (3, 6, 5):
+        table = {}
+        for _, u, nm in layers:
+            cout = eng.rw.unit[u].base if nm in ("conv1", "conv2") else eng.rw.unit[u].depth
+            table[(u, nm)] = tile if (tile != 5 or cout % 128 == 0) else 6
+        eng._set_tiles(table)
+        assert torch.equal(eng.resnet(x, n_zero=1), ref), tile
+    tuned = HmmrEngine(weights, None, dtype=dt, device=gpu_device, autotune=True)
+    assert torch.equal(tuned.resnet(x, n_zero=1), ref)
+    assert 41 in tuned._tiles and len(tuned._tiles[41]) == len(layers)
+    assert torch.equal(tuned.resnet(x[:33], n_zero=0), eng.resnet(x[:33], n_zero=0))
