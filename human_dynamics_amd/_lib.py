@@ -103,6 +103,8 @@ SIGNATURES = {
     "hmmr_smpl_fwd": (C.c_int, [C.POINTER(SmplConsts), _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int,
                                 _fp, _fp, _fp, _fp, _vp, C.c_size_t, _vp]),
     "hmmr_crop_frames": (C.c_int, [_vp, _ip, C.c_int, C.c_int, C.c_int, _fp, _vp]),
+    "hmmr_render_handoff": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, _fp, C.c_int64, _fp, C.c_int, C.c_int, C.c_int,
+                                      _fp, _fp, _fp, _vp]),
     "hmmr_eval_joints": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _vp]),
     "hmmr_eval_verts": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int, C.c_int, _fp, _vp]),
     "hmmr_smpl_fwd_strided": (C.c_int, [C.POINTER(SmplConsts), _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int,

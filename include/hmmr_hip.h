@@ -260,6 +260,21 @@ int hmmr_crop_frames(const unsigned char* frames, const int32_t* geom, int n, in
                      float* out, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * Hand-off to a rasteriser after the path (SURVEY f-3).  Replaces, for n frames in one launch, the
+ * per-frame host code of src/util/render/nmr_renderer.py: the camera / keypoint change from the
+ * 224x224 crop to the squared original image (visualize_img_orig :368-401) and the projection that
+ * feeds nr.Renderer.render (VisRenderer.__call__ :139-144, torch_utils.py:11-29:
+ * [s*(x+tx), -s*(y+ty), z]).  cams / verts / kps are read in place (row strides in floats, e.g.
+ * straight out of the packed per-frame records of hmmr_smpl_fwd_strided).
+ * geom [n][5] = {undo_scale, start_x, start_y, proc_size, img_size} per frame, or NULL to stay in
+ * crop coordinates (visualize_img).  Outputs: new_cam [n][3] (may be NULL), proj_verts [n][nv][3],
+ * kp_orig [n][nk][2] (may be NULL).
+ * ------------------------------------------------------------------------- */
+int hmmr_render_handoff(const float* cams, int64_t ld_cam, const float* verts, int64_t ld_verts,
+                        const float* kps, int64_t ld_kps, const float* geom, int n, int nv, int nk,
+                        float* new_cam, float* proj_verts, float* kp_orig, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Evaluation metrics on device (src/evaluation/eval_util.py): per-frame MPJPE after pelvis alignment
  * and after Procrustes alignment (compute_error_3d :30-60 with align_by_pelvis :158 and
  * compute_similarity_transform :177), acceleration (compute_accel :14) and acceleration error
