@@ -131,45 +131,69 @@ __global__ __launch_bounds__(256) void smpl_pose_kernel(
 }
 
 // ---- kernel 2 ------------------------------------------------------------ //
-// 128 vertices x 16 instances per workgroup.  The blend loop walks k four at a time: the 16
-// instances' coefficients are wave-uniform (four s_load_dwordx4-able floats each), every basis
-// value fetched from L2 feeds 16 FMAs, and the basis rows beyond 218 are zero (host-padded to 224).
+// 128 vertices x 16 instances per workgroup.  The blend loop walks k four at a time: the basis
+// values of step k+4 are requested before the FMAs of step k issue (two register sets), the 16
+// instances' coefficient rows sit in LDS and are read as wave-wide broadcasts, every basis value
+// feeds 16 FMAs (packed: v_pk_fma_f32), and the basis rows beyond 218 are zero (host-padded to 224).
 __global__ __launch_bounds__(VT) void smpl_verts_kernel(
     const float* __restrict__ dirs, int vpad, const float* __restrict__ feat, const float* __restrict__ A,
     const int* __restrict__ lbs_idx, const float* __restrict__ lbs_w, int nnz, int nv, int m,
     float* __restrict__ verts, long long ld_verts) {
-    __shared__ __attribute__((aligned(16))) float sA[IB][LDA];
+    __shared__ __attribute__((aligned(16))) float smem[IB * LDA + NFEAT_PAD * IB];
+    float (*sA)[LDA] = (float (*)[LDA])smem;
+    float (*sF)[IB] = (float (*)[IB])(smem + IB * LDA);          // [k][instance]: 4 instances per ds_read_b128
     const int v = blockIdx.x * VT + threadIdx.x;
     const int i0 = blockIdx.y * IB;
     for (int e = threadIdx.x; e < IB * LDA; e += VT) {
         const int ii = e / LDA;
         sA[ii][e % LDA] = (i0 + ii < m) ? A[(long long)(i0 + ii) * LDA + (e % LDA)] : 0.f;
     }
-    float acc[IB][3];
+    // feature rows of the 16 instances, transposed (the scratch buffer is sized for m rounded up to
+    // IB, so tail blocks read -- and ignore -- valid memory)
+    for (int e = threadIdx.x; e < IB * NFEAT_PAD; e += VT) {
+        const int ii = e / NFEAT_PAD, k = e % NFEAT_PAD;
+        sF[k][ii] = feat[(long long)(i0 + ii) * LDF + k];
+    }
+    // accumulators paired over INSTANCES: one v_pk_fma_f32 = two instances' coefficients (adjacent in
+    // LDS) times one broadcast basis value
+    f32x2 acc[IB / 2][3];
 #pragma unroll
-    for (int ii = 0; ii < IB; ++ii) acc[ii][0] = acc[ii][1] = acc[ii][2] = 0.f;
-    // feature rows of the 16 instances are wave-uniform (scalar loads); the scratch buffer is
-    // sized for m rounded up to IB, so tail blocks read (and ignore) valid memory
-    const float* fb = feat + (long long)i0 * LDF;
+    for (int ip = 0; ip < IB / 2; ++ip) acc[ip][0] = acc[ip][1] = acc[ip][2] = f32x2{0.f, 0.f};
     // v_posed = v_template + beta.S + pose_feature.P   (batch_smpl.py:110-112, 131-133)
-    const float* d = dirs + v;             // v < vpad always (grid covers vpad exactly)
-    for (int k = 0; k < NFEAT_PAD; k += 4) {
-        float dv[4][3];
+    // basis row (k, c) starts at the wave-uniform address dirs + (3k + c) * vpad: scalar base + lane offset
+    float dv[2][4][3];
+    auto fetch = [&](int k, int set) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) dv[q][c] = d[(long long)((k + q) * 3 + c) * vpad];
+            for (int c = 0; c < 3; ++c) dv[set][q][c] = (dirs + (long long)((k + q) * 3 + c) * vpad)[v];   // v < vpad always
+    };
+    auto blend = [&](int k, int set) {
 #pragma unroll
-        for (int ii = 0; ii < IB; ++ii) {
-            const f32x4 c4 = *(const f32x4*)(fb + ii * LDF + k);
+        for (int q = 0; q < 4; ++q) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                acc[ii][0] = fmaf(c4[q], dv[q][0], acc[ii][0]);
-                acc[ii][1] = fmaf(c4[q], dv[q][1], acc[ii][1]);
-                acc[ii][2] = fmaf(c4[q], dv[q][2], acc[ii][2]);
+            for (int i4 = 0; i4 < IB / 4; ++i4) {
+                const f32x4 c4 = *(const f32x4*)&sF[k + q][4 * i4];
+                const f32x2 lo = {c4[0], c4[1]}, hi = {c4[2], c4[3]};
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const f32x2 b = {dv[set][q][c], dv[set][q][c]};
+                    acc[2 * i4][c] = __builtin_elementwise_fma(lo, b, acc[2 * i4][c]);
+                    acc[2 * i4 + 1][c] = __builtin_elementwise_fma(hi, b, acc[2 * i4 + 1][c]);
+                }
             }
         }
+    };
+    fetch(0, 0);
+    __syncthreads();
+    static_assert(NFEAT_PAD % 8 == 4, "the two-set loop below peels one step");
+    for (int k = 0; k < NFEAT_PAD - 4; k += 8) {
+        fetch(k + 4, 1);
+        blend(k, 0);
+        fetch(k + 8, 0);
+        blend(k + 4, 1);
     }
+    blend(NFEAT_PAD - 4, 0);
     __syncthreads();
     if (v >= nv) return;
     // skinning: T = sum_j W[v,j] A_j over the non-zero weights; v' = T [v_posed; 1]   (batch_smpl.py:141-151)
@@ -201,7 +225,7 @@ __global__ __launch_bounds__(VT) void smpl_verts_kernel(
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (i0 + g + q < m) {
-                const float x = acc[g + q][0], y = acc[g + q][1], z = acc[g + q][2];
+                const float x = acc[(g + q) >> 1][0][(g + q) & 1], y = acc[(g + q) >> 1][1][(g + q) & 1], z = acc[(g + q) >> 1][2][(g + q) & 1];
                 float* o = verts + (long long)(i0 + g + q) * ld_verts + v * 3;
                 o[0] = T[q][0] * x + T[q][1] * y + T[q][2] * z + T[q][3];
                 o[1] = T[q][4] * x + T[q][5] * y + T[q][6] * z + T[q][7];
