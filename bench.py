@@ -105,6 +105,10 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the per-window tail on the ResNet's stream instead of a second stream "
                          "(default: tail of step k overlaps the ResNet of step k+1)")
+    ap.add_argument("--serial", action="store_true",
+                    help="one HIP stream for everything (no tail pipeline, no concurrent ResNet half-batches): the "
+                         "configuration the per-kernel rocprofv3 summaries under profiles/ are taken in, so that "
+                         "kernel durations are not inflated by co-running kernels")
     ap.add_argument("--graph", action="store_true",
                     help="replay the local pass as one hipGraph per step (measured equal to eager launches: "
                          "the step is GPU-bound, the host keeps 150 launches ahead)")
@@ -139,7 +143,9 @@ def main():
     gen.manual_seed(1234 + rank)
     span = torch.rand((plan.f1 - plan.f0, 224, 224, 3), generator=gen, device=device) * 2 - 1
 
-    pipeline = not (args.no_pipeline or args.graph)
+    pipeline = not (args.no_pipeline or args.graph or args.serial)
+    if args.serial or args.graph:
+        eng.resnet_streams = 1
     predictor = hd.ShardedPredictor(tester, n_total, rank, world, use_graph=args.graph,
                                      overlap_gather=not args.serial_gather, pipeline=pipeline)
 
@@ -176,6 +182,10 @@ def main():
         # (a) whole ResNet pass, HIP events on the launch stream, no per-launch instrumentation;
         # (b) one instrumented pass (an event after every launch) only to apportion the pass between
         #     the 53 conv_gemm launches and the 4 bandwidth kernels around them.
+        # Both on ONE stream (no concurrent half-batches): a per-kernel figure, comparable with rocprofv3's
+        # per-kernel durations of `bench.py --serial`.
+        streams_used = eng.resnet_streams
+        eng.resnet_streams = 1
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(2):
             eng.resnet(span, n_zero=1)
@@ -187,6 +197,7 @@ def main():
         pass_ms = e0.elapsed_time(e1) / 5
         eng.resnet(span, prof=True, n_zero=1)
         _, prof = eng.resnet(span, prof=True, n_zero=1)
+        eng.resnet_streams = streams_used
         mask = conv_slot_mask()
         conv_share = float(prof[:len(mask)][mask].sum()) / float(prof[:len(mask)].sum())
         conv_ms = pass_ms * conv_share
@@ -211,6 +222,7 @@ def main():
                     "traffic_source": traffic_src, "mfma_util_pmc": mfma_util,
                     "avg_launch_us": round(avg_launch_s * 1e6, 2),
                     "flops_per_launch": flops_per_launch,
+                    "measured": "one stream, no co-running kernels (the timed steps overlap streams)",
                     "resnet_pass_ms": round(all_ms, 3), "conv_ms": round(conv_ms, 3), "frames_encoded": n_enc}
         # ---- PCIe-inclusive rate (host frames in, host dict out), 1 GPU only, untimed extra
         pcie_fps = None
@@ -232,8 +244,10 @@ def main():
                        "resnet_frames_encoded_per_gpu": plan.f1 - plan.f0 + 1,
                        "resnet_schedule": "de-duplicated (1x per frame + halo; reference-literal is 2.5x)",
                        "smpl_calls_per_frame": 3, "launch": ("hipGraph replay of the local pass" if args.graph else
-                                  "eager, two streams: the f_movie/IEF/SMPL tail of step k runs under the ResNet of step k+1"
-                                  if pipeline else "eager, one stream"),
+                                  "eager; ResNet as %d concurrent half-batch launch sequences%s" % (
+                                      eng.resnet_streams, "; the f_movie/IEF/SMPL tail of step k runs on its own "
+                                      "stream under the ResNet of step k+1" if pipeline else "")
+                                  if (pipeline or eng.resnet_streams > 1) else "eager, one stream"),
                        "weights": "synthetic (seed 0), random-init, reference shapes",
                        "parallelism": ("window-sharded x%d, one RCCL all-gather per step%s" % (
                            world, "" if args.serial_gather else ", overlapped with the compute of the next step"))

@@ -194,3 +194,23 @@ def test_sharded_predictor_two_stream_pipeline_equals_serial(weights, smpl_const
     torch.cuda.synchronize()
     for i, (a, b) in enumerate(zip(got, want)):
         assert torch.equal(a, b), i
+
+
+def test_resnet_concurrent_half_batches_equal_one_pass(weights, gpu_device, monkeypatch):
+    """engine.resnet splits large batches over two HIP streams: same bits as one launch sequence."""
+    import torch
+    from human_dynamics_amd.engine import HmmrEngine
+    x = torch.from_numpy(assets.make_synthetic_frames(131, seed=9)).to(gpu_device)
+    monkeypatch.setenv("HMMR_RESNET_STREAMS", "1")
+    one = HmmrEngine(weights, None, dtype="bf16", device=gpu_device)
+    assert one.resnet_streams == 1
+    ref = one.resnet(x, n_zero=1)
+    monkeypatch.setenv("HMMR_RESNET_STREAMS", "2")
+    two = HmmrEngine(weights, None, dtype="bf16", device=gpu_device)
+    for _ in range(3):
+        got = two.resnet(x, n_zero=1)
+        assert torch.equal(got, ref)
+    assert len(two._side_streams) == 2 and "resnet1" in two._ws
+    three = HmmrEngine(weights, None, dtype="bf16", device=gpu_device)
+    three.resnet_streams = 3
+    assert torch.equal(three.resnet(x, n_zero=0), ref[:131])
