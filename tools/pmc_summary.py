@@ -8,12 +8,14 @@ are known): FETCH_SIZE counts 64 B per 128-B request -> x2; WRITE_SIZE x1; both 
 import collections
 import csv
 import glob
+import os
 import json
 import sys
 
 
 def agg(root, tag, counter):
-    f = glob.glob("%s/pmc_%s/*/*counter_collection.csv" % (root, tag))[0]
+    # gpurun merges into existing local directories: take the newest run (highest rocprofv3 pid prefix)
+    f = max(glob.glob("%s/pmc_%s/*/*counter_collection.csv" % (root, tag)), key=lambda x: int(os.path.basename(x).split("_")[0]))
     d = collections.defaultdict(lambda: [0, 0.0])
     for x in csv.DictReader(open(f)):
         if x["Counter_Name"] == counter:
@@ -48,7 +50,7 @@ def main():
     res["resnet_conv_gemm"] = {"launches": n, "hbm_bytes_per_launch": round((rd + w) / n),
                                "hbm_read_bytes_per_launch": round(rd / n), "hbm_write_bytes_per_launch": round(w / n),
                                "mfma_util": round(busy / (g / 8.0 * 1024.0), 4),
-                               "note": "averaged over the ResNet passes of `bench.py --steps 2 --warmup 1 "
+                               "note": "averaged over the ResNet passes of `HMMR_TILE_CACHE=<tuned> bench.py --serial --steps 2 --warmup 1 "
                                        "--no-cpu-baseline --no-pcie` (every pass encodes 257 frames)"}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res["resnet_conv_gemm"], indent=1))
