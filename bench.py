@@ -157,9 +157,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
-        out = step()
-    predictor.finish()
+    try:
+        for _ in range(args.warmup):
+            out = step()
+        predictor.finish()
+    except Exception as e:          # never lose the whole measurement to the overlap machinery
+        if not pipeline:
+            raise
+        print("bench.py: pipelined mode failed (%r); falling back to one stream" % (e,), file=sys.stderr)
+        pipeline = False
+        eng.resnet_streams = 1
+        predictor = hd.ShardedPredictor(tester, n_total, rank, world, overlap_gather=False, pipeline=False)
+        for _ in range(max(args.warmup, 1)):
+            out = step()
+        predictor.finish()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):

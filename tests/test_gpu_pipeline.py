@@ -214,3 +214,52 @@ def test_resnet_concurrent_half_batches_equal_one_pass(weights, gpu_device, monk
     three = HmmrEngine(weights, None, dtype="bf16", device=gpu_device)
     three.resnet_streams = 3
     assert torch.equal(three.resnet(x, n_zero=0), ref[:131])
+
+
+def test_pipelined_predictor_with_asynchronous_gather(weights, smpl_consts, gpu_device, monkeypatch):
+    """The N > 1 bench path on one GPU: rank 0 of a 2-rank plan in pipeline mode, with the RCCL all-gather
+    replaced by a stand-in that behaves like it (runs on its own stream after the issuing stream, returns a
+    Work whose wait() orders the caller's stream behind it).  Checks the stream choreography of
+    ShardedPredictor._run_pipelined / ready / finish, which the gloo tests (CPU) cannot reach."""
+    import torch
+    from human_dynamics_amd import dist as hd
+    from human_dynamics_amd.evaluation.tester import Tester
+    t = Tester(Config(batch_size=2), weights=weights, smpl=smpl_consts, dtype="bf16", device=gpu_device)
+    n = 48
+    clips = [torch.from_numpy(assets.make_synthetic_frames(n, seed=40 + i)).to(gpu_device) for i in range(4)]
+    whole = hd.ShardedPredictor(t, n, 0, 1)
+    want = [whole.run(c).clone() for c in clips]
+    comm = torch.cuda.Stream(device=gpu_device)
+    calls = []
+
+    class Work(object):
+        def __init__(self, ev):
+            self.ev = ev
+
+        def wait(self):
+            torch.cuda.current_stream().wait_event(self.ev)
+
+    def fake_all_gather(full, local, group=None, async_op=False):
+        comm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(comm):
+            torch.cuda._sleep(2000000)                     # the gather takes a while
+            full[:local.shape[0]].copy_(local)             # rank 0's block; rank 1's block stays as it is
+            ev = torch.cuda.Event()
+            ev.record(comm)
+        calls.append(async_op)
+        return Work(ev)
+    monkeypatch.setattr(hd.dist, "all_gather_into_tensor", fake_all_gather)
+    sp = hd.ShardedPredictor(t, n, 0, 2, pipeline=True, overlap_gather=True)
+    p = sp.plan
+    got, prev = [], None
+    for c in clips:
+        cur = sp.run(c[p.f0:p.f1])
+        if prev is not None:
+            got.append(sp.ready(prev)[:p.o1 - p.o0].clone())
+        prev = cur
+    sp.finish()
+    got.append(prev[:p.o1 - p.o0].clone())
+    torch.cuda.synchronize()
+    assert calls == [True] * 4
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert torch.equal(a, b[p.o0:p.o1]), i
