@@ -39,6 +39,18 @@ class ConvDesc(C.Structure):
     ]
 
 
+class TailDesc(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int), ("h2", _vp), ("m", C.c_int), ("c_mid", C.c_int), ("depth", C.c_int),
+        ("w3", _vp), ("scale3", _fp), ("shift3", _fp),
+        ("res", _vp), ("ldr", C.c_int), ("res_strided", C.c_int), ("res_img_stride", C.c_int64),
+        ("res_row_stride", C.c_int), ("res_px_stride", C.c_int), ("ho", C.c_int), ("wo", C.c_int),
+        ("out", _vp), ("pre_scale", _fp), ("pre_shift", _fp),
+        ("w1", _vp), ("scale1", _fp), ("shift1", _fp), ("relu1", C.c_int), ("n2", C.c_int),
+        ("out_h1", _vp),
+    ]
+
+
 class Layer(C.Structure):
     _fields_ = [("w", _vp), ("scale", _fp), ("shift", _fp), ("tile", C.c_int)]
 
@@ -47,7 +59,7 @@ class ResnetUnit(C.Structure):
     _fields_ = [("conv1", Layer), ("conv2", Layer), ("conv3", Layer), ("shortcut", Layer),
                 ("pre_scale", _fp), ("pre_shift", _fp),
                 ("c_in", C.c_int), ("base", C.c_int), ("depth", C.c_int), ("stride", C.c_int),
-                ("fuse_preact", C.c_int)]
+                ("fuse_preact", C.c_int), ("fuse_tail", C.c_int)]
 
 
 class ResnetWeights(C.Structure):
@@ -103,6 +115,7 @@ SIGNATURES = {
     "hmmr_smpl_fwd": (C.c_int, [C.POINTER(SmplConsts), _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int,
                                 _fp, _fp, _fp, _fp, _vp, C.c_size_t, _vp]),
     "hmmr_crop_frames": (C.c_int, [_vp, _ip, C.c_int, C.c_int, C.c_int, _fp, _vp]),
+    "hmmr_bottleneck_tail": (C.c_int, [C.POINTER(TailDesc), _vp]),
     "hmmr_render_handoff": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, _fp, C.c_int64, _fp, C.c_int, C.c_int, C.c_int,
                                       _fp, _fp, _fp, _vp]),
     "hmmr_eval_joints": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _vp]),
@@ -138,7 +151,7 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError if the .so does not export it
         fn.restype, fn.argtypes = res, args
-    if lib.hmmr_abi_version() != 4:
+    if lib.hmmr_abi_version() != 5:
         raise HmmrError("libhmmr_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -1,0 +1,255 @@
+// Fused tail of a ResNet-v2 bottleneck unit for gfx950 (bf16 operands):
+//
+//     trunk' = conv3(h2) + bias + shortcut                      (1x1, c_mid -> depth; bottleneck_v2 `conv3` + add)
+//     h1'    = relu(bn1'(conv1'(relu(bn_pre'(trunk')))))        (the NEXT unit's `preact` + `conv1`)
+//
+// in ONE kernel (slim resnet_v2.bottleneck as invoked at src/models.py:65-75).  In
+// the layer-per-launch schedule the next unit's conv1 re-reads the whole trunk tensor from HBM
+// (0.41 GB per block-1 unit at 257 frames, a quarter of the unit's traffic); here the trunk tile
+// never leaves the CU between the two GEMMs.
+//
+// One workgroup (8 waves) owns 128 pixels and walks the `depth` output channels of conv3 in
+// chunks of 64, which are exactly the K steps of conv1':
+//
+//   per chunk  (1) conv3 chunk: 4 MFMAs per wave out of LDS (H2 tile x W3 chunk, K = c_mid = 64)
+//              (2) + bias + shortcut, rounded to bf16 IN PLACE in an LDS tile that was pre-filled
+//                  with the shortcut chunk
+//              (3) the tile is streamed out (coalesced 16-B stores = the trunk tensor) and
+//                  pre-activated in place (relu(x*s+b), bf16): it is now K step `chunk` of conv1'
+//              (4) conv1' K step: 4 MFMAs per wave (P tile x W1' chunk) into accumulators that live
+//                  across the chunks
+//   at the end the conv1' accumulators get BN + ReLU and leave through LDS as coalesced stores.
+//
+// MFMA operands are swapped (weights = A, activations = B), so a lane owns 4 CONSECUTIVE CHANNELS
+// of one pixel (D[i][j]: i = channel, j = pixel) -- 8 bytes of a pixel row, which makes steps (2)
+// and the final epilogue plain ds_read_b64 / ds_write_b64 without an fp32 transposition buffer.
+// a*b commutes exactly and the K order is unchanged, so every value equals the one the separate
+// conv3 and (fused-preact) conv1 launches of gemm_conv.hip produce, bit for bit (tested).
+//
+// All global->LDS staging goes through registers (ordinary loads, ds_write_b128): hipcc then counts
+// its own vmcnt waits and `__syncthreads()` stays a bare s_barrier; the shortcut chunk is requested
+// TWO chunks ahead (HBM latency), the weight chunks one ahead (L2).
+// LDS: H2 16 KB + W3 chunk 8 KB + W1' chunk 8 KB + 2 x 16 KB trunk tiles + 4 KB constants = 68 KB
+// -> two workgroups per CU.
+#include "common.h"
+#include "hmmr_hip.h"
+
+namespace {
+
+struct TailArgs {
+    const bf16_t* h2; const bf16_t* w3; const float* scale3; const float* shift3;
+    const bf16_t* res; bf16_t* out;
+    const float* pre_scale; const float* pre_shift;
+    const bf16_t* w1; const float* scale1; const float* shift1; bf16_t* out_h1;
+    int M, depth, ldr, res_strided, Wo, HoWo;
+    long long res_img_stride; int res_row_stride, res_px_stride;
+    int relu1;
+};
+
+constexpr int BM = 128, CM = 64, N2 = 64, NT = 512;
+constexpr int OFF_H2 = 0, OFF_W3 = 16384, OFF_W1 = 24576, OFF_P0 = 32768, OFF_P1 = 49152, OFF_C = 65536;
+
+__device__ __forceinline__ f32x16 mma16(const bf16x8& a, const bf16x8& b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float bf_lo(unsigned v) { return __uint_as_float(v << 16); }
+__device__ __forceinline__ float bf_hi(unsigned v) { return __uint_as_float(v & 0xffff0000u); }
+__device__ __forceinline__ unsigned pack_bf(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    bf16x2 pk = {(bf16_t)a, (bf16_t)b};
+    return __builtin_bit_cast(unsigned, pk);
+}
+
+template <int NCH>
+__global__ __launch_bounds__(NT, 4) void bottleneck_tail_kernel(const TailArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * BM;
+    const int depth = NCH * 64;
+
+    // ---- staging geometry (as gemm_conv.hip): 8 lanes per 128-B row, thread (r0, pslot) owns PHYSICAL slot
+    // pslot of rows r0 and r0 + 64 and fills it with LOGICAL slot lslot
+    const int pslot = tid & 7, r0 = tid >> 3;
+    const int lslot = pslot ^ ((r0 >> 1) & 7);
+    const int st_off = r0 * 128 + pslot * 16;                 // + 64*128 for the second row
+
+    float* sScale3 = (float*)(smem + OFF_C);
+    float* sBias3 = sScale3 + depth;
+    float* sPreS = sBias3 + depth;
+    float* sPreB = sPreS + depth;
+    for (int i = tid; i < depth; i += NT) {
+        sScale3[i] = a.scale3 ? a.scale3[i] : 1.0f;
+        sBias3[i] = a.shift3 ? a.shift3[i] : 0.0f;
+        sPreS[i] = a.pre_scale[i];
+        sPreB[i] = a.pre_shift[i];
+    }
+
+    // rows of this thread and their shortcut addresses (flat rows, or x[:, ::s, ::s] of the unit input)
+    bool rok[2]; long long roff[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int m = m0 + r0 + 64 * p;
+        rok[p] = m < a.M;
+        const int mm = rok[p] ? m : 0;
+        if (a.res_strided) {
+            const int img = mm / a.HoWo, rem = mm - img * a.HoWo;
+            const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+            roff[p] = (long long)img * a.res_img_stride + (long long)oy * a.res_row_stride + (long long)ox * a.res_px_stride;
+        } else {
+            roff[p] = (long long)mm * a.ldr;
+        }
+    }
+    auto load_res = [&](int nc, u32x4 (&r)[2]) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) r[p] = *(const u32x4*)(a.res + roff[p] + nc * 64 + lslot * 8);
+    };
+    auto store_tile2 = [&](int off, const u32x4 (&r)[2]) {
+        *(u32x4*)(smem + off + st_off) = r[0];
+        *(u32x4*)(smem + off + st_off + 64 * 128) = r[1];
+    };
+    auto load_w3 = [&](int nc) { return *(const u32x4*)(a.w3 + (long long)(nc * 64 + r0) * CM + lslot * 8); };
+    auto load_w1 = [&](int nc) { return *(const u32x4*)(a.w1 + (long long)r0 * depth + nc * 64 + lslot * 8); };
+
+    // ---- prologue: H2 tile, weight chunks 0, shortcut chunks 0 (-> LDS) and 1 (-> registers)
+    u32x4 rres[2][2], rw3, rw1;
+    {
+        u32x4 rh[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int m = rok[p] ? m0 + r0 + 64 * p : 0;
+            rh[p] = *(const u32x4*)(a.h2 + (long long)m * CM + lslot * 8);
+        }
+        rw3 = load_w3(0);
+        rw1 = load_w1(0);
+        load_res(0, rres[0]);
+        if (NCH > 1) load_res(1, rres[1]);
+        store_tile2(OFF_H2, rh);
+        *(u32x4*)(smem + OFF_W3 + st_off) = rw3;
+        *(u32x4*)(smem + OFF_W1 + st_off) = rw1;
+        store_tile2(OFF_P0, rres[0]);
+    }
+    __syncthreads();
+
+    // ---- fragment / epilogue geometry: wave (wn, wm) owns channels [32 wn, +32) x pixels [32 wm, +32)
+    const int wn = wave >> 2, wm = wave & 3;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int fsw = (lr >> 1) & 7;
+    auto frag = [&](int tile_off, int row, int kc) {
+        return *(const bf16x8*)(smem + tile_off + row * 128 + (((2 * kc + lh) ^ fsw) << 4));
+    };
+    const int prow = (wm * 32 + lr) * 128;                    // this lane's pixel row inside a trunk tile
+
+    f32x16 acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+
+#pragma unroll
+    for (int nc = 0; nc < NCH; ++nc) {
+        const int pcur = (nc & 1) ? OFF_P1 : OFF_P0, pnxt = (nc & 1) ? OFF_P0 : OFF_P1;
+        // (a) requests for later chunks
+        if (nc + 2 < NCH) load_res(nc + 2, rres[nc & 1]);
+        if (nc + 1 < NCH) { rw3 = load_w3(nc + 1); rw1 = load_w1(nc + 1); }
+        // (b) conv3 chunk: D[channel][pixel]
+        f32x16 acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) acc1 = mma16(frag(OFF_W3, wn * 32 + lr, kc), frag(OFF_H2, wm * 32 + lr, kc), acc1);
+        // (c) + bias + shortcut, rounded to bf16, in place (lane: 4 consecutive channels x 4 groups of its pixel)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int cl = wn * 32 + 8 * g + 4 * lh;             // channel inside the chunk
+            char* p = smem + pcur + prow + ((((cl >> 3)) ^ fsw) << 4) + 8 * lh;
+            const f32x4 s4 = *(const f32x4*)(sScale3 + nc * 64 + cl), b4 = *(const f32x4*)(sBias3 + nc * 64 + cl);
+            const unsigned long long rr = *(const unsigned long long*)p;
+            const unsigned r01 = (unsigned)rr, r23 = (unsigned)(rr >> 32);
+            // the epilogue arithmetic of gemm_conv.hip, rounding for rounding: fma(acc, scale, shift) + shortcut
+            // (scale3 absent -> 1.0f: fma(acc, 1, b) == acc + b exactly)
+            float v0 = fmaf(acc1[4 * g + 0], s4[0], b4[0]), v1 = fmaf(acc1[4 * g + 1], s4[1], b4[1]);
+            float v2 = fmaf(acc1[4 * g + 2], s4[2], b4[2]), v3 = fmaf(acc1[4 * g + 3], s4[3], b4[3]);
+            v0 += bf_lo(r01); v1 += bf_hi(r01); v2 += bf_lo(r23); v3 += bf_hi(r23);
+            const unsigned long long o = (unsigned long long)pack_bf(v0, v1) | ((unsigned long long)pack_bf(v2, v3) << 32);
+            *(unsigned long long*)p = o;
+        }
+        __syncthreads();
+        // (e) stream the trunk chunk out and pre-activate it in place; stage the next shortcut / W3 chunks
+        {
+            const f32x4 s0 = *(const f32x4*)(sPreS + nc * 64 + lslot * 8), s1 = *(const f32x4*)(sPreS + nc * 64 + lslot * 8 + 4);
+            const f32x4 b0 = *(const f32x4*)(sPreB + nc * 64 + lslot * 8), b1 = *(const f32x4*)(sPreB + nc * 64 + lslot * 8 + 4);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                char* q = smem + pcur + st_off + p * (64 * 128);
+                const u32x4 x = *(const u32x4*)q;
+                if (rok[p]) *(u32x4*)(a.out + (long long)(m0 + r0 + 64 * p) * depth + nc * 64 + lslot * 8) = x;
+                u32x4 y;
+                y[0] = pack_bf(fmaxf(fmaf(bf_lo(x[0]), s0[0], b0[0]), 0.f), fmaxf(fmaf(bf_hi(x[0]), s0[1], b0[1]), 0.f));
+                y[1] = pack_bf(fmaxf(fmaf(bf_lo(x[1]), s0[2], b0[2]), 0.f), fmaxf(fmaf(bf_hi(x[1]), s0[3], b0[3]), 0.f));
+                y[2] = pack_bf(fmaxf(fmaf(bf_lo(x[2]), s1[0], b1[0]), 0.f), fmaxf(fmaf(bf_hi(x[2]), s1[1], b1[1]), 0.f));
+                y[3] = pack_bf(fmaxf(fmaf(bf_lo(x[3]), s1[2], b1[2]), 0.f), fmaxf(fmaf(bf_hi(x[3]), s1[3], b1[3]), 0.f));
+                *(u32x4*)q = y;
+            }
+            if (nc + 1 < NCH) {
+                store_tile2(pnxt, rres[(nc + 1) & 1]);
+                *(u32x4*)(smem + OFF_W3 + st_off) = rw3;
+            }
+        }
+        __syncthreads();
+        // (g) conv1' K step `nc`
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) acc2 = mma16(frag(OFF_W1, wn * 32 + lr, kc), frag(pcur, wm * 32 + lr, kc), acc2);
+        __syncthreads();
+        if (nc + 1 < NCH) *(u32x4*)(smem + OFF_W1 + st_off) = rw1;
+    }
+
+    // ---- conv1' epilogue: BN (+ReLU), bf16, through the H2 region, coalesced stores
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int cl = wn * 32 + 8 * g + 4 * lh;
+        const f32x4 s4 = *(const f32x4*)(a.scale1 + cl), b4 = *(const f32x4*)(a.shift1 + cl);
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = fmaf(acc2[4 * g + j], s4[j], b4[j]);
+            if (a.relu1) v[j] = fmaxf(v[j], 0.f);
+        }
+        char* p = smem + OFF_H2 + prow + (((cl >> 3) ^ fsw) << 4) + 8 * lh;
+        *(unsigned long long*)p = (unsigned long long)pack_bf(v[0], v[1]) | ((unsigned long long)pack_bf(v[2], v[3]) << 32);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+        if (rok[p]) *(u32x4*)(a.out_h1 + (long long)(m0 + r0 + 64 * p) * N2 + lslot * 8) = *(const u32x4*)(smem + OFF_H2 + st_off + p * (64 * 128));
+}
+
+}  // namespace
+
+extern "C" int hmmr_bottleneck_tail(const hmmr_tail_desc_t* d, void* stream) {
+    HMMR_REQUIRE(d && d->h2 && d->w3 && d->res && d->out && d->pre_scale && d->pre_shift && d->w1 && d->scale1 &&
+                 d->shift1 && d->out_h1, "hmmr_bottleneck_tail: null argument");
+    HMMR_REQUIRE(d->dtype == HMMR_BF16, "hmmr_bottleneck_tail: bf16 operands only");
+    HMMR_REQUIRE(d->c_mid == CM && d->n2 == N2 && d->depth == 256,
+                 "hmmr_bottleneck_tail: supported shape is c_mid 64 -> depth 256 -> n2 64 (got %d, %d, %d)", d->c_mid,
+                 d->depth, d->n2);
+    HMMR_REQUIRE(d->m > 0, "hmmr_bottleneck_tail: empty launch");
+    HMMR_REQUIRE(d->res_strided || d->ldr >= d->depth, "hmmr_bottleneck_tail: residual row stride < depth");
+    HMMR_REQUIRE(!d->res_strided || (d->ho > 0 && d->wo > 0), "hmmr_bottleneck_tail: strided residual needs ho, wo");
+    TailArgs a;
+    a.h2 = (const bf16_t*)d->h2; a.w3 = (const bf16_t*)d->w3; a.scale3 = d->scale3; a.shift3 = d->shift3;
+    a.res = (const bf16_t*)d->res; a.out = (bf16_t*)d->out; a.pre_scale = d->pre_scale; a.pre_shift = d->pre_shift;
+    a.w1 = (const bf16_t*)d->w1; a.scale1 = d->scale1; a.shift1 = d->shift1; a.out_h1 = (bf16_t*)d->out_h1;
+    a.M = d->m; a.depth = d->depth; a.ldr = d->ldr; a.res_strided = d->res_strided;
+    a.Wo = d->wo > 0 ? d->wo : 1; a.HoWo = d->ho > 0 ? d->ho * d->wo : 1;
+    a.res_img_stride = d->res_img_stride; a.res_row_stride = d->res_row_stride; a.res_px_stride = d->res_px_stride;
+    a.relu1 = d->relu1;
+    const int lds = OFF_C + 4 * 256 * (int)sizeof(float);
+    auto kern = bottleneck_tail_kernel<4>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HMMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)((d->m + BM - 1) / BM)), dim3(NT), lds, (hipStream_t)stream, a);
+    HMMR_CHECK_HIP(hipGetLastError());
+    return 0;
+}

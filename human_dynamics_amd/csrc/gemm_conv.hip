@@ -352,15 +352,20 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 1) void conv
         if (m >= a.M || n >= a.cout) continue;
         float v[8];
         load8(sc + row * BN + col, v);
-        if (a.scale) {
+        // scale and shift together are ONE fused multiply-add, spelled out so that no -ffp-contract mood can
+        // make two builds (or this kernel and bottleneck.hip) round differently
+        if (a.scale && a.shift) {
+            float s[8], b[8]; load8(a.scale + n, s); load8(a.shift + n, b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], s[j], b[j]);
+        } else if (a.scale) {
             float s[8]; load8(a.scale + n, s);
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] *= s[j];
-        }
-        if (a.shift) {
-            float s[8]; load8(a.shift + n, s);
+        } else if (a.shift) {
+            float b[8]; load8(a.shift + n, b);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += s[j];
+            for (int j = 0; j < 8; ++j) v[j] += b[j];
         }
         const bool full = (n + 8 <= a.cout);
         if (!PRO && res) {
@@ -382,7 +387,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 1) void conv
             float s2[8], b2[8], u[8];
             load8(a.scale2 + n, s2); load8(a.shift2 + n, b2);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) u[j] = fmaxf(v[j] * s2[j] + b2[j], 0.f);
+            for (int j = 0; j < 8; ++j) u[j] = fmaxf(fmaf(v[j], s2[j], b2[j]), 0.f);   // = the consumer-side preact_slot
             if (full) store8(out2 + oo, u);
             else for (int j = 0; j < 8 && n + j < a.cout; ++j) out2[oo + j] = elem_traits<TO>::from_f32(u[j]);
         }
@@ -464,15 +469,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a, co
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += p[j];
     }
-    if (a.scale) {
+    if (a.scale && a.shift) {
+        float s[8], b[8]; load8(a.scale + n, s); load8(a.shift + n, b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], s[j], b[j]);
+    } else if (a.scale) {
         float s[8]; load8(a.scale + n, s);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] *= s[j];
-    }
-    if (a.shift) {
-        float s[8]; load8(a.shift + n, s);
+    } else if (a.shift) {
+        float b[8]; load8(a.shift + n, b);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += s[j];
+        for (int j = 0; j < 8; ++j) v[j] += b[j];
     }
     const bool full = (n + 8 <= a.cout);
     const TO* __restrict__ res = (const TO*)a.res;

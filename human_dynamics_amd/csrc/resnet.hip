@@ -227,6 +227,7 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
     // neutral; the packer enables it everywhere.
     int H = 56, cur = 0, pcur = 0;
     bool have_raw = false;            // X[cur] holds the raw input of the unit
+    bool h1_ready = false;            // T1 already holds this unit's conv1 output (previous unit's fused tail)
     for (int u = 0; u < HMMR_RESNET_UNITS; ++u) {
         const hmmr_resnet_unit_t& U = w->unit[u];
         const int Ho = H / U.stride;
@@ -257,15 +258,17 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
             if (hmmr_conv_gemm(&d, s)) return -2;
             if (prof_mark(pf)) return -2;
         }
-        // conv1: 1x1 on preact, BN + ReLU
-        d = hmmr_conv_desc_t{};
-        d.in = xin; d.pro_scale = ps; d.pro_shift = pb;
-        d.w = U.conv1.w; d.scale = U.conv1.scale; d.shift = U.conv1.shift; d.relu = 1; d.tile = U.conv1.tile;
-        d.out = T1; d.in_dtype = d.out_dtype = w->dtype;
-        d.n_img = n; d.hin = H; d.win = H; d.cin = U.c_in;
-        d.in_img_stride = (int64_t)H * H * U.c_in; d.in_row_stride = H * U.c_in; d.in_px_stride = U.c_in;
-        d.kh = d.kw = 1; d.sy = d.sx = 1; d.ho = d.wo = H; d.cout = U.base; d.ldo = U.base;
-        if (hmmr_conv_gemm(&d, s)) return -2;
+        // conv1: 1x1 on preact, BN + ReLU (already in T1 if the previous unit ended in a fused tail)
+        if (!h1_ready) {
+            d = hmmr_conv_desc_t{};
+            d.in = xin; d.pro_scale = ps; d.pro_shift = pb;
+            d.w = U.conv1.w; d.scale = U.conv1.scale; d.shift = U.conv1.shift; d.relu = 1; d.tile = U.conv1.tile;
+            d.out = T1; d.in_dtype = d.out_dtype = w->dtype;
+            d.n_img = n; d.hin = H; d.win = H; d.cin = U.c_in;
+            d.in_img_stride = (int64_t)H * H * U.c_in; d.in_row_stride = H * U.c_in; d.in_px_stride = U.c_in;
+            d.kh = d.kw = 1; d.sy = d.sx = 1; d.ho = d.wo = H; d.cout = U.base; d.ldo = U.base;
+            if (hmmr_conv_gemm(&d, s)) return -2;
+        }
         if (prof_mark(pf)) return -2;
         // conv2: 3x3 conv2d_same(stride): pad 1/1 both for stride 1 (SAME) and stride 2 (explicit pad + VALID)
         d = hmmr_conv_desc_t{};
@@ -295,7 +298,23 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
             d.out2 = pn; d.scale2 = w->unit[u + 1].pre_scale; d.shift2 = w->unit[u + 1].pre_shift;
             HMMR_REQUIRE(d.scale2 && d.shift2, "resnet: unit %d lacks its preact BN", u + 1);
         }
-        if (hmmr_conv_gemm(&d, s)) return -2;
+        h1_ready = false;
+        if (U.fuse_tail) {            // conv3 + add + the next unit's preact + conv1 in one launch (csrc/bottleneck.hip)
+            HMMR_REQUIRE(!last && w->dtype == HMMR_BF16 && U.stride == 1 && U.base == 64 && U.depth == 256 && write_raw &&
+                         !write_pre && next_fused && next_identity && w->unit[u + 1].base == 64 &&
+                         w->unit[u + 1].c_in == 256, "resnet: unit %d cannot fuse its tail", u);
+            const hmmr_resnet_unit_t& N = w->unit[u + 1];
+            hmmr_tail_desc_t t = {};
+            t.dtype = w->dtype; t.h2 = T2; t.m = n * Ho * Ho; t.c_mid = U.base; t.depth = U.depth;
+            t.w3 = U.conv3.w; t.scale3 = U.conv3.scale; t.shift3 = U.conv3.shift;
+            t.res = d.res; t.ldr = d.ldr; t.res_strided = d.res_strided; t.res_img_stride = d.res_img_stride;
+            t.res_row_stride = d.res_row_stride; t.res_px_stride = d.res_px_stride; t.ho = Ho; t.wo = Ho;
+            t.out = xn; t.pre_scale = N.pre_scale; t.pre_shift = N.pre_shift;
+            t.w1 = N.conv1.w; t.scale1 = N.conv1.scale; t.shift1 = N.conv1.shift; t.relu1 = 1; t.n2 = N.base;
+            t.out_h1 = T1;
+            if (hmmr_bottleneck_tail(&t, s)) return -2;
+            h1_ready = true;
+        } else if (hmmr_conv_gemm(&d, s)) return -2;
         if (prof_mark(pf)) return -2;
         have_raw = write_raw;
         cur ^= 1; pcur ^= 1; H = Ho;

@@ -57,7 +57,8 @@ class HmmrEngine(object):
         self.num_conv_layers = num_conv_layers
         self.delta_keys = sorted(int(d) for d in delta_t_values)
         fuse = tuple(b for b in os.environ.get("HMMR_FUSE_PREACT", "block1,block2,block3,block4").split(",") if b)   # dev A/B switch
-        self.rw = (packing.pack_resnet(weights, self.dtype, self.store, fuse_preact_blocks=fuse)
+        tail = os.environ.get("HMMR_FUSE_TAIL", "1") != "0"                                         # dev A/B switch
+        self.rw = (packing.pack_resnet(weights, self.dtype, self.store, fuse_preact_blocks=fuse, fuse_tail=tail)
                    if weights is not None else None)
         self.tw = (packing.pack_temporal(weights, self.temporal_dtype, self.store, num_conv_layers)
                    if weights is not None else None)
@@ -370,3 +371,37 @@ def conv_gemm(x, w_hwio, stride=1, pad=0, scale=None, shift=None, res=None, relu
     o = out[..., :cout].float().cpu().numpy()
     o2 = out2[..., :cout].float().cpu().numpy() if out2 is not None else None
     return o, o2
+
+
+def bottleneck_tail(h2, w3_hwio, bias3, res, pre, w1_hwio, bn1, res_stride=1, device="cuda:0"):
+    """Test/utility entry for hmmr_bottleneck_tail (bf16): h2 [n,h,w,64], w3 [1,1,64,256], res
+    [n,h*s,w*s,256] (s = res_stride), pre = (scale, shift) [256], w1 [1,1,256,64], bn1 = (scale, shift) [64].
+    Returns (trunk [n,h,w,256], h1 [n,h,w,64]) as float32 arrays of the bf16 results."""
+    lib = L.load()
+    dev = torch.device(device)
+    store = packing.DeviceStore(dev)
+    bf = torch.bfloat16
+    x = store.put(np.asarray(h2, np.float32), bf)
+    n, h, w_, cm = x.shape
+    depth, n2 = w3_hwio.shape[3], w1_hwio.shape[3]
+    w3 = store.put(packing.pack_conv_weight(np.asarray(w3_hwio, np.float32)), bf)
+    w1 = store.put(packing.pack_conv_weight(np.asarray(w1_hwio, np.float32)), bf)
+    rt = store.put(np.asarray(res, np.float32), bf)
+    out = torch.zeros((n, h, w_, depth), dtype=bf, device=dev)
+    h1 = torch.zeros((n, h, w_, n2), dtype=bf, device=dev)
+    d = L.TailDesc()
+    d.dtype, d.h2, d.m, d.c_mid, d.depth = L.HMMR_BF16, x.data_ptr(), n * h * w_, cm, depth
+    d.w3, d.shift3 = w3.data_ptr(), store.vec(bias3).data_ptr()
+    d.res = rt.data_ptr()
+    if res_stride == 1:
+        d.ldr = depth
+    else:
+        d.res_strided, d.ho, d.wo = 1, h, w_
+        d.res_img_stride = rt.shape[1] * rt.shape[2] * depth
+        d.res_row_stride, d.res_px_stride = res_stride * rt.shape[2] * depth, res_stride * depth
+    d.out, d.out_h1 = out.data_ptr(), h1.data_ptr()
+    d.pre_scale, d.pre_shift = store.vec(pre[0]).data_ptr(), store.vec(pre[1]).data_ptr()
+    d.w1, d.scale1, d.shift1, d.relu1, d.n2 = w1.data_ptr(), store.vec(bn1[0]).data_ptr(), store.vec(bn1[1]).data_ptr(), 1, n2
+    L.check(lib.hmmr_bottleneck_tail(C.byref(d), torch.cuda.current_stream(dev).cuda_stream), "hmmr_bottleneck_tail")
+    torch.cuda.synchronize(dev)
+    return out.float().cpu().numpy(), h1.float().cpu().numpy()

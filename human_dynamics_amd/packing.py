@@ -77,10 +77,12 @@ def _layer(store, w_packed, dtype, scale=None, shift=None):
     return lay
 
 
-def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3", "block4")):
+def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3", "block4"), fuse_tail=True):
     """fuse_preact_blocks: blocks whose units apply their `preact` BN+ReLU inside the operand
     staging of conv1/shortcut instead of reading a materialised preact tensor (csrc/resnet.hip;
-    measured at batch 256: -4.5 % ResNet time with blocks 1-2 fused, neutral for blocks 3-4)."""
+    measured at batch 256: -4.5 % ResNet time with blocks 1-2 fused, neutral for blocks 3-4).
+    fuse_tail: mark the units whose conv3 + add runs with the next unit's preact + conv1 as one
+    hmmr_bottleneck_tail launch (bf16; block1 unit_1 -> unit_2 -> unit_3)."""
     rw = L.ResnetWeights()
     rw.dtype = dtype
     rw.stem = _layer(store, pack_stem_weight(w["resnet_v2_50/conv1/weights"]), dtype,
@@ -102,6 +104,11 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
                                 shift=w[scope + "/shortcut/biases"])
         s, b = fold_bn(w, scope + "/preact")
         u.pre_scale, u.pre_shift = store.vec(s).data_ptr(), store.vec(b).data_ptr()
+    for i in range(L.RESNET_UNITS - 1):
+        u, nx = rw.unit[i], rw.unit[i + 1]
+        u.fuse_tail = int(bool(fuse_tail) and dtype == L.HMMR_BF16 and u.stride == 1 and u.base == 64 and
+                          u.depth == 256 and nx.c_in == 256 and nx.base == 64 and nx.fuse_preact == 1 and
+                          not nx.shortcut.w)
     s, b = fold_bn(w, "resnet_v2_50/postnorm")
     rw.post_scale, rw.post_shift = store.vec(s).data_ptr(), store.vec(b).data_ptr()
     return rw

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HMMR_ABI_VERSION 4
+#define HMMR_ABI_VERSION 5
 
 enum { HMMR_F32 = 0, HMMR_BF16 = 1 };
 
@@ -116,6 +116,9 @@ typedef struct {
     int c_in, base, depth, stride;
     int fuse_preact;           /* 1: conv1/shortcut apply the preact while staging their operand;
                                   0: the previous unit's conv3 writes the preact tensor */
+    int fuse_tail;             /* 1: this unit's conv3 + add and the NEXT unit's preact + conv1 run as one
+                                  hmmr_bottleneck_tail launch (bf16, base 64 -> depth 256 -> next base 64,
+                                  stride 1, next unit with identity shortcut and fuse_preact) */
 } hmmr_resnet_unit_t;
 
 #define HMMR_RESNET_UNITS 16
@@ -127,6 +130,28 @@ typedef struct {
     const float* post_scale;           /* postnorm BN folded */
     const float* post_shift;
 } hmmr_resnet_weights_t;
+
+/* ------------------------------------------------------------------------- *
+ * Fused tail of a bottleneck unit (slim resnet_v2.bottleneck as invoked at src/models.py:65-75):
+ *   out    = conv3(h2) * scale3 + shift3 + shortcut         (1x1, c_mid -> depth, no ReLU)
+ *   out_h1 = relu(conv1'(relu(out * pre_scale + pre_shift)) * scale1 + shift1)
+ * i.e. this unit's `conv3` + add and the NEXT unit's `preact` + `conv1` in one launch, so the next
+ * conv1 does not re-read the trunk from HBM.  Bit-identical to the two hmmr_conv_gemm launches it
+ * replaces (conv3 with a residual; conv1 with pro_scale/pro_shift).  bf16, c_mid 64, depth 256, n2 64.
+ * The shortcut is read as rows of `ldr` elements, or (res_strided) as x[:, ::s, ::s] of an NHWC
+ * tensor like hmmr_conv_desc_t's strided residual (ho, wo = output grid).
+ * ------------------------------------------------------------------------- */
+typedef struct {
+    int dtype;                      /* HMMR_BF16 */
+    const void* h2; int m; int c_mid; int depth;
+    const void* w3; const float* scale3; const float* shift3;      /* [depth][c_mid]; scale3 may be NULL */
+    const void* res; int ldr; int res_strided; int64_t res_img_stride; int res_row_stride, res_px_stride; int ho, wo;
+    void* out;                      /* [m][depth] */
+    const float* pre_scale; const float* pre_shift;                /* [depth] */
+    const void* w1; const float* scale1; const float* shift1; int relu1; int n2;   /* [n2][depth] */
+    void* out_h1;                   /* [m][n2] */
+} hmmr_tail_desc_t;
+int hmmr_bottleneck_tail(const hmmr_tail_desc_t* d, void* stream);
 
 size_t hmmr_resnet50_workspace_bytes(int n, int dtype);
 /* prof_ms: NULL, or a host array of HMMR_RESNET_PROF_SLOTS floats that receives

@@ -322,3 +322,27 @@ def test_resnet_tile_choice_never_changes_a_bit(dt, weights, gpu_device):
     assert torch.equal(tuned.resnet(x, n_zero=1), ref)
     assert 41 in tuned._tiles and len(tuned._tiles[41]) == len(layers)
     assert torch.equal(tuned.resnet(x[:33], n_zero=0), eng.resnet(x[:33], n_zero=0))
+
+
+@pytest.mark.parametrize("shape,res_stride", [((3, 9, 7), 1), ((2, 8, 8), 2), ((1, 16, 16), 1)])
+def test_bottleneck_tail_equals_conv3_then_fused_preact_conv1(shape, res_stride, gpu_device):
+    """hmmr_bottleneck_tail (conv3 + add + next preact + next conv1 in one launch) == the two
+    hmmr_conv_gemm launches it replaces, bit for bit (M tails: 189 and 128 rows are not multiples of 128)."""
+    from human_dynamics_amd.engine import bottleneck_tail, conv_gemm
+    rng = np.random.default_rng(17)
+    n, h, w = shape
+    h2 = np.maximum(rng.normal(size=(n, h, w, 64)), 0).astype(np.float32)
+    w3 = (rng.normal(size=(1, 1, 64, 256)) / 8).astype(np.float32)
+    b3 = rng.normal(size=256).astype(np.float32)
+    res = rng.normal(size=(n, h * res_stride, w * res_stride, 256)).astype(np.float32)
+    pre = (rng.uniform(0.5, 1.5, 256).astype(np.float32), rng.normal(size=256).astype(np.float32))
+    w1 = (rng.normal(size=(1, 1, 256, 64)) / 16).astype(np.float32)
+    bn1 = (rng.uniform(0.5, 1.5, 64).astype(np.float32), rng.normal(size=64).astype(np.float32))
+    bf = L.HMMR_BF16
+    trunk, _ = conv_gemm(h2, w3, 1, 0, None, b3, res, False, in_dtype=bf, out_dtype=bf, device=gpu_device,
+                         res_stride=res_stride)
+    h1, _ = conv_gemm(trunk, w1, 1, 0, bn1[0], bn1[1], None, True, in_dtype=bf, out_dtype=bf, device=gpu_device, pro=pre)
+    got_trunk, got_h1 = bottleneck_tail(h2, w3, b3, res, pre, w1, bn1, res_stride=res_stride, device=gpu_device)
+    assert np.array_equal(got_trunk, trunk)
+    assert np.array_equal(got_h1, h1)
+    assert np.abs(h1).max() > 0.1

@@ -263,3 +263,20 @@ def test_pipelined_predictor_with_asynchronous_gather(weights, smpl_consts, gpu_
     assert calls == [True] * 4
     for i, (a, b) in enumerate(zip(got, want)):
         assert torch.equal(a, b[p.o0:p.o1]), i
+
+
+def test_resnet_fused_bottleneck_tails_equal_layer_per_launch(weights, gpu_device, monkeypatch):
+    """block1's conv3 -> next conv1 fusion (hmmr_bottleneck_tail) leaves every feature bit unchanged."""
+    import torch
+    from human_dynamics_amd.engine import HmmrEngine
+    x = torch.from_numpy(assets.make_synthetic_frames(9, seed=12)).to(gpu_device)
+    monkeypatch.setenv("HMMR_FUSE_TAIL", "0")
+    plain = HmmrEngine(weights, None, dtype="bf16", device=gpu_device)
+    assert sum(plain.rw.unit[i].fuse_tail for i in range(16)) == 0
+    ref = plain.resnet(x, n_zero=1)
+    monkeypatch.setenv("HMMR_FUSE_TAIL", "1")
+    fused = HmmrEngine(weights, None, dtype="bf16", device=gpu_device)
+    assert [fused.rw.unit[i].fuse_tail for i in range(4)] == [1, 1, 0, 0]
+    assert torch.equal(fused.resnet(x, n_zero=1), ref)
+    f32 = HmmrEngine(weights, None, dtype="f32", device=gpu_device)
+    assert sum(f32.rw.unit[i].fuse_tail for i in range(16)) == 0
