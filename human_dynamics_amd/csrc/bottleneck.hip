@@ -46,8 +46,7 @@ struct TailArgs {
     int relu1;
 };
 
-constexpr int BM = 128, CM = 64, N2 = 64, NT = 512;
-constexpr int OFF_H2 = 0, OFF_W3 = 16384, OFF_W1 = 24576, OFF_P0 = 32768, OFF_P1 = 49152, OFF_C = 65536;
+constexpr int NT = 512;
 
 __device__ __forceinline__ f32x16 mma16(const bf16x8& a, const bf16x8& b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -60,21 +59,44 @@ __device__ __forceinline__ unsigned pack_bf(float a, float b) {
     return __builtin_bit_cast(unsigned, pk);
 }
 
-template <int NCH>
+// BM pixels per workgroup, CM = conv3's K, NCH = depth / 64 chunks, N2 = conv1' output channels.
+//   block1: <128, 64, 4, 64>    block2: <64, 128, 8, 128>
+// Every LDS tile is a stack of [rows][64 bf16] sub-tiles (128-B rows, 16-B slots XOR-swizzled with
+// (row>>1)&7, exactly the operand image of gemm_conv.hip).
+template <int BM, int CM, int NCH, int N2>
+struct TailCfg {
+    static constexpr int KT1 = CM / 64;                        // K steps of conv3
+    static constexpr int RB = BM / 64;                         // 64-row blocks of a pixel tile
+    static constexpr int H2_BYTES = BM * CM * 2, W3_BYTES = 64 * CM * 2, W1_BYTES = N2 * 128, P_BYTES = BM * 128;
+    static constexpr int O_BYTES = BM * N2 * 2;
+    static constexpr int OFF_H2 = 0;                           // later: the conv1' output tile
+    static constexpr int OFF_W3 = OFF_H2 + (H2_BYTES > O_BYTES ? H2_BYTES : O_BYTES);
+    static constexpr int OFF_W1 = OFF_W3 + W3_BYTES;
+    static constexpr int OFF_P0 = OFF_W1 + W1_BYTES, OFF_P1 = OFF_P0 + P_BYTES;
+    static constexpr int OFF_C = OFF_P1 + P_BYTES;
+    static constexpr int LDS = OFF_C + 4 * NCH * 64 * (int)sizeof(float);
+    static constexpr int TM = BM / 32;                         // 32-pixel blocks per tile
+    static_assert((N2 / 32) * TM == 8, "conv1' tile must map one 32x32 block to each of the 8 waves");
+    static_assert(2 * TM <= 8, "conv3 chunk needs at most 8 waves");
+};
+
+template <int BM, int CM, int NCH, int N2>
 __global__ __launch_bounds__(NT, 4) void bottleneck_tail_kernel(const TailArgs a) {
+    typedef TailCfg<BM, CM, NCH, N2> Cfg;
+    constexpr int KT1 = Cfg::KT1, RB = Cfg::RB, TM = Cfg::TM;
+    constexpr int depth = NCH * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m0 = blockIdx.x * BM;
-    const int depth = NCH * 64;
 
-    // ---- staging geometry (as gemm_conv.hip): 8 lanes per 128-B row, thread (r0, pslot) owns PHYSICAL slot
-    // pslot of rows r0 and r0 + 64 and fills it with LOGICAL slot lslot
+    // ---- staging geometry (as gemm_conv.hip): 8 lanes per 128-B row; one pass of the workgroup fills 64 rows;
+    // thread (r0, pslot) owns PHYSICAL slot pslot of row r0 of every pass and fills it with LOGICAL slot lslot
     const int pslot = tid & 7, r0 = tid >> 3;
     const int lslot = pslot ^ ((r0 >> 1) & 7);
-    const int st_off = r0 * 128 + pslot * 16;                 // + 64*128 for the second row
+    const int st_off = r0 * 128 + pslot * 16;
 
-    float* sScale3 = (float*)(smem + OFF_C);
+    float* sScale3 = (float*)(smem + Cfg::OFF_C);
     float* sBias3 = sScale3 + depth;
     float* sPreS = sBias3 + depth;
     float* sPreB = sPreS + depth;
@@ -85,10 +107,10 @@ __global__ __launch_bounds__(NT, 4) void bottleneck_tail_kernel(const TailArgs a
         sPreB[i] = a.pre_shift[i];
     }
 
-    // rows of this thread and their shortcut addresses (flat rows, or x[:, ::s, ::s] of the unit input)
-    bool rok[2]; long long roff[2];
+    // pixel rows of this thread and their shortcut addresses (flat rows, or x[:, ::s, ::s] of the unit input)
+    bool rok[RB]; long long roff[RB];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < RB; ++p) {
         const int m = m0 + r0 + 64 * p;
         rok[p] = m < a.M;
         const int mm = rok[p] ? m : 0;
@@ -100,45 +122,63 @@ __global__ __launch_bounds__(NT, 4) void bottleneck_tail_kernel(const TailArgs a
             roff[p] = (long long)mm * a.ldr;
         }
     }
-    auto load_res = [&](int nc, u32x4 (&r)[2]) {
+    auto load_res = [&](int nc, u32x4 (&r)[RB]) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) r[p] = *(const u32x4*)(a.res + roff[p] + nc * 64 + lslot * 8);
+        for (int p = 0; p < RB; ++p) r[p] = *(const u32x4*)(a.res + roff[p] + nc * 64 + lslot * 8);
     };
-    auto store_tile2 = [&](int off, const u32x4 (&r)[2]) {
-        *(u32x4*)(smem + off + st_off) = r[0];
-        *(u32x4*)(smem + off + st_off + 64 * 128) = r[1];
+    auto store_rows = [&](int off, const u32x4 (&r)[RB]) {       // a [BM][64] tile
+#pragma unroll
+        for (int p = 0; p < RB; ++p) *(u32x4*)(smem + off + st_off + p * (64 * 128)) = r[p];
     };
-    auto load_w3 = [&](int nc) { return *(const u32x4*)(a.w3 + (long long)(nc * 64 + r0) * CM + lslot * 8); };
-    auto load_w1 = [&](int nc) { return *(const u32x4*)(a.w1 + (long long)r0 * depth + nc * 64 + lslot * 8); };
+    auto load_w3 = [&](int nc, u32x4 (&r)[KT1]) {                // rows = 64 channels of chunk nc, KT1 K steps
+#pragma unroll
+        for (int kt = 0; kt < KT1; ++kt) r[kt] = *(const u32x4*)(a.w3 + (long long)(nc * 64 + r0) * CM + kt * 64 + lslot * 8);
+    };
+    auto store_w3 = [&](const u32x4 (&r)[KT1]) {
+#pragma unroll
+        for (int kt = 0; kt < KT1; ++kt) *(u32x4*)(smem + Cfg::OFF_W3 + kt * (64 * 128) + st_off) = r[kt];
+    };
+    auto load_w1 = [&](int nc, u32x4 (&r)[N2 / 64]) {            // rows = N2 output channels, K step nc
+#pragma unroll
+        for (int p = 0; p < N2 / 64; ++p) r[p] = *(const u32x4*)(a.w1 + (long long)(r0 + 64 * p) * depth + nc * 64 + lslot * 8);
+    };
+    auto store_w1 = [&](const u32x4 (&r)[N2 / 64]) {
+#pragma unroll
+        for (int p = 0; p < N2 / 64; ++p) *(u32x4*)(smem + Cfg::OFF_W1 + st_off + p * (64 * 128)) = r[p];
+    };
 
     // ---- prologue: H2 tile, weight chunks 0, shortcut chunks 0 (-> LDS) and 1 (-> registers)
-    u32x4 rres[2][2], rw3, rw1;
+    u32x4 rres[2][RB], rw3[KT1], rw1[N2 / 64];
     {
-        u32x4 rh[2];
+        u32x4 rh[KT1][RB];
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int m = rok[p] ? m0 + r0 + 64 * p : 0;
-            rh[p] = *(const u32x4*)(a.h2 + (long long)m * CM + lslot * 8);
-        }
-        rw3 = load_w3(0);
-        rw1 = load_w1(0);
+        for (int kt = 0; kt < KT1; ++kt)
+#pragma unroll
+            for (int p = 0; p < RB; ++p) {
+                const int m = rok[p] ? m0 + r0 + 64 * p : 0;
+                rh[kt][p] = *(const u32x4*)(a.h2 + (long long)m * CM + kt * 64 + lslot * 8);
+            }
+        load_w3(0, rw3);
+        load_w1(0, rw1);
         load_res(0, rres[0]);
         if (NCH > 1) load_res(1, rres[1]);
-        store_tile2(OFF_H2, rh);
-        *(u32x4*)(smem + OFF_W3 + st_off) = rw3;
-        *(u32x4*)(smem + OFF_W1 + st_off) = rw1;
-        store_tile2(OFF_P0, rres[0]);
+#pragma unroll
+        for (int kt = 0; kt < KT1; ++kt) store_rows(Cfg::OFF_H2 + kt * (BM * 128), rh[kt]);
+        store_w3(rw3);
+        store_w1(rw1);
+        store_rows(Cfg::OFF_P0, rres[0]);
     }
     __syncthreads();
 
-    // ---- fragment / epilogue geometry: wave (wn, wm) owns channels [32 wn, +32) x pixels [32 wm, +32)
-    const int wn = wave >> 2, wm = wave & 3;
+    // ---- fragment / epilogue geometry: wave (wn, wm) owns channels [32 wn, +32) x pixels [32 wm, +32);
+    // conv3 chunks have 64 channels, so only the waves with wn < 2 work in that phase
+    const int wn = wave / TM, wm = wave % TM;
     const int lr = lane & 31, lh = lane >> 5;
     const int fsw = (lr >> 1) & 7;
     auto frag = [&](int tile_off, int row, int kc) {
         return *(const bf16x8*)(smem + tile_off + row * 128 + (((2 * kc + lh) ^ fsw) << 4));
     };
-    const int prow = (wm * 32 + lr) * 128;                    // this lane's pixel row inside a trunk tile
+    const int prow = (wm * 32 + lr) * 128;                    // this lane's pixel row inside a [BM][64] tile
 
     f32x16 acc2;
 #pragma unroll
@@ -146,31 +186,37 @@ __global__ __launch_bounds__(NT, 4) void bottleneck_tail_kernel(const TailArgs a
 
 #pragma unroll
     for (int nc = 0; nc < NCH; ++nc) {
-        const int pcur = (nc & 1) ? OFF_P1 : OFF_P0, pnxt = (nc & 1) ? OFF_P0 : OFF_P1;
+        const int pcur = (nc & 1) ? Cfg::OFF_P1 : Cfg::OFF_P0, pnxt = (nc & 1) ? Cfg::OFF_P0 : Cfg::OFF_P1;
         // (a) requests for later chunks
         if (nc + 2 < NCH) load_res(nc + 2, rres[nc & 1]);
-        if (nc + 1 < NCH) { rw3 = load_w3(nc + 1); rw1 = load_w1(nc + 1); }
-        // (b) conv3 chunk: D[channel][pixel]
-        f32x16 acc1;
+        if (nc + 1 < NCH) { load_w3(nc + 1, rw3); load_w1(nc + 1, rw1); }
+        if (wn < 2) {
+            // (b) conv3 chunk: D[channel][pixel]
+            f32x16 acc1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
 #pragma unroll
-        for (int kc = 0; kc < 4; ++kc) acc1 = mma16(frag(OFF_W3, wn * 32 + lr, kc), frag(OFF_H2, wm * 32 + lr, kc), acc1);
-        // (c) + bias + shortcut, rounded to bf16, in place (lane: 4 consecutive channels x 4 groups of its pixel)
+            for (int kt = 0; kt < KT1; ++kt)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int cl = wn * 32 + 8 * g + 4 * lh;             // channel inside the chunk
-            char* p = smem + pcur + prow + ((((cl >> 3)) ^ fsw) << 4) + 8 * lh;
-            const f32x4 s4 = *(const f32x4*)(sScale3 + nc * 64 + cl), b4 = *(const f32x4*)(sBias3 + nc * 64 + cl);
-            const unsigned long long rr = *(const unsigned long long*)p;
-            const unsigned r01 = (unsigned)rr, r23 = (unsigned)(rr >> 32);
-            // the epilogue arithmetic of gemm_conv.hip, rounding for rounding: fma(acc, scale, shift) + shortcut
-            // (scale3 absent -> 1.0f: fma(acc, 1, b) == acc + b exactly)
-            float v0 = fmaf(acc1[4 * g + 0], s4[0], b4[0]), v1 = fmaf(acc1[4 * g + 1], s4[1], b4[1]);
-            float v2 = fmaf(acc1[4 * g + 2], s4[2], b4[2]), v3 = fmaf(acc1[4 * g + 3], s4[3], b4[3]);
-            v0 += bf_lo(r01); v1 += bf_hi(r01); v2 += bf_lo(r23); v3 += bf_hi(r23);
-            const unsigned long long o = (unsigned long long)pack_bf(v0, v1) | ((unsigned long long)pack_bf(v2, v3) << 32);
-            *(unsigned long long*)p = o;
+                for (int kc = 0; kc < 4; ++kc)
+                    acc1 = mma16(frag(Cfg::OFF_W3 + kt * (64 * 128), wn * 32 + lr, kc),
+                                 frag(Cfg::OFF_H2 + kt * (BM * 128), wm * 32 + lr, kc), acc1);
+            // (c) + bias + shortcut, rounded to bf16, in place (lane: 4 consecutive channels x 4 groups of its pixel)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cl = wn * 32 + 8 * g + 4 * lh;             // channel inside the chunk
+                char* p = smem + pcur + prow + ((((cl >> 3)) ^ fsw) << 4) + 8 * lh;
+                const f32x4 s4 = *(const f32x4*)(sScale3 + nc * 64 + cl), b4 = *(const f32x4*)(sBias3 + nc * 64 + cl);
+                const unsigned long long rr = *(const unsigned long long*)p;
+                const unsigned r01 = (unsigned)rr, r23 = (unsigned)(rr >> 32);
+                // the epilogue arithmetic of gemm_conv.hip, rounding for rounding: fma(acc, scale, shift) + shortcut
+                // (scale3 absent -> 1.0f: fma(acc, 1, b) == acc + b exactly)
+                float v0 = fmaf(acc1[4 * g + 0], s4[0], b4[0]), v1 = fmaf(acc1[4 * g + 1], s4[1], b4[1]);
+                float v2 = fmaf(acc1[4 * g + 2], s4[2], b4[2]), v3 = fmaf(acc1[4 * g + 3], s4[3], b4[3]);
+                v0 += bf_lo(r01); v1 += bf_hi(r01); v2 += bf_lo(r23); v3 += bf_hi(r23);
+                const unsigned long long o = (unsigned long long)pack_bf(v0, v1) | ((unsigned long long)pack_bf(v2, v3) << 32);
+                *(unsigned long long*)p = o;
+            }
         }
         __syncthreads();
         // (e) stream the trunk chunk out and pre-activate it in place; stage the next shortcut / W3 chunks
@@ -178,7 +224,7 @@ __global__ __launch_bounds__(NT, 4) void bottleneck_tail_kernel(const TailArgs a
             const f32x4 s0 = *(const f32x4*)(sPreS + nc * 64 + lslot * 8), s1 = *(const f32x4*)(sPreS + nc * 64 + lslot * 8 + 4);
             const f32x4 b0 = *(const f32x4*)(sPreB + nc * 64 + lslot * 8), b1 = *(const f32x4*)(sPreB + nc * 64 + lslot * 8 + 4);
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
+            for (int p = 0; p < RB; ++p) {
                 char* q = smem + pcur + st_off + p * (64 * 128);
                 const u32x4 x = *(const u32x4*)q;
                 if (rok[p]) *(u32x4*)(a.out + (long long)(m0 + r0 + 64 * p) * depth + nc * 64 + lslot * 8) = x;
@@ -190,36 +236,55 @@ __global__ __launch_bounds__(NT, 4) void bottleneck_tail_kernel(const TailArgs a
                 *(u32x4*)q = y;
             }
             if (nc + 1 < NCH) {
-                store_tile2(pnxt, rres[(nc + 1) & 1]);
-                *(u32x4*)(smem + OFF_W3 + st_off) = rw3;
+                store_rows(pnxt, rres[(nc + 1) & 1]);
+                store_w3(rw3);
             }
         }
         __syncthreads();
         // (g) conv1' K step `nc`
 #pragma unroll
-        for (int kc = 0; kc < 4; ++kc) acc2 = mma16(frag(OFF_W1, wn * 32 + lr, kc), frag(pcur, wm * 32 + lr, kc), acc2);
+        for (int kc = 0; kc < 4; ++kc) acc2 = mma16(frag(Cfg::OFF_W1, wn * 32 + lr, kc), frag(pcur, wm * 32 + lr, kc), acc2);
         __syncthreads();
-        if (nc + 1 < NCH) *(u32x4*)(smem + OFF_W1 + st_off) = rw1;
+        if (nc + 1 < NCH) store_w1(rw1);
     }
 
-    // ---- conv1' epilogue: BN (+ReLU), bf16, through the H2 region, coalesced stores
+    // ---- conv1' epilogue: BN (+ReLU), bf16, through the H2 region ([BM][64] sub-tiles), coalesced stores
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const int cl = wn * 32 + 8 * g + 4 * lh;
-        const f32x4 s4 = *(const f32x4*)(a.scale1 + cl), b4 = *(const f32x4*)(a.shift1 + cl);
+        const int n2 = wn * 32 + 8 * g + 4 * lh;
+        const f32x4 s4 = *(const f32x4*)(a.scale1 + n2), b4 = *(const f32x4*)(a.shift1 + n2);
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             v[j] = fmaf(acc2[4 * g + j], s4[j], b4[j]);
             if (a.relu1) v[j] = fmaxf(v[j], 0.f);
         }
-        char* p = smem + OFF_H2 + prow + (((cl >> 3) ^ fsw) << 4) + 8 * lh;
+        const int cl = n2 & 63;
+        char* p = smem + Cfg::OFF_H2 + (n2 >> 6) * (BM * 128) + prow + (((cl >> 3) ^ fsw) << 4) + 8 * lh;
         *(unsigned long long*)p = (unsigned long long)pack_bf(v[0], v[1]) | ((unsigned long long)pack_bf(v[2], v[3]) << 32);
     }
     __syncthreads();
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
-        if (rok[p]) *(u32x4*)(a.out_h1 + (long long)(m0 + r0 + 64 * p) * N2 + lslot * 8) = *(const u32x4*)(smem + OFF_H2 + st_off + p * (64 * 128));
+    for (int st = 0; st < N2 / 64; ++st)
+#pragma unroll
+        for (int p = 0; p < RB; ++p)
+            if (rok[p])
+                *(u32x4*)(a.out_h1 + (long long)(m0 + r0 + 64 * p) * N2 + st * 64 + lslot * 8) =
+                    *(const u32x4*)(smem + Cfg::OFF_H2 + st * (BM * 128) + st_off + p * (64 * 128));
+}
+
+template <int BM, int CM, int NCH, int N2>
+int launch_tail(const TailArgs& a, hipStream_t stream) {
+    typedef TailCfg<BM, CM, NCH, N2> Cfg;
+    auto kern = bottleneck_tail_kernel<BM, CM, NCH, N2>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HMMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)((a.M + BM - 1) / BM)), dim3(NT), Cfg::LDS, stream, a);
+    HMMR_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 
 }  // namespace
@@ -228,9 +293,10 @@ extern "C" int hmmr_bottleneck_tail(const hmmr_tail_desc_t* d, void* stream) {
     HMMR_REQUIRE(d && d->h2 && d->w3 && d->res && d->out && d->pre_scale && d->pre_shift && d->w1 && d->scale1 &&
                  d->shift1 && d->out_h1, "hmmr_bottleneck_tail: null argument");
     HMMR_REQUIRE(d->dtype == HMMR_BF16, "hmmr_bottleneck_tail: bf16 operands only");
-    HMMR_REQUIRE(d->c_mid == CM && d->n2 == N2 && d->depth == 256,
-                 "hmmr_bottleneck_tail: supported shape is c_mid 64 -> depth 256 -> n2 64 (got %d, %d, %d)", d->c_mid,
-                 d->depth, d->n2);
+    const bool b1 = d->c_mid == 64 && d->depth == 256 && d->n2 == 64;
+    const bool b2 = d->c_mid == 128 && d->depth == 512 && d->n2 == 128;
+    HMMR_REQUIRE(b1 || b2, "hmmr_bottleneck_tail: supported shapes are 64 -> 256 -> 64 and 128 -> 512 -> 128 (got %d, %d, %d)",
+                 d->c_mid, d->depth, d->n2);
     HMMR_REQUIRE(d->m > 0, "hmmr_bottleneck_tail: empty launch");
     HMMR_REQUIRE(d->res_strided || d->ldr >= d->depth, "hmmr_bottleneck_tail: residual row stride < depth");
     HMMR_REQUIRE(!d->res_strided || (d->ho > 0 && d->wo > 0), "hmmr_bottleneck_tail: strided residual needs ho, wo");
@@ -242,14 +308,5 @@ extern "C" int hmmr_bottleneck_tail(const hmmr_tail_desc_t* d, void* stream) {
     a.Wo = d->wo > 0 ? d->wo : 1; a.HoWo = d->ho > 0 ? d->ho * d->wo : 1;
     a.res_img_stride = d->res_img_stride; a.res_row_stride = d->res_row_stride; a.res_px_stride = d->res_px_stride;
     a.relu1 = d->relu1;
-    const int lds = OFF_C + 4 * 256 * (int)sizeof(float);
-    auto kern = bottleneck_tail_kernel<4>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HMMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)((d->m + BM - 1) / BM)), dim3(NT), lds, (hipStream_t)stream, a);
-    HMMR_CHECK_HIP(hipGetLastError());
-    return 0;
+    return b1 ? launch_tail<128, 64, 4, 64>(a, (hipStream_t)stream) : launch_tail<64, 128, 8, 128>(a, (hipStream_t)stream);
 }

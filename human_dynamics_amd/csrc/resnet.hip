@@ -300,9 +300,10 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
         }
         h1_ready = false;
         if (U.fuse_tail) {            // conv3 + add + the next unit's preact + conv1 in one launch (csrc/bottleneck.hip)
-            HMMR_REQUIRE(!last && w->dtype == HMMR_BF16 && U.stride == 1 && U.base == 64 && U.depth == 256 && write_raw &&
-                         !write_pre && next_fused && next_identity && w->unit[u + 1].base == 64 &&
-                         w->unit[u + 1].c_in == 256, "resnet: unit %d cannot fuse its tail", u);
+            HMMR_REQUIRE(!last && w->dtype == HMMR_BF16 && U.stride == 1 && write_raw && !write_pre && next_fused &&
+                         next_identity && w->unit[u + 1].base == U.base && w->unit[u + 1].c_in == U.depth &&
+                         ((U.base == 64 && U.depth == 256) || (U.base == 128 && U.depth == 512)),
+                         "resnet: unit %d cannot fuse its tail", u);
             const hmmr_resnet_unit_t& N = w->unit[u + 1];
             hmmr_tail_desc_t t = {};
             t.dtype = w->dtype; t.h2 = T2; t.m = n * Ho * Ho; t.c_mid = U.base; t.depth = U.depth;

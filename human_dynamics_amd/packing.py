@@ -82,7 +82,7 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
     staging of conv1/shortcut instead of reading a materialised preact tensor (csrc/resnet.hip;
     measured at batch 256: -4.5 % ResNet time with blocks 1-2 fused, neutral for blocks 3-4).
     fuse_tail: mark the units whose conv3 + add runs with the next unit's preact + conv1 as one
-    hmmr_bottleneck_tail launch (bf16; block1 unit_1 -> unit_2 -> unit_3)."""
+    hmmr_bottleneck_tail launch (bf16; the stride-1 units of block1 and block2)."""
     rw = L.ResnetWeights()
     rw.dtype = dtype
     rw.stem = _layer(store, pack_stem_weight(w["resnet_v2_50/conv1/weights"]), dtype,
@@ -106,9 +106,10 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
         u.pre_scale, u.pre_shift = store.vec(s).data_ptr(), store.vec(b).data_ptr()
     for i in range(L.RESNET_UNITS - 1):
         u, nx = rw.unit[i], rw.unit[i + 1]
-        u.fuse_tail = int(bool(fuse_tail) and dtype == L.HMMR_BF16 and u.stride == 1 and u.base == 64 and
-                          u.depth == 256 and nx.c_in == 256 and nx.base == 64 and nx.fuse_preact == 1 and
-                          not nx.shortcut.w)
+        shapes = ((64, 256),) if fuse_tail == "block1" else ((64, 256), (128, 512))
+        u.fuse_tail = int(bool(fuse_tail) and dtype == L.HMMR_BF16 and u.stride == 1 and
+                          (u.base, u.depth) in shapes and nx.c_in == u.depth and nx.base == u.base and
+                          nx.fuse_preact == 1 and not nx.shortcut.w)
     s, b = fold_bn(w, "resnet_v2_50/postnorm")
     rw.post_scale, rw.post_shift = store.vec(s).data_ptr(), store.vec(b).data_ptr()
     return rw

@@ -117,8 +117,8 @@ typedef struct {
     int fuse_preact;           /* 1: conv1/shortcut apply the preact while staging their operand;
                                   0: the previous unit's conv3 writes the preact tensor */
     int fuse_tail;             /* 1: this unit's conv3 + add and the NEXT unit's preact + conv1 run as one
-                                  hmmr_bottleneck_tail launch (bf16, base 64 -> depth 256 -> next base 64,
-                                  stride 1, next unit with identity shortcut and fuse_preact) */
+                                  hmmr_bottleneck_tail launch (bf16, stride 1, block1 or block2 shapes, next unit
+                                  of the same block with identity shortcut and fuse_preact) */
 } hmmr_resnet_unit_t;
 
 #define HMMR_RESNET_UNITS 16
@@ -137,7 +137,8 @@ typedef struct {
  *   out_h1 = relu(conv1'(relu(out * pre_scale + pre_shift)) * scale1 + shift1)
  * i.e. this unit's `conv3` + add and the NEXT unit's `preact` + `conv1` in one launch, so the next
  * conv1 does not re-read the trunk from HBM.  Bit-identical to the two hmmr_conv_gemm launches it
- * replaces (conv3 with a residual; conv1 with pro_scale/pro_shift).  bf16, c_mid 64, depth 256, n2 64.
+ * replaces (conv3 with a residual; conv1 with pro_scale/pro_shift).  bf16; (c_mid, depth, n2) = (64, 256, 64)
+ * [block1] or (128, 512, 128) [block2].
  * The shortcut is read as rows of `ldr` elements, or (res_strided) as x[:, ::s, ::s] of an NHWC
  * tensor like hmmr_conv_desc_t's strided residual (ho, wo = output grid).
  * ------------------------------------------------------------------------- */

@@ -324,20 +324,22 @@ def test_resnet_tile_choice_never_changes_a_bit(dt, weights, gpu_device):
     assert torch.equal(tuned.resnet(x[:33], n_zero=0), eng.resnet(x[:33], n_zero=0))
 
 
-@pytest.mark.parametrize("shape,res_stride", [((3, 9, 7), 1), ((2, 8, 8), 2), ((1, 16, 16), 1)])
-def test_bottleneck_tail_equals_conv3_then_fused_preact_conv1(shape, res_stride, gpu_device):
+@pytest.mark.parametrize("chans", [(64, 256, 64), (128, 512, 128)])
+@pytest.mark.parametrize("shape,res_stride", [((3, 9, 7), 1), ((2, 8, 8), 2), ((4, 28, 28), 1)])
+def test_bottleneck_tail_equals_conv3_then_fused_preact_conv1(shape, res_stride, chans, gpu_device):
     """hmmr_bottleneck_tail (conv3 + add + next preact + next conv1 in one launch) == the two
-    hmmr_conv_gemm launches it replaces, bit for bit (M tails: 189 and 128 rows are not multiples of 128)."""
+    hmmr_conv_gemm launches it replaces, bit for bit (189 rows: M tail; 3136 rows: many workgroups)."""
     from human_dynamics_amd.engine import bottleneck_tail, conv_gemm
     rng = np.random.default_rng(17)
     n, h, w = shape
-    h2 = np.maximum(rng.normal(size=(n, h, w, 64)), 0).astype(np.float32)
-    w3 = (rng.normal(size=(1, 1, 64, 256)) / 8).astype(np.float32)
-    b3 = rng.normal(size=256).astype(np.float32)
-    res = rng.normal(size=(n, h * res_stride, w * res_stride, 256)).astype(np.float32)
-    pre = (rng.uniform(0.5, 1.5, 256).astype(np.float32), rng.normal(size=256).astype(np.float32))
-    w1 = (rng.normal(size=(1, 1, 256, 64)) / 16).astype(np.float32)
-    bn1 = (rng.uniform(0.5, 1.5, 64).astype(np.float32), rng.normal(size=64).astype(np.float32))
+    cm, depth, n2 = chans
+    h2 = np.maximum(rng.normal(size=(n, h, w, cm)), 0).astype(np.float32)
+    w3 = (rng.normal(size=(1, 1, cm, depth)) / 8).astype(np.float32)
+    b3 = rng.normal(size=depth).astype(np.float32)
+    res = rng.normal(size=(n, h * res_stride, w * res_stride, depth)).astype(np.float32)
+    pre = (rng.uniform(0.5, 1.5, depth).astype(np.float32), rng.normal(size=depth).astype(np.float32))
+    w1 = (rng.normal(size=(1, 1, depth, n2)) / 16).astype(np.float32)
+    bn1 = (rng.uniform(0.5, 1.5, n2).astype(np.float32), rng.normal(size=n2).astype(np.float32))
     bf = L.HMMR_BF16
     trunk, _ = conv_gemm(h2, w3, 1, 0, None, b3, res, False, in_dtype=bf, out_dtype=bf, device=gpu_device,
                          res_stride=res_stride)

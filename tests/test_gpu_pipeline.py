@@ -266,7 +266,7 @@ def test_pipelined_predictor_with_asynchronous_gather(weights, smpl_consts, gpu_
 
 
 def test_resnet_fused_bottleneck_tails_equal_layer_per_launch(weights, gpu_device, monkeypatch):
-    """block1's conv3 -> next conv1 fusion (hmmr_bottleneck_tail) leaves every feature bit unchanged."""
+    """The conv3 -> next conv1 fusion of blocks 1-2 (hmmr_bottleneck_tail) leaves every feature bit unchanged."""
     import torch
     from human_dynamics_amd.engine import HmmrEngine
     x = torch.from_numpy(assets.make_synthetic_frames(9, seed=12)).to(gpu_device)
@@ -276,7 +276,7 @@ def test_resnet_fused_bottleneck_tails_equal_layer_per_launch(weights, gpu_devic
     ref = plain.resnet(x, n_zero=1)
     monkeypatch.setenv("HMMR_FUSE_TAIL", "1")
     fused = HmmrEngine(weights, None, dtype="bf16", device=gpu_device)
-    assert [fused.rw.unit[i].fuse_tail for i in range(4)] == [1, 1, 0, 0]
+    assert [fused.rw.unit[i].fuse_tail for i in range(8)] == [1, 1, 0, 1, 1, 1, 0, 0]
     assert torch.equal(fused.resnet(x, n_zero=1), ref)
     f32 = HmmrEngine(weights, None, dtype="f32", device=gpu_device)
     assert sum(f32.rw.unit[i].fuse_tail for i in range(16)) == 0
