@@ -213,7 +213,8 @@ def main():
         conv_share = float(prof[:len(mask)][mask].sum()) / float(prof[:len(mask)].sum())
         conv_ms = pass_ms * conv_share
         all_ms = pass_ms
-        n_conv = int(mask.sum())
+        n_tails = sum(int(eng.rw.unit[i].fuse_tail) for i in range(16))      # conv3 + next conv1 as ONE launch
+        n_conv = int(mask.sum()) - n_tails
         flops_per_launch = RESNET_FLOPS_PER_FRAME * n_enc / n_conv
         avg_launch_s = conv_ms * 1e-3 / n_conv
         achieved = flops_per_launch / avg_launch_s
@@ -227,7 +228,8 @@ def main():
             rc = json.load(open(pm[-1])).get("resnet_conv_gemm", {})
             traffic, mfma_util = rc.get("hbm_bytes_per_launch"), rc.get("mfma_util")
             traffic_src = "profiles/" + os.path.basename(pm[-1])
-        roofline = {"bound": "mfma", "kernel": "conv_gemm_kernel (ResNet-v2-50, %d launches/pass)" % n_conv,
+        roofline = {"bound": "mfma", "kernel": "conv_gemm_kernel / bottleneck_tail_kernel / stem_fused_kernel (ResNet-v2-50, %d MFMA launches/pass, "
+                                                    "%d of them fused conv3+conv1 tails)" % (n_conv, n_tails),
                     "achieved": round(achieved / 1e12, 2), "peak": round(peak / 1e12, 1), "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "B/launch",
                     "traffic_source": traffic_src, "mfma_util_pmc": mfma_util,
