@@ -167,6 +167,9 @@ __global__ __launch_bounds__(NT, 4) void bottleneck_tail_kernel(const TailArgs a
         store_w3(rw3);
         store_w1(rw1);
         store_rows(Cfg::OFF_P0, rres[0]);
+        // weight chunks are re-requested the moment their registers are free (right after the ds_write of
+        // the previous chunk), so each request has a whole chunk iteration to come back from L2
+        if (NCH > 1) { load_w3(1, rw3); load_w1(1, rw1); }
     }
     __syncthreads();
 
@@ -189,7 +192,6 @@ __global__ __launch_bounds__(NT, 4) void bottleneck_tail_kernel(const TailArgs a
         const int pcur = (nc & 1) ? Cfg::OFF_P1 : Cfg::OFF_P0, pnxt = (nc & 1) ? Cfg::OFF_P0 : Cfg::OFF_P1;
         // (a) requests for later chunks
         if (nc + 2 < NCH) load_res(nc + 2, rres[nc & 1]);
-        if (nc + 1 < NCH) { load_w3(nc + 1, rw3); load_w1(nc + 1, rw1); }
         if (wn < 2) {
             // (b) conv3 chunk: D[channel][pixel]
             f32x16 acc1;
@@ -238,6 +240,7 @@ __global__ __launch_bounds__(NT, 4) void bottleneck_tail_kernel(const TailArgs a
             if (nc + 1 < NCH) {
                 store_rows(pnxt, rres[(nc + 1) & 1]);
                 store_w3(rw3);
+                if (nc + 2 < NCH) load_w3(nc + 2, rw3);
             }
         }
         __syncthreads();
@@ -245,7 +248,10 @@ __global__ __launch_bounds__(NT, 4) void bottleneck_tail_kernel(const TailArgs a
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) acc2 = mma16(frag(Cfg::OFF_W1, wn * 32 + lr, kc), frag(pcur, wm * 32 + lr, kc), acc2);
         __syncthreads();
-        if (nc + 1 < NCH) store_w1(rw1);
+        if (nc + 1 < NCH) {
+            store_w1(rw1);
+            if (nc + 2 < NCH) load_w1(nc + 2, rw1);
+        }
     }
 
     // ---- conv1' epilogue: BN (+ReLU), bf16, through the H2 region ([BM][64] sub-tiles), coalesced stores
