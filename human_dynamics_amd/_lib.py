@@ -48,6 +48,7 @@ class TailDesc(C.Structure):
         ("out", _vp), ("pre_scale", _fp), ("pre_shift", _fp),
         ("w1", _vp), ("scale1", _fp), ("shift1", _fp), ("relu1", C.c_int), ("n2", C.c_int),
         ("out_h1", _vp),
+        ("h1", _vp), ("hin", C.c_int), ("win", C.c_int), ("w2", _vp), ("scale2", _fp), ("shift2", _fp),
     ]
 
 

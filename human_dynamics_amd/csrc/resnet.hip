@@ -270,14 +270,18 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
             if (hmmr_conv_gemm(&d, s)) return -2;
         }
         if (prof_mark(pf)) return -2;
-        // conv2: 3x3 conv2d_same(stride): pad 1/1 both for stride 1 (SAME) and stride 2 (explicit pad + VALID)
-        d = hmmr_conv_desc_t{};
-        d.in = T1; d.w = U.conv2.w; d.scale = U.conv2.scale; d.shift = U.conv2.shift; d.relu = 1; d.tile = U.conv2.tile;
-        d.out = T2; d.in_dtype = d.out_dtype = w->dtype;
-        d.n_img = n; d.hin = H; d.win = H; d.cin = U.base;
-        d.in_img_stride = (int64_t)H * H * U.base; d.in_row_stride = H * U.base; d.in_px_stride = U.base;
-        d.kh = d.kw = 3; d.sy = d.sx = U.stride; d.py = d.px = 1; d.ho = d.wo = Ho; d.cout = U.base; d.ldo = U.base;
-        if (hmmr_conv_gemm(&d, s)) return -2;
+        // conv2: 3x3 conv2d_same(stride): pad 1/1 both for stride 1 (SAME) and stride 2 (explicit pad + VALID);
+        // with fuse_tail == 2 it runs inside the fused tail below
+        const bool conv2_in_tail = U.fuse_tail == 2;
+        if (!conv2_in_tail) {
+            d = hmmr_conv_desc_t{};
+            d.in = T1; d.w = U.conv2.w; d.scale = U.conv2.scale; d.shift = U.conv2.shift; d.relu = 1; d.tile = U.conv2.tile;
+            d.out = T2; d.in_dtype = d.out_dtype = w->dtype;
+            d.n_img = n; d.hin = H; d.win = H; d.cin = U.base;
+            d.in_img_stride = (int64_t)H * H * U.base; d.in_row_stride = H * U.base; d.in_px_stride = U.base;
+            d.kh = d.kw = 3; d.sy = d.sx = U.stride; d.py = d.px = 1; d.ho = d.wo = Ho; d.cout = U.base; d.ldo = U.base;
+            if (hmmr_conv_gemm(&d, s)) return -2;
+        }
         if (prof_mark(pf)) return -2;
         // conv3: 1x1 + bias, + shortcut (no ReLU after the add)
         d = hmmr_conv_desc_t{};
@@ -306,14 +310,22 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
                          "resnet: unit %d cannot fuse its tail", u);
             const hmmr_resnet_unit_t& N = w->unit[u + 1];
             hmmr_tail_desc_t t = {};
-            t.dtype = w->dtype; t.h2 = T2; t.m = n * Ho * Ho; t.c_mid = U.base; t.depth = U.depth;
+            t.dtype = w->dtype; t.m = n * Ho * Ho; t.c_mid = U.base; t.depth = U.depth;
+            if (conv2_in_tail) {      // h2 never exists in HBM; the conv1' output goes to T2 (T1 is still being read
+                                      // by neighbouring tiles' halos), and the two buffers swap roles afterwards
+                HMMR_REQUIRE(U.base == 64 && U.conv2.scale && U.conv2.shift, "resnet: unit %d cannot fuse its conv2", u);
+                t.h1 = T1; t.hin = H; t.win = H; t.w2 = U.conv2.w; t.scale2 = U.conv2.scale; t.shift2 = U.conv2.shift;
+            } else {
+                t.h2 = T2;
+            }
             t.w3 = U.conv3.w; t.scale3 = U.conv3.scale; t.shift3 = U.conv3.shift;
             t.res = d.res; t.ldr = d.ldr; t.res_strided = d.res_strided; t.res_img_stride = d.res_img_stride;
             t.res_row_stride = d.res_row_stride; t.res_px_stride = d.res_px_stride; t.ho = Ho; t.wo = Ho;
             t.out = xn; t.pre_scale = N.pre_scale; t.pre_shift = N.pre_shift;
             t.w1 = N.conv1.w; t.scale1 = N.conv1.scale; t.shift1 = N.conv1.shift; t.relu1 = 1; t.n2 = N.base;
-            t.out_h1 = T1;
+            t.out_h1 = conv2_in_tail ? T2 : T1;
             if (hmmr_bottleneck_tail(&t, s)) return -2;
+            if (conv2_in_tail) { T* tmp = T1; T1 = T2; T2 = tmp; }
             h1_ready = true;
         } else if (hmmr_conv_gemm(&d, s)) return -2;
         if (prof_mark(pf)) return -2;

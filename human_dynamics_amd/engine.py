@@ -57,7 +57,7 @@ class HmmrEngine(object):
         self.num_conv_layers = num_conv_layers
         self.delta_keys = sorted(int(d) for d in delta_t_values)
         fuse = tuple(b for b in os.environ.get("HMMR_FUSE_PREACT", "block1,block2,block3,block4").split(",") if b)   # dev A/B switch
-        tail = {"0": False, "1": True}.get(os.environ.get("HMMR_FUSE_TAIL", "1"), os.environ.get("HMMR_FUSE_TAIL"))   # dev A/B switch: 0, 1, or "block1"
+        tail = {"0": False, "1": True}.get(os.environ.get("HMMR_FUSE_TAIL", "1"), os.environ.get("HMMR_FUSE_TAIL"))   # dev A/B switch: 0, 1, "block1", "noconv2"
         self.rw = (packing.pack_resnet(weights, self.dtype, self.store, fuse_preact_blocks=fuse, fuse_tail=tail)
                    if weights is not None else None)
         self.tw = (packing.pack_temporal(weights, self.temporal_dtype, self.store, num_conv_layers)
@@ -373,9 +373,10 @@ def conv_gemm(x, w_hwio, stride=1, pad=0, scale=None, shift=None, res=None, relu
     return o, o2
 
 
-def bottleneck_tail(h2, w3_hwio, bias3, res, pre, w1_hwio, bn1, res_stride=1, device="cuda:0"):
+def bottleneck_tail(h2, w3_hwio, bias3, res, pre, w1_hwio, bn1, res_stride=1, device="cuda:0", conv2=None):
     """Test/utility entry for hmmr_bottleneck_tail (bf16): h2 [n,h,w,64], w3 [1,1,64,256], res
     [n,h*s,w*s,256] (s = res_stride), pre = (scale, shift) [256], w1 [1,1,256,64], bn1 = (scale, shift) [64].
+    With conv2 = (w2 [3,3,64,64], scale2, shift2) the first argument is h1 and the 3x3 conv runs inside the launch.
     Returns (trunk [n,h,w,256], h1 [n,h,w,64]) as float32 arrays of the bf16 results."""
     lib = L.load()
     dev = torch.device(device)
@@ -390,7 +391,13 @@ def bottleneck_tail(h2, w3_hwio, bias3, res, pre, w1_hwio, bn1, res_stride=1, de
     out = torch.zeros((n, h, w_, depth), dtype=bf, device=dev)
     h1 = torch.zeros((n, h, w_, n2), dtype=bf, device=dev)
     d = L.TailDesc()
-    d.dtype, d.h2, d.m, d.c_mid, d.depth = L.HMMR_BF16, x.data_ptr(), n * h * w_, cm, depth
+    d.dtype, d.m, d.c_mid, d.depth = L.HMMR_BF16, n * h * w_, cm, depth
+    if conv2 is None:
+        d.h2 = x.data_ptr()
+    else:                                  # h2 argument is h1; conv2 = (w2_hwio [3,3,64,64], scale2, shift2)
+        w2 = store.put(packing.pack_conv_weight(np.asarray(conv2[0], np.float32)), bf)
+        d.h1, d.hin, d.win, d.w2 = x.data_ptr(), h, w_, w2.data_ptr()
+        d.scale2, d.shift2 = store.vec(conv2[1]).data_ptr(), store.vec(conv2[2]).data_ptr()
     d.w3, d.shift3 = w3.data_ptr(), store.vec(bias3).data_ptr()
     d.res = rt.data_ptr()
     if res_stride == 1:
