@@ -213,8 +213,9 @@ def main():
         conv_share = float(prof[:len(mask)][mask].sum()) / float(prof[:len(mask)].sum())
         conv_ms = pass_ms * conv_share
         all_ms = pass_ms
-        n_tails = sum(int(eng.rw.unit[i].fuse_tail) for i in range(16))      # conv3 + next conv1 as ONE launch
-        n_conv = int(mask.sum()) - n_tails
+        # fused tails: conv3 + next conv1 (fuse_tail 1) or conv2 + conv3 + next conv1 (fuse_tail 2) as ONE launch
+        n_tails = sum(int(eng.rw.unit[i].fuse_tail > 0) for i in range(16))
+        n_conv = int(mask.sum()) - sum(int(eng.rw.unit[i].fuse_tail) for i in range(16))
         flops_per_launch = RESNET_FLOPS_PER_FRAME * n_enc / n_conv
         avg_launch_s = conv_ms * 1e-3 / n_conv
         achieved = flops_per_launch / avg_launch_s
@@ -229,7 +230,7 @@ def main():
             traffic, mfma_util = rc.get("hbm_bytes_per_launch"), rc.get("mfma_util")
             traffic_src = "profiles/" + os.path.basename(pm[-1])
         roofline = {"bound": "mfma", "kernel": "conv_gemm_kernel / bottleneck_tail_kernel / stem_fused_kernel (ResNet-v2-50, %d MFMA launches/pass, "
-                                                    "%d of them fused conv3+conv1 tails)" % (n_conv, n_tails),
+                                                    "%d of them fused bottleneck tails)" % (n_conv, n_tails),
                     "achieved": round(achieved / 1e12, 2), "peak": round(peak / 1e12, 1), "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "B/launch",
                     "traffic_source": traffic_src, "mfma_util_pmc": mfma_util,
