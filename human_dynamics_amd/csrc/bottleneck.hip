@@ -44,7 +44,7 @@ struct TailArgs {
     int M, depth, ldr, res_strided, Wo, HoWo;
     long long res_img_stride; int res_row_stride, res_px_stride;
     int relu1;
-    // conv2 in front (CONV2 kernels): h1 [n][H][W][64], 3x3 SAME stride 1, folded BN + ReLU
+    // conv2 in front (CONV2 kernels): h1 [n][H][W][c_mid], 3x3 SAME stride 1, folded BN + ReLU
     const bf16_t* h1; const bf16_t* w2; const float* scale2; const float* shift2; int H, W;
 };
 
@@ -84,7 +84,7 @@ struct TailCfg {
 
 template <int BM, int CM, int NCH, int N2, bool CONV2>
 __global__ __launch_bounds__(NT, 4) void bottleneck_tail_kernel(const TailArgs a) {
-    static_assert(!CONV2 || (BM == 128 && CM == 64), "the conv2 phase is written for the block-1 shape");
+    static_assert(!CONV2 || (CM / 32) * (BM / 32) == 8, "conv2 tile must map one 32x32 block to each of the 8 waves");
     typedef TailCfg<BM, CM, NCH, N2> Cfg;
     constexpr int KT1 = Cfg::KT1, RB = Cfg::RB, TM = Cfg::TM;
     constexpr int depth = NCH * 64;
@@ -167,17 +167,17 @@ __global__ __launch_bounds__(NT, 4) void bottleneck_tail_kernel(const TailArgs a
     load_res(0, rres[0]);
     if (NCH > 1) load_res(1, rres[1]);
     if constexpr (CONV2) {
-        // ---- conv2: 3x3 SAME stride 1 over h1, K step = one tap (c_in = 64), D[channel][pixel]; two LDS
-        // stages of {pixels [128][64], W2 tap [64][64]} in the region the tail uses afterwards, operands staged
-        // through registers two and three taps ahead (zero for the out-of-image taps)
-        constexpr int STAGE = BM * 128 + 64 * 128;
+        // ---- conv2: 3x3 SAME stride 1 over h1 [.., CM], K steps = 9 taps x CM/64 channel blocks, D[channel][pixel];
+        // two LDS stages of {pixels [BM][64], W2 block [CM][64]} in the region the tail uses afterwards, operands
+        // staged through registers two and three K steps ahead (zero for the out-of-image taps)
+        constexpr int STAGE = BM * 128 + CM * 128, NK = 9 * KT1, WP = CM / 64;
         const bf16_t* pbase[RB]; unsigned pmask[RB];
 #pragma unroll
         for (int p = 0; p < RB; ++p) {
             const int m = rok[p] ? m0 + r0 + 64 * p : 0;
             const int img = m / (a.H * a.W), rem = m - img * (a.H * a.W);
             const int oy = rem / a.W, ox = rem - oy * a.W;
-            pbase[p] = a.h1 + ((long long)m) * 64 + lslot * 8;
+            pbase[p] = a.h1 + ((long long)m) * CM + lslot * 8;
             unsigned mk = 0u;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
@@ -186,34 +186,37 @@ __global__ __launch_bounds__(NT, 4) void bottleneck_tail_kernel(const TailArgs a
             }
             pmask[p] = rok[p] ? mk : 0u;
         }
-        u32x4 ra[2][RB], rb[2];                                // two register sets: taps t+2 and t+3 in flight
-        auto load_tap = [&](int t, int set) {
-            const int off = ((t / 3 - 1) * a.W + (t % 3 - 1)) * 64;
+        u32x4 ra[2][RB], rb[2][WP];                            // two register sets: K steps k+2 and k+3 in flight
+        auto load_step = [&](int k, int set) {
+            const int t = k / KT1, kt = k % KT1;
+            const int off = ((t / 3 - 1) * a.W + (t % 3 - 1)) * CM + kt * 64;
 #pragma unroll
             for (int p = 0; p < RB; ++p) {
                 u32x4 v = {0u, 0u, 0u, 0u};
                 if ((pmask[p] >> t) & 1u) v = *(const u32x4*)(pbase[p] + off);
                 ra[set][p] = v;
             }
-            rb[set] = *(const u32x4*)(a.w2 + (long long)r0 * 576 + t * 64 + lslot * 8);
+#pragma unroll
+            for (int p = 0; p < WP; ++p) rb[set][p] = *(const u32x4*)(a.w2 + (long long)(r0 + 64 * p) * (9 * CM) + k * 64 + lslot * 8);
         };
-        auto store_tap = [&](int stage, int set) {
+        auto store_step = [&](int stage, int set) {
             store_rows(stage * STAGE, ra[set]);
-            *(u32x4*)(smem + stage * STAGE + BM * 128 + st_off) = rb[set];
+#pragma unroll
+            for (int p = 0; p < WP; ++p) *(u32x4*)(smem + stage * STAGE + BM * 128 + st_off + p * (64 * 128)) = rb[set][p];
         };
         f32x16 acc0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
-        load_tap(0, 0);
-        store_tap(0, 0);
-        load_tap(1, 1);
-        load_tap(2, 0);
+        load_step(0, 0);
+        store_step(0, 0);
+        load_step(1, 1);
+        load_step(2, 0);
         __syncthreads();
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int cur = t & 1;
-            if (t + 1 < 9) store_tap(cur ^ 1, (t + 1) & 1);
-            if (t + 3 < 9) load_tap(t + 3, (t + 1) & 1);
+        for (int k = 0; k < NK; ++k) {
+            const int cur = k & 1;
+            if (k + 1 < NK) store_step(cur ^ 1, (k + 1) & 1);
+            if (k + 3 < NK) load_step(k + 3, (k + 1) & 1);
 #pragma unroll
             for (int kc = 0; kc < 4; ++kc)
                 acc0 = mma16(frag(cur * STAGE + BM * 128, wn * 32 + lr, kc), frag(cur * STAGE, wm * 32 + lr, kc), acc0);
@@ -222,12 +225,12 @@ __global__ __launch_bounds__(NT, 4) void bottleneck_tail_kernel(const TailArgs a
         // BN + ReLU, bf16 -> the H2 tile (all stage reads are behind the barrier above)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int cl = wn * 32 + 8 * g + 4 * lh;
-            const f32x4 s4 = *(const f32x4*)(a.scale2 + cl), b4 = *(const f32x4*)(a.shift2 + cl);
+            const int n = wn * 32 + 8 * g + 4 * lh, cl = n & 63;
+            const f32x4 s4 = *(const f32x4*)(a.scale2 + n), b4 = *(const f32x4*)(a.shift2 + n);
             float v[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(acc0[4 * g + j], s4[j], b4[j]), 0.f);
-            char* q = smem + Cfg::OFF_H2 + prow + (((cl >> 3) ^ fsw) << 4) + 8 * lh;
+            char* q = smem + Cfg::OFF_H2 + (n >> 6) * (BM * 128) + prow + (((cl >> 3) ^ fsw) << 4) + 8 * lh;
             *(unsigned long long*)q = (unsigned long long)pack_bf(v[0], v[1]) | ((unsigned long long)pack_bf(v[2], v[3]) << 32);
         }
     } else {
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(NT, 4) void bottleneck_tail_kernel(const TailArgs a
 template <int BM, int CM, int NCH, int N2, bool CONV2>
 int launch_tail(const TailArgs& a, hipStream_t stream) {
     typedef TailCfg<BM, CM, NCH, N2> Cfg;
-    static_assert(!CONV2 || 2 * (BM * 128 + 64 * 128) <= Cfg::OFF_C, "conv2 stages must fit below the constants");
+    static_assert(!CONV2 || 2 * (BM * 128 + CM * 128) <= Cfg::OFF_C, "conv2 stages must fit below the constants");
     auto kern = bottleneck_tail_kernel<BM, CM, NCH, N2, CONV2>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -368,8 +371,8 @@ extern "C" int hmmr_bottleneck_tail(const hmmr_tail_desc_t* d, void* stream) {
                  d->shift1 && d->out_h1, "hmmr_bottleneck_tail: null argument");
     const bool conv2 = d->h1 != nullptr;
     HMMR_REQUIRE(!conv2 || (!d->h2 && d->w2 && d->scale2 && d->shift2 && d->hin > 0 && d->win > 0 &&
-                            d->m % (d->hin * d->win) == 0 && d->c_mid == 64),
-                 "hmmr_bottleneck_tail: conv2 in front needs h1, w2, scale2, shift2, hin, win (c_mid 64; h2 must be NULL)");
+                            d->m % (d->hin * d->win) == 0),
+                 "hmmr_bottleneck_tail: conv2 in front needs h1, w2, scale2, shift2, hin, win (and h2 == NULL)");
     HMMR_REQUIRE(d->dtype == HMMR_BF16, "hmmr_bottleneck_tail: bf16 operands only");
     const bool b1 = d->c_mid == 64 && d->depth == 256 && d->n2 == 64;
     const bool b2 = d->c_mid == 128 && d->depth == 512 && d->n2 == 128;
@@ -388,10 +391,9 @@ extern "C" int hmmr_bottleneck_tail(const hmmr_tail_desc_t* d, void* stream) {
     a.relu1 = d->relu1;
     a.h1 = (const bf16_t*)d->h1; a.w2 = (const bf16_t*)d->w2; a.scale2 = d->scale2; a.shift2 = d->shift2;
     a.H = d->hin; a.W = d->win;
-    if (conv2) {
-        HMMR_REQUIRE(b1, "hmmr_bottleneck_tail: conv2 in front is implemented for the 64 -> 256 -> 64 shape");
-        return launch_tail<128, 64, 4, 64, true>(a, (hipStream_t)stream);
-    }
+    if (conv2)
+        return b1 ? launch_tail<128, 64, 4, 64, true>(a, (hipStream_t)stream)
+                  : launch_tail<64, 128, 8, 128, true>(a, (hipStream_t)stream);
     return b1 ? launch_tail<128, 64, 4, 64, false>(a, (hipStream_t)stream)
               : launch_tail<64, 128, 8, 128, false>(a, (hipStream_t)stream);
 }

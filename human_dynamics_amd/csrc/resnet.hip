@@ -313,7 +313,7 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
             t.dtype = w->dtype; t.m = n * Ho * Ho; t.c_mid = U.base; t.depth = U.depth;
             if (conv2_in_tail) {      // h2 never exists in HBM; the conv1' output goes to T2 (T1 is still being read
                                       // by neighbouring tiles' halos), and the two buffers swap roles afterwards
-                HMMR_REQUIRE(U.base == 64 && U.conv2.scale && U.conv2.shift, "resnet: unit %d cannot fuse its conv2", u);
+                HMMR_REQUIRE(U.conv2.scale && U.conv2.shift, "resnet: unit %d cannot fuse its conv2", u);
                 t.h1 = T1; t.hin = H; t.win = H; t.w2 = U.conv2.w; t.scale2 = U.conv2.scale; t.shift2 = U.conv2.shift;
             } else {
                 t.h2 = T2;

@@ -57,7 +57,7 @@ class HmmrEngine(object):
         self.num_conv_layers = num_conv_layers
         self.delta_keys = sorted(int(d) for d in delta_t_values)
         fuse = tuple(b for b in os.environ.get("HMMR_FUSE_PREACT", "block1,block2,block3,block4").split(",") if b)   # dev A/B switch
-        tail = {"0": False, "1": True}.get(os.environ.get("HMMR_FUSE_TAIL", "1"), os.environ.get("HMMR_FUSE_TAIL"))   # dev A/B switch: 0, 1, "block1", "noconv2"
+        tail = {"0": False, "1": True}.get(os.environ.get("HMMR_FUSE_TAIL", "1"), os.environ.get("HMMR_FUSE_TAIL"))   # dev A/B switch: 0, 1, "block1", "noconv2", "conv2b1"
         self.rw = (packing.pack_resnet(weights, self.dtype, self.store, fuse_preact_blocks=fuse, fuse_tail=tail)
                    if weights is not None else None)
         self.tw = (packing.pack_temporal(weights, self.temporal_dtype, self.store, num_conv_layers)

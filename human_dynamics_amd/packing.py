@@ -110,7 +110,7 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
         u.fuse_tail = int(bool(fuse_tail) and dtype == L.HMMR_BF16 and u.stride == 1 and
                           (u.base, u.depth) in shapes and nx.c_in == u.depth and nx.base == u.base and
                           nx.fuse_preact == 1 and not nx.shortcut.w)
-        if u.fuse_tail and u.base == 64 and fuse_tail != "noconv2":
+        if u.fuse_tail and fuse_tail != "noconv2" and (u.base == 64 or fuse_tail != "conv2b1"):
             u.fuse_tail = 2               # the unit's 3x3 conv2 runs inside the same launch too
     s, b = fold_bn(w, "resnet_v2_50/postnorm")
     rw.post_scale, rw.post_shift = store.vec(s).data_ptr(), store.vec(b).data_ptr()

@@ -116,7 +116,7 @@ typedef struct {
     int c_in, base, depth, stride;
     int fuse_preact;           /* 1: conv1/shortcut apply the preact while staging their operand;
                                   0: the previous unit's conv3 writes the preact tensor */
-    int fuse_tail;             /* 2: as 1, with this unit's conv2 inside the same launch as well (block1 shape);
+    int fuse_tail;             /* 2: as 1, with this unit's conv2 inside the same launch as well;
                                   1: this unit's conv3 + add and the NEXT unit's preact + conv1 run as one
                                   hmmr_bottleneck_tail launch (bf16, stride 1, block1 or block2 shapes, next unit
                                   of the same block with identity shortcut and fuse_preact) */
@@ -152,7 +152,7 @@ typedef struct {
     const float* pre_scale; const float* pre_shift;                /* [depth] */
     const void* w1; const float* scale1; const float* shift1; int relu1; int n2;   /* [n2][depth] */
     void* out_h1;                   /* [m][n2] */
-    /* optional conv2 in front (block-1 shape only): h2 = NULL and h2 := relu(conv3x3(h1) * scale2 + shift2),
+    /* optional conv2 in front: h2 = NULL and h2 := relu(conv3x3(h1) * scale2 + shift2),
      * SAME padding, stride 1, computed per tile inside the same launch (slim bottleneck_v2 `conv2`) */
     const void* h1; int hin, win;   /* [m / (hin*win)][hin][win][c_mid] */
     const void* w2; const float* scale2; const float* shift2;      /* [c_mid][9 * c_mid], K = (ky, kx, ci) */

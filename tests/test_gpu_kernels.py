@@ -350,21 +350,23 @@ def test_bottleneck_tail_equals_conv3_then_fused_preact_conv1(shape, res_stride,
     assert np.abs(h1).max() > 0.1
 
 
+@pytest.mark.parametrize("chans", [(64, 256, 64), (128, 512, 128)])
 @pytest.mark.parametrize("shape", [(3, 9, 7), (1, 16, 16), (2, 56, 56)])
-def test_bottleneck_tail_with_conv2_in_front(shape, gpu_device):
+def test_bottleneck_tail_with_conv2_in_front(shape, chans, gpu_device):
     """conv2 (3x3 SAME) + conv3 + add + next preact + next conv1 in ONE launch == three hmmr_conv_gemm launches."""
     from human_dynamics_amd.engine import bottleneck_tail, conv_gemm
     rng = np.random.default_rng(23)
     n, h, w = shape
-    h1 = np.maximum(rng.normal(size=(n, h, w, 64)), 0).astype(np.float32)
-    w2 = (rng.normal(size=(3, 3, 64, 64)) / 24).astype(np.float32)
-    bn2 = (rng.uniform(0.5, 1.5, 64).astype(np.float32), rng.normal(size=64).astype(np.float32) * 0.2)
-    w3 = (rng.normal(size=(1, 1, 64, 256)) / 8).astype(np.float32)
-    b3 = rng.normal(size=256).astype(np.float32)
-    res = rng.normal(size=(n, h, w, 256)).astype(np.float32)
-    pre = (rng.uniform(0.5, 1.5, 256).astype(np.float32), rng.normal(size=256).astype(np.float32))
-    w1 = (rng.normal(size=(1, 1, 256, 64)) / 16).astype(np.float32)
-    bn1 = (rng.uniform(0.5, 1.5, 64).astype(np.float32), rng.normal(size=64).astype(np.float32))
+    cm, depth, n2 = chans
+    h1 = np.maximum(rng.normal(size=(n, h, w, cm)), 0).astype(np.float32)
+    w2 = (rng.normal(size=(3, 3, cm, cm)) / (3 * cm ** 0.5)).astype(np.float32)
+    bn2 = (rng.uniform(0.5, 1.5, cm).astype(np.float32), rng.normal(size=cm).astype(np.float32) * 0.2)
+    w3 = (rng.normal(size=(1, 1, cm, depth)) / 8).astype(np.float32)
+    b3 = rng.normal(size=depth).astype(np.float32)
+    res = rng.normal(size=(n, h, w, depth)).astype(np.float32)
+    pre = (rng.uniform(0.5, 1.5, depth).astype(np.float32), rng.normal(size=depth).astype(np.float32))
+    w1 = (rng.normal(size=(1, 1, depth, n2)) / 16).astype(np.float32)
+    bn1 = (rng.uniform(0.5, 1.5, n2).astype(np.float32), rng.normal(size=n2).astype(np.float32))
     bf = L.HMMR_BF16
     h2, _ = conv_gemm(h1, w2, 1, 1, bn2[0], bn2[1], None, True, in_dtype=bf, out_dtype=bf, device=gpu_device)
     trunk, _ = conv_gemm(h2, w3, 1, 0, None, b3, res, False, in_dtype=bf, out_dtype=bf, device=gpu_device)
