@@ -36,6 +36,7 @@ class ConvDesc(C.Structure):
         ("relu", C.c_int), ("tile", C.c_int),
         ("split_k", C.c_int), ("ws", _vp), ("ws_bytes", C.c_size_t),
         ("pro_scale", _fp), ("pro_shift", _fp),
+        ("out_b", _vp), ("ldo_b", C.c_int), ("n_split", C.c_int), ("relu_b", C.c_int),
     ]
 
 
@@ -57,7 +58,7 @@ class Layer(C.Structure):
 
 
 class ResnetUnit(C.Structure):
-    _fields_ = [("conv1", Layer), ("conv2", Layer), ("conv3", Layer), ("shortcut", Layer),
+    _fields_ = [("conv1", Layer), ("conv2", Layer), ("conv3", Layer), ("shortcut", Layer), ("sc_c1", Layer),
                 ("pre_scale", _fp), ("pre_shift", _fp),
                 ("c_in", C.c_int), ("base", C.c_int), ("depth", C.c_int), ("stride", C.c_int),
                 ("fuse_preact", C.c_int), ("fuse_tail", C.c_int)]
@@ -152,7 +153,7 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError if the .so does not export it
         fn.restype, fn.argtypes = res, args
-    if lib.hmmr_abi_version() != 5:
+    if lib.hmmr_abi_version() != 6:
         raise HmmrError("libhmmr_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -42,6 +42,7 @@ struct ConvArgs {
     const void* in; const void* w; const float* scale; const float* shift;
     const void* res; void* out; void* out2; const float* scale2; const float* shift2;
     const float* pro_scale; const float* pro_shift;     // fused pre-activation of the A operand (PRO)
+    void* out_b; int ldo_b, n_split, relu_b;            // column split: channels >= n_split go to out_b
     int M, K, cout, ldo, ldr;
     int Wo, HoWo, Hin, Win;
     long long in_img_stride; int in_row_stride, in_px_stride;
@@ -374,9 +375,16 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 1) void conv
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] += rr[j];
         }
-        if (a.relu) {
+        const bool second = a.out_b && n >= a.n_split;      // column split: the second convolution's channels
+        if (second ? a.relu_b : a.relu) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        if (second) {
+            TO* ob = (TO*)a.out_b + (long long)m * a.ldo_b + (n - a.n_split);
+            if (full) store8(ob, v);
+            else for (int j = 0; j < 8 && n + j < a.cout; ++j) ob[j] = elem_traits<TO>::from_f32(v[j]);
+            continue;
         }
         const long long oo = (long long)m * a.ldo + n;
         if (out) {
@@ -551,6 +559,9 @@ extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
                  "hmmr_conv_gemm: residual rows must be readable up to cout rounded up to 8");
     HMMR_REQUIRE(!d->out2 || (d->scale2 && d->shift2), "hmmr_conv_gemm: out2 needs scale2/shift2");
     HMMR_REQUIRE(!d->pro_scale == !d->pro_shift, "hmmr_conv_gemm: pro_scale and pro_shift go together");
+    HMMR_REQUIRE(!d->out_b || (d->out && !d->out2 && !d->res && d->split_k <= 1 && d->n_split > 0 && d->n_split < d->cout &&
+                               d->n_split % 8 == 0 && d->ldo_b % 8 == 0 && d->ldo_b >= d->cout - d->n_split),
+                 "hmmr_conv_gemm: bad column split (out_b needs out, n_split %% 8 == 0, no out2 / res / split_k)");
     HMMR_REQUIRE(!d->pro_scale || !d->res, "hmmr_conv_gemm: a fused pre-activation (pro_*) cannot be combined with a residual");
     HMMR_REQUIRE(!d->pro_scale || (d->py == 0 && d->px == 0 && d->kh == 1 && d->kw == 1),
                  "hmmr_conv_gemm: the fused pre-activation is for un-padded 1x1 gathers (padding must stay zero)");
@@ -558,6 +569,7 @@ extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
     a.in = d->in; a.w = d->w; a.scale = d->scale; a.shift = d->shift; a.res = d->res;
     a.out = d->out; a.out2 = d->out2; a.scale2 = d->scale2; a.shift2 = d->shift2;
     a.pro_scale = d->pro_scale; a.pro_shift = d->pro_shift;
+    a.out_b = d->out_b; a.ldo_b = d->ldo_b; a.n_split = d->n_split; a.relu_b = d->relu_b;
     a.M = d->n_img * d->ho * d->wo; a.K = K; a.cout = d->cout; a.ldo = d->ldo; a.ldr = d->ldr;
     a.Wo = d->wo; a.HoWo = d->ho * d->wo; a.Hin = d->hin; a.Win = d->win;
     a.in_img_stride = d->in_img_stride; a.in_row_stride = d->in_row_stride; a.in_px_stride = d->in_px_stride;

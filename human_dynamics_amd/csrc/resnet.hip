@@ -247,6 +247,7 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
         T* xn = X[cur ^ 1];
         T* pn = P[pcur ^ 1];
         hmmr_conv_desc_t d;
+        const bool sc_c1 = U.shortcut.w && U.sc_c1.w && !h1_ready && U.stride == 1;
         if (U.shortcut.w) {           // 1x1 conv on preact, bias, no BN/ReLU (stride is 1 here)
             d = hmmr_conv_desc_t{};
             d.in = xin; d.pro_scale = ps; d.pro_shift = pb;
@@ -255,8 +256,13 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
             d.n_img = n; d.hin = H; d.win = H; d.cin = U.c_in;
             d.in_img_stride = (int64_t)H * H * U.c_in; d.in_row_stride = H * U.c_in; d.in_px_stride = U.c_in;
             d.kh = d.kw = 1; d.sy = d.sx = U.stride; d.ho = d.wo = Ho; d.cout = U.depth; d.ldo = U.depth;
+            if (sc_c1) {              // ... and conv1 over the same operand as extra output columns (-> T1, BN + ReLU)
+                d.w = U.sc_c1.w; d.scale = U.sc_c1.scale; d.shift = U.sc_c1.shift;
+                d.cout = U.depth + U.base; d.out_b = T1; d.ldo_b = U.base; d.n_split = U.depth; d.relu_b = 1;
+            }
             if (hmmr_conv_gemm(&d, s)) return -2;
             if (prof_mark(pf)) return -2;
+            if (sc_c1) h1_ready = true;
         }
         // conv1: 1x1 on preact, BN + ReLU (already in T1 if the previous unit ended in a fused tail)
         if (!h1_ready) {

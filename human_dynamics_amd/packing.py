@@ -77,7 +77,8 @@ def _layer(store, w_packed, dtype, scale=None, shift=None):
     return lay
 
 
-def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3", "block4"), fuse_tail=True):
+def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3", "block4"), fuse_tail=True,
+                fuse_sc=True):
     """fuse_preact_blocks: blocks whose units apply their `preact` BN+ReLU inside the operand
     staging of conv1/shortcut instead of reading a materialised preact tensor (csrc/resnet.hip;
     measured at batch 256: -4.5 % ResNet time with blocks 1-2 fused, neutral for blocks 3-4).
@@ -102,6 +103,14 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
         if has_sc:
             u.shortcut = _layer(store, pack_conv_weight(w[scope + "/shortcut/weights"]), dtype,
                                 shift=w[scope + "/shortcut/biases"])
+            if fuse_sc and stride == 1 and (c_in >= 512 or fuse_sc == "all"):   # measured: pays in blocks 3-4 only
+                # shortcut and conv1 read the same operand: one [depth + base][c_in] filter bank, conv1's columns
+                # after the shortcut's; scale 1 on the shortcut columns (fma(v, 1, b) == v + b exactly)
+                both = np.concatenate([w[scope + "/shortcut/weights"], w[scope + "/conv1/weights"]], axis=3)
+                s1, b1 = fold_bn(w, scope + "/conv1/BatchNorm")
+                u.sc_c1 = _layer(store, pack_conv_weight(both), dtype,
+                                 np.concatenate([np.ones(depth, np.float32), s1]),
+                                 np.concatenate([np.asarray(w[scope + "/shortcut/biases"], np.float32), b1]))
         s, b = fold_bn(w, scope + "/preact")
         u.pre_scale, u.pre_shift = store.vec(s).data_ptr(), store.vec(b).data_ptr()
     for i in range(L.RESNET_UNITS - 1):

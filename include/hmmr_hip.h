@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HMMR_ABI_VERSION 5
+#define HMMR_ABI_VERSION 6
 
 enum { HMMR_F32 = 0, HMMR_BF16 = 1 };
 
@@ -89,6 +89,12 @@ typedef struct {
      * floats each, or both NULL.  Only for 1x1, un-padded convolutions. */
     const float* pro_scale;
     const float* pro_shift;
+    /* column split: output channels [n_split, cout) go to out_b (row stride ldo_b, channel n - n_split)
+     * with ReLU flag relu_b instead of `out` / `relu` -- two convolutions over the same input as ONE
+     * GEMM (the conv shortcut and conv1 of a block's first bottleneck unit).  n_split % 8 == 0; not
+     * with out2, res or split_k.  out_b == NULL: off. */
+    void* out_b;
+    int ldo_b, n_split, relu_b;
 } hmmr_conv_desc_t;
 
 int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream);
@@ -111,6 +117,9 @@ typedef struct {
 
 typedef struct {
     hmmr_layer_t conv1, conv2, conv3, shortcut;   /* shortcut.w == NULL: identity / subsample */
+    hmmr_layer_t sc_c1;        /* optional: rows [shortcut (depth); conv1 (base)] of one [depth+base][c_in] filter
+                                  bank with scale = [1..1; BN scale], shift = [bias; BN shift]: both convs as
+                                  one column-split GEMM.  w == NULL: two launches. */
     const float* pre_scale;    /* this unit's folded `preact` BN, [c_in] */
     const float* pre_shift;
     int c_in, base, depth, stride;

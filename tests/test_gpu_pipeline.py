@@ -280,3 +280,23 @@ def test_resnet_fused_bottleneck_tails_equal_layer_per_launch(weights, gpu_devic
     assert torch.equal(fused.resnet(x, n_zero=1), ref)
     f32 = HmmrEngine(weights, None, dtype="f32", device=gpu_device)
     assert sum(f32.rw.unit[i].fuse_tail for i in range(16)) == 0
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+def test_resnet_shortcut_and_conv1_as_one_gemm(dt, weights, gpu_device, monkeypatch):
+    """The first unit of every block runs its conv shortcut and conv1 as one column-split GEMM: same bits."""
+    import torch
+    from human_dynamics_amd.engine import HmmrEngine
+    x = torch.from_numpy(assets.make_synthetic_frames(7, seed=15)).to(gpu_device)
+    monkeypatch.setenv("HMMR_FUSE_SC", "0")
+    plain = HmmrEngine(weights, None, dtype=dt, device=gpu_device)
+    assert not any(plain.rw.unit[i].sc_c1.w for i in range(16))
+    ref = plain.resnet(x, n_zero=1)
+    monkeypatch.setenv("HMMR_FUSE_SC", "all")
+    fused = HmmrEngine(weights, None, dtype=dt, device=gpu_device)
+    assert [bool(fused.rw.unit[i].sc_c1.w) for i in (0, 1, 3, 7, 13)] == [True, False, True, True, True]
+    assert torch.equal(fused.resnet(x, n_zero=1), ref)
+    monkeypatch.setenv("HMMR_FUSE_SC", "1")            # default: only where it was measured faster (blocks 3-4)
+    dflt = HmmrEngine(weights, None, dtype=dt, device=gpu_device)
+    assert [bool(dflt.rw.unit[i].sc_c1.w) for i in (0, 3, 7, 13)] == [False, False, True, True]
+    assert torch.equal(dflt.resnet(x, n_zero=1), ref)

@@ -121,5 +121,5 @@ def test_window_plan_matches_oracle():
 def test_ctypes_struct_sizes_are_plausible():
     # catches accidental field drift between include/hmmr_hip.h and _lib.py
     assert C.sizeof(_lib.Layer) == 32
-    assert C.sizeof(_lib.ResnetUnit) == 4 * 32 + 16 + 16 + 8
+    assert C.sizeof(_lib.ResnetUnit) == 5 * 32 + 16 + 16 + 8
     assert C.sizeof(_lib.ConvDesc) % 8 == 0
