@@ -40,14 +40,15 @@ def main():
         res["kernels"][k[:110]] = {"launches": n, "hbm_read_MB_per_launch": round(rd / 1e6, 1),
                                    "hbm_write_MB_per_launch": round(w / 1e6, 1),
                                    "mfma_util": None if util is None else round(util, 4)}
-    # the ResNet convolutions are the bf16->bf16 instantiations of conv_gemm_kernel
-    rn = [k for k in fe if "conv_gemm_kernelIDF16bDF16b" in k or "stem_fused_kernel" in k]
+    # the ResNet's MFMA launches: the bf16->bf16 instantiations of conv_gemm_kernel, the fused bottleneck tails
+    # and the fused stem
+    rn = [k for k in fe if "conv_gemm_kernelIDF16bDF16b" in k or "stem_fused_kernel" in k or "bottleneck_tail_kernel" in k]
     n = sum(fe[k][0] for k in rn)
     rd = sum(2 * 1024 * fe[k][1] for k in rn)
     w = sum(1024 * wr[k][1] for k in rn if k in wr)
     busy = sum(mf[k][1] for k in rn if k in mf)
     g = sum(gui[k][1] for k in rn if k in gui)
-    res["resnet_conv_gemm"] = {"launches": n, "hbm_bytes_per_launch": round((rd + w) / n),
+    res["resnet_conv_gemm"] = {"launches": n, "hbm_bytes_per_pass": round((rd + w) / n * 41), "launches_per_pass": 41, "hbm_bytes_per_launch": round((rd + w) / n),
                                "hbm_read_bytes_per_launch": round(rd / n), "hbm_write_bytes_per_launch": round(w / n),
                                "mfma_util": round(busy / (g / 8.0 * 1024.0), 4),
                                "note": "averaged over the ResNet passes of `HMMR_TILE_CACHE=<tuned> bench.py --serial --steps 2 --warmup 1 "
