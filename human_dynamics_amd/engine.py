@@ -98,7 +98,7 @@ class HmmrEngine(object):
         return torch.from_numpy(np.ascontiguousarray(a)).to(self.device).to(dtype).contiguous()
 
     # -- ResNet launch tuning ----------------------------------------------------
-    _TUNE_TILES = (5, 6, 3)        # 8-wave 128x128, 8-wave 128x64, 4-wave 64x64 (hmmr_conv_desc_t.tile)
+    _TUNE_TILES = tuple(int(t) for t in os.environ.get("HMMR_TUNE_TILES", "5,6,3,1,2").split(","))   # hmmr_conv_desc_t.tile candidates (8-wave 128x128 / 128x64, 4-wave 64x64 / 128x128 / 128x64)
     _TUNE_MIN_FRAMES = 32
     _SPLIT_MIN_FRAMES = 128
 
@@ -121,7 +121,7 @@ class HmmrEngine(object):
         candidate tile (every layer timed in place, behind its real producer), fastest wins per layer.
         The tile never changes a result bit (each output element is one fixed-order K reduction), it
         only moves the balance between tile-count quantisation, occupancy and operand reuse, which
-        flips between layers as the batch grows.  ~60 ms once per batch size."""
+        flips between layers as the batch grows.  ~90 ms once per batch size."""
         layers = self._resnet_layers()
         nt = n + n_zero
         nbytes = self.lib.hmmr_resnet50_workspace_bytes(nt, self.dtype)
