@@ -311,11 +311,11 @@ def test_resnet_tile_choice_never_changes_a_bit(dt, weights, gpu_device):
     x = torch.from_numpy(assets.make_synthetic_frames(40, seed=3)).to(gpu_device)
     ref = eng.resnet(x, n_zero=1).clone()
     layers = eng._resnet_layers()
-    for tile in (3, 6, 5):
+    for tile in (3, 6, 5, 2, 1):
         table = {}
         for _, u, nm in layers:
             cout = eng.rw.unit[u].base if nm in ("conv1", "conv2") else eng.rw.unit[u].depth
-            table[(u, nm)] = tile if (tile != 5 or cout % 128 == 0) else 6
+            table[(u, nm)] = tile if (tile not in (1, 5) or cout % 128 == 0) else 6
         eng._set_tiles(table)
         assert torch.equal(eng.resnet(x, n_zero=1), ref), tile
     tuned = HmmrEngine(weights, None, dtype=dt, device=gpu_device, autotune=True)
