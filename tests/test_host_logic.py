@@ -123,3 +123,19 @@ def test_ctypes_struct_sizes_are_plausible():
     assert C.sizeof(_lib.Layer) == 32
     assert C.sizeof(_lib.ResnetUnit) == 5 * 32 + 16 + 16 + 8
     assert C.sizeof(_lib.ConvDesc) % 8 == 0
+
+
+def test_packer_marks_the_fused_launches(weights):
+    """Which units the packer folds into one launch (host-side decision, no GPU needed): the stride-1
+    units of blocks 1-2 end in a fused tail with their conv2 inside, the first units of blocks 3-4 run
+    shortcut + conv1 as one column-split GEMM; fp32 keeps every layer separate except the column split."""
+    from human_dynamics_amd import packing
+    rw = packing.pack_resnet(weights, _lib.HMMR_BF16, packing.DeviceStore("cpu"))
+    assert [rw.unit[i].fuse_tail for i in range(16)] == [2, 2, 0, 2, 2, 2, 0] + [0] * 9
+    assert [i for i in range(16) if rw.unit[i].sc_c1.w] == [7, 13]
+    assert [rw.unit[i].fuse_preact for i in range(16)] == [0] + [1] * 15
+    rw32 = packing.pack_resnet(weights, _lib.HMMR_F32, packing.DeviceStore("cpu"))
+    assert sum(rw32.unit[i].fuse_tail for i in range(16)) == 0
+    assert [i for i in range(16) if rw32.unit[i].sc_c1.w] == [7, 13]
+    off = packing.pack_resnet(weights, _lib.HMMR_BF16, packing.DeviceStore("cpu"), fuse_tail=False, fuse_sc=False)
+    assert sum(off.unit[i].fuse_tail for i in range(16)) == 0 and not any(off.unit[i].sc_c1.w for i in range(16))
