@@ -50,6 +50,7 @@ class TailDesc(C.Structure):
         ("w1", _vp), ("scale1", _fp), ("shift1", _fp), ("relu1", C.c_int), ("n2", C.c_int),
         ("out_h1", _vp),
         ("h1", _vp), ("hin", C.c_int), ("win", C.c_int), ("w2", _vp), ("scale2", _fp), ("shift2", _fp),
+        ("xp", _vp), ("wsc", _vp), ("shift_sc", _fp),
     ]
 
 

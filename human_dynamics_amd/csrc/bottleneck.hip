@@ -46,6 +46,9 @@ struct TailArgs {
     int relu1;
     // conv2 in front (CONV2 kernels): h1 [n][H][W][c_mid], 3x3 SAME stride 1, folded BN + ReLU
     const bf16_t* h1; const bf16_t* w2; const float* scale2; const float* shift2; int H, W;
+    // conv shortcut computed in the kernel (SC kernels): shortcut = xp [M][64] x wsc [depth][64] + shift_sc, rounded
+    // to bf16 like the tensor the separate launch would have written; `res` is not read
+    const bf16_t* xp; const bf16_t* wsc; const float* shift_sc;
 };
 
 constexpr int NT = 512;
@@ -65,7 +68,7 @@ __device__ __forceinline__ unsigned pack_bf(float a, float b) {
 //   block1: <128, 64, 4, 64>    block2: <64, 128, 8, 128>
 // Every LDS tile is a stack of [rows][64 bf16] sub-tiles (128-B rows, 16-B slots XOR-swizzled with
 // (row>>1)&7, exactly the operand image of gemm_conv.hip).
-template <int BM, int CM, int NCH, int N2>
+template <int BM, int CM, int NCH, int N2, bool SC = false>
 struct TailCfg {
     static constexpr int KT1 = CM / 64;                        // K steps of conv3
     static constexpr int RB = BM / 64;                         // 64-row blocks of a pixel tile
@@ -75,17 +78,21 @@ struct TailCfg {
     static constexpr int OFF_W3 = OFF_H2 + (H2_BYTES > O_BYTES ? H2_BYTES : O_BYTES);
     static constexpr int OFF_W1 = OFF_W3 + W3_BYTES;
     static constexpr int OFF_P0 = OFF_W1 + W1_BYTES, OFF_P1 = OFF_P0 + P_BYTES;
-    static constexpr int OFF_C = OFF_P1 + P_BYTES;
-    static constexpr int LDS = OFF_C + 4 * NCH * 64 * (int)sizeof(float);
+    // SC: one trunk tile only (nothing is pre-filled); the P1 slot holds the shortcut's input tile [BM][64] and a
+    // [64][64] chunk of its filters follows
+    static constexpr int OFF_XP = OFF_P1, OFF_WS = OFF_P1 + P_BYTES;
+    static constexpr int OFF_C = OFF_WS + (SC ? 64 * 128 : 0);
+    static constexpr int LDS = OFF_C + (SC ? 5 : 4) * NCH * 64 * (int)sizeof(float);
     static constexpr int TM = BM / 32;                         // 32-pixel blocks per tile
     static_assert((N2 / 32) * TM == 8, "conv1' tile must map one 32x32 block to each of the 8 waves");
     static_assert(2 * TM <= 8, "conv3 chunk needs at most 8 waves");
 };
 
-template <int BM, int CM, int NCH, int N2, bool CONV2>
+template <int BM, int CM, int NCH, int N2, bool CONV2, bool SC>
 __global__ __launch_bounds__(NT, 4) void bottleneck_tail_kernel(const TailArgs a) {
+    static_assert(!SC || (BM == 128 && CM == 64), "the in-kernel shortcut is written for c_in = 64 (block1/unit_1)");
     static_assert(!CONV2 || (CM / 32) * (BM / 32) == 8, "conv2 tile must map one 32x32 block to each of the 8 waves");
-    typedef TailCfg<BM, CM, NCH, N2> Cfg;
+    typedef TailCfg<BM, CM, NCH, N2, SC> Cfg;
     constexpr int KT1 = Cfg::KT1, RB = Cfg::RB, TM = Cfg::TM;
     constexpr int depth = NCH * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -108,7 +115,9 @@ __global__ __launch_bounds__(NT, 4) void bottleneck_tail_kernel(const TailArgs a
         sBias3[i] = a.shift3 ? a.shift3[i] : 0.0f;
         sPreS[i] = a.pre_scale[i];
         sPreB[i] = a.pre_shift[i];
+        if constexpr (SC) (sPreB + depth)[i] = a.shift_sc ? a.shift_sc[i] : 0.0f;
     }
+    [[maybe_unused]] const float* sBiasSc = sPreB + depth;
 
     // pixel rows of this thread and their shortcut addresses (flat rows, or x[:, ::s, ::s] of the unit input)
     bool rok[RB]; long long roff[RB];
@@ -162,10 +171,23 @@ __global__ __launch_bounds__(NT, 4) void bottleneck_tail_kernel(const TailArgs a
 
     // ---- prologue: weight chunks 0 and shortcut chunks 0, 1 are requested first (they fly while conv2 runs)
     u32x4 rres[2][RB], rw3[KT1], rw1[N2 / 64];
+    [[maybe_unused]] u32x4 rws;
+    auto load_ws = [&](int nc) { return *(const u32x4*)(a.wsc + (long long)(nc * 64 + r0) * 64 + lslot * 8); };
     load_w3(0, rw3);
     load_w1(0, rw1);
-    load_res(0, rres[0]);
-    if (NCH > 1) load_res(1, rres[1]);
+    if constexpr (SC) {
+        // the shortcut's operand tile and filter chunk 0 go to LDS right away (their slots are not used by conv2)
+        u32x4 rx[RB];
+#pragma unroll
+        for (int p = 0; p < RB; ++p) rx[p] = *(const u32x4*)(a.xp + (long long)(rok[p] ? m0 + r0 + 64 * p : 0) * 64 + lslot * 8);
+        rws = load_ws(0);
+        store_rows(Cfg::OFF_XP, rx);
+        *(u32x4*)(smem + Cfg::OFF_WS + st_off) = rws;
+        if (NCH > 1) rws = load_ws(1);
+    } else {
+        load_res(0, rres[0]);
+        if (NCH > 1) load_res(1, rres[1]);
+    }
     if constexpr (CONV2) {
         // ---- conv2: 3x3 SAME stride 1 over h1 [.., CM], K steps = 9 taps x CM/64 channel blocks, D[channel][pixel];
         // two LDS stages of {pixels [BM][64], W2 block [CM][64]} in the region the tail uses afterwards, operands
@@ -247,7 +269,7 @@ __global__ __launch_bounds__(NT, 4) void bottleneck_tail_kernel(const TailArgs a
     }
     store_w3(rw3);
     store_w1(rw1);
-    store_rows(Cfg::OFF_P0, rres[0]);
+    if constexpr (!SC) store_rows(Cfg::OFF_P0, rres[0]);
     // weight chunks are re-requested the moment their registers are free (right after the ds_write of
     // the previous chunk), so each request has a whole chunk iteration to come back from L2
     if (NCH > 1) { load_w3(1, rw3); load_w1(1, rw1); }
@@ -259,9 +281,10 @@ __global__ __launch_bounds__(NT, 4) void bottleneck_tail_kernel(const TailArgs a
 
 #pragma unroll
     for (int nc = 0; nc < NCH; ++nc) {
-        const int pcur = (nc & 1) ? Cfg::OFF_P1 : Cfg::OFF_P0, pnxt = (nc & 1) ? Cfg::OFF_P0 : Cfg::OFF_P1;
+        const int pcur = (!SC && (nc & 1)) ? Cfg::OFF_P1 : Cfg::OFF_P0;
+        [[maybe_unused]] const int pnxt = (nc & 1) ? Cfg::OFF_P0 : Cfg::OFF_P1;
         // (a) requests for later chunks
-        if (nc + 2 < NCH) load_res(nc + 2, rres[nc & 1]);
+        if constexpr (!SC) if (nc + 2 < NCH) load_res(nc + 2, rres[nc & 1]);
         if (wn < 2) {
             // (b) conv3 chunk: D[channel][pixel]
             f32x16 acc1;
@@ -273,14 +296,30 @@ __global__ __launch_bounds__(NT, 4) void bottleneck_tail_kernel(const TailArgs a
                 for (int kc = 0; kc < 4; ++kc)
                     acc1 = mma16(frag(Cfg::OFF_W3 + kt * (64 * 128), wn * 32 + lr, kc),
                                  frag(Cfg::OFF_H2 + kt * (BM * 128), wm * 32 + lr, kc), acc1);
+            // (b') SC: the shortcut chunk itself, D[channel][pixel] in the same lane layout
+            [[maybe_unused]] f32x16 accs;
+            if constexpr (SC) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accs[r] = 0.f;
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc)
+                    accs = mma16(frag(Cfg::OFF_WS, wn * 32 + lr, kc), frag(Cfg::OFF_XP, wm * 32 + lr, kc), accs);
+            }
             // (c) + bias + shortcut, rounded to bf16, in place (lane: 4 consecutive channels x 4 groups of its pixel)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int cl = wn * 32 + 8 * g + 4 * lh;             // channel inside the chunk
                 char* p = smem + pcur + prow + ((((cl >> 3)) ^ fsw) << 4) + 8 * lh;
                 const f32x4 s4 = *(const f32x4*)(sScale3 + nc * 64 + cl), b4 = *(const f32x4*)(sBias3 + nc * 64 + cl);
-                const unsigned long long rr = *(const unsigned long long*)p;
-                const unsigned r01 = (unsigned)rr, r23 = (unsigned)(rr >> 32);
+                unsigned r01, r23;
+                if constexpr (SC) {      // what the separate shortcut launch stores: bf16(acc + bias)
+                    const f32x4 c4 = *(const f32x4*)(sBiasSc + nc * 64 + cl);
+                    r01 = pack_bf(accs[4 * g + 0] + c4[0], accs[4 * g + 1] + c4[1]);
+                    r23 = pack_bf(accs[4 * g + 2] + c4[2], accs[4 * g + 3] + c4[3]);
+                } else {
+                    const unsigned long long rr = *(const unsigned long long*)p;
+                    r01 = (unsigned)rr; r23 = (unsigned)(rr >> 32);
+                }
                 // the epilogue arithmetic of gemm_conv.hip, rounding for rounding: fma(acc, scale, shift) + shortcut
                 // (scale3 absent -> 1.0f: fma(acc, 1, b) == acc + b exactly)
                 float v0 = fmaf(acc1[4 * g + 0], s4[0], b4[0]), v1 = fmaf(acc1[4 * g + 1], s4[1], b4[1]);
@@ -308,7 +347,12 @@ __global__ __launch_bounds__(NT, 4) void bottleneck_tail_kernel(const TailArgs a
                 *(u32x4*)q = y;
             }
             if (nc + 1 < NCH) {
-                store_rows(pnxt, rres[(nc + 1) & 1]);
+                if constexpr (SC) {
+                    *(u32x4*)(smem + Cfg::OFF_WS + st_off) = rws;
+                    if (nc + 2 < NCH) rws = load_ws(nc + 2);
+                } else {
+                    store_rows(pnxt, rres[(nc + 1) & 1]);
+                }
                 store_w3(rw3);
                 if (nc + 2 < NCH) load_w3(nc + 2, rw3);
             }
@@ -349,11 +393,11 @@ __global__ __launch_bounds__(NT, 4) void bottleneck_tail_kernel(const TailArgs a
                     *(const u32x4*)(smem + Cfg::OFF_H2 + st * (BM * 128) + st_off + p * (64 * 128));
 }
 
-template <int BM, int CM, int NCH, int N2, bool CONV2>
+template <int BM, int CM, int NCH, int N2, bool CONV2, bool SC = false>
 int launch_tail(const TailArgs& a, hipStream_t stream) {
-    typedef TailCfg<BM, CM, NCH, N2> Cfg;
+    typedef TailCfg<BM, CM, NCH, N2, SC> Cfg;
     static_assert(!CONV2 || 2 * (BM * 128 + CM * 128) <= Cfg::OFF_C, "conv2 stages must fit below the constants");
-    auto kern = bottleneck_tail_kernel<BM, CM, NCH, N2, CONV2>;
+    auto kern = bottleneck_tail_kernel<BM, CM, NCH, N2, CONV2, SC>;
     static bool attr_set = false;
     if (!attr_set) {
         HMMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS));
@@ -367,7 +411,7 @@ int launch_tail(const TailArgs& a, hipStream_t stream) {
 }  // namespace
 
 extern "C" int hmmr_bottleneck_tail(const hmmr_tail_desc_t* d, void* stream) {
-    HMMR_REQUIRE(d && (d->h2 || d->h1) && d->w3 && d->res && d->out && d->pre_scale && d->pre_shift && d->w1 && d->scale1 &&
+    HMMR_REQUIRE(d && (d->h2 || d->h1) && d->w3 && (d->res || d->xp) && d->out && d->pre_scale && d->pre_shift && d->w1 && d->scale1 &&
                  d->shift1 && d->out_h1, "hmmr_bottleneck_tail: null argument");
     const bool conv2 = d->h1 != nullptr;
     HMMR_REQUIRE(!conv2 || (!d->h2 && d->w2 && d->scale2 && d->shift2 && d->hin > 0 && d->win > 0 &&
@@ -379,7 +423,11 @@ extern "C" int hmmr_bottleneck_tail(const hmmr_tail_desc_t* d, void* stream) {
     HMMR_REQUIRE(b1 || b2, "hmmr_bottleneck_tail: supported shapes are 64 -> 256 -> 64 and 128 -> 512 -> 128 (got %d, %d, %d)",
                  d->c_mid, d->depth, d->n2);
     HMMR_REQUIRE(d->m > 0, "hmmr_bottleneck_tail: empty launch");
-    HMMR_REQUIRE(d->res_strided || d->ldr >= d->depth, "hmmr_bottleneck_tail: residual row stride < depth");
+    const bool sc = d->xp != nullptr;
+    HMMR_REQUIRE(!sc || (conv2 && !d->res && d->wsc && d->c_mid == 64 && d->depth == 256 && d->n2 == 64),
+                 "hmmr_bottleneck_tail: the in-kernel conv shortcut (xp, wsc) needs conv2 in front, res == NULL and the "
+                 "64 -> 256 -> 64 shape with a 64-channel shortcut input");
+    HMMR_REQUIRE(sc || d->res_strided || d->ldr >= d->depth, "hmmr_bottleneck_tail: residual row stride < depth");
     HMMR_REQUIRE(!d->res_strided || (d->ho > 0 && d->wo > 0), "hmmr_bottleneck_tail: strided residual needs ho, wo");
     TailArgs a;
     a.h2 = (const bf16_t*)d->h2; a.w3 = (const bf16_t*)d->w3; a.scale3 = d->scale3; a.shift3 = d->shift3;
@@ -391,6 +439,8 @@ extern "C" int hmmr_bottleneck_tail(const hmmr_tail_desc_t* d, void* stream) {
     a.relu1 = d->relu1;
     a.h1 = (const bf16_t*)d->h1; a.w2 = (const bf16_t*)d->w2; a.scale2 = d->scale2; a.shift2 = d->shift2;
     a.H = d->hin; a.W = d->win;
+    a.xp = (const bf16_t*)d->xp; a.wsc = (const bf16_t*)d->wsc; a.shift_sc = d->shift_sc;
+    if (sc) return launch_tail<128, 64, 4, 64, true, true>(a, (hipStream_t)stream);
     if (conv2)
         return b1 ? launch_tail<128, 64, 4, 64, true>(a, (hipStream_t)stream)
                   : launch_tail<64, 128, 8, 128, true>(a, (hipStream_t)stream);

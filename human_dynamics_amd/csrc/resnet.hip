@@ -248,7 +248,12 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
         T* pn = P[pcur ^ 1];
         hmmr_conv_desc_t d;
         const bool sc_c1 = U.shortcut.w && U.sc_c1.w && !h1_ready && U.stride == 1;
-        if (U.shortcut.w) {           // 1x1 conv on preact, bias, no BN/ReLU (stride is 1 here)
+        const bool sc_in_tail = U.fuse_tail == 3;        // the conv shortcut is computed inside the fused tail
+        if (sc_in_tail) {
+            HMMR_REQUIRE(U.shortcut.w && !U.shortcut.scale && !fused && U.c_in == 64 && U.stride == 1,
+                         "resnet: unit %d cannot compute its shortcut inside the tail", u);
+            if (prof_mark(pf)) return -2;
+        } else if (U.shortcut.w) {    // 1x1 conv on preact, bias, no BN/ReLU (stride is 1 here)
             d = hmmr_conv_desc_t{};
             d.in = xin; d.pro_scale = ps; d.pro_shift = pb;
             d.w = U.shortcut.w; d.scale = U.shortcut.scale; d.shift = U.shortcut.shift; d.tile = U.shortcut.tile;
@@ -278,7 +283,7 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
         if (prof_mark(pf)) return -2;
         // conv2: 3x3 conv2d_same(stride): pad 1/1 both for stride 1 (SAME) and stride 2 (explicit pad + VALID);
         // with fuse_tail == 2 it runs inside the fused tail below
-        const bool conv2_in_tail = U.fuse_tail == 2;
+        const bool conv2_in_tail = U.fuse_tail >= 2;
         if (!conv2_in_tail) {
             d = hmmr_conv_desc_t{};
             d.in = T1; d.w = U.conv2.w; d.scale = U.conv2.scale; d.shift = U.conv2.shift; d.relu = 1; d.tile = U.conv2.tile;
@@ -325,8 +330,13 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
                 t.h2 = T2;
             }
             t.w3 = U.conv3.w; t.scale3 = U.conv3.scale; t.shift3 = U.conv3.shift;
-            t.res = d.res; t.ldr = d.ldr; t.res_strided = d.res_strided; t.res_img_stride = d.res_img_stride;
-            t.res_row_stride = d.res_row_stride; t.res_px_stride = d.res_px_stride; t.ho = Ho; t.wo = Ho;
+            if (sc_in_tail) {
+                t.xp = xin; t.wsc = U.shortcut.w; t.shift_sc = U.shortcut.shift;
+            } else {
+                t.res = d.res; t.ldr = d.ldr; t.res_strided = d.res_strided; t.res_img_stride = d.res_img_stride;
+                t.res_row_stride = d.res_row_stride; t.res_px_stride = d.res_px_stride;
+            }
+            t.ho = Ho; t.wo = Ho;
             t.out = xn; t.pre_scale = N.pre_scale; t.pre_shift = N.pre_shift;
             t.w1 = N.conv1.w; t.scale1 = N.conv1.scale; t.shift1 = N.conv1.shift; t.relu1 = 1; t.n2 = N.base;
             t.out_h1 = conv2_in_tail ? T2 : T1;

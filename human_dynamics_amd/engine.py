@@ -57,7 +57,7 @@ class HmmrEngine(object):
         self.num_conv_layers = num_conv_layers
         self.delta_keys = sorted(int(d) for d in delta_t_values)
         fuse = tuple(b for b in os.environ.get("HMMR_FUSE_PREACT", "block1,block2,block3,block4").split(",") if b)   # dev A/B switch
-        tail = {"0": False, "1": True}.get(os.environ.get("HMMR_FUSE_TAIL", "1"), os.environ.get("HMMR_FUSE_TAIL"))   # dev A/B switch: 0, 1, "block1", "noconv2", "conv2b1"
+        tail = {"0": False, "1": True}.get(os.environ.get("HMMR_FUSE_TAIL", "1"), os.environ.get("HMMR_FUSE_TAIL"))   # dev A/B switch: 0, 1, "block1", "noconv2", "conv2b1", "nosc"
         fsc = {"0": False, "1": True}.get(os.environ.get("HMMR_FUSE_SC", "1"), "all")               # dev A/B switch: 0, 1, all
         self.rw = (packing.pack_resnet(weights, self.dtype, self.store, fuse_preact_blocks=fuse, fuse_tail=tail, fuse_sc=fsc)
                    if weights is not None else None)
@@ -374,7 +374,7 @@ def conv_gemm(x, w_hwio, stride=1, pad=0, scale=None, shift=None, res=None, relu
     return o, o2
 
 
-def bottleneck_tail(h2, w3_hwio, bias3, res, pre, w1_hwio, bn1, res_stride=1, device="cuda:0", conv2=None):
+def bottleneck_tail(h2, w3_hwio, bias3, res, pre, w1_hwio, bn1, res_stride=1, device="cuda:0", conv2=None, shortcut=None):
     """Test/utility entry for hmmr_bottleneck_tail (bf16): h2 [n,h,w,64], w3 [1,1,64,256], res
     [n,h*s,w*s,256] (s = res_stride), pre = (scale, shift) [256], w1 [1,1,256,64], bn1 = (scale, shift) [64].
     With conv2 = (w2 [3,3,64,64], scale2, shift2) the first argument is h1 and the 3x3 conv runs inside the launch.
@@ -388,7 +388,7 @@ def bottleneck_tail(h2, w3_hwio, bias3, res, pre, w1_hwio, bn1, res_stride=1, de
     depth, n2 = w3_hwio.shape[3], w1_hwio.shape[3]
     w3 = store.put(packing.pack_conv_weight(np.asarray(w3_hwio, np.float32)), bf)
     w1 = store.put(packing.pack_conv_weight(np.asarray(w1_hwio, np.float32)), bf)
-    rt = store.put(np.asarray(res, np.float32), bf)
+    rt = store.put(np.asarray(res, np.float32), bf) if res is not None else None
     out = torch.zeros((n, h, w_, depth), dtype=bf, device=dev)
     h1 = torch.zeros((n, h, w_, n2), dtype=bf, device=dev)
     d = L.TailDesc()
@@ -400,8 +400,15 @@ def bottleneck_tail(h2, w3_hwio, bias3, res, pre, w1_hwio, bn1, res_stride=1, de
         d.h1, d.hin, d.win, d.w2 = x.data_ptr(), h, w_, w2.data_ptr()
         d.scale2, d.shift2 = store.vec(conv2[1]).data_ptr(), store.vec(conv2[2]).data_ptr()
     d.w3, d.shift3 = w3.data_ptr(), store.vec(bias3).data_ptr()
-    d.res = rt.data_ptr()
-    if res_stride == 1:
+    if shortcut is not None:               # (xp [n,h,w,64], wsc [1,1,64,256], bias): the shortcut conv runs in the launch
+        xp = store.put(np.asarray(shortcut[0], np.float32), bf)
+        wsc = store.put(packing.pack_conv_weight(np.asarray(shortcut[1], np.float32)), bf)
+        d.xp, d.wsc, d.shift_sc = xp.data_ptr(), wsc.data_ptr(), store.vec(shortcut[2]).data_ptr()
+    else:
+        d.res = rt.data_ptr()
+    if shortcut is not None:
+        pass
+    elif res_stride == 1:
         d.ldr = depth
     else:
         d.res_strided, d.ho, d.wo = 1, h, w_

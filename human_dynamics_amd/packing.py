@@ -121,6 +121,8 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
                           nx.fuse_preact == 1 and not nx.shortcut.w)
         if u.fuse_tail and fuse_tail != "noconv2" and (u.base == 64 or fuse_tail != "conv2b1"):
             u.fuse_tail = 2               # the unit's 3x3 conv2 runs inside the same launch too
+            if u.shortcut.w and u.c_in == 64 and not u.fuse_preact and fuse_tail != "nosc":
+                u.fuse_tail = 3           # ... and so does its conv shortcut (block1/unit_1)
     s, b = fold_bn(w, "resnet_v2_50/postnorm")
     rw.post_scale, rw.post_shift = store.vec(s).data_ptr(), store.vec(b).data_ptr()
     return rw

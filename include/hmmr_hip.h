@@ -125,7 +125,8 @@ typedef struct {
     int c_in, base, depth, stride;
     int fuse_preact;           /* 1: conv1/shortcut apply the preact while staging their operand;
                                   0: the previous unit's conv3 writes the preact tensor */
-    int fuse_tail;             /* 2: as 1, with this unit's conv2 inside the same launch as well;
+    int fuse_tail;             /* 3: as 2, and the unit's conv shortcut is computed in that launch too (c_in 64);
+                                  2: as 1, with this unit's conv2 inside the same launch as well;
                                   1: this unit's conv3 + add and the NEXT unit's preact + conv1 run as one
                                   hmmr_bottleneck_tail launch (bf16, stride 1, block1 or block2 shapes, next unit
                                   of the same block with identity shortcut and fuse_preact) */
@@ -165,6 +166,10 @@ typedef struct {
      * SAME padding, stride 1, computed per tile inside the same launch (slim bottleneck_v2 `conv2`) */
     const void* h1; int hin, win;   /* [m / (hin*win)][hin][win][c_mid] */
     const void* w2; const float* scale2; const float* shift2;      /* [c_mid][9 * c_mid], K = (ky, kx, ci) */
+    /* optional conv shortcut computed in the launch (block1/unit_1: needs h1; res = NULL):
+     * shortcut = xp x wsc + shift_sc, rounded to bf16 as the separate launch would store it */
+    const void* xp;                 /* [m][64]: the (pre-activated) input of the unit */
+    const void* wsc; const float* shift_sc;                        /* [depth][64], [depth] */
 } hmmr_tail_desc_t;
 int hmmr_bottleneck_tail(const hmmr_tail_desc_t* d, void* stream);
 

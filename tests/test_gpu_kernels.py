@@ -374,3 +374,32 @@ def test_bottleneck_tail_with_conv2_in_front(shape, chans, gpu_device):
     got_trunk, got_h1 = bottleneck_tail(h1, w3, b3, res, pre, w1, bn1, device=gpu_device, conv2=(w2, bn2[0], bn2[1]))
     assert np.array_equal(got_trunk, trunk)
     assert np.array_equal(got_h1, nxt)
+
+
+@pytest.mark.parametrize("shape", [(3, 9, 7), (2, 56, 56)])
+def test_bottleneck_tail_with_conv2_and_shortcut_inside(shape, gpu_device):
+    """block1/unit_1 as ONE launch: conv shortcut + conv2 + conv3 + add + next preact + next conv1
+    == four hmmr_conv_gemm launches, bit for bit."""
+    from human_dynamics_amd.engine import bottleneck_tail, conv_gemm
+    rng = np.random.default_rng(29)
+    n, h, w = shape
+    xp = np.maximum(rng.normal(size=(n, h, w, 64)), 0).astype(np.float32)
+    wsc = (rng.normal(size=(1, 1, 64, 256)) / 8).astype(np.float32)
+    bsc = rng.normal(size=256).astype(np.float32)
+    h1 = np.maximum(rng.normal(size=(n, h, w, 64)), 0).astype(np.float32)
+    w2 = (rng.normal(size=(3, 3, 64, 64)) / 24).astype(np.float32)
+    bn2 = (rng.uniform(0.5, 1.5, 64).astype(np.float32), rng.normal(size=64).astype(np.float32) * 0.2)
+    w3 = (rng.normal(size=(1, 1, 64, 256)) / 8).astype(np.float32)
+    b3 = rng.normal(size=256).astype(np.float32)
+    pre = (rng.uniform(0.5, 1.5, 256).astype(np.float32), rng.normal(size=256).astype(np.float32))
+    w1 = (rng.normal(size=(1, 1, 256, 64)) / 16).astype(np.float32)
+    bn1 = (rng.uniform(0.5, 1.5, 64).astype(np.float32), rng.normal(size=64).astype(np.float32))
+    bf = L.HMMR_BF16
+    sc, _ = conv_gemm(xp, wsc, 1, 0, None, bsc, None, False, in_dtype=bf, out_dtype=bf, device=gpu_device)
+    h2, _ = conv_gemm(h1, w2, 1, 1, bn2[0], bn2[1], None, True, in_dtype=bf, out_dtype=bf, device=gpu_device)
+    trunk, _ = conv_gemm(h2, w3, 1, 0, None, b3, sc, False, in_dtype=bf, out_dtype=bf, device=gpu_device)
+    nxt, _ = conv_gemm(trunk, w1, 1, 0, bn1[0], bn1[1], None, True, in_dtype=bf, out_dtype=bf, device=gpu_device, pro=pre)
+    got_trunk, got_h1 = bottleneck_tail(h1, w3, b3, None, pre, w1, bn1, device=gpu_device, conv2=(w2, bn2[0], bn2[1]),
+                                        shortcut=(xp, wsc, bsc))
+    assert np.array_equal(got_trunk, trunk)
+    assert np.array_equal(got_h1, nxt)
