@@ -59,7 +59,9 @@ class HmmrEngine(object):
         fuse = tuple(b for b in os.environ.get("HMMR_FUSE_PREACT", "block1,block2,block3,block4").split(",") if b)   # dev A/B switch
         tail = {"0": False, "1": True}.get(os.environ.get("HMMR_FUSE_TAIL", "1"), os.environ.get("HMMR_FUSE_TAIL"))   # dev A/B switch: 0, 1, "block1", "noconv2", "conv2b1", "nosc"
         fsc = {"0": False, "1": True}.get(os.environ.get("HMMR_FUSE_SC", "1"), "all")               # dev A/B switch: 0, 1, all
-        self.rw = (packing.pack_resnet(weights, self.dtype, self.store, fuse_preact_blocks=fuse, fuse_tail=tail, fuse_sc=fsc)
+        pfirst = os.environ.get("HMMR_PREACT_FIRST", "0") != "0"                                    # dev A/B switch
+        self.rw = (packing.pack_resnet(weights, self.dtype, self.store, fuse_preact_blocks=fuse, fuse_tail=tail, fuse_sc=fsc,
+                                       fuse_preact_first=pfirst)
                    if weights is not None else None)
         self.tw = (packing.pack_temporal(weights, self.temporal_dtype, self.store, num_conv_layers)
                    if weights is not None else None)

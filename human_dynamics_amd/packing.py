@@ -78,7 +78,7 @@ def _layer(store, w_packed, dtype, scale=None, shift=None):
 
 
 def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3", "block4"), fuse_tail=True,
-                fuse_sc=True):
+                fuse_sc=True, fuse_preact_first=False):
     """fuse_preact_blocks: blocks whose units apply their `preact` BN+ReLU inside the operand
     staging of conv1/shortcut instead of reading a materialised preact tensor (csrc/resnet.hip;
     measured at batch 256: -4.5 % ResNet time with blocks 1-2 fused, neutral for blocks 3-4).
@@ -94,6 +94,11 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
         u = rw.unit[i]
         u.c_in, u.base, u.depth, u.stride = c_in, base, depth, stride
         u.fuse_preact = int(i > 0 and scope.split("/")[1] in fuse_preact_blocks)
+        if has_sc and i > 0 and not fuse_preact_first:
+            # a block's first unit feeds its preact to a WIDE conv shortcut as well: every N tile of a fused-preact
+            # launch repeats the transform, so here the previous unit's conv3 writes the (small, already
+            # down-sampled) preact tensor once and both consumers take the plain LDS-DMA operand path
+            u.fuse_preact = 0
         s, b = fold_bn(w, scope + "/conv1/BatchNorm")
         u.conv1 = _layer(store, pack_conv_weight(w[scope + "/conv1/weights"]), dtype, s, b)
         s, b = fold_bn(w, scope + "/conv2/BatchNorm")
