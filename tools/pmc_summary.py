@@ -24,6 +24,9 @@ def agg(root, tag, counter):
     return d
 
 
+LPP = int(sys.argv[3]) if len(sys.argv) > 3 else 40      # MFMA launches per ResNet pass (bench.py roofline.kernel)
+
+
 def main():
     root, out = sys.argv[1], sys.argv[2]
     fe, wr = agg(root, "FETCH_SIZE", "FETCH_SIZE"), agg(root, "WRITE_SIZE", "WRITE_SIZE")
@@ -48,7 +51,7 @@ def main():
     w = sum(1024 * wr[k][1] for k in rn if k in wr)
     busy = sum(mf[k][1] for k in rn if k in mf)
     g = sum(gui[k][1] for k in rn if k in gui)
-    res["resnet_conv_gemm"] = {"launches": n, "hbm_bytes_per_pass": round((rd + w) / n * 41), "launches_per_pass": 41, "hbm_bytes_per_launch": round((rd + w) / n),
+    res["resnet_conv_gemm"] = {"launches": n, "hbm_bytes_per_pass": round((rd + w) / n * LPP), "launches_per_pass": LPP, "hbm_bytes_per_launch": round((rd + w) / n),
                                "hbm_read_bytes_per_launch": round(rd / n), "hbm_write_bytes_per_launch": round(w / n),
                                "mfma_util": round(busy / (g / 8.0 * 1024.0), 4),
                                "note": "averaged over the ResNet passes of `HMMR_TILE_CACHE=<tuned> bench.py --serial --steps 2 --warmup 1 "
