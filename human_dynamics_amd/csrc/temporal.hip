@@ -105,7 +105,7 @@ extern "C" int hmmr_temporal_fwd(const hmmr_temporal_weights_t* w, const float* 
         float* dst = (i == w->num_blocks - 1) ? strips : net[i & 1];
         if (hmmr_groupnorm_relu(cur, B.gn1_gamma, B.gn1_beta, b, t, C, 32, h, w->dtype, stream)) return -2;
         hmmr_conv_desc_t d = {};
-        d.in = h; d.w = B.conv1.w; d.scale = B.conv1.scale; d.shift = B.conv1.shift;
+        d.in = h; d.w = B.conv1.w; d.scale = B.conv1.scale; d.shift = B.conv1.shift; d.tile = B.conv1.tile;
         d.out = h1; d.in_dtype = w->dtype; d.out_dtype = HMMR_F32;
         d.n_img = b; d.hin = t; d.win = 1; d.cin = C;
         d.in_img_stride = (int64_t)t * C; d.in_row_stride = C; d.in_px_stride = C;
@@ -113,7 +113,7 @@ extern "C" int hmmr_temporal_fwd(const hmmr_temporal_weights_t* w, const float* 
         d.split_k = TEMPORAL_SPLIT_K; d.ws = skws; d.ws_bytes = skbytes;
         if (hmmr_conv_gemm(&d, stream)) return -2;
         if (hmmr_groupnorm_relu(h1, B.gn2_gamma, B.gn2_beta, b, t, C, 32, h, w->dtype, stream)) return -2;
-        d.w = B.conv2.w; d.scale = B.conv2.scale; d.shift = B.conv2.shift;
+        d.w = B.conv2.w; d.scale = B.conv2.scale; d.shift = B.conv2.shift; d.tile = B.conv2.tile;
         d.res = cur; d.ldr = C; d.out = dst;            // residual adds the BLOCK INPUT (models.py:226)
         if (hmmr_conv_gemm(&d, stream)) return -2;
         cur = dst;
