@@ -12,6 +12,8 @@ tensors), which is how the N>1 plumbing is tested without GPUs.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -138,7 +140,8 @@ class ShardedPredictor(object):
         else:
             self.idx = None
         nbuf = 2 if (self.overlap or self.pipeline) else 1
-        self.s_tail = torch.cuda.Stream(device=eng.device, priority=-1) if self.pipeline else None
+        self.s_tail = (torch.cuda.Stream(device=eng.device, priority=int(os.environ.get("HMMR_TAIL_PRIORITY", "0")))
+                       if self.pipeline else None)     # env: dev A/B switch
         self.done = [None] * nbuf
         self.locals = [torch.zeros((p.out_per_rank, self.rec_len), dtype=torch.float32, device=eng.device)
                        for _ in range(nbuf)]

@@ -210,7 +210,7 @@ class HmmrEngine(object):
             return (phi, pm) if prof else phi
         cur = torch.cuda.current_stream(self.device)
         while len(self._side_streams) < parts:
-            self._side_streams.append(torch.cuda.Stream(device=self.device))
+            self._side_streams.append(torch.cuda.Stream(device=self.device, priority=int(os.environ.get("HMMR_RESNET_PRIORITY", "-1"))))
         cuts = [(i * n) // parts for i in range(parts + 1)]
         if self.autotune:                                    # tune every part size before anything overlaps
             for i in range(parts):
