@@ -51,6 +51,7 @@ class TailDesc(C.Structure):
         ("out_h1", _vp),
         ("h1", _vp), ("hin", C.c_int), ("win", C.c_int), ("w2", _vp), ("scale2", _fp), ("shift2", _fp),
         ("xp", _vp), ("wsc", _vp), ("shift_sc", _fp),
+        ("conv2_stride", C.c_int), ("out_pre", _vp),
     ]
 
 

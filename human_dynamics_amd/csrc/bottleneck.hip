@@ -45,7 +45,8 @@ struct TailArgs {
     long long res_img_stride; int res_row_stride, res_px_stride;
     int relu1;
     // conv2 in front (CONV2 kernels): h1 [n][H][W][c_mid], 3x3 SAME stride 1, folded BN + ReLU
-    const bf16_t* h1; const bf16_t* w2; const float* scale2; const float* shift2; int H, W;
+    const bf16_t* h1; const bf16_t* w2; const float* scale2; const float* shift2; int H, W, S;   // S = conv2 stride
+    bf16_t* out_pre;        // PH2 == false: the pre-activated trunk goes to HBM here (may be NULL), `out` may be NULL
     // conv shortcut computed in the kernel (SC kernels): shortcut = xp [M][64] x wsc [depth][64] + shift_sc, rounded
     // to bf16 like the tensor the separate launch would have written; `res` is not read
     const bf16_t* xp; const bf16_t* wsc; const float* shift_sc;
@@ -88,8 +89,11 @@ struct TailCfg {
     static_assert(2 * TM <= 8, "conv3 chunk needs at most 8 waves");
 };
 
-template <int BM, int CM, int NCH, int N2, bool CONV2, bool SC>
+// PH2 = false: no next-unit conv1 -- the launch ends after the trunk chunk has been streamed out (raw and/or
+// pre-activated): the stride-2 last unit of a block, whose successor also owns a conv shortcut.
+template <int BM, int CM, int NCH, int N2, bool CONV2, bool SC, bool PH2>
 __global__ __launch_bounds__(NT, 4) void bottleneck_tail_kernel(const TailArgs a) {
+    static_assert(PH2 || (CONV2 && !SC), "the single-phase tail is used with conv2 in front and a loaded shortcut");
     static_assert(!SC || (BM == 128 && CM == 64), "the in-kernel shortcut is written for c_in = 64 (block1/unit_1)");
     static_assert(!CONV2 || (CM / 32) * (BM / 32) == 8, "conv2 tile must map one 32x32 block to each of the 8 waves");
     typedef TailCfg<BM, CM, NCH, N2, SC> Cfg;
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(NT, 4) void bottleneck_tail_kernel(const TailArgs a
     [[maybe_unused]] u32x4 rws;
     auto load_ws = [&](int nc) { return *(const u32x4*)(a.wsc + (long long)(nc * 64 + r0) * 64 + lslot * 8); };
     load_w3(0, rw3);
-    load_w1(0, rw1);
+    if constexpr (PH2) load_w1(0, rw1);
     if constexpr (SC) {
         // the shortcut's operand tile and filter chunk 0 go to LDS right away (their slots are not used by conv2)
         u32x4 rx[RB];
@@ -197,13 +201,15 @@ __global__ __launch_bounds__(NT, 4) void bottleneck_tail_kernel(const TailArgs a
 #pragma unroll
         for (int p = 0; p < RB; ++p) {
             const int m = rok[p] ? m0 + r0 + 64 * p : 0;
-            const int img = m / (a.H * a.W), rem = m - img * (a.H * a.W);
-            const int oy = rem / a.W, ox = rem - oy * a.W;
-            pbase[p] = a.h1 + ((long long)m) * CM + lslot * 8;
+            // output pixel (oy, ox) of the Ho x Wo grid reads input pixels (oy*S - 1 + ky, ox*S - 1 + kx): SAME for
+            // stride 1, slim's conv2d_same (pad 1 + VALID) for stride 2
+            const int img = m / a.HoWo, rem = m - img * a.HoWo;
+            const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+            pbase[p] = a.h1 + (((long long)img * a.H + oy * a.S) * a.W + ox * a.S) * CM + lslot * 8;
             unsigned mk = 0u;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                const int iy = oy - 1 + t / 3, ix = ox - 1 + t % 3;
+                const int iy = oy * a.S - 1 + t / 3, ix = ox * a.S - 1 + t % 3;
                 if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) mk |= 1u << t;
             }
             pmask[p] = rok[p] ? mk : 0u;
@@ -268,11 +274,11 @@ __global__ __launch_bounds__(NT, 4) void bottleneck_tail_kernel(const TailArgs a
         for (int kt = 0; kt < KT1; ++kt) store_rows(Cfg::OFF_H2 + kt * (BM * 128), rh[kt]);
     }
     store_w3(rw3);
-    store_w1(rw1);
+    if constexpr (PH2) store_w1(rw1);
     if constexpr (!SC) store_rows(Cfg::OFF_P0, rres[0]);
     // weight chunks are re-requested the moment their registers are free (right after the ds_write of
     // the previous chunk), so each request has a whole chunk iteration to come back from L2
-    if (NCH > 1) { load_w3(1, rw3); load_w1(1, rw1); }
+    if (NCH > 1) { load_w3(1, rw3); if constexpr (PH2) load_w1(1, rw1); }
     __syncthreads();
 
     f32x16 acc2;
@@ -338,13 +344,15 @@ __global__ __launch_bounds__(NT, 4) void bottleneck_tail_kernel(const TailArgs a
             for (int p = 0; p < RB; ++p) {
                 char* q = smem + pcur + st_off + p * (64 * 128);
                 const u32x4 x = *(const u32x4*)q;
-                if (rok[p]) *(u32x4*)(a.out + (long long)(m0 + r0 + 64 * p) * depth + nc * 64 + lslot * 8) = x;
+                if (rok[p] && (PH2 || a.out)) *(u32x4*)(a.out + (long long)(m0 + r0 + 64 * p) * depth + nc * 64 + lslot * 8) = x;
+                if constexpr (!PH2) { if (!a.out_pre) continue; }
                 u32x4 y;
                 y[0] = pack_bf(fmaxf(fmaf(bf_lo(x[0]), s0[0], b0[0]), 0.f), fmaxf(fmaf(bf_hi(x[0]), s0[1], b0[1]), 0.f));
                 y[1] = pack_bf(fmaxf(fmaf(bf_lo(x[1]), s0[2], b0[2]), 0.f), fmaxf(fmaf(bf_hi(x[1]), s0[3], b0[3]), 0.f));
                 y[2] = pack_bf(fmaxf(fmaf(bf_lo(x[2]), s1[0], b1[0]), 0.f), fmaxf(fmaf(bf_hi(x[2]), s1[1], b1[1]), 0.f));
                 y[3] = pack_bf(fmaxf(fmaf(bf_lo(x[3]), s1[2], b1[2]), 0.f), fmaxf(fmaf(bf_hi(x[3]), s1[3], b1[3]), 0.f));
-                *(u32x4*)q = y;
+                if constexpr (PH2) *(u32x4*)q = y;
+                else if (rok[p]) *(u32x4*)(a.out_pre + (long long)(m0 + r0 + 64 * p) * depth + nc * 64 + lslot * 8) = y;
             }
             if (nc + 1 < NCH) {
                 if constexpr (SC) {
@@ -358,15 +366,18 @@ __global__ __launch_bounds__(NT, 4) void bottleneck_tail_kernel(const TailArgs a
             }
         }
         __syncthreads();
-        // (g) conv1' K step `nc`
+        if constexpr (PH2) {
+            // (g) conv1' K step `nc`
 #pragma unroll
-        for (int kc = 0; kc < 4; ++kc) acc2 = mma16(frag(Cfg::OFF_W1, wn * 32 + lr, kc), frag(pcur, wm * 32 + lr, kc), acc2);
-        __syncthreads();
-        if (nc + 1 < NCH) {
-            store_w1(rw1);
-            if (nc + 2 < NCH) load_w1(nc + 2, rw1);
+            for (int kc = 0; kc < 4; ++kc) acc2 = mma16(frag(Cfg::OFF_W1, wn * 32 + lr, kc), frag(pcur, wm * 32 + lr, kc), acc2);
+            __syncthreads();
+            if (nc + 1 < NCH) {
+                store_w1(rw1);
+                if (nc + 2 < NCH) load_w1(nc + 2, rw1);
+            }
         }
     }
+    if constexpr (!PH2) return;
 
     // ---- conv1' epilogue: BN (+ReLU), bf16, through the H2 region ([BM][64] sub-tiles), coalesced stores
 #pragma unroll
@@ -393,11 +404,11 @@ __global__ __launch_bounds__(NT, 4) void bottleneck_tail_kernel(const TailArgs a
                     *(const u32x4*)(smem + Cfg::OFF_H2 + st * (BM * 128) + st_off + p * (64 * 128));
 }
 
-template <int BM, int CM, int NCH, int N2, bool CONV2, bool SC = false>
+template <int BM, int CM, int NCH, int N2, bool CONV2, bool SC = false, bool PH2 = true>
 int launch_tail(const TailArgs& a, hipStream_t stream) {
     typedef TailCfg<BM, CM, NCH, N2, SC> Cfg;
     static_assert(!CONV2 || 2 * (BM * 128 + CM * 128) <= Cfg::OFF_C, "conv2 stages must fit below the constants");
-    auto kern = bottleneck_tail_kernel<BM, CM, NCH, N2, CONV2, SC>;
+    auto kern = bottleneck_tail_kernel<BM, CM, NCH, N2, CONV2, SC, PH2>;
     static bool attr_set = false;
     if (!attr_set) {
         HMMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS));
@@ -411,15 +422,22 @@ int launch_tail(const TailArgs& a, hipStream_t stream) {
 }  // namespace
 
 extern "C" int hmmr_bottleneck_tail(const hmmr_tail_desc_t* d, void* stream) {
-    HMMR_REQUIRE(d && (d->h2 || d->h1) && d->w3 && (d->res || d->xp) && d->out && d->pre_scale && d->pre_shift && d->w1 && d->scale1 &&
-                 d->shift1 && d->out_h1, "hmmr_bottleneck_tail: null argument");
+    HMMR_REQUIRE(d && (d->h2 || d->h1) && d->w3 && (d->res || d->xp), "hmmr_bottleneck_tail: null argument");
+    const bool ph2 = d->w1 != nullptr;
+    HMMR_REQUIRE(!ph2 || (d->out && d->pre_scale && d->pre_shift && d->scale1 && d->shift1 && d->out_h1 && !d->out_pre),
+                 "hmmr_bottleneck_tail: the next conv1 needs out, pre_scale/pre_shift, scale1/shift1, out_h1 (and no out_pre)");
+    HMMR_REQUIRE(ph2 || (d->h1 && !d->xp && (d->out || d->out_pre) && (!d->out_pre || (d->pre_scale && d->pre_shift))),
+                 "hmmr_bottleneck_tail: without a next conv1 (w1 == NULL) the launch needs conv2 in front (h1), a loaded "
+                 "shortcut, and out and/or out_pre (+ pre_scale/pre_shift)");
     const bool conv2 = d->h1 != nullptr;
     HMMR_REQUIRE(!conv2 || (!d->h2 && d->w2 && d->scale2 && d->shift2 && d->hin > 0 && d->win > 0 &&
-                            d->m % (d->hin * d->win) == 0),
-                 "hmmr_bottleneck_tail: conv2 in front needs h1, w2, scale2, shift2, hin, win (and h2 == NULL)");
+                            d->ho > 0 && d->wo > 0 && d->m % (d->ho * d->wo) == 0 &&
+                            (d->conv2_stride <= 1 ? (d->ho == d->hin && d->wo == d->win)
+                                                  : (d->conv2_stride == 2 && d->ho == (d->hin + 1) / 2 && d->wo == (d->win + 1) / 2))),
+                 "hmmr_bottleneck_tail: conv2 in front needs h1, w2, scale2, shift2, hin, win, ho, wo (stride 1 or 2; h2 == NULL)");
     HMMR_REQUIRE(d->dtype == HMMR_BF16, "hmmr_bottleneck_tail: bf16 operands only");
-    const bool b1 = d->c_mid == 64 && d->depth == 256 && d->n2 == 64;
-    const bool b2 = d->c_mid == 128 && d->depth == 512 && d->n2 == 128;
+    const bool b1 = d->c_mid == 64 && d->depth == 256 && (!ph2 || d->n2 == 64);
+    const bool b2 = d->c_mid == 128 && d->depth == 512 && (!ph2 || d->n2 == 128);
     HMMR_REQUIRE(b1 || b2, "hmmr_bottleneck_tail: supported shapes are 64 -> 256 -> 64 and 128 -> 512 -> 128 (got %d, %d, %d)",
                  d->c_mid, d->depth, d->n2);
     HMMR_REQUIRE(d->m > 0, "hmmr_bottleneck_tail: empty launch");
@@ -438,7 +456,11 @@ extern "C" int hmmr_bottleneck_tail(const hmmr_tail_desc_t* d, void* stream) {
     a.res_img_stride = d->res_img_stride; a.res_row_stride = d->res_row_stride; a.res_px_stride = d->res_px_stride;
     a.relu1 = d->relu1;
     a.h1 = (const bf16_t*)d->h1; a.w2 = (const bf16_t*)d->w2; a.scale2 = d->scale2; a.shift2 = d->shift2;
-    a.H = d->hin; a.W = d->win;
+    a.H = d->hin; a.W = d->win; a.S = d->conv2_stride > 1 ? d->conv2_stride : 1; a.out_pre = (bf16_t*)d->out_pre;
+    if (conv2 && d->ho > 0) { a.Wo = d->wo; a.HoWo = d->ho * d->wo; }
+    if (!ph2)
+        return b1 ? launch_tail<128, 64, 4, 64, true, false, false>(a, (hipStream_t)stream)
+                  : launch_tail<64, 128, 8, 128, true, false, false>(a, (hipStream_t)stream);
     a.xp = (const bf16_t*)d->xp; a.wsc = (const bf16_t*)d->wsc; a.shift_sc = d->shift_sc;
     if (sc) return launch_tail<128, 64, 4, 64, true, true>(a, (hipStream_t)stream);
     if (conv2)

@@ -395,7 +395,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 1) void conv
             float s2[8], b2[8], u[8];
             load8(a.scale2 + n, s2); load8(a.shift2 + n, b2);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) u[j] = fmaxf(fmaf(v[j], s2[j], b2[j]), 0.f);   // = the consumer-side preact_slot
+            for (int j = 0; j < 8; ++j) {       // the preact of the STORED value: = the consumer-side preact_slot, bit for bit
+                const float vr = elem_traits<TO>::to_f32(elem_traits<TO>::from_f32(v[j]));
+                u[j] = fmaxf(fmaf(vr, s2[j], b2[j]), 0.f);
+            }
             if (full) store8(out2 + oo, u);
             else for (int j = 0; j < 8 && n + j < a.cout; ++j) out2[oo + j] = elem_traits<TO>::from_f32(u[j]);
         }
@@ -521,7 +524,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a, co
         float s2[8], b2[8], u[8];
         load8(a.scale2 + n, s2); load8(a.shift2 + n, b2);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) u[j] = fmaxf(v[j] * s2[j] + b2[j], 0.f);
+        for (int j = 0; j < 8; ++j) {
+            const float vr = elem_traits<TO>::to_f32(elem_traits<TO>::from_f32(v[j]));
+            u[j] = fmaxf(fmaf(vr, s2[j], b2[j]), 0.f);
+        }
         if (full) store8(out2 + oo, u);
         else for (int j = 0; j < 8 && n + j < a.cout; ++j) out2[oo + j] = elem_traits<TO>::from_f32(u[j]);
     }

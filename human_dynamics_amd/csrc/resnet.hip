@@ -283,7 +283,7 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
         if (prof_mark(pf)) return -2;
         // conv2: 3x3 conv2d_same(stride): pad 1/1 both for stride 1 (SAME) and stride 2 (explicit pad + VALID);
         // with fuse_tail == 2 it runs inside the fused tail below
-        const bool conv2_in_tail = U.fuse_tail >= 2;
+        const bool conv2_in_tail = U.fuse_tail >= 2;     // (4: the single-phase tail of a stride-2 unit)
         if (!conv2_in_tail) {
             d = hmmr_conv_desc_t{};
             d.in = T1; d.w = U.conv2.w; d.scale = U.conv2.scale; d.shift = U.conv2.shift; d.relu = 1; d.tile = U.conv2.tile;
@@ -314,7 +314,20 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
             HMMR_REQUIRE(d.scale2 && d.shift2, "resnet: unit %d lacks its preact BN", u + 1);
         }
         h1_ready = false;
-        if (U.fuse_tail) {            // conv3 + add + the next unit's preact + conv1 in one launch (csrc/bottleneck.hip)
+        if (U.fuse_tail == 4) {       // stride-2 last unit of a block: conv2 + conv3 + add in one launch, no next conv1
+            HMMR_REQUIRE(!last && w->dtype == HMMR_BF16 && U.conv2.scale && U.conv2.shift && !U.shortcut.w &&
+                         ((U.base == 64 && U.depth == 256) || (U.base == 128 && U.depth == 512)),
+                         "resnet: unit %d cannot run as a single-phase tail", u);
+            hmmr_tail_desc_t t = {};
+            t.dtype = w->dtype; t.m = n * Ho * Ho; t.c_mid = U.base; t.depth = U.depth;
+            t.h1 = T1; t.hin = H; t.win = H; t.conv2_stride = U.stride; t.ho = Ho; t.wo = Ho;
+            t.w2 = U.conv2.w; t.scale2 = U.conv2.scale; t.shift2 = U.conv2.shift;
+            t.w3 = U.conv3.w; t.scale3 = U.conv3.scale; t.shift3 = U.conv3.shift;
+            t.res = d.res; t.ldr = d.ldr; t.res_strided = d.res_strided; t.res_img_stride = d.res_img_stride;
+            t.res_row_stride = d.res_row_stride; t.res_px_stride = d.res_px_stride;
+            t.out = d.out; t.out_pre = d.out2; t.pre_scale = d.scale2; t.pre_shift = d.shift2;
+            if (hmmr_bottleneck_tail(&t, s)) return -2;
+        } else if (U.fuse_tail) {     // conv3 + add + the next unit's preact + conv1 in one launch (csrc/bottleneck.hip)
             HMMR_REQUIRE(!last && w->dtype == HMMR_BF16 && U.stride == 1 && write_raw && !write_pre && next_fused &&
                          next_identity && w->unit[u + 1].base == U.base && w->unit[u + 1].c_in == U.depth &&
                          ((U.base == 64 && U.depth == 256) || (U.base == 128 && U.depth == 512)),

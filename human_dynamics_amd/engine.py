@@ -57,7 +57,7 @@ class HmmrEngine(object):
         self.num_conv_layers = num_conv_layers
         self.delta_keys = sorted(int(d) for d in delta_t_values)
         fuse = tuple(b for b in os.environ.get("HMMR_FUSE_PREACT", "block1,block2,block3,block4").split(",") if b)   # dev A/B switch
-        tail = {"0": False, "1": True}.get(os.environ.get("HMMR_FUSE_TAIL", "1"), os.environ.get("HMMR_FUSE_TAIL"))   # dev A/B switch: 0, 1, "block1", "noconv2", "conv2b1", "nosc"
+        tail = {"0": False, "1": True}.get(os.environ.get("HMMR_FUSE_TAIL", "1"), os.environ.get("HMMR_FUSE_TAIL"))   # dev A/B switch: 0, 1, "block1", "noconv2", "conv2b1", "nosc", "nostride2"
         fsc = {"0": False, "1": True}.get(os.environ.get("HMMR_FUSE_SC", "1"), "all")               # dev A/B switch: 0, 1, all
         pfirst = os.environ.get("HMMR_PREACT_FIRST", "0") != "0"                                    # dev A/B switch
         self.rw = (packing.pack_resnet(weights, self.dtype, self.store, fuse_preact_blocks=fuse, fuse_tail=tail, fuse_sc=fsc,
@@ -395,6 +395,7 @@ def bottleneck_tail(h2, w3_hwio, bias3, res, pre, w1_hwio, bn1, res_stride=1, de
     h1 = torch.zeros((n, h, w_, n2), dtype=bf, device=dev)
     d = L.TailDesc()
     d.dtype, d.m, d.c_mid, d.depth = L.HMMR_BF16, n * h * w_, cm, depth
+    d.ho, d.wo = h, w_
     if conv2 is None:
         d.h2 = x.data_ptr()
     else:                                  # h2 argument is h1; conv2 = (w2_hwio [3,3,64,64], scale2, shift2)
@@ -422,3 +423,41 @@ def bottleneck_tail(h2, w3_hwio, bias3, res, pre, w1_hwio, bn1, res_stride=1, de
     L.check(lib.hmmr_bottleneck_tail(C.byref(d), torch.cuda.current_stream(dev).cuda_stream), "hmmr_bottleneck_tail")
     torch.cuda.synchronize(dev)
     return out.float().cpu().numpy(), h1.float().cpu().numpy()
+
+
+def bottleneck_tail_single(h1, conv2, stride, w3_hwio, bias3, res, pre, want_raw=True, want_pre=True, device="cuda:0"):
+    """Test/utility entry for the single-phase hmmr_bottleneck_tail (a block's stride-2 last unit):
+    h1 [n,h,w,cm], conv2 = (w2 [3,3,cm,cm], scale2, shift2) with `stride`, w3 [1,1,cm,depth], res [n,h,w,depth]
+    (sub-sampled by `stride` as the identity shortcut), pre = (scale, shift).  Returns (trunk, preact) float32."""
+    lib = L.load()
+    dev = torch.device(device)
+    store = packing.DeviceStore(dev)
+    bf = torch.bfloat16
+    x = store.put(np.asarray(h1, np.float32), bf)
+    n, h, w_, cm = x.shape
+    ho, wo = (h + stride - 1) // stride, (w_ + stride - 1) // stride
+    depth = w3_hwio.shape[3]
+    w2 = store.put(packing.pack_conv_weight(np.asarray(conv2[0], np.float32)), bf)
+    w3 = store.put(packing.pack_conv_weight(np.asarray(w3_hwio, np.float32)), bf)
+    rt = store.put(np.asarray(res, np.float32), bf)
+    out = torch.zeros((n, ho, wo, depth), dtype=bf, device=dev)
+    outp = torch.zeros((n, ho, wo, depth), dtype=bf, device=dev)
+    d = L.TailDesc()
+    d.dtype, d.m, d.c_mid, d.depth = L.HMMR_BF16, n * ho * wo, cm, depth
+    d.h1, d.hin, d.win, d.ho, d.wo, d.conv2_stride = x.data_ptr(), h, w_, ho, wo, stride
+    d.w2, d.scale2, d.shift2 = w2.data_ptr(), store.vec(conv2[1]).data_ptr(), store.vec(conv2[2]).data_ptr()
+    d.w3, d.shift3 = w3.data_ptr(), store.vec(bias3).data_ptr()
+    d.res = rt.data_ptr()
+    if stride == 1:
+        d.ldr = depth
+    else:
+        d.res_strided = 1
+        d.res_img_stride = rt.shape[1] * rt.shape[2] * depth
+        d.res_row_stride, d.res_px_stride = stride * rt.shape[2] * depth, stride * depth
+    if want_raw:
+        d.out = out.data_ptr()
+    if want_pre:
+        d.out_pre, d.pre_scale, d.pre_shift = outp.data_ptr(), store.vec(pre[0]).data_ptr(), store.vec(pre[1]).data_ptr()
+    L.check(lib.hmmr_bottleneck_tail(C.byref(d), torch.cuda.current_stream(dev).cuda_stream), "hmmr_bottleneck_tail")
+    torch.cuda.synchronize(dev)
+    return (out.float().cpu().numpy() if want_raw else None), (outp.float().cpu().numpy() if want_pre else None)

@@ -128,6 +128,11 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
             u.fuse_tail = 2               # the unit's 3x3 conv2 runs inside the same launch too
             if u.shortcut.w and u.c_in == 64 and not u.fuse_preact and fuse_tail != "nosc":
                 u.fuse_tail = 3           # ... and so does its conv shortcut (block1/unit_1)
+    for i in range(L.RESNET_UNITS - 1):
+        u = rw.unit[i]
+        if (fuse_tail and fuse_tail != "nostride2" and dtype == L.HMMR_BF16 and u.stride == 2 and not u.shortcut.w and
+                (u.base, u.depth) in ((64, 256), (128, 512))):
+            u.fuse_tail = 4               # a block's stride-2 last unit: conv2 + conv3 + add as one launch
     s, b = fold_bn(w, "resnet_v2_50/postnorm")
     rw.post_scale, rw.post_shift = store.vec(s).data_ptr(), store.vec(b).data_ptr()
     return rw

@@ -55,7 +55,8 @@ typedef struct {
     const float* shift;    /* [cout_pad] or NULL (=0): bias / folded BN shift     */
     const void* res;       /* residual added before the ReLU, out_dtype, or NULL  */
     void* out;             /* [M, ldo] out_dtype, may be NULL if out2 is set      */
-    void* out2;            /* optional second output relu(v*scale2+shift2), or NULL */
+    void* out2;            /* optional second output relu(out*scale2+shift2) of the value as STORED in `out`'s
+                              dtype (= what a consumer applying pro_scale/pro_shift to `out` computes), or NULL */
     const float* scale2;
     const float* shift2;
     int in_dtype;          /* HMMR_F32 / HMMR_BF16 */
@@ -125,7 +126,8 @@ typedef struct {
     int c_in, base, depth, stride;
     int fuse_preact;           /* 1: conv1/shortcut apply the preact while staging their operand;
                                   0: the previous unit's conv3 writes the preact tensor */
-    int fuse_tail;             /* 3: as 2, and the unit's conv shortcut is computed in that launch too (c_in 64);
+    int fuse_tail;             /* 4: stride-2 unit: conv2 + conv3 + add as one launch, no next conv1;
+                                  3: as 2, and the unit's conv shortcut is computed in that launch too (c_in 64);
                                   2: as 1, with this unit's conv2 inside the same launch as well;
                                   1: this unit's conv3 + add and the NEXT unit's preact + conv1 run as one
                                   hmmr_bottleneck_tail launch (bf16, stride 1, block1 or block2 shapes, next unit
@@ -170,6 +172,11 @@ typedef struct {
      * shortcut = xp x wsc + shift_sc, rounded to bf16 as the separate launch would store it */
     const void* xp;                 /* [m][64]: the (pre-activated) input of the unit */
     const void* wsc; const float* shift_sc;                        /* [depth][64], [depth] */
+    /* conv2 stride (0/1 or 2; ho, wo = its output grid, m = images * ho * wo) and the single-phase form for a
+     * block's stride-2 last unit: w1 == NULL -> no next conv1; `out` (raw trunk) and/or `out_pre`
+     * (relu(out * pre_scale + pre_shift), what the next unit's conv1 AND conv shortcut read) are written */
+    int conv2_stride;
+    void* out_pre;                  /* [m][depth] or NULL */
 } hmmr_tail_desc_t;
 int hmmr_bottleneck_tail(const hmmr_tail_desc_t* d, void* stream);
 

@@ -403,3 +403,30 @@ def test_bottleneck_tail_with_conv2_and_shortcut_inside(shape, gpu_device):
                                         shortcut=(xp, wsc, bsc))
     assert np.array_equal(got_trunk, trunk)
     assert np.array_equal(got_h1, nxt)
+
+
+@pytest.mark.parametrize("chans", [(64, 256), (128, 512)])
+@pytest.mark.parametrize("shape,stride", [((2, 14, 14), 2), ((3, 9, 7), 2), ((1, 16, 16), 1)])
+def test_bottleneck_tail_single_phase_strided(shape, stride, chans, gpu_device):
+    """A block's stride-2 last unit as one launch: conv2 (3x3, stride 2, slim conv2d_same) + conv3 + sub-sampled
+    identity shortcut, writing the raw trunk and/or the next unit's preact == the hmmr_conv_gemm launches."""
+    from human_dynamics_amd.engine import bottleneck_tail_single, conv_gemm
+    rng = np.random.default_rng(31)
+    n, h, w = shape
+    cm, depth = chans
+    h1 = np.maximum(rng.normal(size=(n, h, w, cm)), 0).astype(np.float32)
+    w2 = (rng.normal(size=(3, 3, cm, cm)) / (3 * cm ** 0.5)).astype(np.float32)
+    bn2 = (rng.uniform(0.5, 1.5, cm).astype(np.float32), rng.normal(size=cm).astype(np.float32) * 0.2)
+    w3 = (rng.normal(size=(1, 1, cm, depth)) / 8).astype(np.float32)
+    b3 = rng.normal(size=depth).astype(np.float32)
+    res = rng.normal(size=(n, h, w, depth)).astype(np.float32)
+    pre = (rng.uniform(0.5, 1.5, depth).astype(np.float32), rng.normal(size=depth).astype(np.float32))
+    bf = L.HMMR_BF16
+    h2, _ = conv_gemm(h1, w2, stride, 1, bn2[0], bn2[1], None, True, in_dtype=bf, out_dtype=bf, device=gpu_device)
+    trunk, preact = conv_gemm(h2, w3, 1, 0, None, b3, res, False, scale2=pre[0], shift2=pre[1], in_dtype=bf, out_dtype=bf,
+                              device=gpu_device, res_stride=stride)
+    got_raw, got_pre = bottleneck_tail_single(h1, (w2, bn2[0], bn2[1]), stride, w3, b3, res, pre, device=gpu_device)
+    assert np.array_equal(got_raw, trunk)
+    assert np.array_equal(got_pre, preact)
+    only_pre = bottleneck_tail_single(h1, (w2, bn2[0], bn2[1]), stride, w3, b3, res, pre, want_raw=False, device=gpu_device)
+    assert only_pre[0] is None and np.array_equal(only_pre[1], preact)

@@ -131,7 +131,7 @@ def test_packer_marks_the_fused_launches(weights):
     shortcut + conv1 as one column-split GEMM; fp32 keeps every layer separate except the column split."""
     from human_dynamics_amd import packing
     rw = packing.pack_resnet(weights, _lib.HMMR_BF16, packing.DeviceStore("cpu"))
-    assert [rw.unit[i].fuse_tail for i in range(16)] == [3, 2, 0, 2, 2, 2, 0] + [0] * 9
+    assert [rw.unit[i].fuse_tail for i in range(16)] == [3, 2, 4, 2, 2, 2, 4] + [0] * 9
     assert [i for i in range(16) if rw.unit[i].sc_c1.w] == [7, 13]
     assert [i for i in range(16) if not rw.unit[i].fuse_preact] == [0, 3, 7, 13]      # the blocks' first units
     rw32 = packing.pack_resnet(weights, _lib.HMMR_F32, packing.DeviceStore("cpu"))
