@@ -30,7 +30,17 @@
 // its own vmcnt waits and `__syncthreads()` stays a bare s_barrier; the shortcut chunk is requested
 // TWO chunks ahead (HBM latency), the weight chunks one ahead (L2).
 // LDS: H2 16 KB + W3 chunk 8 KB + W1' chunk 8 KB + 2 x 16 KB trunk tiles + 4 KB constants = 68 KB
-// -> two workgroups per CU.
+// -> two workgroups per CU (block 2: 64-pixel tiles, 72 KB).
+//
+// Optional phases, all selected at compile time and all bit-identical to the launches they replace:
+//   CONV2  the unit's 3x3 conv2 (stride 1 or 2, + BN + ReLU) runs first, over h1, as 9 x c_mid/64 K steps
+//          through two LDS stages in the region the tail uses afterwards: h2 never exists in HBM;
+//   SC     (block1/unit_1, 64-channel input) the conv shortcut is computed per chunk from the unit's input
+//          tile instead of being loaded: the shortcut tensor is neither written nor read;
+//   !PH2   no next conv1 (a block's stride-2 last unit): the chunks are streamed out raw and/or
+//          pre-activated and the launch ends.
+// So a whole bottleneck unit of blocks 1-2 is one launch:
+//   [conv shortcut] + conv2 + conv3 + add + [next preact + next conv1].
 #include "common.h"
 #include "hmmr_hip.h"
 
