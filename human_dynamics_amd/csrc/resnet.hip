@@ -23,7 +23,8 @@
 
 // csrc/stem.hip
 int hmmr_stem_fused(const float* images, int n_real, int n, const void* wts, const float* bias,
-                    const float* pscale, const float* pshift, void* out, int dtype, hipStream_t s);
+                    const float* pscale, const float* pshift, void* out, int dtype, hipStream_t s,
+                    const void* w1, const float* s1, const float* b1, void* out_h1);
 
 static constexpr int IMG = 224, PADH = 230, PADW = 232;
 
@@ -188,9 +189,16 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
     // ~1 % slower than the three-kernel route, which therefore stays the fp32 default.
     static const int stem_env = [] { const char* e = getenv("HMMR_STEM"); return !e ? 0 : (e[0] == 'u' ? 1 : 2); }();
     const bool unfused = stem_env == 1 || (stem_env == 0 && w->dtype == HMMR_F32);
+    bool stem_c1 = false;
     if (!unfused) {
-        if (hmmr_stem_fused(images, n_real, n, w->stem.w, w->stem.shift, w->unit[0].pre_scale,
-                            w->unit[0].pre_shift, P[0], w->dtype, s)) return -2;
+        // bf16: block1/unit_1's conv1 is computed on each pooled tile inside the same launch (-> T1)
+        static const bool stem_c1_env = [] { const char* e = getenv("HMMR_STEM_C1"); return !e || e[0] != '0'; }();
+        const hmmr_resnet_unit_t& U0 = w->unit[0];
+        stem_c1 = stem_c1_env && w->dtype == HMMR_BF16 && !U0.sc_c1.w && U0.c_in == 64 && U0.base == 64 &&
+                  U0.conv1.scale && U0.conv1.shift;
+        if (hmmr_stem_fused(images, n_real, n, w->stem.w, w->stem.shift, U0.pre_scale, U0.pre_shift, P[0], w->dtype, s,
+                            stem_c1 ? U0.conv1.w : nullptr, U0.conv1.scale, U0.conv1.shift, stem_c1 ? T1 : nullptr))
+            return -2;
         if (prof_mark(pf)) return -2;
         if (prof_mark(pf)) return -2;     // (keeps the profile slot numbering of the 3-kernel route)
         if (prof_mark(pf)) return -2;
@@ -227,7 +235,7 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
     // neutral; the packer enables it everywhere.
     int H = 56, cur = 0, pcur = 0;
     bool have_raw = false;            // X[cur] holds the raw input of the unit
-    bool h1_ready = false;            // T1 already holds this unit's conv1 output (previous unit's fused tail)
+    bool h1_ready = stem_c1;          // T1 already holds this unit's conv1 output (previous unit's fused tail / the stem)
     for (int u = 0; u < HMMR_RESNET_UNITS; ++u) {
         const hmmr_resnet_unit_t& U = w->unit[u];
         const int Ho = H / U.stride;

@@ -64,7 +64,9 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const float* __restrict
                                                          const float* __restrict__ bias,
                                                          const float* __restrict__ pscale,
                                                          const float* __restrict__ pshift, T* __restrict__ out,
-                                                         int n_real) {
+                                                         int n_real, const T* __restrict__ w1,
+                                                         const float* __restrict__ s1, const float* __restrict__ b1,
+                                                         T* __restrict__ out_h1) {
     typedef StemLds<T> LD;
     typedef typename StemFrag<T>::type frag_t;
     constexpr int CPT = (int)sizeof(T);           // 32-byte MFMA chunks per tap: 2 (bf16) / 4 (fp32)
@@ -194,25 +196,71 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const float* __restrict
 #pragma unroll
         for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j] * sc[j] + sh[j], 0.f);
         store8(out + (((long long)n * POOL + PT * ty + py) * POOL + PT * tx + px) * CO + v8 * 8, m);
+        if constexpr (sizeof(T) == 2) {
+            // block1/unit_1's conv1 follows in this launch: keep the tile as its operand image ([64 pixels][64 ch],
+            // 128-B rows, 16-B slots XOR-swizzled like gemm_conv.hip) in the patch region, which is free by now
+            if (out_h1) store8((T*)(s_patch + pp * 128 + ((v8 ^ ((pp >> 1) & 7)) << 4)), m);
+        }
+    }
+    if constexpr (sizeof(T) == 2) {
+        if (!out_h1) return;
+        // ---- 5. conv1 of block1/unit_1 (1x1, 64 -> 64, BN + ReLU) on the tile just written: D[channel][pixel]
+        // = W1 (A operand, fragments straight from L2: 8 KB, shared by every workgroup) x tile (B operand from LDS);
+        // four 32x32 blocks, one per wave; same K order and epilogue arithmetic as the hmmr_conv_gemm launch
+        __syncthreads();                              // tile complete; every read of s_c is done
+        const int lr = lane & 31, lh = lane >> 5, fsw = (lr >> 1) & 7;
+        const int wn = wave >> 1, wm = wave & 1;
+        f32x16 acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            const bf16x8 a = *(const bf16x8*)(w1 + (long long)(wn * 32 + lr) * 64 + kc * 16 + lh * 8);
+            const bf16x8 b = *(const bf16x8*)(s_patch + (wm * 32 + lr) * 128 + (((2 * kc + lh) ^ fsw) << 4));
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc1, 0, 0, 0);
+        }
+        char* s_o = smem + LD::PATCH;                 // output tile [64 pixels][64 ch] in the (dead) conv staging region
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int cl = wn * 32 + 8 * g + 4 * lh;
+            const f32x4 s4 = *(const f32x4*)(s1 + cl), b4 = *(const f32x4*)(b1 + cl);
+            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+            bf16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (bf16_t)fmaxf(fmaf(acc1[4 * g + j], s4[j], b4[j]), 0.f);
+            *(bf16x4*)(s_o + (wm * 32 + lr) * 128 + (((cl >> 3) ^ fsw) << 4) + 8 * lh) = o;
+        }
+        __syncthreads();
+        for (int it = tid; it < PT * PT * (CO / 8); it += 256) {
+            const int ps = it & 7, pp = it >> 3, ls = ps ^ ((pp >> 1) & 7);
+            const int py = pp / PT, px = pp - py * PT;
+            *(u32x4*)(out_h1 + (((long long)n * POOL + PT * ty + py) * POOL + PT * tx + px) * CO + ls * 8) =
+                *(const u32x4*)(s_o + pp * 128 + ps * 16);
+        }
     }
 }
 }  // namespace
 
 // images [n_real,224,224,3] fp32 (+ n - n_real implicit zero images) -> out [n,56,56,64] (dtype)
+// w1 / s1 / b1 / out_h1 (bf16 only, may be NULL): block1/unit_1's conv1 [64][64] + folded BN, computed on the
+// pooled tile in the same launch -> out_h1 [n,56,56,64]
 int hmmr_stem_fused(const float* images, int n_real, int n, const void* wts, const float* bias,
-                    const float* pscale, const float* pshift, void* out, int dtype, hipStream_t s) {
+                    const float* pscale, const float* pshift, void* out, int dtype, hipStream_t s,
+                    const void* w1, const float* s1, const float* b1, void* out_h1) {
     if (dtype == HMMR_BF16) {
         auto kern = stem_fused_kernel<bf16_t>;
         static bool set16 = false;
         if (!set16) { HMMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, StemLds<bf16_t>::TOTAL)); set16 = true; }
         hipLaunchKernelGGL(kern, dim3((POOL / PT) * (POOL / PT), n), dim3(256), StemLds<bf16_t>::TOTAL, s, images,
-                           (const bf16_t*)wts, bias, pscale, pshift, (bf16_t*)out, n_real);
+                           (const bf16_t*)wts, bias, pscale, pshift, (bf16_t*)out, n_real, (const bf16_t*)w1, s1, b1,
+                           (bf16_t*)out_h1);
     } else {
         auto kern = stem_fused_kernel<float>;
         static bool set32 = false;
         if (!set32) { HMMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, StemLds<float>::TOTAL)); set32 = true; }
         hipLaunchKernelGGL(kern, dim3((POOL / PT) * (POOL / PT), n), dim3(256), StemLds<float>::TOTAL, s, images,
-                           (const float*)wts, bias, pscale, pshift, (float*)out, n_real);
+                           (const float*)wts, bias, pscale, pshift, (float*)out, n_real, (const float*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
     }
     HMMR_CHECK_HIP(hipGetLastError());
     return 0;

@@ -1,4 +1,6 @@
 """GPU parity of the whole path behind the reference's Tester surface."""
+import os
+
 import numpy as np
 import pytest
 
@@ -300,3 +302,24 @@ def test_resnet_shortcut_and_conv1_as_one_gemm(dt, weights, gpu_device, monkeypa
     dflt = HmmrEngine(weights, None, dtype=dt, device=gpu_device)
     assert [bool(dflt.rw.unit[i].sc_c1.w) for i in (0, 3, 7, 13)] == [False, False, True, True]
     assert torch.equal(dflt.resnet(x, n_zero=1), ref)
+
+
+def test_stem_with_first_conv1_inside(weights, gpu_device):
+    """The fused stem also computes block1/unit_1's conv1 on every pooled tile: same features, bit for bit.
+    (HMMR_STEM_C1 is read once per process by the library, so the comparison runs in two subprocesses.)"""
+    import subprocess
+    import sys
+    code = (
+        "import sys, hashlib, torch; sys.path.insert(0, '.');"
+        "from human_dynamics_amd import assets; from human_dynamics_amd.engine import HmmrEngine;"
+        "e = HmmrEngine(assets.make_synthetic_weights(0), None, dtype='bf16', device='%s');"
+        "x = torch.from_numpy(assets.make_synthetic_frames(5, seed=33)).to('%s');"
+        "print('HASH', hashlib.sha1(e.resnet(x, n_zero=1).cpu().numpy().tobytes()).hexdigest())" % (gpu_device, gpu_device))
+    out = {}
+    for v in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HMMR_STEM_C1=v), capture_output=True, text=True,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        lines = [l for l in r.stdout.splitlines() if l.startswith("HASH")]
+        assert lines, r.stderr[-500:]
+        out[v] = lines[-1]
+    assert out["0"] == out["1"]
