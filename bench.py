@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=256, help="output frames per GPU per step")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "bf16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive leg (used for PMC passes)")
     ap.add_argument("--serial-gather", action="store_true",
@@ -226,7 +226,7 @@ def main():
         flops_per_launch = RESNET_FLOPS_PER_FRAME * n_enc / n_conv
         avg_launch_s = conv_ms * 1e-3 / n_conv
         achieved = flops_per_launch / avg_launch_s
-        peak = PEAK_BF16 if args.dtype == "bf16" else PEAK_F32
+        peak = {"bf16": PEAK_BF16, "bf16x3": PEAK_BF16 / 3, "f32": PEAK_F32}[args.dtype]
         # HBM traffic per launch comes from separate rocprofv3 --pmc passes of this same command
         # (FETCH_SIZE x2, WRITE_SIZE x1, KiB; tools/pmc_summary.py) committed under profiles/
         traffic, traffic_src, mfma_util = None, None, None

@@ -13,7 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # HMMR_LIB_PATH lets a development run A/B two builds of the library; the default is the in-tree build
 LIB_PATH = os.environ.get("HMMR_LIB_PATH") or os.path.join(HERE, "libhmmr_hip.so")
 
-HMMR_F32, HMMR_BF16 = 0, 1
+HMMR_F32, HMMR_BF16, HMMR_BF16X3 = 0, 1, 2
+ABI_VERSION = 7
 RESNET_UNITS = 16
 RESNET_PROF_SLOTS = 64
 MAX_TEMPORAL_BLOCKS = 8
@@ -53,6 +54,11 @@ class TailDesc(C.Structure):
         ("xp", _vp), ("wsc", _vp), ("shift_sc", _fp),
         ("conv2_stride", C.c_int), ("out_pre", _vp),
     ]
+
+
+class Debug(C.Structure):
+    """hmmr_debug_t: development switches, all zero = product defaults."""
+    _fields_ = [("stem_route", C.c_int), ("stem_no_conv1", C.c_int), ("reserved", C.c_int * 6)]
 
 
 class Layer(C.Structure):
@@ -103,6 +109,8 @@ class SmplConsts(C.Structure):
 SIGNATURES = {
     "hmmr_abi_version": (C.c_int, []),
     "hmmr_last_error": (C.c_char_p, []),
+    "hmmr_set_debug": (None, [C.POINTER(Debug)]),
+    "hmmr_get_debug": (None, [C.POINTER(Debug)]),
     "hmmr_conv_gemm": (C.c_int, [C.POINTER(ConvDesc), _vp]),
     "hmmr_conv_splitk_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "hmmr_resnet50_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
@@ -155,7 +163,7 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError if the .so does not export it
         fn.restype, fn.argtypes = res, args
-    if lib.hmmr_abi_version() != 6:
+    if lib.hmmr_abi_version() != ABI_VERSION:
         raise HmmrError("libhmmr_hip.so ABI version mismatch")
     _lib = lib
     return lib

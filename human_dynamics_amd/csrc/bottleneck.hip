@@ -419,10 +419,10 @@ int launch_tail(const TailArgs& a, hipStream_t stream) {
     typedef TailCfg<BM, CM, NCH, N2, SC> Cfg;
     static_assert(!CONV2 || 2 * (BM * 128 + CM * 128) <= Cfg::OFF_C, "conv2 stages must fit below the constants");
     auto kern = bottleneck_tail_kernel<BM, CM, NCH, N2, CONV2, SC, PH2>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce once;              // per kernel instantiation, per device
+    if (const unsigned long long bit = once.due()) {
         HMMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS));
-        attr_set = true;
+        once.mark(bit);
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)((a.M + BM - 1) / BM)), dim3(NT), Cfg::LDS, stream, a);
     HMMR_CHECK_HIP(hipGetLastError());

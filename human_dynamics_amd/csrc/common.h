@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -33,6 +35,24 @@ void hmmr_set_error(const char* fmt, ...);
         }                                                                            \
     } while (0)
 
+// Development switches (include/hmmr_hip.h: hmmr_debug_t), owned by api.cpp
+struct hmmr_debug_s;
+const struct hmmr_debug_s* hmmr_debug_state();
+
+// "has this (kernel, device) pair had its one-time hipFuncSetAttribute?"  One bit per device; a redundant call
+// from a racing thread is harmless, so relaxed atomics are enough.
+struct DeviceOnce {
+    std::atomic<unsigned long long> done{0ull};
+    // returns the bit to publish with mark() when the one-time work is still due on the current device, else 0
+    unsigned long long due() const {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        const unsigned long long bit = 1ull << (dev & 63);
+        return (done.load(std::memory_order_relaxed) & bit) ? 0ull : bit;
+    }
+    void mark(unsigned long long bit) { done.fetch_or(bit, std::memory_order_relaxed); }
+};
+
 // XCD-aware, bijective remap of a 1-D block id: the hardware dispatches block
 // b to XCD b % 8; give each XCD a contiguous range of logical ids so tiles
 // that share an operand panel hit the same private L2 (speed only).
@@ -55,6 +75,27 @@ template <> struct elem_traits<bf16_t> {
     __device__ static __forceinline__ bf16_t from_f32(float v) { return (bf16_t)v; }
 };
 
+// HMMR_BF16X3 storage ("split" tensors): every group of 8 consecutive channels is 32 bytes,
+// [hi0..hi7][lo0..lo7] with hi = bf16(x), lo = bf16(x - hi): x ~ hi + lo carries 16 mantissa bits
+// (relative error <= 2^-17).  The element is 4 bytes wide for all address arithmetic (offsets are
+// multiples of 8 elements); a 16-byte slot holds the hi OR the lo half of one group.  The GEMM
+// kernels multiply two split operands with three bf16 MFMAs (hi*hi + hi*lo + lo*hi, fp32
+// accumulate): ~16-bit operands at a third of the bf16 MFMA rate, 5x the fp32-MFMA rate.
+struct bsplit_t { unsigned int raw; };
+static_assert(sizeof(bsplit_t) == 4, "bsplit_t is addressed as a 4-byte element");
+template <> struct elem_traits<bsplit_t> {
+    static constexpr int EPS = 4;      // "elements" of address arithmetic per 16-byte slot
+};
+
+// the value an output element has after being stored in type T and read back
+template <typename T> __device__ __forceinline__ float stored_value(float v);
+template <> __device__ __forceinline__ float stored_value<float>(float v) { return v; }
+template <> __device__ __forceinline__ float stored_value<bf16_t>(float v) { return (float)(bf16_t)v; }
+template <> __device__ __forceinline__ float stored_value<bsplit_t>(float v) {
+    const float hi = (float)(bf16_t)v;
+    return hi + (float)(bf16_t)(v - hi);
+}
+
 // 8 consecutive elements <-> 8 floats
 __device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
     const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
@@ -65,6 +106,11 @@ __device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
     const bf16x8 a = *(const bf16x8*)p;
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+}
+__device__ __forceinline__ void load8(const bsplit_t* p, float (&v)[8]) {      // p: start of an 8-channel group
+    const bf16x8 hi = *(const bf16x8*)p, lo = *((const bf16x8*)p + 1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)hi[i] + (float)lo[i];
 }
 __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
     f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
@@ -78,6 +124,17 @@ __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
     *(bf16x8*)p = a;
 }
 
+__device__ __forceinline__ void store8(bsplit_t* p, const float (&v)[8]) {
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        hi[i] = (bf16_t)v[i];
+        lo[i] = (bf16_t)(v[i] - (float)hi[i]);
+    }
+    *(bf16x8*)p = hi;
+    *((bf16x8*)p + 1) = lo;
+}
+
 // 8 consecutive elements held as raw 16-byte pieces -> 8 floats
 template <typename T> __device__ __forceinline__ void unpack8(const u32x4 (&r)[(int)(8 * sizeof(T) / 16)], float (&v)[8]);
 template <> __device__ __forceinline__ void unpack8<float>(const u32x4 (&r)[2], float (&v)[8]) {
@@ -89,5 +146,12 @@ template <> __device__ __forceinline__ void unpack8<bf16_t>(const u32x4 (&r)[1],
     for (int i = 0; i < 4; ++i) {
         v[2 * i] = __uint_as_float(r[0][i] << 16);            // bf16 -> f32 is a 16-bit shift
         v[2 * i + 1] = __uint_as_float(r[0][i] & 0xffff0000u);
+    }
+}
+template <> __device__ __forceinline__ void unpack8<bsplit_t>(const u32x4 (&r)[2], float (&v)[8]) {   // r[0] = hi, r[1] = lo
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(r[0][i] << 16) + __uint_as_float(r[1][i] << 16);
+        v[2 * i + 1] = __uint_as_float(r[0][i] & 0xffff0000u) + __uint_as_float(r[1][i] & 0xffff0000u);
     }
 }

@@ -34,6 +34,7 @@
 //     range of tiles that share A rows.
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 #include "common.h"
 #include "hmmr_hip.h"
@@ -56,6 +57,8 @@ struct ConvArgs {
 template <typename TA> struct Frag;
 template <> struct Frag<float>  { typedef f32x4 type; };
 template <> struct Frag<bf16_t> { typedef bf16x8 type; };
+struct split_frag { bf16x8 hi, lo; };
+template <> struct Frag<bsplit_t> { typedef split_frag type; };
 
 __device__ __forceinline__ f32x16 mma(const f32x4& a, const f32x4& b, f32x16 c) {
 #pragma unroll
@@ -64,6 +67,37 @@ __device__ __forceinline__ f32x16 mma(const f32x4& a, const f32x4& b, f32x16 c) 
 }
 __device__ __forceinline__ f32x16 mma(const bf16x8& a, const bf16x8& b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// split operands: (ah + al)(bh + bl) ~ ah*bh + ah*bl + al*bh; every bf16 product is exact in fp32, the
+// dropped al*bl term is <= 2^-18 of |a*b|.  The two small terms go first.
+__device__ __forceinline__ f32x16 mma(const split_frag& a, const split_frag& b, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, c, 0, 0, 0);
+}
+// fragment of MFMA chunk c out of a 128-byte LDS row (fsw = the row's slot swizzle, lh = lane half).
+// bf16 / fp32: 4 chunks of two 16-byte slots (one per lane half).  split: 2 chunks of two 8-channel
+// groups (one per lane half), each group = a hi slot followed by a lo slot.
+template <typename TA> struct FragIO {
+    static constexpr int CHUNKS = 4;
+    __device__ static __forceinline__ typename Frag<TA>::type read(const char* row, int c, int lh, int fsw) {
+        return *(const typename Frag<TA>::type*)(row + (((2 * c + lh) ^ fsw) << 4));
+    }
+};
+template <> struct FragIO<bsplit_t> {
+    static constexpr int CHUNKS = 2;
+    __device__ static __forceinline__ split_frag read(const char* row, int c, int lh, int fsw) {
+        const int g = 2 * (2 * c + lh);
+        split_frag f;
+        f.hi = *(const bf16x8*)(row + ((g ^ fsw) << 4));
+        f.lo = *(const bf16x8*)(row + (((g + 1) ^ fsw) << 4));
+        return f;
+    }
+};
+// ragged tail of an output row (cout % 8 != 0): element-wise stores; split rows are whole groups (host-checked)
+template <typename TO> __device__ __forceinline__ void store_tail(TO* p, const float (&v)[8], int cnt) {
+    if constexpr (!std::is_same<TO, bsplit_t>::value)
+        for (int j = 0; j < cnt; ++j) p[j] = elem_traits<TO>::from_f32(v[j]);
 }
 
 // 64 zero bytes in HBM: out-of-bounds gather slots of the LDS-DMA path read from here
@@ -281,23 +315,37 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 1) void conv
     // one K step of MFMAs out of LDS stage `sbuf`; fragments of 32-B chunk c+1 are fetched before
     // the MFMAs of chunk c issue
     auto compute_stage = [&](const char* sbuf) {
-        frag_t fa[2][FM], fb[2][FN];
+        constexpr int NCHK = FragIO<TA>::CHUNKS;
+        // split fragments are twice as wide: 8-wave 128x128 tiles keep ONE fragment set (the 128-VGPR budget of
+        // two workgroups per CU has no room for a second one next to the prefetched residual)
+        constexpr bool DBUF = !(std::is_same<TA, bsplit_t>::value && WGM * WGN == 8 && FM * FN >= 2);
+        frag_t fa[DBUF ? 2 : 1][FM], fb[DBUF ? 2 : 1][FN];
         auto read_frags = [&](int c, int slot_) {
-            const int so = (((2 * c + lh) ^ fsw) << 4);
 #pragma unroll
-            for (int i = 0; i < FM; ++i) fa[slot_][i] = *(const frag_t*)(sbuf + a_row_off + i * 32 * 128 + so);
+            for (int i = 0; i < FM; ++i) fa[slot_][i] = FragIO<TA>::read(sbuf + a_row_off + i * 32 * 128, c, lh, fsw);
 #pragma unroll
-            for (int j = 0; j < FN; ++j) fb[slot_][j] = *(const frag_t*)(sbuf + b_row_off + j * 32 * 128 + so);
+            for (int j = 0; j < FN; ++j) fb[slot_][j] = FragIO<TA>::read(sbuf + b_row_off + j * 32 * 128, c, lh, fsw);
         };
-        read_frags(0, 0);
+        if constexpr (DBUF) {
+            read_frags(0, 0);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (c + 1 < 4) read_frags(c + 1, (c + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of this chunk's MFMAs
+            for (int c = 0; c < NCHK; ++c) {
+                if (c + 1 < NCHK) read_frags(c + 1, (c + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of this chunk's MFMAs
 #pragma unroll
-            for (int i = 0; i < FM; ++i)
+                for (int i = 0; i < FM; ++i)
 #pragma unroll
-                for (int j = 0; j < FN; ++j) acc[i][j] = mma(fa[c & 1][i], fb[c & 1][j], acc[i][j]);
+                    for (int j = 0; j < FN; ++j) acc[i][j] = mma(fa[c & 1][i], fb[c & 1][j], acc[i][j]);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < NCHK; ++c) {
+                read_frags(c, 0);
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) acc[i][j] = mma(fa[0][i], fb[0][j], acc[i][j]);
+            }
         }
     };
     // split-K: slice blockIdx.y owns K steps [kt0, kt1) and writes a raw fp32 partial plane
@@ -383,24 +431,24 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 1) void conv
         if (second) {
             TO* ob = (TO*)a.out_b + (long long)m * a.ldo_b + (n - a.n_split);
             if (full) store8(ob, v);
-            else for (int j = 0; j < 8 && n + j < a.cout; ++j) ob[j] = elem_traits<TO>::from_f32(v[j]);
+            else store_tail(ob, v, a.cout - n);
             continue;
         }
         const long long oo = (long long)m * a.ldo + n;
         if (out) {
             if (full) store8(out + oo, v);
-            else for (int j = 0; j < 8 && n + j < a.cout; ++j) out[oo + j] = elem_traits<TO>::from_f32(v[j]);
+            else store_tail(out + oo, v, a.cout - n);
         }
         if (out2) {
             float s2[8], b2[8], u[8];
             load8(a.scale2 + n, s2); load8(a.shift2 + n, b2);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {       // the preact of the STORED value: = the consumer-side preact_slot, bit for bit
-                const float vr = elem_traits<TO>::to_f32(elem_traits<TO>::from_f32(v[j]));
+                const float vr = stored_value<TO>(v[j]);
                 u[j] = fmaxf(fmaf(vr, s2[j], b2[j]), 0.f);
             }
             if (full) store8(out2 + oo, u);
-            else for (int j = 0; j < 8 && n + j < a.cout; ++j) out2[oo + j] = elem_traits<TO>::from_f32(u[j]);
+            else store_tail(out2 + oo, u, a.cout - n);
         }
     }
 }
@@ -417,10 +465,10 @@ static int launch_cfg(const ConvArgs& base, int slices, hipStream_t stream) {
     constexpr int kloop = NSTAGE * (BM + BN) * 128, epi = BM * BN * 4;
     constexpr int lds = kloop > epi ? kloop : epi;
     auto kern = conv_gemm_kernel<TA, TO, BM, BN, WGM, WGN, PRO, UTAP, NSTAGE>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce once;              // per kernel instantiation, per device
+    if (const unsigned long long bit = once.due()) {
         HMMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
+        once.mark(bit);
     }
     constexpr int BKE_ = 8 * elem_traits<TA>::EPS;
     const int nk = a.K / BKE_;
@@ -457,7 +505,12 @@ static int launch_typed(const ConvArgs& a, int tile, int slices, hipStream_t str
     const bool utap = ((size_t)1 << a.cin_log2) * sizeof(TA) >= 128;
     if (a.pro_scale) {
         if (!utap) { hmmr_set_error("hmmr_conv_gemm: fused pre-activation needs cin*sizeof >= 128"); return -1; }
-        return launch_tiled<TA, TO, true, true>(a, tile, slices, stream);
+        if constexpr (std::is_same<TA, bsplit_t>::value) {
+            hmmr_set_error("hmmr_conv_gemm: the fused pre-activation is not available for split (bf16x3) operands");
+            return -1;
+        } else {
+            return launch_tiled<TA, TO, true, true>(a, tile, slices, stream);
+        }
     }
     return utap ? launch_tiled<TA, TO, false, true>(a, tile, slices, stream)
                 : launch_tiled<TA, TO, false, false>(a, tile, slices, stream);
@@ -518,18 +571,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a, co
     const long long oo = (long long)m * a.ldo + n;
     if (out) {
         if (full) store8(out + oo, v);
-        else for (int j = 0; j < 8 && n + j < a.cout; ++j) out[oo + j] = elem_traits<TO>::from_f32(v[j]);
+        else store_tail(out + oo, v, a.cout - n);
     }
     if (out2) {
         float s2[8], b2[8], u[8];
         load8(a.scale2 + n, s2); load8(a.shift2 + n, b2);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float vr = elem_traits<TO>::to_f32(elem_traits<TO>::from_f32(v[j]));
+            const float vr = stored_value<TO>(v[j]);
             u[j] = fmaxf(fmaf(vr, s2[j], b2[j]), 0.f);
         }
         if (full) store8(out2 + oo, u);
-        else for (int j = 0; j < 8 && n + j < a.cout; ++j) out2[oo + j] = elem_traits<TO>::from_f32(u[j]);
+        else store_tail(out2 + oo, u, a.cout - n);
     }
 }
 
@@ -547,12 +600,16 @@ static int ilog2_exact(int v) {
 extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
     HMMR_REQUIRE(d && d->in && d->w && (d->out || d->out2), "hmmr_conv_gemm: null operand");
     const int esz = d->in_dtype == HMMR_BF16 ? 2 : 4;
-    const int eps = 16 / esz;
+    // alignment unit of the gather in elements: one 16-byte slot, or one 32-byte hi/lo group of a split tensor
+    const int eps = d->in_dtype == HMMR_BF16X3 ? 8 : 16 / esz;
     const int cl2 = ilog2_exact(d->cin);
     HMMR_REQUIRE(cl2 >= 0 && d->cin % eps == 0, "hmmr_conv_gemm: cin=%d must be a power of two >= %d", d->cin, eps);
     const int K = d->kh * d->kw * d->cin;
     HMMR_REQUIRE(d->kh * d->kw <= 32, "hmmr_conv_gemm: at most 32 filter taps");
-    HMMR_REQUIRE(K % (8 * eps) == 0, "hmmr_conv_gemm: K=%d must be a multiple of %d", K, 8 * eps);
+    const int bke = 128 / esz;             // elements per 128-byte K step
+    HMMR_REQUIRE(K % bke == 0, "hmmr_conv_gemm: K=%d must be a multiple of %d", K, bke);
+    HMMR_REQUIRE(d->out_dtype != HMMR_BF16X3 || d->cout % 8 == 0,
+                 "hmmr_conv_gemm: a split (bf16x3) output needs cout %% 8 == 0 (rows are whole hi/lo groups)");
     HMMR_REQUIRE(d->ldo % 8 == 0, "hmmr_conv_gemm: ldo=%d must be a multiple of 8", d->ldo);
     // every gathered 16-byte slot must stay aligned: ix = ox*sx + kx - px
     const bool px_ok = d->in_px_stride % eps == 0 ||
@@ -586,10 +643,10 @@ extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
     a.kt_per_slice = 0; a.out_slice_stride = 0;
     if (a.M <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    const bool in16 = d->in_dtype == HMMR_BF16, in32 = d->in_dtype == HMMR_F32;
-    const bool out16 = d->out_dtype == HMMR_BF16, out32 = d->out_dtype == HMMR_F32;
-    HMMR_REQUIRE((in16 || in32) && (out16 || out32), "hmmr_conv_gemm: unsupported dtypes %d -> %d", d->in_dtype, d->out_dtype);
-    const int nk = K / (8 * eps);
+    const bool in16 = d->in_dtype == HMMR_BF16, in32 = d->in_dtype == HMMR_F32, inx3 = d->in_dtype == HMMR_BF16X3;
+    const bool out16 = d->out_dtype == HMMR_BF16, out32 = d->out_dtype == HMMR_F32, outx3 = d->out_dtype == HMMR_BF16X3;
+    HMMR_REQUIRE((in16 || in32 || inx3) && (out16 || out32 || outx3), "hmmr_conv_gemm: unsupported dtypes %d -> %d", d->in_dtype, d->out_dtype);
+    const int nk = K / bke;
     int slices = d->split_k > 1 ? d->split_k : 1;
     if (slices > nk) slices = nk;
     slices = (nk + ((nk + slices - 1) / slices) - 1) / ((nk + slices - 1) / slices);   // no empty slice
@@ -603,11 +660,14 @@ extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
         p.scale = p.shift = nullptr; p.res = nullptr; p.out2 = nullptr; p.scale2 = p.shift2 = nullptr;
         // (a fused pre-activation, if any, stays: it acts on the A operand)
         p.relu = 0; p.out = d->ws; p.ldo = ldw; p.out_slice_stride = plane;
-        const int rc = in16 ? launch_typed<bf16_t, float>(p, d->tile, slices, s) : launch_typed<float, float>(p, d->tile, slices, s);
+        const int rc = in16 ? launch_typed<bf16_t, float>(p, d->tile, slices, s)
+                     : inx3 ? launch_typed<bsplit_t, float>(p, d->tile, slices, s)
+                            : launch_typed<float, float>(p, d->tile, slices, s);
         if (rc) return rc;
         const long long nvec = (long long)a.M * ((a.cout + 7) / 8);
         const unsigned grid = (unsigned)((nvec + 255) / 256);
         if (out16) hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, a, (const float*)d->ws, slices, ldw, plane);
+        else if (outx3) hipLaunchKernelGGL(splitk_reduce_kernel<bsplit_t>, dim3(grid), dim3(256), 0, s, a, (const float*)d->ws, slices, ldw, plane);
         else hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(grid), dim3(256), 0, s, a, (const float*)d->ws, slices, ldw, plane);
         HMMR_CHECK_HIP(hipGetLastError());
         return 0;
@@ -616,6 +676,9 @@ extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
     if (in16 && out32) return launch_typed<bf16_t, float>(a, d->tile, 1, s);
     if (in32 && out32) return launch_typed<float, float>(a, d->tile, 1, s);
     if (in32 && out16) return launch_typed<float, bf16_t>(a, d->tile, 1, s);
+    if (inx3 && outx3) return launch_typed<bsplit_t, bsplit_t>(a, d->tile, 1, s);
+    if (inx3 && out32) return launch_typed<bsplit_t, float>(a, d->tile, 1, s);
+    if (in32 && outx3) return launch_typed<float, bsplit_t>(a, d->tile, 1, s);
     hmmr_set_error("hmmr_conv_gemm: unsupported dtypes %d -> %d", d->in_dtype, d->out_dtype);
     return -1;
 }

@@ -99,10 +99,14 @@ extern "C" int hmmr_ief_fwd(const hmmr_ief_weights_t* w, const float* strips, in
     const IefBufs L = ief_layout(m, w->dtype);
     char* base = (char*)ws;
     const void* xin = strips;
-    if (w->dtype == HMMR_BF16) {
+    if (w->dtype != HMMR_F32) {
         const long long n8 = (long long)m * 2048 / 8;
-        hipLaunchKernelGGL(cast_rows_kernel<bf16_t>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, strips,
-                           (bf16_t*)(base + L.xin), n8);
+        if (w->dtype == HMMR_BF16)
+            hipLaunchKernelGGL(cast_rows_kernel<bf16_t>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, strips,
+                               (bf16_t*)(base + L.xin), n8);
+        else
+            hipLaunchKernelGGL(cast_rows_kernel<bsplit_t>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, strips,
+                               (bsplit_t*)(base + L.xin), n8);
         HMMR_CHECK_HIP(hipGetLastError());
         xin = base + L.xin;
     }

@@ -18,6 +18,8 @@
 // (scale = gamma*rsqrt(var+1e-5), shift = beta - mean*scale).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "hmmr_hip.h"
 
@@ -27,6 +29,33 @@ int hmmr_stem_fused(const float* images, int n_real, int n, const void* wts, con
                     const void* w1, const float* s1, const float* b1, void* out_h1);
 
 static constexpr int IMG = 224, PADH = 230, PADW = 232;
+
+// split (bf16x3) image: one 8-"channel" group = two RGBX pixels; PADW is even, so a pair never straddles a row
+__global__ void stem_repack_split_kernel(const float* __restrict__ img, bsplit_t* __restrict__ out, long long npairs,
+                                         long long n_real) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npairs;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int xp = (int)(i % (PADW / 2));
+        const long long t = i / (PADW / 2);
+        const int y = (int)(t % PADH);
+        const long long n = t / PADH;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        const int sy = y - 3;
+        if (n < n_real && (unsigned)sy < (unsigned)IMG) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int sx = 2 * xp + q - 3;
+                if ((unsigned)sx < (unsigned)IMG) {
+                    const float* p = img + ((n * IMG + sy) * IMG + sx) * 3;
+                    v[4 * q] = p[0]; v[4 * q + 1] = p[1]; v[4 * q + 2] = p[2];
+                }
+            }
+        }
+        store8(out + i * 8, v);
+    }
+}
 
 template <typename T>
 __global__ void stem_repack_kernel(const float* __restrict__ img, T* __restrict__ out, long long npix,
@@ -187,14 +216,14 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
     // (re-pack, implicit GEMM, pool) for A/B measurements.
     // In fp32-operand mode the fused kernel needs 104 KB of LDS (one workgroup per CU) and measures
     // ~1 % slower than the three-kernel route, which therefore stays the fp32 default.
-    static const int stem_env = [] { const char* e = getenv("HMMR_STEM"); return !e ? 0 : (e[0] == 'u' ? 1 : 2); }();
-    const bool unfused = stem_env == 1 || (stem_env == 0 && w->dtype == HMMR_F32);
+    const hmmr_debug_t* dbg = hmmr_debug_state();
+    HMMR_REQUIRE(!(dbg->stem_route == 2 && w->dtype == HMMR_BF16X3), "resnet: there is no fused stem kernel for bf16x3 tensors");
+    const bool unfused = dbg->stem_route == 1 || (dbg->stem_route == 0 && w->dtype != HMMR_BF16);
     bool stem_c1 = false;
     if (!unfused) {
         // bf16: block1/unit_1's conv1 is computed on each pooled tile inside the same launch (-> T1)
-        static const bool stem_c1_env = [] { const char* e = getenv("HMMR_STEM_C1"); return !e || e[0] != '0'; }();
         const hmmr_resnet_unit_t& U0 = w->unit[0];
-        stem_c1 = stem_c1_env && w->dtype == HMMR_BF16 && !U0.sc_c1.w && U0.c_in == 64 && U0.base == 64 &&
+        stem_c1 = !dbg->stem_no_conv1 && w->dtype == HMMR_BF16 && !U0.sc_c1.w && U0.c_in == 64 && U0.base == 64 &&
                   U0.conv1.scale && U0.conv1.shift;
         if (hmmr_stem_fused(images, n_real, n, w->stem.w, w->stem.shift, U0.pre_scale, U0.pre_shift, P[0], w->dtype, s,
                             stem_c1 ? U0.conv1.w : nullptr, U0.conv1.scale, U0.conv1.shift, stem_c1 ? T1 : nullptr))
@@ -205,7 +234,10 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
     } else {
         const long long npix = (long long)n * PADH * PADW;
         const int grid = (int)((npix + 255) / 256 < 8192 ? (npix + 255) / 256 : 8192);
-        hipLaunchKernelGGL(stem_repack_kernel<T>, dim3(grid), dim3(256), 0, s, images, xpad, npix, (long long)n_real);
+        if constexpr (std::is_same<T, bsplit_t>::value)
+            hipLaunchKernelGGL(stem_repack_split_kernel, dim3(grid), dim3(256), 0, s, images, xpad, npix / 2, (long long)n_real);
+        else
+            hipLaunchKernelGGL(stem_repack_kernel<T>, dim3(grid), dim3(256), 0, s, images, xpad, npix, (long long)n_real);
         HMMR_CHECK_HIP(hipGetLastError());
         if (prof_mark(pf)) return -2;
         hmmr_conv_desc_t d = {};
@@ -392,6 +424,7 @@ extern "C" int hmmr_resnet50_fwd(const hmmr_resnet_weights_t* w, const float* im
     HMMR_REQUIRE(w->unit[0].c_in == 64 && w->unit[15].depth == 2048, "hmmr_resnet50_fwd: bad unit table");
     if (w->dtype == HMMR_BF16) return resnet_fwd_t<bf16_t>(w, images, n, nt, phi, (char*)ws, (hipStream_t)stream, prof_ms);
     if (w->dtype == HMMR_F32) return resnet_fwd_t<float>(w, images, n, nt, phi, (char*)ws, (hipStream_t)stream, prof_ms);
+    if (w->dtype == HMMR_BF16X3) return resnet_fwd_t<bsplit_t>(w, images, n, nt, phi, (char*)ws, (hipStream_t)stream, prof_ms);
     hmmr_set_error("hmmr_resnet50_fwd: bad dtype %d", w->dtype);
     return -1;
 }

@@ -249,15 +249,21 @@ int hmmr_stem_fused(const float* images, int n_real, int n, const void* wts, con
                     const void* w1, const float* s1, const float* b1, void* out_h1) {
     if (dtype == HMMR_BF16) {
         auto kern = stem_fused_kernel<bf16_t>;
-        static bool set16 = false;
-        if (!set16) { HMMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, StemLds<bf16_t>::TOTAL)); set16 = true; }
+        static DeviceOnce once16;
+        if (const unsigned long long bit = once16.due()) {
+            HMMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, StemLds<bf16_t>::TOTAL));
+            once16.mark(bit);
+        }
         hipLaunchKernelGGL(kern, dim3((POOL / PT) * (POOL / PT), n), dim3(256), StemLds<bf16_t>::TOTAL, s, images,
                            (const bf16_t*)wts, bias, pscale, pshift, (bf16_t*)out, n_real, (const bf16_t*)w1, s1, b1,
                            (bf16_t*)out_h1);
     } else {
         auto kern = stem_fused_kernel<float>;
-        static bool set32 = false;
-        if (!set32) { HMMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, StemLds<float>::TOTAL)); set32 = true; }
+        static DeviceOnce once32;
+        if (const unsigned long long bit = once32.due()) {
+            HMMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, StemLds<float>::TOTAL));
+            once32.mark(bit);
+        }
         hipLaunchKernelGGL(kern, dim3((POOL / PT) * (POOL / PT), n), dim3(256), StemLds<float>::TOTAL, s, images,
                            (const float*)wts, bias, pscale, pshift, (float*)out, n_real, (const float*)nullptr,
                            (const float*)nullptr, (const float*)nullptr, (float*)nullptr);

@@ -48,19 +48,27 @@ __global__ __launch_bounds__(256) void groupnorm_relu_kernel(const float* __rest
     const float var = block_sum_256(q, red) / (float)cnt;
     const float rstd = rsqrtf(var + GN_EPS);
     TO* ob = out + (long long)b * t * c + g * cpg;
-    for (int i = threadIdx.x; i < cnt; i += 256) {
-        const int tt = i / cpg, j = i % cpg;
-        // x*gain + (beta - mean*gain) evaluated as (x - mean)*gain + beta: same value,
-        // without the cancellation of two large products when var -> 0
-        const float gain = rstd * gamma[g * cpg + j];
-        ob[tt * c + j] = elem_traits<TO>::from_f32(fmaxf((xb[tt * c + j] - mean) * gain + beta[g * cpg + j], 0.f));
+    const int v8 = cpg / 8;                // 8-channel vectors per row of the group (cpg % 8 == 0, host-checked)
+    for (int i = threadIdx.x; i < t * v8; i += 256) {
+        const int tt = i / v8, j = (i % v8) * 8;
+        float xv[8], gm[8], bt[8], o[8];
+        load8(xb + tt * c + j, xv); load8(gamma + g * cpg + j, gm); load8(beta + g * cpg + j, bt);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            // x*gain + (beta - mean*gain) evaluated as (x - mean)*gain + beta: same value,
+            // without the cancellation of two large products when var -> 0
+            const float gain = rstd * gm[e];
+            o[e] = fmaxf((xv[e] - mean) * gain + bt[e], 0.f);
+        }
+        store8(ob + tt * c + j, o);
     }
 }
 
 extern "C" int hmmr_groupnorm_relu(const float* x, const float* gamma, const float* beta, int b, int t,
                                    int c, int groups, void* out, int out_dtype, void* stream) {
     HMMR_REQUIRE(x && gamma && beta && out, "hmmr_groupnorm_relu: null argument");
-    HMMR_REQUIRE(b > 0 && t > 0 && groups > 0 && c % groups == 0, "hmmr_groupnorm_relu: bad shape");
+    HMMR_REQUIRE(b > 0 && t > 0 && groups > 0 && c % groups == 0 && (c / groups) % 8 == 0,
+                 "hmmr_groupnorm_relu: bad shape (channels per group must be a multiple of 8)");
     hipStream_t s = (hipStream_t)stream;
     if (out_dtype == HMMR_BF16)
         hipLaunchKernelGGL(groupnorm_relu_kernel<bf16_t>, dim3(b * groups), dim3(256), 0, s, x, gamma, beta,
@@ -68,6 +76,9 @@ extern "C" int hmmr_groupnorm_relu(const float* x, const float* gamma, const flo
     else if (out_dtype == HMMR_F32)
         hipLaunchKernelGGL(groupnorm_relu_kernel<float>, dim3(b * groups), dim3(256), 0, s, x, gamma, beta,
                            (float*)out, t, c, groups);
+    else if (out_dtype == HMMR_BF16X3)
+        hipLaunchKernelGGL(groupnorm_relu_kernel<bsplit_t>, dim3(b * groups), dim3(256), 0, s, x, gamma, beta,
+                           (bsplit_t*)out, t, c, groups);
     else { hmmr_set_error("hmmr_groupnorm_relu: bad dtype %d", out_dtype); return -1; }
     HMMR_CHECK_HIP(hipGetLastError());
     return 0;
@@ -155,9 +166,12 @@ extern "C" int hmmr_hallucinator_fwd(const hmmr_hallucinator_weights_t* w, const
     const size_t skb = hmmr_conv_splitk_workspace_bytes(m, C, TEMPORAL_SPLIT_K);
     hipStream_t s = (hipStream_t)stream;
     const void* xin = phi;
-    if (w->dtype == HMMR_BF16) {
+    if (w->dtype != HMMR_F32) {
         const long long n8 = (long long)m * C / 8;
-        hipLaunchKernelGGL(hal_cast_kernel<bf16_t>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, phi, (bf16_t*)x, n8);
+        if (w->dtype == HMMR_BF16)
+            hipLaunchKernelGGL(hal_cast_kernel<bf16_t>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, phi, (bf16_t*)x, n8);
+        else
+            hipLaunchKernelGGL(hal_cast_kernel<bsplit_t>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, phi, (bsplit_t*)x, n8);
         HMMR_CHECK_HIP(hipGetLastError());
         xin = x;
     }

@@ -8,13 +8,13 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from ..engine import HmmrEngine
+from ..engine import DEFAULT_DTYPE, HmmrEngine
 from ..evaluation.tester import load_weights
 
 
 class FeatureExtractor(object):
     def __init__(self, model_path, img_size=224, batch_size=64, sess=None, weights=None,
-                 dtype="bf16", device="cuda:0"):
+                 dtype=DEFAULT_DTYPE, device="cuda:0"):
         if img_size != 224:
             raise ValueError("the ResNet stage is built for 224x224 crops")
         self.model_path = model_path

@@ -15,7 +15,29 @@ from . import _lib as L
 from . import assets, packing
 
 DTYPES = {"f32": L.HMMR_F32, "fp32": L.HMMR_F32, "float32": L.HMMR_F32,
-          "bf16": L.HMMR_BF16, "bfloat16": L.HMMR_BF16}
+          "bf16": L.HMMR_BF16, "bfloat16": L.HMMR_BF16,
+          "bf16x3": L.HMMR_BF16X3, "split": L.HMMR_BF16X3}
+DTYPE_NAMES = {L.HMMR_F32: "f32", L.HMMR_BF16: "bf16", L.HMMR_BF16X3: "bf16x3"}
+# The drop-in default: split-bf16 operands (hi/lo pairs, three bf16 MFMAs per product, fp32 accumulate) --
+# the fastest mode whose end-to-end vertices / joints stay within the reference tolerance of 1e-4.
+# 'bf16' is the opt-in throughput mode (vertex error ~7e-3), 'f32' the exact-fp32 MFMA mode.
+DEFAULT_DTYPE = "bf16x3"
+
+
+def set_debug(stem_route=0, stem_no_conv1=0):
+    """Development switches of libhmmr_hip.so (hmmr_debug_t; process-wide, zeros = product defaults)."""
+    d = L.Debug()
+    d.stem_route, d.stem_no_conv1 = int(stem_route), int(stem_no_conv1)
+    L.load().hmmr_set_debug(C.byref(d))
+
+
+def _debug_from_env():
+    """HMMR_STEM=unfused|fused and HMMR_STEM_C1=0 (tools/ A/B scripts) -> hmmr_set_debug; the library itself
+    never reads the environment."""
+    e = os.environ.get("HMMR_STEM", "")
+    c1 = os.environ.get("HMMR_STEM_C1", "1")
+    if e or c1 == "0":
+        set_debug(stem_route={"u": 1, "f": 2}.get(e[:1], 0), stem_no_conv1=int(c1 == "0"))
 
 
 def _dt(d):
@@ -41,10 +63,11 @@ class HmmrEngine(object):
     src/tf_smpl layout.  dtype: GEMM operand type of ResNet / temporal / IEF
     ('bf16' or 'f32'); SMPL is always fp32."""
 
-    def __init__(self, weights, smpl, dtype="bf16", device="cuda:0", num_conv_layers=3,
+    def __init__(self, weights, smpl, dtype=DEFAULT_DTYPE, device="cuda:0", num_conv_layers=3,
                  delta_t_values=(-5, 5), joint_type="cocoplus", resnet_chunk=0,
                  temporal_dtype=None, ief_dtype=None, autotune=True):
         self.lib = L.load()
+        _debug_from_env()
         if not torch.cuda.is_available():
             raise L.HmmrError("HmmrEngine needs a HIP device (torch.cuda.is_available() is False)")
         self.device = torch.device(device)
@@ -60,14 +83,17 @@ class HmmrEngine(object):
         tail = {"0": False, "1": True}.get(os.environ.get("HMMR_FUSE_TAIL", "1"), os.environ.get("HMMR_FUSE_TAIL"))   # dev A/B switch: 0, 1, "block1", "noconv2", "conv2b1", "nosc", "nostride2"
         fsc = {"0": False, "1": True}.get(os.environ.get("HMMR_FUSE_SC", "1"), "all")               # dev A/B switch: 0, 1, all
         pfirst = os.environ.get("HMMR_PREACT_FIRST", "0") != "0"                                    # dev A/B switch
-        self.rw = (packing.pack_resnet(weights, self.dtype, self.store, fuse_preact_blocks=fuse, fuse_tail=tail, fuse_sc=fsc,
+        # every stage is packed only when its variables exist: a ResNet-only checkpoint (hmr_noS5.ckpt-642561, what
+        # FeatureExtractor is given: src/datasets/resnet_extractor.py:31-40) has no AZ_FC_* / single_view_ief* names
+        w = weights if weights is not None else {}
+        self.rw = (packing.pack_resnet(w, self.dtype, self.store, fuse_preact_blocks=fuse, fuse_tail=tail, fuse_sc=fsc,
                                        fuse_preact_first=pfirst)
-                   if weights is not None else None)
-        self.tw = (packing.pack_temporal(weights, self.temporal_dtype, self.store, num_conv_layers)
-                   if weights is not None else None)
-        self.hw = packing.pack_hallucinator(weights, self.temporal_dtype, self.store) if weights is not None else None
-        if weights is not None:
-            self.iw, self.reg_keys = packing.pack_ief(weights, self.ief_dtype, self.store, self.delta_keys)
+                   if "resnet_v2_50/conv1/weights" in w else None)
+        self.tw = (packing.pack_temporal(w, self.temporal_dtype, self.store, num_conv_layers)
+                   if assets.temporal_scopes(0)[1] + "/weights" in w else None)
+        self.hw = packing.pack_hallucinator(w, self.temporal_dtype, self.store)
+        if "single_view_ief/3D_module/fc1/weights" in w and "mean_param" in w:
+            self.iw, self.reg_keys = packing.pack_ief(w, self.ief_dtype, self.store, self.delta_keys)
         else:
             self.iw, self.reg_keys = None, [0]
         self.sc = packing.pack_smpl(smpl, self.store, joint_type) if smpl is not None else None
@@ -91,6 +117,11 @@ class HmmrEngine(object):
         self._side_streams = []
 
     # -- helpers ---------------------------------------------------------------
+    @staticmethod
+    def _need(packed, names):
+        if packed is None:
+            raise L.HmmrError("the loaded weights have no %s variables: this stage was not packed" % names)
+
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
@@ -187,6 +218,7 @@ class HmmrEngine(object):
         every layer launch ends in a partial round of workgroups (tile-count quantisation, worst in
         blocks 3-4 where a 256-frame batch is only 1.5-3 rounds), and a second, independent launch
         sequence fills those tails.  Per-frame independent => bit-identical; measured -4 %."""
+        self._need(self.rw, "resnet_v2_50/*")
         images = self.to_device(images)
         n = images.shape[0]
         assert n == 0 or tuple(images.shape[1:]) == (224, 224, 3), images.shape
@@ -230,6 +262,7 @@ class HmmrEngine(object):
 
     def temporal(self, phi):
         """phi [b,t,2048] fp32 -> movie strips [b,t,2048].  az_fc2_groupnorm, src/models.py:121-141."""
+        self._need(self.tw, "AZ_FC_block*")
         phi = self.to_device(phi)
         b, t, c = phi.shape
         assert c == 2048
@@ -257,6 +290,7 @@ class HmmrEngine(object):
     def ief(self, strips):
         """strips [m,2048] -> omegas [R,m,85]; R = 1 + len(delta_t_values), deltas in sorted order.
         batch_pred_omega, src/models.py:233-267."""
+        self._need(self.iw, "single_view_ief*/3D_module/* and mean_param")
         strips = self.to_device(strips)
         m = strips.shape[0]
         R = self.iw.num_regressors
@@ -315,7 +349,7 @@ class HmmrEngine(object):
         x = self.to_device(x)
         b, t, c = x.shape
         g, be = self.to_device(gamma), self.to_device(beta)
-        out = torch.empty((b, t, c), dtype=packing.TORCH_DT[out_dtype], device=self.device)
+        out = packing.empty_act((b, t, c), out_dtype, self.device)
         L.check(self.lib.hmmr_groupnorm_relu(x.data_ptr(), g.data_ptr(), be.data_ptr(), b, t, c, groups,
                                              out.data_ptr(), out_dtype, self._stream()), "hmmr_groupnorm_relu")
         return out
@@ -337,7 +371,7 @@ def conv_gemm(x, w_hwio, stride=1, pad=0, scale=None, shift=None, res=None, relu
     wo = (w_ + 2 * px - kw) // stride + 1
     wt = store.put(packing.pack_conv_weight(np.asarray(w_hwio, np.float32)), packing.TORCH_DT[in_dtype])
     ldo = (cout + 7) // 8 * 8
-    out = torch.zeros((n, ho, wo, ldo), dtype=packing.TORCH_DT[out_dtype], device=dev)
+    out = packing.empty_act((n, ho, wo, ldo), out_dtype, dev, zero=True)
     d = L.ConvDesc()
     d.in_, d.w, d.out = xt.data_ptr(), wt.data_ptr(), out.data_ptr()
     d.scale = store.vec(scale).data_ptr() if scale is not None else None
@@ -371,8 +405,8 @@ def conv_gemm(x, w_hwio, stride=1, pad=0, scale=None, shift=None, res=None, relu
         d.split_k, d.ws, d.ws_bytes = split_k, skws.data_ptr(), nb
     L.check(lib.hmmr_conv_gemm(C.byref(d), torch.cuda.current_stream(dev).cuda_stream), "hmmr_conv_gemm")
     torch.cuda.synchronize(dev)
-    o = out[..., :cout].float().cpu().numpy()
-    o2 = out2[..., :cout].float().cpu().numpy() if out2 is not None else None
+    o = packing.act_to_f32(out, out_dtype)[..., :cout].cpu().numpy()
+    o2 = packing.act_to_f32(out2, out_dtype)[..., :cout].cpu().numpy() if out2 is not None else None
     return o, o2
 
 

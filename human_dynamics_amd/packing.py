@@ -19,7 +19,38 @@ import torch
 from . import _lib as L
 from . import assets
 
-TORCH_DT = {L.HMMR_F32: torch.float32, L.HMMR_BF16: torch.bfloat16}
+SPLIT = "split"      # storage marker of HMMR_BF16X3 tensors (int32 words holding bf16 hi/lo halves)
+TORCH_DT = {L.HMMR_F32: torch.float32, L.HMMR_BF16: torch.bfloat16, L.HMMR_BF16X3: SPLIT}
+
+
+def to_split(t):
+    """fp32 tensor [..., C] (C % 8 == 0) -> int32 tensor [..., C] in the HMMR_BF16X3 layout: every group of 8
+    channels is 32 bytes, [hi x8][lo x8] with hi = bf16(x), lo = bf16(x - hi) (include/hmmr_hip.h)."""
+    t = t.to(torch.float32)
+    C = t.shape[-1]
+    assert C % 8 == 0, "split tensors need a channel count that is a multiple of 8"
+    hi = t.to(torch.bfloat16)
+    lo = (t - hi.to(torch.float32)).to(torch.bfloat16)
+    g = torch.stack([hi.reshape(t.shape[:-1] + (C // 8, 8)), lo.reshape(t.shape[:-1] + (C // 8, 8))], dim=-2)
+    return g.reshape(t.shape[:-1] + (2 * C,)).contiguous().view(torch.int32)
+
+
+def from_split(t):
+    """inverse of to_split: int32 [..., C] -> fp32 [..., C] (hi + lo)."""
+    C = t.shape[-1]
+    g = t.contiguous().view(torch.bfloat16).reshape(t.shape[:-1] + (C // 8, 2, 8)).to(torch.float32)
+    return (g[..., 0, :] + g[..., 1, :]).reshape(t.shape[:-1] + (C,))
+
+
+def empty_act(shape, dtype, device, zero=False):
+    """Activation tensor of a stage dtype code (split tensors are int32 words)."""
+    td = TORCH_DT[dtype]
+    td = torch.int32 if td is SPLIT else td
+    return (torch.zeros if zero else torch.empty)(shape, dtype=td, device=device)
+
+
+def act_to_f32(t, dtype):
+    return from_split(t) if TORCH_DT[dtype] is SPLIT else t.float()
 
 
 def _pad_rows(a, mult=128):
@@ -60,7 +91,9 @@ class DeviceStore(object):
 
     def put(self, arr, dtype=torch.float32):
         t = torch.from_numpy(np.ascontiguousarray(arr)).to(self.device)
-        if t.dtype != dtype:
+        if dtype is SPLIT:
+            t = to_split(t)
+        elif t.dtype != dtype:
             t = t.to(dtype)
         self.tensors.append(t)
         return t
@@ -93,7 +126,9 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
     for i, (scope, c_in, base, depth, stride, has_sc) in enumerate(units):
         u = rw.unit[i]
         u.c_in, u.base, u.depth, u.stride = c_in, base, depth, stride
-        u.fuse_preact = int(i > 0 and scope.split("/")[1] in fuse_preact_blocks)
+        # (the operand-staging preact works slot by slot; a split tensor keeps hi and lo in different slots, so
+        #  bf16x3 units read the preact tensor their predecessor's conv3 wrote)
+        u.fuse_preact = int(i > 0 and scope.split("/")[1] in fuse_preact_blocks and dtype != L.HMMR_BF16X3)
         if has_sc and i > 0 and not fuse_preact_first:
             # a block's first unit feeds its preact to a WIDE conv shortcut as well: every N tile of a fused-preact
             # launch repeats the transform, so here the previous unit's conv3 writes the (small, already

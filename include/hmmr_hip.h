@@ -31,12 +31,26 @@
 extern "C" {
 #endif
 
-#define HMMR_ABI_VERSION 6
+#define HMMR_ABI_VERSION 7
 
-enum { HMMR_F32 = 0, HMMR_BF16 = 1 };
+/* HMMR_BF16X3: "split" tensors -- every group of 8 consecutive channels is 32 bytes, [hi x8][lo x8] with
+ * hi = bf16(x), lo = bf16(x - hi) (4 bytes per element, ~16 mantissa bits); GEMMs on them issue three bf16
+ * MFMAs per operand pair (hi*hi + hi*lo + lo*hi, fp32 accumulate).  The parity-grade throughput mode. */
+enum { HMMR_F32 = 0, HMMR_BF16 = 1, HMMR_BF16X3 = 2 };
 
 int hmmr_abi_version(void);
 const char* hmmr_last_error(void);
+
+/* Development switches for A/B measurements and tests.  Process-wide; all zero = the product defaults.  No
+ * switch changes a result beyond what its comment says; the library never reads the environment. */
+typedef struct hmmr_debug_s {
+    int stem_route;        /* 0: default (fused stem kernel for bf16, re-pack + GEMM + pool otherwise);
+                              1: always the three-kernel route; 2: always the fused kernel (not for bf16x3) */
+    int stem_no_conv1;     /* 1: the fused bf16 stem leaves block1/unit_1's conv1 to its own launch */
+    int reserved[6];
+} hmmr_debug_t;
+void hmmr_set_debug(const hmmr_debug_t* d);     /* NULL = defaults */
+void hmmr_get_debug(hmmr_debug_t* d);
 
 /* ------------------------------------------------------------------------- *
  * Generic implicit-GEMM convolution / fully-connected building block.
@@ -59,7 +73,7 @@ typedef struct {
                               dtype (= what a consumer applying pro_scale/pro_shift to `out` computes), or NULL */
     const float* scale2;
     const float* shift2;
-    int in_dtype;          /* HMMR_F32 / HMMR_BF16 */
+    int in_dtype;          /* HMMR_F32 / HMMR_BF16 / HMMR_BF16X3 */
     int out_dtype;
     /* input geometry (element strides) */
     int n_img, hin, win, cin;          /* cin: channels per tap, power of two, >= 32B/elt */

@@ -24,7 +24,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "libhmmr_hip.so does not export %s" % n
     assert sorted(_lib.SIGNATURES) == names        # the ctypes table covers the header one to one
-    assert lib.hmmr_abi_version() == 6
+    assert lib.hmmr_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_workspace_queries_need_no_gpu():
@@ -36,6 +36,24 @@ def test_workspace_queries_need_no_gpu():
     assert lib.hmmr_smpl_workspace_bytes(256) >= 256 * (224 + 288) * 4
     assert lib.hmmr_temporal_workspace_bytes(8, 20, _lib.HMMR_F32) >= 4 * 160 * 2048 * 4
     assert lib.hmmr_ief_workspace_bytes(160, 3, _lib.HMMR_F32) > 0
+    # split (bf16x3) tensors are 4 bytes per element, like fp32
+    assert lib.hmmr_resnet50_workspace_bytes(64, _lib.HMMR_BF16X3) == f32
+
+
+def test_debug_switches_round_trip():
+    import ctypes as C
+    lib = _lib.load()
+    d = _lib.Debug()
+    lib.hmmr_get_debug(C.byref(d))
+    assert (d.stem_route, d.stem_no_conv1) == (0, 0)          # product defaults
+    d.stem_route, d.stem_no_conv1 = 1, 1
+    lib.hmmr_set_debug(C.byref(d))
+    e = _lib.Debug()
+    lib.hmmr_get_debug(C.byref(e))
+    assert (e.stem_route, e.stem_no_conv1) == (1, 1)
+    lib.hmmr_set_debug(None)
+    lib.hmmr_get_debug(C.byref(e))
+    assert (e.stem_route, e.stem_no_conv1) == (0, 0)
 
 
 def test_argument_validation_reports_errors():

@@ -1,0 +1,200 @@
+"""GPU parity of the split-bf16 ("bf16x3", HMMR_BF16X3) mode: the throughput mode that has to stay
+inside the reference tolerance (vertices / joints within 1e-4 of the fp32 TF graph,
+BASELINE.json north_star; the reference computes in fp32 throughout, tester.py:64-66).
+
+Operands are bf16 hi/lo pairs (x ~ hi + lo, 16 mantissa bits), every product is three bf16 MFMAs
+(hi*hi + hi*lo + lo*hi) accumulated in fp32, activations between layers stay hi/lo pairs.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import Config
+from human_dynamics_amd import _lib as L
+from human_dynamics_amd import assets
+from test_gpu_kernels import _ref_conv
+
+pytestmark = pytest.mark.gpu
+F64 = torch.float64
+X3 = L.HMMR_BF16X3
+
+
+def _split_round(a):
+    """The value a split tensor holds for fp32 input a (hi + lo)."""
+    t = torch.tensor(np.asarray(a, np.float32))
+    hi = t.to(torch.bfloat16).to(torch.float32)
+    return (hi.to(F64) + (t - hi).to(torch.bfloat16).to(F64)).numpy()
+
+
+def test_split_layout_round_trip():
+    """to_split / from_split: 16 mantissa bits, 32-byte groups [hi x8][lo x8]."""
+    from human_dynamics_amd.packing import from_split, to_split
+    x = torch.randn(5, 7, 64, generator=torch.Generator().manual_seed(0)) * 3
+    s = to_split(x)
+    assert s.dtype == torch.int32 and s.shape == x.shape
+    y = from_split(s)
+    assert float(((x - y).abs() / x.abs().clamp_min(1e-30)).max()) < 2.0 ** -16
+    raw = s.view(torch.bfloat16).reshape(5, 7, 8, 2, 8)
+    assert torch.equal(raw[..., 0, :].reshape(5, 7, 64), x.to(torch.bfloat16))
+
+
+CASES = [
+    # name, n, h, w, cin, cout, k, stride, pad, flags
+    ("1x1_64_64", 2, 12, 12, 64, 64, 1, 1, 0, ""),
+    ("1x1_256_64_bnrelu", 1, 28, 28, 256, 64, 1, 1, 0, "sbr"),
+    ("1x1_64_256_res_out2", 2, 14, 14, 64, 256, 1, 1, 0, "bR2"),
+    ("3x3_s1", 2, 14, 14, 64, 64, 3, 1, 1, "sbr"),
+    ("3x3_s2", 2, 14, 14, 128, 128, 3, 2, 1, "sbr"),
+    ("3x3_s1_odd", 1, 7, 7, 512, 512, 3, 1, 1, "sbr"),
+    ("4x4_cin16", 2, 9, 9, 16, 64, 4, 1, 1, "b"),          # two taps per 128-byte K step
+    ("fc_ragged_85", 37, 1, 1, 1024, 85, 1, 1, 0, "b"),
+    ("fc_2048_1024", 37, 1, 1, 2048, 1024, 1, 1, 0, "br"),
+    ("1x1_strided_res", 1, 14, 14, 64, 256, 1, 1, 0, "bS"),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 5, 6])
+@pytest.mark.parametrize("out_dt", ["f32", "x3"])
+def test_conv_gemm_split(case, tile, out_dt, gpu_device):
+    """Against a float64 convolution of the SAME 16-bit operands: what is left is the dropped lo*lo
+    term (2^-18 per product) and fp32 accumulation; and against the unrounded fp32 operands with the
+    tolerance the mode promises."""
+    from human_dynamics_amd.engine import conv_gemm
+    name, n, h, w_, cin, cout, k, stride, pad, flags = case
+    if tile in (1, 5) and cout % 128:
+        pytest.skip("128-wide tiles are only selected for cout % 128 == 0")
+    if out_dt == "x3" and cout % 8:
+        pytest.skip("split outputs are whole 8-channel groups")
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(name.encode()) % 1000)
+    x = rng.normal(size=(n, h, w_, cin)).astype(np.float32)
+    w = (rng.normal(size=(k, k, cin, cout)) / np.sqrt(k * k * cin)).astype(np.float32)
+    ho = (h + 2 * pad - k) // stride + 1
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32) if "s" in flags else None
+    shift = rng.normal(size=cout).astype(np.float32) if "b" in flags else None
+    res, res_stride = None, 1
+    if "R" in flags:
+        res = rng.normal(size=(n, ho, ho, cout)).astype(np.float32)
+    if "S" in flags:
+        res = rng.normal(size=(n, 2 * ho, 2 * ho, cout)).astype(np.float32)
+        res_stride = 2
+    s2 = rng.uniform(0.5, 1.5, cout).astype(np.float32) if "2" in flags else None
+    b2 = rng.normal(size=cout).astype(np.float32) if "2" in flags else None
+    odt = X3 if out_dt == "x3" else L.HMMR_F32
+    out, out2 = conv_gemm(x, w, stride, pad, scale, shift, res, "r" in flags, s2, b2, in_dtype=X3, out_dtype=odt,
+                          tile=tile, device=gpu_device, res_stride=res_stride)
+    res_r = res if (res is None or out_dt == "f32") else _split_round(res)     # the residual is read in the output type
+    ref, ref2 = _ref_conv(_split_round(x), _split_round(w), stride, pad, scale, shift, res_r, "r" in flags, s2, b2,
+                          res_stride)
+    mag = max(1.0, np.abs(ref).max())
+    err = np.abs(out - ref).max()
+    assert err < 2e-5 * mag, "%s tile %d: max abs err %.3e vs same-operand f64" % (name, tile, err)
+    if ref2 is not None:
+        assert np.abs(out2 - ref2).max() < 3e-5 * max(1.0, np.abs(ref2).max())
+    exact, _ = _ref_conv(x, w, stride, pad, scale, shift, res, "r" in flags, None, None, res_stride)
+    assert np.abs(out - exact).max() < 6e-5 * mag          # vs the unrounded operands: 2^-17-sized inputs
+
+
+@pytest.mark.parametrize("split_k", [2, 4])
+def test_conv_gemm_split_with_split_k(split_k, gpu_device):
+    from human_dynamics_amd.engine import conv_gemm
+    rng = np.random.default_rng(split_k)
+    x = rng.normal(size=(3, 20, 1, 256)).astype(np.float32)
+    w = (rng.normal(size=(3, 1, 256, 200)) / np.sqrt(768)).astype(np.float32)
+    b = rng.normal(size=200).astype(np.float32)
+    res = rng.normal(size=(3, 20, 1, 200)).astype(np.float32)
+    out, _ = conv_gemm(x, w, 1, (1, 0), None, b, res, True, in_dtype=X3, device=gpu_device, split_k=split_k)
+    ref, _ = _ref_conv(_split_round(x), _split_round(w), 1, (1, 0), None, b, res, True, None, None)
+    assert np.abs(out - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+    x2 = np.concatenate([x, rng.normal(size=(5, 20, 1, 256)).astype(np.float32)])
+    res2 = np.concatenate([res, rng.normal(size=(5, 20, 1, 200)).astype(np.float32)])
+    out2, _ = conv_gemm(x2, w, 1, (1, 0), None, b, res2, True, in_dtype=X3, device=gpu_device, split_k=split_k)
+    assert np.array_equal(out2[:3], out)                    # batch independence, bit for bit
+
+
+def test_conv_gemm_f32_in_split_out(gpu_device):
+    """The IEF theta GEMM: fp32 operand, split output + split residual."""
+    from human_dynamics_amd.engine import conv_gemm
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=(37, 1, 1, 128)).astype(np.float32)
+    w = (rng.normal(size=(1, 1, 128, 1024)) / 12).astype(np.float32)
+    res = rng.normal(size=(37, 1, 1, 1024)).astype(np.float32)
+    out, _ = conv_gemm(x, w, 1, 0, None, None, res, True, in_dtype=L.HMMR_F32, out_dtype=X3, device=gpu_device)
+    ref, _ = _ref_conv(x, w, 1, 0, None, None, _split_round(res), True, None, None)
+    assert np.abs(out - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+
+
+@pytest.fixture(scope="module")
+def eng_x3(weights, smpl_consts, gpu_device):
+    from human_dynamics_amd.engine import HmmrEngine
+    return HmmrEngine(weights, smpl_consts, dtype="bf16x3", device=gpu_device)
+
+
+def test_groupnorm_relu_split_output(eng_x3):
+    from human_dynamics_amd.packing import from_split
+    from oracle import hmmr_oracle as O
+    rng = np.random.default_rng(0)
+    x = (rng.normal(size=(3, 20, 2048)) * 2 + 0.5).astype(np.float32)
+    g = rng.uniform(0.5, 1.5, 2048).astype(np.float32)
+    b = rng.normal(size=2048).astype(np.float32)
+    out = from_split(eng_x3.groupnorm_relu(x, g, b, out_dtype=X3)).cpu().numpy()
+    ref = torch.relu(O.group_norm_time(torch.tensor(x, dtype=F64), torch.tensor(g, dtype=F64),
+                                       torch.tensor(b, dtype=F64))).numpy()
+    assert np.abs(out - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_resnet_split_matches_oracle(eng_x3, golden_window):
+    """BASELINE config-2-shaped check at 3 frames (the batch-64 version is test_gpu_sizes.py)."""
+    frames = assets.make_synthetic_frames(3, seed=1)
+    phi = eng_x3.resnet(frames).cpu().numpy()
+    ref = golden_window["phi"][:3]
+    err = np.abs(phi - ref).max()
+    rel = np.linalg.norm(phi - ref) / np.linalg.norm(ref)
+    print("ResNet bf16x3: phi max-abs-err %.3e rel-L2 %.3e (|phi|max %.2f)" % (err, rel, np.abs(ref).max()))
+    assert rel < 1e-4 and err < 1e-3
+
+
+def test_resnet_split_batch_independence(eng_x3):
+    frames = assets.make_synthetic_frames(5, seed=9)
+    frames[2] = 0.0
+    a = eng_x3.resnet(frames).cpu().numpy()
+    b = eng_x3.resnet(frames[2:3]).cpu().numpy()
+    c = eng_x3.resnet(frames[:2], n_zero=1).cpu().numpy()
+    assert np.array_equal(a[2:3], b) and np.array_equal(a[:3], c)
+
+
+def test_temporal_and_ief_split_match_oracle(eng_x3, golden_window):
+    phi = golden_window["phi"].reshape(1, 20, 2048)
+    out = eng_x3.temporal(phi).cpu().numpy()
+    e1 = np.abs(out[0] - golden_window["strips"]).max()
+    om = eng_x3.ief(golden_window["strips"]).cpu().numpy()
+    e2 = np.abs(om - golden_window["omegas_all"]).max()
+    print("bf16x3: strips max-abs-err %.3e, omegas max-abs-err %.3e" % (e1, e2))
+    assert e1 < 2e-4 and e2 < 5e-5
+
+
+def test_predict_split_meets_reference_tolerance(weights, smpl_consts, gpu_device, golden_window):
+    """BASELINE config 1 in the throughput mode: vertices and joints within 1e-4 of the float64
+    reference-graph oracle (north_star)."""
+    from human_dynamics_amd.evaluation.tester import Tester
+    from test_gpu_pipeline import _check
+    frames = assets.make_synthetic_frames(20, seed=1)
+    t = Tester(Config(batch_size=1), weights=weights, smpl=smpl_consts, device=gpu_device)     # the default dtype
+    assert t.engine.dtype == X3
+    res = t.predict(frames[None])
+    errs = _check(res, golden_window, 1e-4)
+    print("bf16x3 end to end: verts %.3e joints %.3e omegas %.3e" % (errs["verts"], errs["joints"], errs["omegas"]))
+
+
+def test_predict_all_images_split_matches_golden_video(weights, smpl_consts, gpu_device, golden_video):
+    from human_dynamics_amd.evaluation.tester import Tester
+    from test_gpu_pipeline import _check
+    frames = assets.make_synthetic_frames(24, seed=7)
+    t = Tester(Config(batch_size=2), weights=weights, smpl=smpl_consts, dtype="bf16x3", device=gpu_device)
+    res = t.predict_all_images(frames)
+    _check(res, dict(golden_video), 1e-4)
+    lit = Tester(Config(batch_size=2), weights=weights, smpl=smpl_consts, dtype="bf16x3", device=gpu_device,
+                 dedup=False).predict_all_images(frames)
+    for k in res:
+        assert np.array_equal(res[k], lit[k]), k
