@@ -129,6 +129,32 @@ template <> __device__ __forceinline__ u32x4 preact_slot<bf16_t>(const u32x4& v,
     return o;
 }
 
+// split tensors keep the hi and the lo half of an 8-channel group in neighbouring slots, i.e. in neighbouring lanes of
+// the staging geometry (lslot ^ 1 <-> lane ^ 1): the two lanes swap their raw slots (DPP quad_perm [1,0,3,2]), both
+// rebuild x = hi + lo, apply relu(x*s + b) and split the result again; each keeps the half its own slot stores.
+// Value for value this is store8<bsplit_t>(relu(fma(load8<bsplit_t>(x), s, b))), the producer-side `out2` of the epilogue.
+__device__ __forceinline__ u32x4 preact_slot_split(const u32x4& v, const f32x4* sc, const f32x4* sh, bool is_lo) {
+    u32x4 other, o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) other[i] = (unsigned)__builtin_amdgcn_mov_dpp((int)v[i], 0xB1, 0xF, 0xF, true);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned h = is_lo ? other[i] : v[i], l = is_lo ? v[i] : other[i];
+        const float x0 = __uint_as_float(h << 16) + __uint_as_float(l << 16);
+        const float x1 = __uint_as_float(h & 0xffff0000u) + __uint_as_float(l & 0xffff0000u);
+        const int e = 2 * i;
+        const float a = fmaxf(fmaf(x0, sc[e >> 2][e & 3], sh[e >> 2][e & 3]), 0.f);
+        const float b = fmaxf(fmaf(x1, sc[(e + 1) >> 2][(e + 1) & 3], sh[(e + 1) >> 2][(e + 1) & 3]), 0.f);
+        const bf16_t ah = (bf16_t)a, bh = (bf16_t)b;
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+        bf16x2 pk;
+        if (is_lo) pk = bf16x2{(bf16_t)(a - (float)ah), (bf16_t)(b - (float)bh)};
+        else pk = bf16x2{ah, bh};
+        o[i] = __builtin_bit_cast(unsigned, pk);
+    }
+    return o;
+}
+
 // Operands go HBM -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave instruction, LDS image
 // lane-linear, swizzle applied to the per-lane SOURCE slot).
 // PRO  = true : the A operand instead takes the register route HBM -> VGPR -> (x*scale[ci] +
@@ -207,8 +233,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 1) void conv
         return ky * a.in_row_stride + kx * a.in_px_stride + ci;
     };
 
+    constexpr bool SPLIT = std::is_same<TA, bsplit_t>::value;
+    constexpr int PCH = SPLIT ? 8 : EPS;                      // channels whose preact constants this lane needs
     u32x4 ra[PRO ? PA : 1];
-    f32x4 psc[PRO ? EPS / 4 : 1], psh[PRO ? EPS / 4 : 1];     // scale/shift of this lane's EPS channels
+    f32x4 psc[PRO ? PCH / 4 : 1], psh[PRO ? PCH / 4 : 1];     // scale/shift of this lane's channels
     // A operand of K step kt, LDS-DMA route (non-PRO)
     auto glds_a = [&](int kt, int buf) {
         int tap;
@@ -240,9 +268,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 1) void conv
         if constexpr (PRO) {
             int tap;
             const int koff = tap_of(kt * BKE, tap);
-            const int ci = ((kt * BKE) & cin_mask) + lslot * EPS;
+            // (split: the 8 channels of the group this lane holds the hi or the lo half of)
+            const int ci = ((kt * BKE) & cin_mask) + (SPLIT ? (lslot >> 1) * 8 : lslot * EPS);
 #pragma unroll
-            for (int q = 0; q < EPS / 4; ++q) {
+            for (int q = 0; q < PCH / 4; ++q) {
                 psc[q] = *(const f32x4*)(a.pro_scale + ci + 4 * q);
                 psh[q] = *(const f32x4*)(a.pro_shift + ci + 4 * q);
             }
@@ -257,7 +286,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 1) void conv
         if constexpr (PRO) {
             char* sa = smem + buf * STAGE + r0 * 128 + pslot * 16;
 #pragma unroll
-            for (int p = 0; p < PA; ++p) *(u32x4*)(sa + p * (RPP * 128)) = preact_slot<TA>(ra[p], psc, psh);
+            for (int p = 0; p < PA; ++p) {
+                if constexpr (SPLIT) *(u32x4*)(sa + p * (RPP * 128)) = preact_slot_split(ra[p], psc, psh, lslot & 1);
+                else *(u32x4*)(sa + p * (RPP * 128)) = preact_slot<TA>(ra[p], psc, psh);
+            }
 #pragma unroll
             for (int p = 0; p < PB; ++p) *(u32x4*)(sa + A_BYTES + p * (RPP * 128)) = rb[p];
         }
@@ -505,12 +537,7 @@ static int launch_typed(const ConvArgs& a, int tile, int slices, hipStream_t str
     const bool utap = ((size_t)1 << a.cin_log2) * sizeof(TA) >= 128;
     if (a.pro_scale) {
         if (!utap) { hmmr_set_error("hmmr_conv_gemm: fused pre-activation needs cin*sizeof >= 128"); return -1; }
-        if constexpr (std::is_same<TA, bsplit_t>::value) {
-            hmmr_set_error("hmmr_conv_gemm: the fused pre-activation is not available for split (bf16x3) operands");
-            return -1;
-        } else {
-            return launch_tiled<TA, TO, true, true>(a, tile, slices, stream);
-        }
+        return launch_tiled<TA, TO, true, true>(a, tile, slices, stream);
     }
     return utap ? launch_tiled<TA, TO, false, true>(a, tile, slices, stream)
                 : launch_tiled<TA, TO, false, false>(a, tile, slices, stream);

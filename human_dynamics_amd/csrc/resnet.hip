@@ -114,7 +114,7 @@ __global__ void maxpool_bn_relu_kernel(const T* __restrict__ in, T* __restrict__
         float s[8], b[8];
         load8(scale + cv * 8, s); load8(shift + cv * 8, b);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j] * s[j] + b[j], 0.f);
+        for (int j = 0; j < 8; ++j) m[j] = fmaxf(fmaf(m[j], s[j], b[j]), 0.f);   // one explicit fma: = stem.hip, bit for bit
         store8(out + i * 8, m);
     }
 }

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const float* __restrict
         float sc[8], sh[8];
         load8(pscale + v8 * 8, sc); load8(pshift + v8 * 8, sh);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j] * sc[j] + sh[j], 0.f);
+        for (int j = 0; j < 8; ++j) m[j] = fmaxf(fmaf(m[j], sc[j], sh[j]), 0.f);   // one explicit fma: = maxpool_bn_relu_kernel
         store8(out + (((long long)n * POOL + PT * ty + py) * POOL + PT * tx + px) * CO + v8 * 8, m);
         if constexpr (sizeof(T) == 2) {
             // block1/unit_1's conv1 follows in this launch: keep the tile as its operand image ([64 pixels][64 ch],

@@ -357,13 +357,17 @@ class HmmrEngine(object):
 
 def conv_gemm(x, w_hwio, stride=1, pad=0, scale=None, shift=None, res=None, relu=False,
               scale2=None, shift2=None, in_dtype=L.HMMR_F32, out_dtype=L.HMMR_F32, tile=0,
-              device="cuda:0", res_stride=1, split_k=0, pro=None):
+              device="cuda:0", res_stride=1, split_k=0, pro=None, raw=False):
     """Test/utility entry: run one NHWC convolution through hmmr_conv_gemm.
-    x [n,h,w,cin] (numpy/torch), w_hwio [kh,kw,cin,cout].  Returns (out, out2)."""
+    x [n,h,w,cin] (numpy/torch), w_hwio [kh,kw,cin,cout].  Returns (out, out2) as float32 arrays, or with
+    raw=True the device tensors in their storage type; x may itself be such a device tensor."""
     lib = L.load()
     dev = torch.device(device)
     store = packing.DeviceStore(dev)
-    xt = store.put(np.asarray(x, np.float32), packing.TORCH_DT[in_dtype])
+    if isinstance(x, torch.Tensor) and x.is_cuda:
+        xt = x.contiguous()
+    else:
+        xt = store.put(np.asarray(x, np.float32), packing.TORCH_DT[in_dtype])
     n, h, w_, cin = xt.shape
     kh, kw, _, cout = w_hwio.shape
     py, px = (pad, pad) if isinstance(pad, int) else pad
@@ -405,6 +409,8 @@ def conv_gemm(x, w_hwio, stride=1, pad=0, scale=None, shift=None, res=None, relu
         d.split_k, d.ws, d.ws_bytes = split_k, skws.data_ptr(), nb
     L.check(lib.hmmr_conv_gemm(C.byref(d), torch.cuda.current_stream(dev).cuda_stream), "hmmr_conv_gemm")
     torch.cuda.synchronize(dev)
+    if raw:
+        return out, out2
     o = packing.act_to_f32(out, out_dtype)[..., :cout].cpu().numpy()
     o2 = packing.act_to_f32(out2, out_dtype)[..., :cout].cpu().numpy() if out2 is not None else None
     return o, o2

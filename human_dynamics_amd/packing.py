@@ -126,9 +126,7 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
     for i, (scope, c_in, base, depth, stride, has_sc) in enumerate(units):
         u = rw.unit[i]
         u.c_in, u.base, u.depth, u.stride = c_in, base, depth, stride
-        # (the operand-staging preact works slot by slot; a split tensor keeps hi and lo in different slots, so
-        #  bf16x3 units read the preact tensor their predecessor's conv3 wrote)
-        u.fuse_preact = int(i > 0 and scope.split("/")[1] in fuse_preact_blocks and dtype != L.HMMR_BF16X3)
+        u.fuse_preact = int(i > 0 and scope.split("/")[1] in fuse_preact_blocks)
         if has_sc and i > 0 and not fuse_preact_first:
             # a block's first unit feeds its preact to a WIDE conv shortcut as well: every N tile of a fused-preact
             # launch repeats the transform, so here the previous unit's conv3 writes the (small, already

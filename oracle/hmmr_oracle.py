@@ -63,6 +63,77 @@ def _conv(x, w_hwio, dtype, stride=1, pad=0, bias=None):
     return F.conv2d(x, wt, b, stride=stride, padding=pad)
 
 
+# --------------------------------------------------------------------------- #
+# Storage-precision emulation (NOT part of the reference): the HIP path's reduced-precision modes
+# round the GEMM operands and every tensor they store between launches; an oracle that rounds at
+# exactly those points (and nowhere else, accumulating in float64) turns "bf16-sized error" into a
+# tight comparison.  emulate = None | 'bf16' | 'bf16x3'.
+# --------------------------------------------------------------------------- #
+def quantize(x, emulate):
+    """x as the HIP path stores it: bf16 (round to nearest even), or the bf16x3 hi/lo pair
+    (hi = bf16(x), lo = bf16(x - hi); x ~ hi + lo)."""
+    if emulate is None:
+        return x
+    x32 = x.to(torch.float32)
+    hi = x32.to(torch.bfloat16).to(torch.float32)
+    if emulate == "bf16":
+        return hi.to(x.dtype)
+    if emulate == "bf16x3":
+        return (hi.to(torch.float64) + (x32 - hi).to(torch.bfloat16).to(torch.float64)).to(x.dtype)
+    raise ValueError("emulate must be None, 'bf16' or 'bf16x3'")
+
+
+def _fold_bn32(w, prefix):
+    """Inference BN folded the way human_dynamics_amd/packing.py folds it (float64 -> float32
+    scale and shift), which is what the HIP epilogues apply as one fused multiply-add."""
+    g = np.asarray(w[prefix + "/gamma"], np.float64)
+    b = np.asarray(w[prefix + "/beta"], np.float64)
+    m = np.asarray(w[prefix + "/moving_mean"], np.float64)
+    v = np.asarray(w[prefix + "/moving_variance"], np.float64)
+    scale = g / np.sqrt(v + BN_EPS)
+    return scale.astype(np.float32), (b - m * scale).astype(np.float32)
+
+
+def resnet_v2_50_emulated(images_nhwc, w, emulate):
+    """resnet_v2_50 below with the rounding points of csrc/resnet.hip in mode `emulate`: image and
+    filters as operands, and every tensor the launch sequence stores (stem conv + bias, each unit's
+    pre-activation, h1, h2, conv shortcut, trunk).  Arithmetic between rounding points is float64
+    (the HIP path accumulates in fp32, so agreement is to fp32 roundoff plus the rare operand that
+    such a difference tips over a rounding boundary)."""
+    dt = torch.float64
+    q = lambda t: quantize(t, emulate)
+
+    def conv(x, name, stride=1, pad=0):
+        wt = q(_t(w[name], dt)).permute(3, 2, 0, 1).contiguous()
+        return F.conv2d(x, wt, None, stride=stride, padding=pad)
+
+    def affine(x, scale, shift):
+        return x * _t(scale, dt).view(1, -1, 1, 1) + _t(shift, dt).view(1, -1, 1, 1)
+
+    x = q(_t(images_nhwc, dt)).permute(0, 3, 1, 2).contiguous()
+    x = q(conv(x, "resnet_v2_50/conv1/weights", 2, 3) + _t(w["resnet_v2_50/conv1/biases"], dt).view(1, -1, 1, 1))
+    x = F.max_pool2d(F.pad(x, (0, 1, 0, 1), value=float("-inf")), 3, stride=2)
+    raw, c_in = x, 64
+    for bname, base, n_units, bstride in _BLOCKS:
+        depth = 4 * base
+        for u in range(1, n_units + 1):
+            stride = bstride if u == n_units else 1
+            sc = "resnet_v2_50/%s/unit_%d/bottleneck_v2" % (bname, u)
+            preact = q(torch.relu(affine(raw, *_fold_bn32(w, sc + "/preact"))))
+            if c_in == depth:
+                shortcut = raw if stride == 1 else raw[:, :, ::stride, ::stride]
+            else:
+                shortcut = q(conv(preact, sc + "/shortcut/weights", stride)
+                             + _t(w[sc + "/shortcut/biases"], dt).view(1, -1, 1, 1))
+            r = q(torch.relu(affine(conv(preact, sc + "/conv1/weights"), *_fold_bn32(w, sc + "/conv1/BatchNorm"))))
+            r = q(torch.relu(affine(conv(r, sc + "/conv2/weights", stride, 1), *_fold_bn32(w, sc + "/conv2/BatchNorm"))))
+            r = conv(r, sc + "/conv3/weights") + _t(w[sc + "/conv3/biases"], dt).view(1, -1, 1, 1)
+            raw = q(shortcut + r)
+            c_in = depth
+    x = torch.relu(affine(raw, *_fold_bn32(w, "resnet_v2_50/postnorm")))
+    return x.mean(dim=(2, 3))
+
+
 def resnet_v2_50(images_nhwc, w, dtype=torch.float64, return_endpoints=False):
     """images [N,224,224,3] -> phi [N,2048].
 
@@ -135,16 +206,19 @@ def temporal_conv3(x, w_hwio, bias):
     return out
 
 
-def az_fc2_groupnorm(phi_btc, w, num_conv_layers=3, dtype=torch.float64):
+def az_fc2_groupnorm(phi_btc, w, num_conv_layers=3, dtype=torch.float64, emulate=None):
+    """emulate: round the two GEMM operands of each temporal conv as csrc/temporal.hip stores them (the
+    GroupNorm+ReLU output and the filters); trunk, statistics and conv outputs stay unrounded."""
+    q = lambda t: quantize(t, emulate)
     net = _t(phi_btc, dtype)
     for i in range(num_conv_layers):
         n = "block_%d" % i
         gn1, c1 = "AZ_FC_block_preact_gn1" + n, "AZ_FC_block2_conv1" + n
         gn2, c2 = "AZ_FC_block_preact_gn2" + n, "AZ_FC_block2_conv2" + n
-        h = torch.relu(group_norm_time(net, _t(w[gn1 + "/gamma"], dtype), _t(w[gn1 + "/beta"], dtype)))
-        h = temporal_conv3(h, _t(w[c1 + "/weights"], dtype), _t(w[c1 + "/biases"], dtype))
-        h = torch.relu(group_norm_time(h, _t(w[gn2 + "/gamma"], dtype), _t(w[gn2 + "/beta"], dtype)))
-        h = temporal_conv3(h, _t(w[c2 + "/weights"], dtype), _t(w[c2 + "/biases"], dtype))
+        h = q(torch.relu(group_norm_time(net, _t(w[gn1 + "/gamma"], dtype), _t(w[gn1 + "/beta"], dtype))))
+        h = temporal_conv3(h, q(_t(w[c1 + "/weights"], dtype)), _t(w[c1 + "/biases"], dtype))
+        h = q(torch.relu(group_norm_time(h, _t(w[gn2 + "/gamma"], dtype), _t(w[gn2 + "/beta"], dtype))))
+        h = temporal_conv3(h, q(_t(w[c2 + "/weights"], dtype)), _t(w[c2 + "/biases"], dtype))
         net = h + net                                   # src/models.py:226
     return net
 
@@ -161,12 +235,23 @@ def fc2_res(phi_btc, w, dtype=torch.float64):
 # --------------------------------------------------------------------------- #
 # IEF: hmr_ief / call_hmr_ief / batch_pred_omega, src/models.py:233-415
 # --------------------------------------------------------------------------- #
-def hmr_ief(phi, omega_start, w, scope, num_stage=3, dtype=torch.float64):
+def hmr_ief(phi, omega_start, w, scope, num_stage=3, dtype=torch.float64, emulate=None):
+    """emulate: the rounding points of csrc/ief.hip -- phi and the phi rows of fc1, fc2, fc3 as operands;
+    the stored phi.W1 + b1, h1 and h2; the theta state and its rows of fc1 stay fp32."""
+    q = lambda t: quantize(t, emulate)
     p = scope + "/3D_module"
     W1, b1 = _t(w[p + "/fc1/weights"], dtype), _t(w[p + "/fc1/biases"], dtype)
     W2, b2 = _t(w[p + "/fc2/weights"], dtype), _t(w[p + "/fc2/biases"], dtype)
     W3, b3 = _t(w[p + "/fc3/weights"], dtype), _t(w[p + "/fc3/biases"], dtype)
     theta = omega_start
+    if emulate is not None:
+        nphi = phi.shape[1]
+        pre = q(q(phi) @ q(W1[:nphi]) + b1)
+        for _ in range(num_stage):
+            h = q(torch.relu(pre + theta @ W1[nphi:]))
+            h = q(torch.relu(h @ q(W2) + b2))
+            theta = theta + (h @ q(W3) + b3)
+        return theta
     for _ in range(num_stage):
         state = torch.cat([phi, theta], dim=1)          # models.py:402
         h = torch.relu(state @ W1 + b1)                 # dropout = identity at test
@@ -175,15 +260,15 @@ def hmr_ief(phi, omega_start, w, scope, num_stage=3, dtype=torch.float64):
     return theta
 
 
-def call_hmr_ief(phi, omega_start, w, delta_t_values=(-5, 5), dtype=torch.float64):
+def call_hmr_ief(phi, omega_start, w, delta_t_values=(-5, 5), dtype=torch.float64, emulate=None):
     """use_optcam=True, use_delta_from_pred=True as tester.py:196-207 calls it."""
-    theta_here = hmr_ief(phi, omega_start, w, "single_view_ief", dtype=dtype)
+    theta_here = hmr_ief(phi, omega_start, w, "single_view_ief", dtype=dtype, emulate=emulate)
     deltas = {}
     for dt in delta_t_values:
         scope = "single_view_ief" + ("_future%d" % dt if dt > 0 else "_past%d" % abs(dt))
         beta = theta_here[:, -10:]
         start = theta_here[:, 3:3 + 72]                 # models.py:349-356
-        d = hmr_ief(phi, start, w, scope, dtype=dtype)
+        d = hmr_ief(phi, start, w, scope, dtype=dtype, emulate=emulate)
         n = d.shape[0]
         deltas[dt] = torch.cat([torch.ones(n, 1, dtype=dtype), torch.zeros(n, 2, dtype=dtype),
                                 d, beta], dim=1)        # models.py:367-371
@@ -277,7 +362,7 @@ class OracleTester(object):
 
     def __init__(self, weights, smpl, batch_size=8, sequence_length=20,
                  num_conv_layers=3, delta_t_values=(-5, 5), pred_mode="pred",
-                 dtype=torch.float64):
+                 dtype=torch.float64, emulate=None):
         self.w, self.smpl = weights, smpl
         self.batch_size, self.sequence_length = batch_size, sequence_length
         self.num_conv_layers = num_conv_layers
@@ -285,18 +370,24 @@ class OracleTester(object):
         self.delta_t_values = [int(d) for d in delta_t_values]
         self.pred_mode = pred_mode
         self.dtype = dtype
+        self.emulate = emulate          # None | 'bf16' | 'bf16x3': storage-precision emulation of the HIP modes
+        if emulate is not None and (dtype != torch.float64 or pred_mode != "pred"):
+            raise ValueError("storage-precision emulation runs in float64, pred_mode 'pred'")
         self.img_size = 224
 
     # -- stages, exposed separately so each HIP stage can be checked alone ----
     def features(self, frames_nhwc, chunk=16):
         out = []
         for i in range(0, len(frames_nhwc), chunk):
-            out.append(resnet_v2_50(frames_nhwc[i:i + chunk], self.w, self.dtype))
+            if self.emulate is not None:
+                out.append(resnet_v2_50_emulated(frames_nhwc[i:i + chunk], self.w, self.emulate))
+            else:
+                out.append(resnet_v2_50(frames_nhwc[i:i + chunk], self.w, self.dtype))
         return torch.cat(out, dim=0)
 
     def movie_strips(self, phi_btc):
         if self.pred_mode == "pred":
-            return az_fc2_groupnorm(phi_btc, self.w, self.num_conv_layers, self.dtype)
+            return az_fc2_groupnorm(phi_btc, self.w, self.num_conv_layers, self.dtype, self.emulate)
         if self.pred_mode == "hal":
             return fc2_res(phi_btc, self.w, self.dtype)
         raise Exception("Pred mode {} not recognized".format(self.pred_mode))
@@ -304,7 +395,7 @@ class OracleTester(object):
     def omegas(self, strips_nc):
         n = strips_nc.shape[0]
         mean = _t(self.w["mean_param"], self.dtype).reshape(1, 85).expand(n, 85)
-        return call_hmr_ief(_t(strips_nc, self.dtype), mean, self.w, self.delta_t_values, self.dtype)
+        return call_hmr_ief(_t(strips_nc, self.dtype), mean, self.w, self.delta_t_values, self.dtype, self.emulate)
 
     def smpl_outputs(self, omega, cams):
         """One OmegasPred.compute_smpl (src/omega.py:263-304)."""

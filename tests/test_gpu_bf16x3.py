@@ -96,6 +96,30 @@ def test_conv_gemm_split(case, tile, out_dt, gpu_device):
     assert np.abs(out - exact).max() < 6e-5 * mag          # vs the unrounded operands: 2^-17-sized inputs
 
 
+@pytest.mark.parametrize("tile", [0, 3, 5, 6, 1])
+def test_conv_gemm_split_fused_preactivation(tile, gpu_device):
+    """A = relu(x*scale[ci] + shift[ci]) applied while staging a split operand (hi and lo halves sit in
+    neighbouring lanes): equal, bit for bit, to pre-activating on the producer side (`out2`)."""
+    from human_dynamics_amd.engine import conv_gemm
+    rng = np.random.default_rng(7)
+    x = rng.normal(size=(2, 14, 14, 256)).astype(np.float32)
+    w = (rng.normal(size=(1, 1, 256, 128)) / 16).astype(np.float32)
+    ps = rng.uniform(0.5, 1.5, 256).astype(np.float32)
+    pb = rng.normal(size=256).astype(np.float32)
+    s = rng.uniform(0.5, 1.5, 128).astype(np.float32)
+    b = rng.normal(size=128).astype(np.float32)
+    out, _ = conv_gemm(x, w, 1, 0, s, b, None, True, in_dtype=X3, tile=tile, device=gpu_device, pro=(ps, pb))
+    xa = _split_round(np.maximum(_split_round(x) * ps.astype(np.float64) + pb, 0).astype(np.float32))
+    ref, _ = _ref_conv(xa, _split_round(w), 1, 0, s, b, None, True, None, None)
+    assert np.abs(out - ref).max() < 3e-5 * max(1.0, np.abs(ref).max())
+    # producer-side route: an identity 1x1 conv writes relu(x*ps+pb) as its second output, the GEMM reads that
+    eye = np.eye(256, dtype=np.float32).reshape(1, 1, 256, 256)
+    _, pre = conv_gemm(x, eye, 1, 0, None, None, None, False, ps, pb, in_dtype=X3, out_dtype=X3, device=gpu_device,
+                       raw=True)               # the split words themselves: re-splitting hi + lo may pick another pair
+    out_b, _ = conv_gemm(pre, w, 1, 0, s, b, None, True, in_dtype=X3, tile=tile, device=gpu_device)
+    assert np.array_equal(out, out_b)
+
+
 @pytest.mark.parametrize("split_k", [2, 4])
 def test_conv_gemm_split_with_split_k(split_k, gpu_device):
     from human_dynamics_amd.engine import conv_gemm

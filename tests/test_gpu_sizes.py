@@ -1,0 +1,182 @@
+"""GPU parity at the sizes BASELINE.json quotes (configs 2, 3 and 4), with the tile table the
+autotuner picks at those sizes, and the tight versions of the reduced-precision checks:
+the HIP path against an oracle that rounds at the same storage points (oracle.quantize).
+
+The float64 oracle is run on a sample of the frames / windows so that the file stays within a
+couple of minutes; every sampled element is compared, not a statistic.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import Config
+from human_dynamics_amd import assets
+
+pytestmark = pytest.mark.gpu
+F64 = torch.float64
+
+
+def _oracle():
+    from oracle import hmmr_oracle as O
+    return O
+
+
+@pytest.fixture(scope="module")
+def engines(weights, smpl_consts, gpu_device):
+    from human_dynamics_amd.engine import HmmrEngine
+    return {dt: HmmrEngine(weights, smpl_consts, dtype=dt, device=gpu_device) for dt in ("bf16x3", "bf16", "f32")}
+
+
+# --------------------------------------------------------------------------- config 2
+@pytest.mark.parametrize("dt,emulate,tol_rel", [("bf16x3", None, 5e-5), ("bf16x3", "bf16x3", 5e-6), ("f32", None, 5e-6)])
+def test_config2_resnet_batch64(engines, weights, dt, emulate, tol_rel):
+    """BASELINE config 2: batch = 64 frames through the ResNet; phi against the float64 oracle on every
+    8th frame.  emulate = the oracle rounds operands and stored tensors exactly where that mode does."""
+    O = _oracle()
+    frames = assets.make_synthetic_frames(64, seed=21)
+    phi = engines[dt].resnet(frames).cpu().numpy()
+    assert phi.shape == (64, 2048) and np.isfinite(phi).all()
+    idx = np.arange(0, 64, 8)
+    if emulate is None:
+        ref = O.resnet_v2_50(frames[idx], weights, F64).numpy()
+    else:
+        ref = O.resnet_v2_50_emulated(frames[idx], weights, emulate).numpy()
+    rel = np.linalg.norm(phi[idx] - ref) / np.linalg.norm(ref)
+    err = np.abs(phi[idx] - ref).max()
+    print("config 2 [%s vs oracle%s]: phi rel-L2 %.3e max-abs %.3e" % (dt, "/" + emulate if emulate else "", rel, err))
+    assert rel < tol_rel
+
+
+def test_config2_resnet_batch64_bf16_error_is_the_predicted_size(engines, weights):
+    """bf16 operands: 53 layers of 8-bit roundings in a ReLU network decorrelate under ANY perturbation (a
+    relative 1e-7 nudge of the pre-rounding values moves phi by 1.8e-3 in the emulating oracle itself), so an
+    element-wise match with the emulation is not attainable.  What is: the HIP path's error equals, within
+    +-40 %, the error the rounding model predicts, and the HIP-vs-emulation distance is below both."""
+    O = _oracle()
+    frames = assets.make_synthetic_frames(64, seed=21)
+    phi = engines["bf16"].resnet(frames).cpu().numpy()
+    idx = np.arange(0, 64, 8)
+    exact = O.resnet_v2_50(frames[idx], weights, F64).numpy()
+    emu = O.resnet_v2_50_emulated(frames[idx], weights, "bf16").numpy()
+    nrm = np.linalg.norm(exact)
+    e_hip, e_emu, d = (np.linalg.norm(phi[idx] - exact) / nrm, np.linalg.norm(emu - exact) / nrm,
+                       np.linalg.norm(phi[idx] - emu) / nrm)
+    print("config 2 [bf16]: HIP vs exact %.3e, emulation vs exact %.3e, HIP vs emulation %.3e" % (e_hip, e_emu, d))
+    assert 0.6 * e_emu < e_hip < 1.4 * e_emu and e_hip < 8e-3
+    assert d < 0.75 * max(e_hip, e_emu)
+
+
+# --------------------------------------------------------------------------- config 3
+def test_config3_64_windows(weights, smpl_consts, gpu_device):
+    """BASELINE config 3: 64 windows x T=20 (1280 frames): ResNet + f_movie + IEF in the default
+    (bf16x3) mode; omega_0 and both delta omegas of three sampled windows against the float64 oracle."""
+    from human_dynamics_amd.evaluation.tester import Tester
+    O = _oracle()
+    frames = assets.make_synthetic_frames(1280, seed=31).reshape(64, 20, 224, 224, 3)
+    t = Tester(Config(batch_size=64), weights=weights, smpl=smpl_consts, device=gpu_device)
+    out = t.predict_device(torch.from_numpy(frames).to(gpu_device))
+    om = out["omegas"].cpu().numpy()
+    omd = out["omegas_delta"].cpu().numpy()
+    assert om.shape == (64, 20, 85) and omd.shape == (64, 20, 2, 85)
+    sel = [0, 29, 63]
+    ot = O.OracleTester(weights, smpl_consts, batch_size=len(sel), dtype=F64)
+    ref = ot.predict(frames[sel])
+    e0 = np.abs(om[sel] - ref["omegas"]).max()
+    e1 = np.abs(omd[sel] - ref["omegas_delta"]).max()
+    ev = np.abs(out["verts"].cpu().numpy()[sel] - ref["verts"]).max()
+    print("config 3 [bf16x3]: omegas %.3e omegas_delta %.3e verts %.3e" % (e0, e1, ev))
+    assert e0 < 1e-4 and e1 < 1e-4 and ev < 1e-4
+
+
+# --------------------------------------------------------------------------- config 4
+def _windows_of(frames, starts, T=20, margin=6):
+    """The reference's padded windows (tester.py:281-295) that keep output frames [s, s+8)."""
+    N = len(frames)
+    out = np.zeros((len(starts), T) + frames.shape[1:], np.float32)
+    for k, s in enumerate(starts):
+        for j in range(T):
+            f = s - margin + j
+            if 0 <= f < N:
+                out[k, j] = frames[f]
+    return out
+
+
+C4_STARTS = [0, 96, 168, 248]
+
+
+@pytest.fixture(scope="module")
+def config4_ref(weights, smpl_consts):
+    O = _oracle()
+    frames = assets.make_synthetic_frames(256, seed=41)
+    ot = O.OracleTester(weights, smpl_consts, batch_size=len(C4_STARTS), dtype=F64)
+    return frames, ot.predict(_windows_of(frames, C4_STARTS))
+
+
+@pytest.mark.parametrize("dt,tol", [("bf16x3", 1e-4), ("f32", 1e-4)])
+def test_config4_256_frame_video(weights, smpl_consts, gpu_device, config4_ref, dt, tol):
+    """BASELINE config 4: a 256-frame video through predict_all_images (B=8, T=20 -> 32 windows, the
+    autotuned tile table of a 257-frame ResNet pass): vertices / joints of four sampled windows (first,
+    last, two inside) within 1e-4 of the float64 oracle run on the reference's own padded windows."""
+    from human_dynamics_amd.evaluation.tester import Tester
+    frames, ref = config4_ref
+    t = Tester(Config(batch_size=8), weights=weights, smpl=smpl_consts, dtype=dt, device=gpu_device)
+    res = t.predict_all_images(frames)
+    assert res["verts"].shape == (256, 6890, 3) and res["verts_delta"].shape == (256, 2, 6890, 3)
+    starts = C4_STARTS
+    errs = {}
+    for k in ("verts", "joints", "kps", "omegas", "verts_delta", "joints_delta"):
+        got = np.stack([res[k][s:s + 8] for s in starts])
+        errs[k] = float(np.abs(got - ref[k][:, 6:14]).max())
+    print("config 4 [%s]: " % dt + " ".join("%s %.2e" % kv for kv in sorted(errs.items())))
+    for k, e in errs.items():
+        assert e < tol, (k, e)
+
+
+def test_bf16_mode_against_its_emulation(weights, smpl_consts, gpu_device):
+    """The bf16-operand throughput mode end to end, next to the float64 oracle that rounds at the same
+    storage points."""
+    from human_dynamics_amd.evaluation.tester import Tester
+    O = _oracle()
+    frames = assets.make_synthetic_frames(20, seed=1)[None]
+    t = Tester(Config(batch_size=1), weights=weights, smpl=smpl_consts, dtype="bf16", device=gpu_device)
+    res = t.predict(frames)
+    emu = O.OracleTester(weights, smpl_consts, batch_size=1, dtype=F64, emulate="bf16").predict(frames)
+    exact = O.OracleTester(weights, smpl_consts, batch_size=1, dtype=F64).predict(frames)
+    e_emu = {k: float(np.abs(res[k] - emu[k]).max()) for k in ("verts", "joints", "omegas")}
+    e_ref = {k: float(np.abs(res[k] - exact[k]).max()) for k in ("verts", "joints", "omegas")}
+    print("bf16 end to end: vs its emulation %s; vs the unrounded graph %s" % (e_emu, e_ref))
+    e_pred = {k: float(np.abs(emu[k] - exact[k]).max()) for k in ("verts", "joints", "omegas")}
+    print("bf16 end to end: what the rounding model predicts %s" % e_pred)
+    # (element-wise agreement with the emulation is not attainable, see the config-2 test above: the gate is the
+    #  predicted error SIZE -- 2.5e-2 m instead of round 1's 0.25 m)
+    for k in ("verts", "joints"):
+        assert e_ref[k] < 3.0 * e_pred[k] and e_ref[k] < 2.5e-2, (k, e_ref[k], e_pred[k])
+
+
+# --------------------------------------------------------------------------- fused stem
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+def test_fused_stem_equals_three_kernel_route(weights, gpu_device, dt):
+    """stem.hip (7x7/2 conv + bias + pool1 + unit_1 preact [+ unit_1 conv1] in one launch) against the
+    re-pack + implicit-GEMM + pool route, through the whole ResNet: image-edge tiles, interior tiles
+    and the n_zero tail all feed phi, bit for bit."""
+    from human_dynamics_amd.engine import HmmrEngine, set_debug
+    eng = HmmrEngine(weights, None, dtype=dt, device=gpu_device, autotune=False)
+    x = torch.from_numpy(assets.make_synthetic_frames(9, seed=13)).to(gpu_device)
+    x[3] = 0.0
+    x[4, :7, :, :] = 5.0                     # strong top rows / left columns: edge tiles matter
+    x[4, :, :7, :] = -5.0
+    x[5, -9:, :, :] = 4.0
+    x[5, :, -9:, :] = -4.0
+    try:
+        outs = {}
+        for name, route, no_c1 in (("three_kernel", 1, 0), ("fused", 2, 0), ("fused_no_conv1", 2, 1), ("default", 0, 0)):
+            set_debug(stem_route=route, stem_no_conv1=no_c1)
+            outs[name] = eng.resnet(x, n_zero=2).clone()
+    finally:
+        set_debug()
+    ref = outs["three_kernel"]
+    assert float(ref.abs().max()) > 0.1
+    for name, o in outs.items():
+        assert torch.equal(o, ref), "%s stem route differs from the three-kernel route: max |d| %.3e" % (
+            name, float((o - ref).abs().max()))
+    assert torch.equal(ref[-1], ref[-2]) and torch.equal(ref[-1], ref[3])    # zero images: tail == explicit

@@ -142,3 +142,38 @@ def test_dedup_windowing_equals_literal_on_features(weights, smpl_consts, golden
     strips = T.movie_strips(wins)[:, margin:-margin].reshape(-1, 2048)[:24]
     om0, _ = T.omegas(strips)
     assert np.abs(om0.numpy() - golden_video["omegas"]).max() < 1e-5
+
+
+def test_quantize_models_the_two_storage_formats():
+    """oracle.quantize: bf16 = 8 mantissa bits, bf16x3 = a bf16 hi/lo pair (16 bits); identical to
+    human_dynamics_amd.packing.to_split / from_split on the host side."""
+    from human_dynamics_amd.packing import from_split, to_split
+    x = torch.randn(4, 64, generator=torch.Generator().manual_seed(0), dtype=torch.float64) * 7
+    assert O.quantize(x, None) is x
+    q16, q3 = O.quantize(x, "bf16"), O.quantize(x, "bf16x3")
+    assert float(((q16 - x).abs() / x.abs()).max()) < 2.0 ** -8
+    assert float(((q3 - x).abs() / x.abs()).max()) < 2.0 ** -16
+    assert torch.equal(q3.to(torch.float32), from_split(to_split(x.to(torch.float32))))
+    assert torch.equal(O.quantize(q3, "bf16x3"), q3)            # idempotent
+
+
+def test_storage_emulating_resnet(weights):
+    """resnet_v2_50_emulated: with no rounding it is the plain restatement (folded fp32 BN constants:
+    1e-7); with bf16 / bf16x3 storage it predicts the error SIZE of those HIP modes; and the bf16 chain is
+    chaotic -- a relative 1e-7 nudge before each rounding moves phi by a large fraction of the bf16 error,
+    which is why the GPU tests gate that mode on the error size, not on element-wise agreement."""
+    frames = assets.make_synthetic_frames(1, seed=1)
+    exact = O.resnet_v2_50(frames, weights, torch.float64)
+    rel = lambda a, b: float(torch.linalg.norm(a - b) / torch.linalg.norm(b))
+    assert rel(O.resnet_v2_50_emulated(frames, weights, None), exact) < 1e-6
+    e16 = O.resnet_v2_50_emulated(frames, weights, "bf16")
+    e3 = O.resnet_v2_50_emulated(frames, weights, "bf16x3")
+    assert 1e-3 < rel(e16, exact) < 1e-2 and rel(e3, exact) < 2e-5
+    assert rel(e16, exact) > 200 * rel(e3, exact)
+    orig, g = O.quantize, torch.Generator().manual_seed(0)
+    try:
+        O.quantize = lambda x, em: orig(x if em is None else x * (1 + 1e-7 * torch.randn(x.shape, generator=g, dtype=x.dtype)), em)
+        nudged = O.resnet_v2_50_emulated(frames, weights, "bf16")
+    finally:
+        O.quantize = orig
+    assert rel(nudged, e16) > 0.2 * rel(e16, exact)
