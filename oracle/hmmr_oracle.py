@@ -1,24 +1,27 @@
 """CPU oracle for HMMR's inference hot path -- TEST INFRASTRUCTURE ONLY.
 
-*** PARITY: PARTLY PINNED ***  The reference (akanazawa/human_dynamics) has no tests and no
-golden vectors, and TensorFlow 1.8 / tf-slim cannot be installed in this image (SURVEY.md
-section 8c).  This file is a literal restatement of the reference graph in PyTorch-CPU (float64 or
-float32), written from the reference sources and the TF-1.8 semantics of the un-vendored ops it
-calls.
+*** PARITY: PINNED TO THE REFERENCE'S OWN SOURCE, EXECUTED; TF LAYER SEMANTICS RESTATED ***
+The reference (akanazawa/human_dynamics) has no tests and no golden vectors, and TensorFlow 1.8 /
+tf-slim cannot be installed in this image.  This file is a restatement of the
+reference graph in PyTorch-CPU (float64 or float32), written from the reference sources and the TF-1.8
+semantics of the un-vendored ops it calls.  It is pinned as follows.
 
-  * PINNED to the reference's own source: smpl_forward / batch_rodrigues /
-    batch_global_rigid_transformation / batch_orth_proj_idrot, the OmegasPred container semantics
-    (smpl_outputs), the sliding-window arithmetic, and the WIRING + checkpoint variable names of
-    az_fc2_groupnorm / az_fc_block2 and batch_pred_omega / call_hmr_ief / hmr_ief.
-    tests/golden/make_reference_golden.py imports src/tf_smpl/*, src/omega.py, src/models.py and
-    Tester.predict_all_images from the reference tree and EXECUTES them on a NumPy stand-in for
-    the TF ops they call (oracle/tf_shim.py); this oracle agrees with those outputs to 1e-9 or
-    better (tests/test_reference_golden.py).
-  * UNPINNED (restatement only): resnet_v2_50 (its wiring lives in tf.contrib.slim, outside the
-    reference tree), and the SEMANTICS of the three tf.contrib layers under f_movie / IEF
-    (group_norm, conv2d SAME, fully_connected), which tf_shim.py restates from TF 1.8.  These are
-    pinned only by the algebraic known-answer tests in tests/test_oracle.py and by the fixtures this
-    file generated itself (tests/golden/window_b1_t20.npz, video_n24_b2_t20.npz).
+  * Reference source EXECUTED (tests/golden/make_reference_golden.py, make_resnet_golden.py import the
+    files from /root/reference and run them unmodified, in float64, on oracle/tf_shim.py, a NumPy
+    stand-in for the TF ops and tf.contrib layers they call); this oracle agrees with the outputs to 1e-9
+    or better (tests/test_reference_golden.py):
+      - src/tf_smpl/*, src/omega.py: smpl_forward / batch_rodrigues / batch_global_rigid_transformation
+        / batch_orth_proj_idrot and the OmegasPred container semantics (smpl_outputs);
+      - Tester.predict_all_images: the sliding-window arithmetic;
+      - src/models.py: az_fc2_groupnorm / az_fc_block2, batch_pred_omega / call_hmr_ief / hmr_ief
+        (wiring + checkpoint variable names), fc2_res, and encoder_resnet -- the latter on
+        oracle/slim_resnet_v2.py, a function-for-function transcription of slim's resnet_v2.py /
+        resnet_utils.py kept apart from this file: phi and all 17 collected unit outputs agree to 1e-12.
+  * What remains a restatement (it lives inside TensorFlow, which cannot run here): the SEMANTICS of the
+    tf.contrib layers -- conv2d SAME/VALID, batch_norm (inference), max_pool2d SAME, group_norm,
+    fully_connected -- stated once in oracle/tf_shim.py (NumPy, explicit padding arithmetic) and once here
+    (PyTorch conv2d / pooling): two independent implementations that agree, plus the algebraic
+    known-answer tests of tests/test_oracle.py.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
 this module.  The product path (human_dynamics_amd) never does.

@@ -10,8 +10,10 @@ pins the SMPL / projection / container / windowing rows of the path to the refer
 instead of to a restatement.  Every op below has exactly the documented TF semantics; nothing here
 is specific to the reference.
 
-Not covered (so those rows stay pinned by the restated oracle only): tf.contrib.slim's
-resnet_v2_50, tf.contrib.layers.group_norm / conv2d, slim.fully_connected.
+The tf.contrib layers the reference calls (slim conv2d / batch_norm / max_pool2d / fully_connected /
+arg_scope, contrib group_norm) are restated further down with their TF-1.8 semantics, and slim's
+resnet_v2 / resnet_utils network definition is transcribed in oracle/slim_resnet_v2.py, so that the
+reference's own encoder_resnet (src/models.py:50-77) can be executed as well.
 """
 from __future__ import annotations
 
@@ -287,14 +289,96 @@ _SCOPES = []
 AUTO_REUSE = "AUTO_REUSE"
 
 
+class _Scope(str):
+    """What `with tf.variable_scope(...) as sc` binds: usable as the scope string, with the two attributes
+    slim's resnet_v2 reads."""
+    @property
+    def name(self):
+        return str(self)
+
+    @property
+    def original_name_scope(self):
+        return str(self) + "/"
+
+
 @contextlib.contextmanager
 def variable_scope(name_or_scope=None, default_name=None, values=None, reuse=None, **kw):   # noqa: F811
     name = name_or_scope if name_or_scope is not None else default_name
     _SCOPES.append(str(name))
     try:
-        yield "/".join(_SCOPES)
+        yield _Scope("/".join(_SCOPES))
     finally:
         _SCOPES.pop()
+
+
+# ---- slim.arg_scope / add_arg_scope (tensorflow/contrib/framework/python/ops/arg_scope.py) -------------
+_ARG_SCOPES = [{}]          # stack of {function key: {kwarg: value}}
+
+
+def _key(fn):
+    return getattr(fn, "_key_op", None) or (fn.__module__, fn.__name__)
+
+
+@contextlib.contextmanager
+def arg_scope(list_ops_or_scope, **kwargs):
+    """`with arg_scope([ops], **defaults)` or `with arg_scope(saved_scope_dict)` (re-enter a scope)."""
+    if isinstance(list_ops_or_scope, dict):
+        assert not kwargs
+        _ARG_SCOPES.append({k: dict(v) for k, v in list_ops_or_scope.items()})
+        try:
+            yield list_ops_or_scope
+        finally:
+            _ARG_SCOPES.pop()
+        return
+    cur = {k: dict(v) for k, v in _ARG_SCOPES[-1].items()}
+    for op in list_ops_or_scope:
+        assert hasattr(op, "_key_op"), "%r is not decorated with @add_arg_scope" % (op,)
+        cur.setdefault(_key(op), {}).update(kwargs)
+    _ARG_SCOPES.append(cur)
+    try:
+        yield cur
+    finally:
+        _ARG_SCOPES.pop()
+
+
+def add_arg_scope(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        defaults = _ARG_SCOPES[-1].get(_key(wrapped))
+        if defaults:
+            merged = dict(defaults)
+            merged.update(kwargs)          # explicit keyword arguments win over the scope's
+            kwargs = merged
+        return fn(*args, **kwargs)
+    wrapped._key_op = (fn.__module__, fn.__name__)
+    return wrapped
+
+
+# ---- slim.utils: outputs collections (tensorflow/contrib/layers/python/layers/utils.py) ----------------
+COLLECTIONS = {}            # {collection name: [(alias, Tensor)]}
+
+
+class _Utils(object):
+    @staticmethod
+    def collect_named_outputs(collections, alias, outputs):
+        if collections:
+            COLLECTIONS.setdefault(collections, []).append((alias, outputs))
+        return outputs
+
+    @staticmethod
+    def convert_collection_to_dict(collection, clear_collection=False):
+        return dict(COLLECTIONS.get(collection, []))
+
+    @staticmethod
+    def last_dimension(shape, min_rank=1):
+        dims = shape.as_list() if hasattr(shape, "as_list") else list(shape)
+        assert len(dims) >= min_rank
+        return dims[-1]
+
+
+slim_utils = _Utils()
 
 
 def _var(scope, leaf):
@@ -322,23 +406,106 @@ def _dropout(inputs, keep_prob=0.5, is_training=True, scope=None, **kw):
     return inputs
 
 
-def _conv2d(inputs, num_outputs, kernel_size, stride=1, padding="SAME", data_format="NHWC", rate=1,
-            activation_fn=_relu, weights_initializer=None, scope=None, reuse=None, **kw):
-    """tf.contrib.layers.conv2d on NHWC with stride 1 / rate 1: SAME zero padding, + bias."""
-    assert padding == "SAME" and data_format == "NHWC" and stride == 1 and rate == 1
-    w, b = _var(scope, "weights"), _var(scope, "biases")            # HWIO
+def _same_pads(size, k, s):
+    """TF 'SAME': out = ceil(size / s); total pad = max((out-1)*s + k - size, 0), the smaller half first."""
+    out = -(-size // s)
+    total = max((out - 1) * s + k - size, 0)
+    return out, total // 2, total - total // 2
+
+
+def _pair(v):
+    return [int(e) for e in v] if isinstance(v, (list, tuple)) else [int(v), int(v)]
+
+
+@add_arg_scope
+def _conv2d(inputs, num_outputs, kernel_size, stride=1, padding="SAME", data_format=None, rate=1,
+            activation_fn=_relu, normalizer_fn=None, normalizer_params=None, weights_initializer=None,
+            weights_regularizer=None, biases_initializer="zeros", biases_regularizer=None, reuse=None,
+            variables_collections=None, outputs_collections=None, trainable=True, scope=None, **kw):
+    """tf.contrib.layers.conv2d == slim.conv2d (layers.py `convolution`), NHWC, rate 1:
+    outputs = conv(inputs, weights) with 'SAME' or 'VALID' padding; then EITHER normalizer_fn(outputs,
+    **normalizer_params) (no bias) OR + biases; then activation_fn.  Variables live under `scope`."""
+    assert data_format in (None, "NHWC") and rate == 1 and padding in ("SAME", "VALID")
+    kh, kw_ = _pair(kernel_size)
+    sy, sx = _pair(stride)
+    with variable_scope(scope, "Conv") as sc:
+        w = _var_here("weights")                                    # HWIO
+        x = _a(inputs)
+        assert w.shape[:2] == (kh, kw_) and w.shape[2] == x.shape[3] and w.shape[3] == int(num_outputs), (w.shape, x.shape)
+        H, W = x.shape[1], x.shape[2]
+        if padding == "SAME":
+            Ho, pt, pb = _same_pads(H, kh, sy)
+            Wo, pl, pr = _same_pads(W, kw_, sx)
+            xp = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
+        else:
+            Ho, Wo, xp = (H - kh) // sy + 1, (W - kw_) // sx + 1, x
+        y = np.zeros((x.shape[0], Ho, Wo, w.shape[3]), DTYPE)
+        for i in np.arange(kh):
+            for j in np.arange(kw_):
+                y = y + np.matmul(xp[:, i:i + (Ho - 1) * sy + 1:sy, j:j + (Wo - 1) * sx + 1:sx, :], w[i, j])
+        y = Tensor(y)
+        if normalizer_fn is not None:
+            y = normalizer_fn(y, **(normalizer_params or {}))
+        elif biases_initializer is not None:
+            y = Tensor(_a(y) + _var_here("biases"))
+        if activation_fn is not None:
+            y = activation_fn(y)
+        return slim_utils.collect_named_outputs(outputs_collections, sc.name, y)
+
+
+def _var_here(leaf):
+    """Variable `leaf` of the innermost variable_scope."""
+    name = "/".join(_SCOPES + [leaf])
+    USED_VARIABLES.append(name)
+    if name not in WEIGHTS:
+        raise KeyError("the reference asked for variable %r which the weight dict lacks" % name)
+    return np.asarray(WEIGHTS[name], DTYPE)
+
+
+@add_arg_scope
+def _batch_norm(inputs, decay=0.999, center=True, scale=False, epsilon=0.001, activation_fn=None,
+                param_initializers=None, updates_collections=None, is_training=True, reuse=None,
+                variables_collections=None, outputs_collections=None, trainable=True, scope=None, **kw):
+    """slim.batch_norm (layers.py `batch_norm`) in inference mode: is_training=False normalises with the
+    moving statistics: gamma * (x - moving_mean) * rsqrt(moving_variance + epsilon) + beta; default scope
+    'BatchNorm'; `gamma` exists only with scale=True."""
+    assert not is_training, "inference only"
+    with variable_scope(scope, "BatchNorm") as sc:
+        x = _a(inputs)
+        beta = _var_here("beta") if center else 0.0
+        gamma = _var_here("gamma") if scale else 1.0
+        mean, var = _var_here("moving_mean"), _var_here("moving_variance")
+        y = Tensor((x - mean) / np.sqrt(var + epsilon) * gamma + beta)
+        if activation_fn is not None:
+            y = activation_fn(y)
+        return slim_utils.collect_named_outputs(outputs_collections, sc.name, y)
+
+
+@add_arg_scope
+def _max_pool2d(inputs, kernel_size, stride=2, padding="VALID", data_format=None, outputs_collections=None,
+                scope=None):
+    """slim.max_pool2d = nn.max_pool; 'SAME' pads like _same_pads and padded positions never win."""
+    assert data_format in (None, "NHWC") and padding in ("SAME", "VALID")
+    kh, kw_ = _pair(kernel_size)
+    sy, sx = _pair(stride)
     x = _a(inputs)
-    kh, kw_, cin, cout = w.shape
-    assert [kh, kw_] == [int(k) for k in kernel_size] and cout == int(num_outputs)
-    ph, pw = kh - 1, kw_ - 1
-    xp = np.pad(x, ((0, 0), (ph // 2, ph - ph // 2), (pw // 2, pw - pw // 2), (0, 0)))
     H, W = x.shape[1], x.shape[2]
-    y = np.zeros(x.shape[:3] + (cout,), DTYPE) + b
+    if padding == "SAME":
+        Ho, pt, pb = _same_pads(H, kh, sy)
+        Wo, pl, pr = _same_pads(W, kw_, sx)
+        xp = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)), constant_values=-np.inf)
+    else:
+        Ho, Wo, xp = (H - kh) // sy + 1, (W - kw_) // sx + 1, x
+    y = np.full((x.shape[0], Ho, Wo, x.shape[3]), -np.inf, DTYPE)
     for i in np.arange(kh):
         for j in np.arange(kw_):
-            y = y + np.matmul(xp[:, i:i + H, j:j + W, :], w[i, j])
-    y = Tensor(y)
-    return activation_fn(y) if activation_fn is not None else y
+            y = np.maximum(y, xp[:, i:i + (Ho - 1) * sy + 1:sy, j:j + (Wo - 1) * sx + 1:sx, :])
+    return slim_utils.collect_named_outputs(outputs_collections, scope, Tensor(y))
+
+
+def reduce_mean(x, axis=None, keepdims=None, name=None, keep_dims=None):
+    ax = None if axis is None else tuple(int(a) for a in np.atleast_1d(_a(axis)))
+    return Tensor(np.mean(_a(x), axis=ax, keepdims=bool(keepdims or keep_dims)))
 
 
 def _group_norm(inputs, groups=32, channels_axis=-1, reduction_axes=(-3, -2), center=True, scale=True,
@@ -391,15 +558,26 @@ def install(precision=np.float64):
     put("tensorflow.contrib", contrib)
     for sub in ("tensorflow.contrib.slim", "tensorflow.contrib.layers", "tensorflow.contrib.layers.python",
                 "tensorflow.contrib.layers.python.layers", "tensorflow.contrib.layers.python.layers.initializers",
-                "tensorflow.contrib.framework"):
+                "tensorflow.contrib.framework", "tensorflow.contrib.slim.python", "tensorflow.contrib.slim.python.slim",
+                "tensorflow.contrib.slim.python.slim.nets"):
         m = types.ModuleType(sub)
         m.variance_scaling_initializer = lambda *a, **k: None
+        m.l2_regularizer = lambda *a, **k: None
         m.fully_connected, m.dropout = _fully_connected, _dropout
         m.conv2d, m.group_norm = _conv2d, _group_norm
+        m.batch_norm, m.max_pool2d = _batch_norm, _max_pool2d
+        m.arg_scope, m.add_arg_scope = arg_scope, add_arg_scope
+        m.utils = slim_utils
         m.get_variables = lambda *a, **k: []
         put(sub, m)
         setattr(contrib, sub.split(".")[2], sys.modules[sub]) if sub.count(".") == 2 else None
     me.contrib = contrib
+    # slim's network definition (tf.contrib.slim.python.slim.nets.{resnet_utils,resnet_v2}), transcribed
+    from oracle import slim_resnet_v2
+    nets = sys.modules["tensorflow.contrib.slim.python.slim.nets"]
+    nets.resnet_v2, nets.resnet_utils = slim_resnet_v2.resnet_v2_module, slim_resnet_v2.resnet_utils
+    put("tensorflow.contrib.slim.python.slim.nets.resnet_v2", slim_resnet_v2.resnet_v2_module)
+    put("tensorflow.contrib.slim.python.slim.nets.resnet_utils", slim_resnet_v2.resnet_utils)
     for stub in ("deepdish", "ipdb", "cv2"):
         put(stub, types.ModuleType(stub))
     return added

@@ -165,3 +165,84 @@ def test_hip_temporal_and_ief_equal_reference_wiring(ref_ti, weights, smpl_const
              np.abs(om[2] - ref_ti["delta_p5"]).max())
     print("HIP (fp32 operands) vs reference models.py wiring: strips %.2e  omegas %.2e" % (e1, e2))
     assert e1 < 1e-4 and e2 < 1e-4
+
+
+# ------------------------------------------------------------------ image encoder (src/models.py:50-77) + fc2_res
+# tests/golden/make_resnet_golden.py EXECUTES the reference's encoder_resnet on a transcription of slim's
+# resnet_v2.py / resnet_utils.py (oracle/slim_resnet_v2.py) and the shim's slim layers: NumPy arithmetic that
+# shares no code with the oracle's PyTorch restatement.
+@pytest.fixture(scope="module")
+def ref_resnet():
+    return dict(np.load(os.path.join(GOLDEN, "reference_resnet.npz")))
+
+
+def _resnet_frames():
+    frames = assets.make_synthetic_frames(2, seed=1)
+    frames[1] = 0.0                        # the zero padding image of predict_all_images
+    return frames
+
+
+def _sample(a):
+    sh, sc = max(1, a.shape[1] // 8), max(1, a.shape[3] // 32)
+    return a[:, ::sh, ::sh, ::sc]
+
+
+def test_resnet_variable_names_are_the_ones_slim_asks_for(ref_resnet, weights):
+    used = [str(u) for u in ref_resnet["used_variables"]]
+    assert len(used) == 270 and all(u in weights for u in used)
+    assert len([k for k in weights if k.startswith("resnet_v2_50/")]) == 270      # and nothing is left over
+    assert "resnet_v2_50/block3/unit_6/bottleneck_v2/conv2/BatchNorm/moving_variance" in used
+    assert "resnet_v2_50/block4/unit_1/bottleneck_v2/shortcut/biases" in used and "resnet_v2_50/postnorm/gamma" in used
+
+
+def test_oracle_resnet_equals_reference_encoder_resnet(ref_resnet, weights):
+    """phi and every bottleneck unit's output: the PyTorch restatement against the reference's
+    encoder_resnet executed on the slim transcription (float64 both)."""
+    phi, ep = O.resnet_v2_50(_resnet_frames(), weights, F64, return_endpoints=True)
+    assert np.abs(phi.numpy() - ref_resnet["phi"]).max() < 1e-12
+    names = [str(n) for n in ref_resnet["end_points"]]
+    assert len(names) == 73
+    checked = 0
+    for key, t in ep.items():
+        alias = {"conv1": "resnet_v2_50/conv1"}.get(key, "resnet_v2_50/%s/bottleneck_v2" % key)
+        if alias not in names:
+            continue                        # pool1 is not one of slim's collected end points
+        got = _sample(t.permute(0, 2, 3, 1).numpy())
+        assert got.shape == ref_resnet["ep:" + alias].shape, alias
+        assert np.abs(got - ref_resnet["ep:" + alias]).max() < 1e-11, alias
+        checked += 1
+    assert checked == 17                    # conv1 + 16 units
+
+
+def test_oracle_fc2_res_equals_reference(weights):
+    g = dict(np.load(os.path.join(GOLDEN, "reference_fc2_res.npz")))
+    wh = assets.make_synthetic_weights(0, with_hallucinator=True)
+    assert sorted(str(u) for u in g["used_variables"]) == sorted(k for k in wh if k.startswith("fc2_res/"))
+    assert np.abs(O.fc2_res(g["phi"], wh, F64).numpy() - g["out"]).max() < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt,tol", [("f32", 2e-5), ("bf16x3", 2e-4)])
+def test_hip_resnet_equals_reference_encoder_resnet(ref_resnet, weights, gpu_device, dt, tol):
+    from human_dynamics_amd.engine import HmmrEngine
+    eng = HmmrEngine(weights, None, dtype=dt, device=gpu_device)
+    phi = eng.resnet(_resnet_frames()).cpu().numpy()
+    err = np.abs(phi - ref_resnet["phi"]).max()
+    rel = np.linalg.norm(phi - ref_resnet["phi"]) / np.linalg.norm(ref_resnet["phi"])
+    print("HIP ResNet (%s) vs reference encoder_resnet: max-abs %.2e rel-L2 %.2e" % (dt, err, rel))
+    assert err < tol
+    phi_z = eng.resnet(_resnet_frames()[:1], n_zero=1).cpu().numpy()          # the n_zero tail == an explicit zero image
+    assert np.array_equal(phi_z, phi)
+
+
+@pytest.mark.gpu
+def test_hip_hallucinator_equals_reference_fc2_res(gpu_device):
+    from human_dynamics_amd.engine import HmmrEngine
+    g = dict(np.load(os.path.join(GOLDEN, "reference_fc2_res.npz")))
+    wh = assets.make_synthetic_weights(0, with_hallucinator=True)
+    for dt, tol in (("f32", 2e-5), ("bf16x3", 1e-4)):
+        eng = HmmrEngine(wh, None, dtype=dt, device=gpu_device)
+        out = eng.hallucinate(g["phi"].astype(np.float32)).cpu().numpy()
+        err = np.abs(out - g["out"]).max()
+        print("HIP fc2_res (%s) vs reference: %.2e" % (dt, err))
+        assert err < tol
