@@ -119,13 +119,21 @@ class ShardedPredictor(object):
     input and replays it afterwards.  (Measured equal to eager launches: the step is GPU-bound.)"""
 
     def __init__(self, tester, n_frames, rank=None, world_size=None, group=None, use_graph=False,
-                 overlap_gather=False, pipeline=False):
+                 overlap_gather=False, pipeline=False, gather_mode="records"):
         if world_size is None:
             world_size = dist.get_world_size() if dist.is_initialized() else 1
         if rank is None:
             rank = dist.get_rank() if dist.is_initialized() else 0
         self.tester, self.group = tester, group
         self.plan = ShardPlan(n_frames, tester.batch_size, tester.sequence_length, tester.fov, world_size, rank)
+        # gather_mode 'theta' (world_size > 1): the ranks exchange only the regressed omegas (R x 85 floats per
+        # frame instead of the 63 K floats of a full record) and every rank evaluates SMPL for the WHOLE video.
+        # Same kernels on the same per-frame operands => the same bits as 'records'; it trades 250x less xGMI
+        # traffic for world_size x the SMPL work, and pays when the gather is not hidden behind the next step.
+        assert gather_mode in ("records", "theta")
+        self.theta = gather_mode == "theta" and world_size > 1
+        if self.theta:
+            overlap_gather = False              # the gathered omegas are consumed at once (SMPL), nothing to overlap
         self.overlap = bool(overlap_gather) and world_size > 1
         self.pipeline = bool(pipeline) and tester.engine.device.type == "cuda"
         self.use_graph = bool(use_graph) and not self.overlap and not self.pipeline
@@ -143,8 +151,9 @@ class ShardedPredictor(object):
         self.s_tail = (torch.cuda.Stream(device=eng.device, priority=int(os.environ.get("HMMR_TAIL_PRIORITY", "0")))
                        if self.pipeline else None)     # env: dev A/B switch
         self.done = [None] * nbuf
-        self.locals = [torch.zeros((p.out_per_rank, self.rec_len), dtype=torch.float32, device=eng.device)
-                       for _ in range(nbuf)]
+        self.n_reg = 1 + len(tester.delta_t_values)
+        self.locals = [torch.zeros((p.out_per_rank, self.n_reg * 85 if self.theta else self.rec_len),
+                                   dtype=torch.float32, device=eng.device) for _ in range(nbuf)]
         self.fulls = [None] * nbuf
         self.pending = [None] * nbuf
         self.calls = 0
@@ -158,8 +167,27 @@ class ShardedPredictor(object):
         """frames [f1-f0,224,224,3] on the device -> out (packed records of this rank)."""
         phi_all = self.tester.features(frames, n_zero=1)            # last row = feature of the zero image
         if self.idx is not None:
-            self.tester.predict_strips_records(phi_all[self.idx], self.plan.o1 - self.plan.o0, out=out)
+            self._tail(phi_all, out)
         return out
+
+    def _tail(self, phi_all, out):
+        """Everything after the ResNet for this rank's windows -> `out` (records, or omegas in theta mode)."""
+        n = self.plan.o1 - self.plan.o0
+        if not self.theta:
+            self.tester.predict_strips_records(phi_all[self.idx], n, out=out)
+        else:
+            om = self.tester.predict_strips_omegas(phi_all[self.idx], n)            # [R, n, 85]
+            out[:n] = om.permute(1, 0, 2).reshape(n, -1)
+
+    def _gather_theta(self, local, slot):
+        """theta mode: all-gather the omegas, then SMPL + record assembly for every frame of the video."""
+        p = self.plan
+        full_om = torch.empty((p.world_size * p.out_per_rank, local.shape[1]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(full_om, local.contiguous(), group=self.group)
+        om = full_om[:p.n_frames].reshape(p.n_frames, self.n_reg, 85).permute(1, 0, 2).contiguous()
+        if self.fulls[slot] is None:
+            self.fulls[slot] = torch.empty((p.n_frames, self.rec_len), dtype=torch.float32, device=local.device)
+        return self.tester.records_from_omegas(om, out=self.fulls[slot])[:p.n_frames]
 
     def run_local(self, frames, out=None):
         eng = self.tester.engine
@@ -202,8 +230,10 @@ class ShardedPredictor(object):
                 self.pending[slot].wait()
                 self.pending[slot] = None
             if self.idx is not None:
-                self.tester.predict_strips_records(phi_all[self.idx], p.o1 - p.o0, out=out)
-            if gather and p.world_size > 1:
+                self._tail(phi_all, out)
+            if gather and self.theta:
+                out = self._gather_theta(out, slot)
+            elif gather and p.world_size > 1:
                 if self.fulls[slot] is None:
                     self.fulls[slot] = torch.empty((p.world_size * p.out_per_rank, self.rec_len), dtype=out.dtype,
                                                    device=out.device)
@@ -228,6 +258,8 @@ class ShardedPredictor(object):
         local = self.run_local(frames, self.locals[slot])
         if not gather:
             return local
+        if self.theta:
+            return self._gather_theta(local, slot)
         if not self.overlap:
             return all_gather_outputs(local, p, self.group)
         if self.fulls[slot] is None:

@@ -36,8 +36,12 @@ def _debug_from_env():
     never reads the environment."""
     e = os.environ.get("HMMR_STEM", "")
     c1 = os.environ.get("HMMR_STEM_C1", "1")
-    if e or c1 == "0":
+    if e or c1 == "0" or _debug_from_env.was_set:
         set_debug(stem_route={"u": 1, "f": 2}.get(e[:1], 0), stem_no_conv1=int(c1 == "0"))
+        _debug_from_env.was_set = bool(e or c1 == "0")
+
+
+_debug_from_env.was_set = False
 
 
 def _dt(d):
@@ -209,7 +213,7 @@ class HmmrEngine(object):
                 "hmmr_resnet50_fwd")
         return np.frombuffer(pm, dtype=np.float32).astype(np.float64) if prof else None
 
-    def resnet(self, images, prof=False, n_zero=0):
+    def resnet(self, images, prof=False, n_zero=0, out=None):
         """images [n,224,224,3] fp32 (device) -> phi [n + n_zero,2048] fp32; the last
         n_zero rows are the features of all-zero images (the padding frames of
         predict_all_images), encoded in the same pass.  encoder_resnet, src/models.py:50-77.
@@ -223,7 +227,9 @@ class HmmrEngine(object):
         n = images.shape[0]
         assert n == 0 or tuple(images.shape[1:]) == (224, 224, 3), images.shape
         nt = n + n_zero
-        phi = torch.empty((nt, 2048), dtype=torch.float32, device=self.device)
+        if out is not None:                                  # caller-owned feature rows (a slice of a longer video's phi)
+            assert out.is_cuda and out.dtype == torch.float32 and out.shape == (nt, 2048) and out.is_contiguous()
+        phi = out if out is not None else torch.empty((nt, 2048), dtype=torch.float32, device=self.device)
         if self.resnet_chunk > 0:                            # dev switch: sequential chunks, heuristic tiles
             chunk, i = self.resnet_chunk, 0
             prof_tot = np.zeros(L.RESNET_PROF_SLOTS, np.float64) if prof else None

@@ -1,0 +1,137 @@
+"""Host-in / host-out `predict_all_images` as a three-stream pipeline.
+
+The reference contract is host ndarray in, dict of host ndarrays out (src/evaluation/tester.py:
+239-241, 257; demo_video.py:172 hands over the whole cropped video).  Through that surface the
+path is bound by PCIe and host copies unless they overlap the kernels, so the video is cut into
+chunks of `chunk` frames and three HIP streams run side by side:
+
+    copy-in stream   chunk k+1: pinned staging buffer -> HBM        (hipMemcpyAsync, double-buffered)
+    compute stream   chunk k  : [uint8 -> float crop] -> ResNet -> phi;  then the per-window tail
+                                (f_movie, IEF, 3 x SMPL) of chunk k-1, whose halo is now encoded
+    copy-out stream  chunk k-2: record fields -> one pinned host array per output key
+
+Only the host-side staging copy (pageable user array -> pinned buffer) occupies the Python thread,
+while the GPU works on the previous chunk.  Every kernel sees exactly the operands it sees in the
+one-shot path (per-frame ResNet, per-window tail), so the result is byte-identical to
+`Tester.predict_all_images(..., stream=False)`; tested on the GPU.
+
+uint8 input ([N,224,224,3], already cropped): uploaded as bytes (4x less H2D) and converted on
+the device by `hmmr_crop_frames` with the identity geometry, i.e. ((x / 255) - 0.5) * 2 evaluated in
+float64 like src/evaluation/run_video.py:73.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+
+OUTPUT_KEYS = ("cams", "joints", "kps", "poses", "shapes", "verts", "omegas")
+
+
+class HostStreamer(object):
+    """Re-usable pinned staging buffers and copy streams of one Tester."""
+
+    def __init__(self, tester, chunk=256):
+        self.t = tester
+        self.eng = tester.engine
+        self.dev = self.eng.device
+        self.margin = (tester.fov - 1) // 2
+        self.g = tester.sequence_length - 2 * self.margin
+        self.chunk = max(self.g, (int(chunk) // self.g) * self.g)          # whole windows per chunk
+        self.s_in = torch.cuda.Stream(device=self.dev)
+        self.s_out = torch.cuda.Stream(device=self.dev)
+        self._pin, self._dev_in, self._geom = {}, {}, None
+        self.layout, self.rec_len = tester.record_layout()
+
+    def _staging(self, dtype):
+        if dtype not in self._pin:
+            shape = (self.chunk, 224, 224, 3)
+            self._pin[dtype] = [torch.empty(shape, dtype=dtype).pin_memory() for _ in range(2)]
+            self._dev_in[dtype] = [torch.empty(shape, dtype=dtype, device=self.dev) for _ in range(2)]
+        return self._pin[dtype], self._dev_in[dtype]
+
+    def _to_float(self, u8, n):
+        """uint8 crops on the device -> float32 in [-1, 1] (identity geometry of hmmr_crop_frames)."""
+        if self._geom is None:
+            self._geom = torch.tensor([[224, 224, 0, 0]] * self.chunk, dtype=torch.int32, device=self.dev)
+        out = torch.empty((n, 224, 224, 3), dtype=torch.float32, device=self.dev)
+        L.check(self.eng.lib.hmmr_crop_frames(u8.data_ptr(), self._geom.data_ptr(), n, 224, 224, out.data_ptr(),
+                                              torch.cuda.current_stream(self.dev).cuda_stream), "hmmr_crop_frames")
+        return out
+
+    def run(self, all_images, want=None):
+        t, eng, dev = self.t, self.eng, self.dev
+        N = len(all_images)
+        keys = [k + s for s in ("", "_delta") for k in OUTPUT_KEYS]
+        if want is not None:
+            unknown = [k for k in want if k not in keys]
+            if unknown:
+                raise KeyError("unknown output keys %s" % unknown)
+            keys = [k for k in keys if k in want]
+        fields = {k: (shp, off, size) for k, shp, off, size in self.layout if k in keys}
+        if N == 0:
+            return {k: np.zeros((0,) + fields[k][0], np.float32) for k in keys}
+        src = all_images if isinstance(all_images, np.ndarray) else np.asarray(all_images)
+        if src.dtype != np.uint8:
+            src = src if src.dtype == np.float32 else src.astype(np.float32)
+        assert src.shape[1:] == (224, 224, 3), src.shape
+        tdt = torch.uint8 if src.dtype == np.uint8 else torch.float32
+        pin, dev_in = self._staging(tdt)
+        C, g, margin, T = self.chunk, self.g, self.margin, t.sequence_length
+        n_chunks = (N + C - 1) // C
+        cur = torch.cuda.current_stream(dev)
+        phi = torch.empty((N + 1, 2048), dtype=torch.float32, device=dev)      # row N: the zero padding image
+        host = {k: torch.empty((N,) + fields[k][0], dtype=torch.float32).pin_memory() for k in keys}
+        recs = [torch.empty((C, self.rec_len), dtype=torch.float32, device=dev) for _ in range(2)]
+        in_free = [None, None]          # compute finished reading dev_in[slot]
+        out_free = [None, None]         # copy-out finished reading recs[slot]
+        ar_T = torch.arange(T, device=dev)
+        eng.resnet(torch.empty((0, 224, 224, 3), dtype=torch.float32, device=dev), n_zero=1, out=phi[N:N + 1])                                 # the zero padding image, once, up front
+        for k in range(n_chunks + 1):
+            if k < n_chunks:
+                lo, hi = k * C, min(N, (k + 1) * C)
+                n, slot = hi - lo, k % 2
+                if in_free[slot] is not None:
+                    in_free[slot].synchronize()                      # the staging pair is free again (chunk k-2 is encoded)
+                pin[slot][:n].copy_(torch.from_numpy(src[lo:hi]))    # the only host-side work of the loop
+                with torch.cuda.stream(self.s_in):
+                    dev_in[slot][:n].copy_(pin[slot][:n], non_blocking=True)
+                    landed = torch.cuda.Event()
+                    landed.record(self.s_in)
+                cur.wait_event(landed)
+                frames = dev_in[slot][:n]
+                if tdt == torch.uint8:
+                    frames = self._to_float(frames, n)
+                eng.resnet(frames, out=phi[lo:hi])
+                in_free[slot] = torch.cuda.Event()
+                in_free[slot].record(cur)
+            if k >= 1:
+                # tail of output frames [o0, o1): their windows reach margin frames into chunk k, encoded just above
+                self._tail(k - 1, N, phi, recs, out_free, host, fields, keys, ar_T)
+        self.s_out.synchronize()
+        cur.synchronize()
+        return {k: host[k].numpy() for k in keys}
+
+    def _tail(self, j, N, phi, recs, out_free, host, fields, keys, ar_T):
+        t, eng, dev = self.t, self.eng, self.dev
+        C, g, margin = self.chunk, self.g, self.margin
+        cur = torch.cuda.current_stream(dev)
+        o0, o1 = j * C, min(N, (j + 1) * C)
+        w0, w1 = o0 // g, (o1 + g - 1) // g
+        f = (torch.arange(w0, w1, device=dev)[:, None] * g - margin) + ar_T[None, :]
+        idx = torch.where((f >= 0) & (f < N), f, torch.full_like(f, N))
+        slot = j % 2
+        if out_free[slot] is not None:
+            cur.wait_event(out_free[slot])                          # the previous copy-out of this buffer is done
+        rec = recs[slot]
+        t.predict_strips_records(phi[idx], o1 - o0, out=rec)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        with torch.cuda.stream(self.s_out):
+            self.s_out.wait_event(ready)
+            for k in keys:
+                shp, off, size = fields[k]
+                host[k][o0:o1].copy_(rec[:o1 - o0, off:off + size].reshape((o1 - o0,) + shp), non_blocking=True)
+            out_free[slot] = torch.cuda.Event()
+            out_free[slot].record(self.s_out)

@@ -109,6 +109,7 @@ class Tester(object):
         self.f_image_enc = get_image_encoder()
         self.f_temporal_enc = get_temporal_encoder()
         self.theta_mean = np.asarray(weights["mean_param"], np.float32).reshape(1, 85)
+        self._streamer = None
 
     # ------------------------------------------------------------------------
     def make_omega_pred(self, registry, use_optcam=False, batch_size=None):
@@ -177,15 +178,19 @@ class Tester(object):
         container that writes verts/joints/kps/poses straight into the record
         (the tail of build_test_model + make_fetch_dict, tester.py:196-227, with the
         containers' cams = omega_0's cams, tester.py:211-213)."""
-        from ..dist import unpack_outputs  # noqa: F401  (layout owner)
+        return self.records_from_omegas(self.engine.ief(strips), out)   # [R, n, 85], deltas in sorted order
+
+    def records_from_omegas(self, om, out=None):
+        """omegas [R, n, 85] (present, then the deltas in sorted order) -> packed per-frame records: one SMPL
+        evaluation per container, written in place.  Per-frame independent, so a rank may evaluate it for
+        frames whose omegas another rank regressed (dist.ShardedPredictor, gather_mode='theta')."""
         eng = self.engine
-        n = strips.shape[0]
+        n = om.shape[1]
         layout, rec_len = self.record_layout()
         off = {k: (o, sz) for k, shp, o, sz in layout}
         if out is None:
             out = torch.empty((n, rec_len), dtype=torch.float32, device=eng.device)
         rec = out[:n]
-        om = eng.ief(strips)                                    # [R, n, 85], deltas in sorted order
         cams0 = om[0][:, :3]
         for r, key in enumerate(eng.reg_keys):
             if key == 0:
@@ -250,6 +255,14 @@ class Tester(object):
         kept = strips[:, margin:T - margin].reshape(-1, strips.shape[-1])[:n_keep]
         return self.predict_records(kept, out)
 
+    def predict_strips_omegas(self, windows, n_keep):
+        """As predict_strips_records, stopping at the regressed omegas [R, n_keep, 85]."""
+        T = self.sequence_length
+        margin = (self.fov - 1) // 2
+        strips = self._movie_strips(windows)
+        kept = strips[:, margin:T - margin].reshape(-1, strips.shape[-1])[:n_keep]
+        return self.engine.ief(kept)
+
     def predict_strips_device(self, windows, n_keep):
         from ..dist import unpack_outputs
         if n_keep == 0:
@@ -269,17 +282,31 @@ class Tester(object):
                torch.arange(T, device=phi.device)[None, :])          # window i = padded[i*g : i*g+T]
         return self.predict_strips_device(padded[idx], N)
 
-    def predict_all_images(self, all_images):
+    def predict_all_images(self, all_images, want=None, stream=True):
         """Wrapper to predict an entire sequence with the sliding-window scheme of
         tester.py:260-312: windows of T frames every g = T - (fov-1) frames over
-        the zero-image-padded video, keeping the centre g predictions of each."""
+        the zero-image-padded video, keeping the centre g predictions of each.
+
+        all_images: [N,224,224,3] float32 in [-1,1] (the reference's contract), or uint8 crops (converted on
+        the device with the reference's arithmetic; a quarter of the upload).  Host input runs as a chunked
+        three-stream pipeline (copy-in / kernels / copy-out, evaluation/streaming.py; byte-identical to the
+        one-shot path, `stream=False`).  want: optional subset of the output keys to compute copies for
+        (e.g. ("joints", "omegas") skips the 250 KB/frame of vertices on the way back)."""
         N = len(all_images)
         if not self.dedup:
             return self._predict_all_images_literal(all_images)
+        host_input = not (isinstance(all_images, torch.Tensor) and all_images.is_cuda)
+        if host_input and stream:
+            if self._streamer is None:
+                from .streaming import HostStreamer
+                self._streamer = HostStreamer(self)
+            return self._streamer.run(all_images, want)
+        if host_input and getattr(all_images, "dtype", None) == np.uint8:
+            raise ValueError("uint8 input goes through the streamed path (stream=True)")
         phi = self.features(all_images, n_zero=1)        # last row: feature of the zero padding image
         out = self.predict_windows_device(phi[:N], phi[N:])
         torch.cuda.synchronize(self.engine.device)
-        return {k: v.float().cpu().numpy() for k, v in out.items()}
+        return {k: v.float().cpu().numpy() for k, v in out.items() if want is None or k in want}
 
     def _predict_all_images_literal(self, all_images):
         B, T = self.batch_size, self.sequence_length

@@ -110,6 +110,18 @@ class _FakeTester(object):
         out[:n_keep] = kept[:, None] + torch.arange(out.shape[1])[None, :] * 1e-3
         return out
 
+    def predict_strips_omegas(self, windows, n_keep):
+        kept = windows[:, 6:14, 0].reshape(-1)[:n_keep]
+        return torch.stack([kept[:, None].repeat(1, 85) + 0.25 * r for r in range(3)])      # [R, n, 85]
+
+    def records_from_omegas(self, om, out=None):
+        n = om.shape[1]
+        assert om.shape[0] == 3 and torch.equal(om[1], om[0] + 0.25) and torch.equal(om[2], om[0] + 0.5)
+        if out is None:
+            out = torch.empty((n, self.record_layout()[1]))
+        out[:n] = om[0][:, :1] + torch.arange(out.shape[1])[None, :] * 1e-3
+        return out
+
 
 def _expected(n, k, width):
     return ((torch.arange(n) + 1000.0 * k)[:, None] + torch.arange(width)[None, :] * 1e-3).float()
@@ -144,3 +156,44 @@ def test_overlapped_gather_pipeline_world2():
     results = mgr.dict()
     mp.spawn(_overlap_worker, args=(2, _free_port(), results), nprocs=2, join=True)
     assert dict(results) == {0: True, 1: True}
+
+
+def _theta_worker(rank, world, port, n, results):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ok = True
+        for mode in ("records", "theta"):
+            sp = hd.ShardedPredictor(_FakeTester(), n, rank, world, gather_mode=mode)
+            frames = torch.zeros((sp.plan.f1 - sp.plan.f0, 4, 4, 3))
+            frames[:, 0, 0, 0] = torch.arange(sp.plan.f0, sp.plan.f1).float()
+            full = sp.run(frames)
+            ok = ok and full.shape[0] == n and bool(torch.allclose(full, _expected(n, 0, full.shape[1])))
+            ok = ok and (sp.theta == (mode == "theta")) and sp.locals[0].shape[1] == (255 if mode == "theta" else full.shape[1])
+        results[rank] = ok
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [200, 4096])
+def test_theta_gather_equals_record_gather_world2(n):
+    """gather_mode='theta': only the omegas cross the wire, every rank rebuilds all records; and the
+    BASELINE configs[4] video (4096 frames, 512 windows) shards over two ranks."""
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_theta_worker, args=(2, _free_port(), n, results), nprocs=2, join=True)
+    assert dict(results) == {0: True, 1: True}
+
+
+def test_config5_plan_4096_frames():
+    """BASELINE configs[4]: 4096 frames, B=8, T=20 -> 512 windows; 1/2/4/8 ranks own 4096/N output frames and
+    encode at most 12 halo frames more."""
+    for world in (1, 2, 4, 8):
+        tot = 0
+        for r in range(world):
+            p = hd.ShardPlan(4096, 8, 20, 13, world, r)
+            assert p.n_windows == 512 and p.o1 - p.o0 == 4096 // world
+            assert (p.f1 - p.f0) - (p.o1 - p.o0) <= 12
+            tot += p.o1 - p.o0
+        assert tot == 4096

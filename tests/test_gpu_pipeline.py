@@ -323,3 +323,38 @@ def test_stem_with_first_conv1_inside(weights, gpu_device):
         assert lines, r.stderr[-500:]
         out[v] = lines[-1]
     assert out["0"] == out["1"]
+
+
+@pytest.mark.parametrize("n,chunk", [(24, 256), (300, 128), (257, 256)])
+def test_streamed_host_path_is_byte_identical_to_one_shot(weights, smpl_consts, gpu_device, n, chunk):
+    """Tester.predict_all_images(host ndarray): the chunked three-stream pipeline (pinned copy-in / kernels /
+    copy-out per key) returns exactly the bytes of the synchronous one-shot path, including chunk seams,
+    a 1-frame last chunk and the zero-image padding of the first and last windows."""
+    from human_dynamics_amd.evaluation.streaming import HostStreamer
+    from human_dynamics_amd.evaluation.tester import Tester
+    t = Tester(Config(batch_size=8), weights=weights, smpl=smpl_consts, dtype="bf16", device=gpu_device)
+    frames = assets.make_synthetic_frames(n, seed=50 + n)
+    ref = t.predict_all_images(frames, stream=False)
+    t._streamer = HostStreamer(t, chunk=chunk)
+    for rep in range(2):                        # second call re-uses the staging buffers
+        got = t.predict_all_images(frames)
+        assert sorted(got) == sorted(ref)
+        for k in ref:
+            assert got[k].dtype == np.float32 and got[k].shape == ref[k].shape, k
+            assert np.array_equal(got[k], ref[k]), (k, rep)
+    sub = t.predict_all_images(frames, want=("joints", "omegas_delta"))
+    assert sorted(sub) == ["joints", "omegas_delta"]
+    assert np.array_equal(sub["joints"], ref["joints"]) and np.array_equal(sub["omegas_delta"], ref["omegas_delta"])
+
+
+def test_streamed_uint8_input_matches_reference_normalisation(weights, smpl_consts, gpu_device):
+    """uint8 crops are uploaded as bytes and normalised on the device with the reference's arithmetic
+    ((x / 255.0 - 0.5) * 2 in float64, run_video.py:73): identical to feeding the float32 array."""
+    from human_dynamics_amd.evaluation.tester import Tester
+    t = Tester(Config(batch_size=8), weights=weights, smpl=smpl_consts, dtype="bf16", device=gpu_device)
+    u8 = np.random.default_rng(3).integers(0, 256, size=(40, 224, 224, 3), dtype=np.uint8)
+    as_float = ((u8 / 255.0 - 0.5) * 2).astype(np.float32)
+    a = t.predict_all_images(u8, want=("omegas", "joints"))
+    b = t.predict_all_images(as_float, want=("omegas", "joints"))
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
