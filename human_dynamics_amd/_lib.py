@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HMMR_LIB_PATH") or os.path.join(HERE, "libhmmr_hip.so")
 
 HMMR_F32, HMMR_BF16, HMMR_BF16X3 = 0, 1, 2
-ABI_VERSION = 7
+ABI_VERSION = 8
 RESNET_UNITS = 16
 RESNET_PROF_SLOTS = 64
 MAX_TEMPORAL_BLOCKS = 8
@@ -100,7 +100,7 @@ class IefWeights(C.Structure):
 
 
 class SmplConsts(C.Structure):
-    _fields_ = [("num_verts", C.c_int), ("num_kps", C.c_int), ("lbs_nnz", C.c_int),
+    _fields_ = [("num_verts", C.c_int), ("num_kps", C.c_int), ("lbs_nnz", C.c_int), ("vpad", C.c_int),
                 ("dirs", _fp), ("j_template", _fp), ("j_shapedirs", _fp), ("parents", _ip),
                 ("lbs_idx", _ip), ("lbs_w", _fp), ("kreg_ptr", _ip), ("kreg_idx", _ip), ("kreg_val", _fp)]
 
@@ -132,6 +132,7 @@ SIGNATURES = {
                                       _fp, _fp, _fp, _vp]),
     "hmmr_eval_joints": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _vp]),
     "hmmr_eval_verts": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int, C.c_int, _fp, _vp]),
+    "hmmr_global_rigid_transformation": (C.c_int, [_fp, _fp, _ip, C.c_int, _fp, _fp, _vp]),
     "hmmr_smpl_fwd_strided": (C.c_int, [C.POINTER(SmplConsts), _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int,
                                         _fp, _fp, _fp, _fp, C.c_int64, _vp, C.c_size_t, _vp]),
 }

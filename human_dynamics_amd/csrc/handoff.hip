@@ -42,8 +42,8 @@ __global__ void render_handoff_kernel(const float* __restrict__ cams, long long 
                                       const float* __restrict__ kps, long long ld_kps,
                                       const float* __restrict__ geom, int nv, int nk,
                                       float* __restrict__ new_cam, float* __restrict__ proj,
-                                      float* __restrict__ kp_out) {
-    const int f = blockIdx.y;
+                                      float* __restrict__ kp_out, int f0) {
+    const int f = f0 + blockIdx.y;
     const float* g = geom ? geom + (long long)f * 5 : nullptr;
     const FrameCam c = frame_camera(cams + (long long)f * ld_cam, g);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -77,9 +77,12 @@ extern "C" int hmmr_render_handoff(const float* cams, int64_t ld_cam, const floa
                  "hmmr_render_handoff: row strides smaller than the rows");
     HMMR_REQUIRE(!kp_orig || kps, "hmmr_render_handoff: kp_orig requested without kps");
     const int work = nv > 2 * nk ? nv : 2 * nk;
-    hipLaunchKernelGGL(render_handoff_kernel, dim3((unsigned)((work + 255) / 256), (unsigned)n), dim3(256), 0,
-                       (hipStream_t)stream, cams, (long long)ld_cam, verts, (long long)ld_verts, kps,
-                       (long long)ld_kps, geom, nv, nk, new_cam, proj_verts, kp_orig);
-    HMMR_CHECK_HIP(hipGetLastError());
+    for (int f0 = 0; f0 < n; f0 += 32768) {            // grid.y is limited to 65535: long videos go in slabs of frames
+        const int nf = n - f0 < 32768 ? n - f0 : 32768;
+        hipLaunchKernelGGL(render_handoff_kernel, dim3((unsigned)((work + 255) / 256), (unsigned)nf), dim3(256), 0,
+                           (hipStream_t)stream, cams, (long long)ld_cam, verts, (long long)ld_verts, kps,
+                           (long long)ld_kps, geom, nv, nk, new_cam, proj_verts, kp_orig, f0);
+        HMMR_CHECK_HIP(hipGetLastError());
+    }
     return 0;
 }

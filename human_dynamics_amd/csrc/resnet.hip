@@ -171,7 +171,7 @@ static int prof_end(Prof& p) {
         p.ms[i] = 0.f;
         if (i < p.slot) HMMR_CHECK_HIP(hipEventElapsedTime(&p.ms[i], p.ev[i], p.ev[i + 1]));
     }
-    for (int i = 0; i <= HMMR_RESNET_PROF_SLOTS; ++i) hipEventDestroy(p.ev[i]);
+    for (int i = 0; i <= HMMR_RESNET_PROF_SLOTS; ++i) (void)hipEventDestroy(p.ev[i]);
     return 0;
 }
 

@@ -269,6 +269,61 @@ __global__ __launch_bounds__(256) void smpl_joints_kernel(
     }
 }
 
+// ---- batch_global_rigid_transformation on its own (src/tf_smpl/batch_lbs.py:133-194, rotate_base=False) ---- //
+// One thread per instance walks the kinematic chain in index order (parents[i] < i), with the same expression
+// order as smpl_pose_kernel: results[i] = results[parent] . [[R_i, J_i - J_parent], [0, 1]]; new_J = its
+// translation; A = results - [0 | results . [J; 0]].
+__global__ __launch_bounds__(64) void smpl_fk_kernel(const float* __restrict__ Rs, const float* __restrict__ Js,
+                                                     const int* __restrict__ parents, int m, float* __restrict__ new_j,
+                                                     float* __restrict__ A44) {
+    const int inst = blockIdx.x * 64 + threadIdx.x;
+    if (inst >= m) return;
+    const float* R = Rs + (long long)inst * NJ * 9;
+    const float* J = Js + (long long)inst * NJ * 3;
+    float G[NJ][12];
+#pragma unroll 1
+    for (int i = 0; i < NJ; ++i) {
+        const int p = i == 0 ? -1 : parents[i];
+        const float* Lc = R + i * 9;
+        float t[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) t[c] = J[i * 3 + c] - (p >= 0 ? J[p * 3 + c] : 0.0f);
+        if (p < 0) {
+#pragma unroll
+            for (int e = 0; e < 9; ++e) G[i][e] = Lc[e];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) G[i][9 + c] = t[c];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc)
+                    G[i][r * 3 + cc] = G[p][r * 3 + 0] * Lc[0 * 3 + cc] + G[p][r * 3 + 1] * Lc[1 * 3 + cc] + G[p][r * 3 + 2] * Lc[2 * 3 + cc];
+                G[i][9 + r] = G[p][r * 3 + 0] * t[0] + G[p][r * 3 + 1] * t[1] + G[p][r * 3 + 2] * t[2] + G[p][9 + r];
+            }
+        }
+        float* nj = new_j + ((long long)inst * NJ + i) * 3;
+        float* o = A44 + ((long long)inst * NJ + i) * 16;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float bone = G[i][r * 3 + 0] * J[i * 3 + 0] + G[i][r * 3 + 1] * J[i * 3 + 1] + G[i][r * 3 + 2] * J[i * 3 + 2];
+            nj[r] = G[i][9 + r];
+            o[r * 4 + 0] = G[i][r * 3 + 0]; o[r * 4 + 1] = G[i][r * 3 + 1]; o[r * 4 + 2] = G[i][r * 3 + 2];
+            o[r * 4 + 3] = G[i][9 + r] - bone;
+        }
+        // bottom row of results - init_bone: [0, 0, 0, 1 - 0] (the homogeneous row; init_bone's w component is 0)
+        o[12] = 0.f; o[13] = 0.f; o[14] = 0.f; o[15] = 1.f;
+    }
+}
+
+extern "C" int hmmr_global_rigid_transformation(const float* Rs, const float* Js, const int32_t* parents, int m,
+                                                float* new_j, float* A, void* stream) {
+    HMMR_REQUIRE(Rs && Js && parents && new_j && A && m > 0, "hmmr_global_rigid_transformation: bad arguments");
+    hipLaunchKernelGGL(smpl_fk_kernel, dim3((m + 63) / 64), dim3(64), 0, (hipStream_t)stream, Rs, Js, (const int*)parents, m, new_j, A);
+    HMMR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------------- //
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -287,6 +342,8 @@ static int smpl_launch(const hmmr_smpl_consts_t* c, const float* theta, int ld_t
     HMMR_REQUIRE(c->lbs_nnz >= 1 && c->lbs_nnz <= NJ, "hmmr_smpl_fwd: lbs_nnz=%d out of range", c->lbs_nnz);
     HMMR_REQUIRE(ws_bytes >= hmmr_smpl_workspace_bytes(m), "hmmr_smpl_fwd: workspace too small");
     HMMR_REQUIRE(!kps || cams, "hmmr_smpl_fwd: kps requested without cams");
+    HMMR_REQUIRE(c->vpad >= (c->num_verts + VT - 1) / VT * VT && c->vpad % VT == 0,
+                 "hmmr_smpl_fwd: dirs row stride vpad=%d must be a multiple of %d covering num_verts=%d", c->vpad, VT, c->num_verts);
     hipStream_t s = (hipStream_t)stream;
     float* feat = (float*)ws;
     float* A = (float*)((char*)ws + align_up(((size_t)m + IB - 1) / IB * IB * LDF * 4, 256));
@@ -295,7 +352,7 @@ static int smpl_launch(const hmmr_smpl_consts_t* c, const float* theta, int ld_t
                        c->j_template, c->j_shapedirs, c->parents, m, feat, A, rs, ld_rs);
     HMMR_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(smpl_verts_kernel, dim3(vtiles, (m + IB - 1) / IB), dim3(VT), 0, s, c->dirs,
-                       vtiles * VT, (const float*)feat, (const float*)A, c->lbs_idx, c->lbs_w, c->lbs_nnz,
+                       c->vpad, (const float*)feat, (const float*)A, c->lbs_idx, c->lbs_w, c->lbs_nnz,
                        c->num_verts, m, verts, ld_verts);
     HMMR_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(smpl_joints_kernel, dim3(m), dim3(256), 0, s, (const float*)verts, c->kreg_ptr,

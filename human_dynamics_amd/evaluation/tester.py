@@ -67,6 +67,8 @@ def window_plan(n_frames, batch_size, sequence_length, fov):
 
 
 class Tester(object):
+    MAX_DEVICE_FRAMES = 1024      # frames per ResNet pass when the video is already in HBM
+    MAX_TAIL_WINDOWS = 128        # windows per f_movie / IEF / SMPL pass of predict_windows_device
 
     def __init__(self, config, pretrained_resnet_path="", sequence_length=None,
                  weights=None, smpl=None, dtype=None, device=None, dedup=True, use_containers=False):
@@ -237,7 +239,15 @@ class Tester(object):
     def features(self, frames, chunk=256, n_zero=0):
         """frames [N,224,224,3] (host or device) -> phi [N + n_zero,2048] on device."""
         if isinstance(frames, torch.Tensor) and frames.is_cuda:
-            return self.engine.resnet(frames, n_zero=n_zero)
+            N, big = len(frames), self.MAX_DEVICE_FRAMES    # long device-resident videos: bounded ResNet workspace (18 MB/frame)
+            if N <= big:
+                return self.engine.resnet(frames, n_zero=n_zero)
+            phi = torch.empty((N + n_zero, 2048), dtype=torch.float32, device=self.engine.device)
+            for i in range(0, N, big):
+                last = i + big >= N
+                self.engine.resnet(frames[i:i + big], n_zero=n_zero if last else 0,
+                                   out=phi[i:min(i + big, N) + (n_zero if last else 0)])
+            return phi
         outs = []
         for i in range(0, len(frames), chunk):
             last = i + chunk >= len(frames)
@@ -280,7 +290,18 @@ class Tester(object):
         padded = torch.cat([phi_zero.expand(margin, -1), phi, phi_zero.expand(num_fill, -1)], dim=0)
         idx = (torch.arange(count * B, device=phi.device)[:, None] * g +
                torch.arange(T, device=phi.device)[None, :])          # window i = padded[i*g : i*g+T]
-        return self.predict_strips_device(padded[idx], N)
+        wmax = self.MAX_TAIL_WINDOWS              # windows per tail pass: bounds the f_movie / IEF / SMPL workspaces
+        if idx.shape[0] <= wmax or N == 0:
+            return self.predict_strips_device(padded[idx], N)
+        from ..dist import unpack_outputs
+        layout, rec_len = self.record_layout()
+        rec = torch.empty((N, rec_len), dtype=torch.float32, device=phi.device)
+        for w0 in range(0, idx.shape[0], wmax):
+            o0, o1 = w0 * g, min(N, (w0 + wmax) * g)
+            if o0 >= N:
+                break
+            self.predict_strips_records(padded[idx[w0:w0 + wmax]], o1 - o0, out=rec[o0:o1])
+        return unpack_outputs(rec, layout)
 
     def predict_all_images(self, all_images, want=None, stream=True):
         """Wrapper to predict an entire sequence with the sliding-window scheme of

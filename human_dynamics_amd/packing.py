@@ -258,7 +258,7 @@ def pack_smpl(smpl, store, joint_type="cocoplus"):
     kidx = np.concatenate(kidx) if kptr[-1] else np.zeros(1, np.int32)
     kval = np.concatenate(kval) if kptr[-1] else np.zeros(1, np.float32)
     sc = L.SmplConsts()
-    sc.num_verts, sc.num_kps, sc.lbs_nnz = nv, nk, nnz
+    sc.num_verts, sc.num_kps, sc.lbs_nnz, sc.vpad = nv, nk, nnz, vpad
     sc.dirs = store.put(dirs).data_ptr()
     sc.j_template = store.put(j_template.astype(np.float32)).data_ptr()
     sc.j_shapedirs = store.put(j_shapedirs.astype(np.float32)).data_ptr()

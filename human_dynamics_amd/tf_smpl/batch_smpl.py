@@ -75,6 +75,14 @@ def load_smpl_constants(path, checkpoint_vars=None):
         "lbs_weights": _undo_chumpy(dd["weights"]).astype(np.float32),
         "cocoplus_regressor": dense_t(dd["cocoplus_regressor"]),
     }
+    # The reference creates these six tensors as (non-trainable) tf.Variables, so `Saver.restore` of a checkpoint that
+    # holds them OVERWRITES the pkl values (batch_smpl.py:35-80 + tester.py:92-116): the checkpoint wins there, and here.
+    if checkpoint_vars is not None and all(k in checkpoint_vars for k in _CKPT_SMPL_VARS):
+        for k in _CKPT_SMPL_VARS:
+            v = np.asarray(checkpoint_vars[k], np.float32)
+            if v.shape != out[k].shape:
+                raise ValueError("checkpoint variable %s has shape %s, the SMPL model %s" % (k, v.shape, out[k].shape))
+            out[k] = v
     return out
 
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HMMR_ABI_VERSION 7
+#define HMMR_ABI_VERSION 8
 
 /* HMMR_BF16X3: "split" tensors -- every group of 8 consecutive channels is 32 bytes, [hi x8][lo x8] with
  * hi = bf16(x), lo = bf16(x - hi) (4 bytes per element, ~16 mantissa bits); GEMMs on them issue three bf16
@@ -285,8 +285,9 @@ typedef struct {
     int num_verts;                     /* 6890 */
     int num_kps;                       /* 25 (cocoplus) or 14 (lsp) */
     int lbs_nnz;                       /* ELL width of the skinning weights (<= 24) */
-    const float* dirs;                 /* [224][3][vpad] planar re-pack of the tf_smpl bases (rows >= 218 zero)
-                                          (vpad = num_verts rounded up to 256): row 0 v_template,
+    int vpad;                          /* row stride of `dirs` in floats: a multiple of 128, >= num_verts */
+    const float* dirs;                 /* [224][3][vpad] planar re-pack of the tf_smpl bases (rows >= 218 zero):
+                                          row 0 v_template,
                                           1..10 shapedirs, 11..217 posedirs; dirs[k][c][v] =
                                           basis[k][3*v + c] (src/tf_smpl/batch_smpl.py:45-63) */
     const float* j_template;           /* [24*3]      J_regressor^T v_template            */
@@ -314,6 +315,10 @@ int hmmr_smpl_fwd_strided(const hmmr_smpl_consts_t* c, const float* theta, int l
                           const float* beta, int ld_beta, const float* cams, int ld_cam, int m,
                           float* verts, float* joints, float* kps, float* rs, int64_t ld_out,
                           void* ws, size_t ws_bytes, void* stream);
+/* batch_global_rigid_transformation on its own (src/tf_smpl/batch_lbs.py:133-194, rotate_base=False):
+ * Rs [m,24,3,3], Js [m,24,3], parents [24] -> new_J [m,24,3], A [m,24,4,4] (relative transforms for LBS). */
+int hmmr_global_rigid_transformation(const float* Rs, const float* Js, const int32_t* parents, int m,
+                                     float* new_j, float* A, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Crop before the path (process_image, src/evaluation/run_video.py:56-107; resize_img,

@@ -103,6 +103,15 @@ def test_smpl_pickle_loads_without_chumpy(tmp_path, smpl_consts):
     for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "cocoplus_regressor", "lbs_weights"):
         assert got[k].shape == smpl_consts[k].shape and np.allclose(got[k], smpl_consts[k]), k
     assert np.array_equal(got["parents"][1:], assets.SMPL_PARENTS[1:]) and got["parents"][0] == -1
+    # a checkpoint that carries the six SMPL variables overrides the pkl (Saver.restore overwrites the tf.Variables the
+    # reference initialised from the pkl): only the kinematic tree still comes from the pkl
+    ck = {k: (smpl_consts[k] * 1.5).astype(np.float32) for k in ("v_template", "shapedirs", "J_regressor", "posedirs",
+                                                                 "lbs_weights", "cocoplus_regressor")}
+    both = load_smpl_constants(path, checkpoint_vars=ck)
+    assert np.array_equal(both["v_template"], ck["v_template"]) and np.array_equal(both["posedirs"], ck["posedirs"])
+    assert np.array_equal(both["parents"], got["parents"])
+    part = load_smpl_constants(path, checkpoint_vars={"v_template": ck["v_template"]})       # incomplete: the pkl stands
+    assert np.allclose(part["v_template"], smpl_consts["v_template"])
 
 
 def test_smpl_constants_fall_back_to_checkpoint_variables(smpl_consts):
