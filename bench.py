@@ -72,6 +72,20 @@ class Cfg(object):
         self.__dict__.update(kw)
 
 
+def usable_cores(cap=32):
+    """Threads worth starting: the cgroup CPU quota of the container (cpu.max) when there is one -- the GPU boxes show
+    256 cores but grant 16 CPUs' worth of time, and oversubscribing a quota stalls the process -- else the affinity
+    mask, capped (PyTorch-CPU convolutions stop scaling past a few dozen threads)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, cap))
+
+
 def conv_slot_mask():
     """Which HMMR_RESNET_PROF_SLOTS are conv_gemm launches (csrc/resnet.hip launch order)."""
     from human_dynamics_amd import assets
@@ -84,12 +98,11 @@ def conv_slot_mask():
 
 def cpu_baseline(windows=16):
     """The CPU oracle on a bounded sample: `windows` 20-frame windows through the
-    reference-literal predict() (ResNet on all 20 frames, 8 kept per window).
-    PyTorch-CPU convolutions stop scaling (and then regress) past a few dozen
-    threads, so the thread count is capped and reported as `cores`."""
+    reference-literal predict() (ResNet on all 20 frames, 8 kept per window), on
+    `cores` threads = what the container may actually use (usable_cores)."""
     from human_dynamics_amd import assets
     from oracle import hmmr_oracle as O
-    cores = min(os.cpu_count() or 1, 32)
+    cores = usable_cores()
     torch.set_num_threads(cores)
     w = assets.make_synthetic_weights(0)
     s = assets.make_synthetic_smpl(2)
@@ -111,7 +124,7 @@ def oracle_window(span_host, f0, n_total, weights, smpl):
     """float64 oracle on the reference's padded window that keeps output frames
     [ERR_WINDOW_START, +8) of the bench video (tester.py:281-295)."""
     from oracle import hmmr_oracle as O
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    torch.set_num_threads(usable_cores())
     win = np.zeros((1, 20, 224, 224, 3), np.float32)
     for j in range(20):
         f = ERR_WINDOW_START - 6 + j

@@ -6,8 +6,9 @@ path is bound by PCIe and host copies unless they overlap the kernels, so the vi
 chunks of `chunk` frames and three HIP streams run side by side:
 
     copy-in stream   chunk k+1: pinned staging buffer -> HBM        (hipMemcpyAsync, double-buffered)
-    compute stream   chunk k  : [uint8 -> float crop] -> ResNet -> phi;  then the per-window tail
-                                (f_movie, IEF, 3 x SMPL) of chunk k-1, whose halo is now encoded
+    compute stream   chunk k  : [uint8 -> float crop] -> ResNet -> phi
+    tail stream      chunk k-1: the per-window tail (f_movie, IEF, 3 x SMPL), whose halo is encoded by now,
+                                underneath the ResNet of chunk k+1
     copy-out stream  chunk k-2: record fields -> one pinned host array per output key
 
 Only the host-side staging copy (pageable user array -> pinned buffer) occupies the Python thread,
@@ -41,13 +42,29 @@ class HostStreamer(object):
         self.chunk = max(self.g, (int(chunk) // self.g) * self.g)          # whole windows per chunk
         self.s_in = torch.cuda.Stream(device=self.dev)
         self.s_out = torch.cuda.Stream(device=self.dev)
+        self.s_tail = torch.cuda.Stream(device=self.dev)       # the ~150 small launches of a chunk's tail run under the next ResNet
         self._pin, self._dev_in, self._geom = {}, {}, None
         self.layout, self.rec_len = tester.record_layout()
+        # staging copies (pageable user array -> pinned buffer) run on a small private pool of plain memcpy workers
+        # (NumPy releases the GIL): torch's intra-op pool would wake one spinning thread per core for every chunk,
+        # which under a container CPU quota stalls the whole process for tens of milliseconds at a time
+        from concurrent.futures import ThreadPoolExecutor
+        self._copy_workers = 8
+        self._pool = ThreadPoolExecutor(max_workers=self._copy_workers)
+
+    def _stage(self, dst_pinned, src):
+        """src (ndarray [n,...]) -> the first n rows of the pinned staging tensor."""
+        n = len(src)
+        dst = dst_pinned.numpy()[:n]
+        step = (n + self._copy_workers - 1) // self._copy_workers
+        futs = [self._pool.submit(np.copyto, dst[i:i + step], src[i:i + step]) for i in range(0, n, step)]
+        for f in futs:
+            f.result()
 
     def _staging(self, dtype):
         if dtype not in self._pin:
             shape = (self.chunk, 224, 224, 3)
-            self._pin[dtype] = [torch.empty(shape, dtype=dtype).pin_memory() for _ in range(2)]
+            self._pin[dtype] = [torch.empty(shape, dtype=dtype, pin_memory=True) for _ in range(2)]
             self._dev_in[dtype] = [torch.empty(shape, dtype=dtype, device=self.dev) for _ in range(2)]
         return self._pin[dtype], self._dev_in[dtype]
 
@@ -82,19 +99,25 @@ class HostStreamer(object):
         n_chunks = (N + C - 1) // C
         cur = torch.cuda.current_stream(dev)
         phi = torch.empty((N + 1, 2048), dtype=torch.float32, device=dev)      # row N: the zero padding image
-        host = {k: torch.empty((N,) + fields[k][0], dtype=torch.float32).pin_memory() for k in keys}
+        host = {k: torch.empty((N,) + fields[k][0], dtype=torch.float32, pin_memory=True) for k in keys}
         recs = [torch.empty((C, self.rec_len), dtype=torch.float32, device=dev) for _ in range(2)]
         in_free = [None, None]          # compute finished reading dev_in[slot]
         out_free = [None, None]         # copy-out finished reading recs[slot]
         ar_T = torch.arange(T, device=dev)
         eng.resnet(torch.empty((0, 224, 224, 3), dtype=torch.float32, device=dev), n_zero=1, out=phi[N:N + 1])                                 # the zero padding image, once, up front
+        import os as _os, time as _time
+        trace = [] if _os.environ.get("HMMR_STREAM_TRACE") else None
+        tr = (lambda tag: trace.append((tag, _time.perf_counter()))) if trace is not None else (lambda tag: None)
         for k in range(n_chunks + 1):
+            tr("chunk %d" % k)
             if k < n_chunks:
                 lo, hi = k * C, min(N, (k + 1) * C)
                 n, slot = hi - lo, k % 2
                 if in_free[slot] is not None:
                     in_free[slot].synchronize()                      # the staging pair is free again (chunk k-2 is encoded)
-                pin[slot][:n].copy_(torch.from_numpy(src[lo:hi]))    # the only host-side work of the loop
+                tr(" waited")
+                self._stage(pin[slot], src[lo:hi])                   # the only host-side work of the loop
+                tr(" staged")
                 with torch.cuda.stream(self.s_in):
                     dev_in[slot][:n].copy_(pin[slot][:n], non_blocking=True)
                     landed = torch.cuda.Event()
@@ -103,14 +126,26 @@ class HostStreamer(object):
                 frames = dev_in[slot][:n]
                 if tdt == torch.uint8:
                     frames = self._to_float(frames, n)
+                tr(" h2d queued")
                 eng.resnet(frames, out=phi[lo:hi])
+                tr(" resnet queued")
                 in_free[slot] = torch.cuda.Event()
                 in_free[slot].record(cur)
             if k >= 1:
                 # tail of output frames [o0, o1): their windows reach margin frames into chunk k, encoded just above
-                self._tail(k - 1, N, phi, recs, out_free, host, fields, keys, ar_T)
+                encoded = torch.cuda.Event()
+                encoded.record(cur)
+                with torch.cuda.stream(self.s_tail):
+                    self.s_tail.wait_event(encoded)
+                    self._tail(k - 1, N, phi, recs, out_free, host, fields, keys, ar_T)
+                tr(" tail queued")
+        self.s_tail.synchronize()
         self.s_out.synchronize()
         cur.synchronize()
+        tr("done")
+        if trace is not None:
+            t0 = trace[0][1]
+            print("\n".join("%8.2f ms %s" % ((t - t0) * 1e3, tag) for tag, t in trace))
         return {k: host[k].numpy() for k in keys}
 
     def _tail(self, j, N, phi, recs, out_free, host, fields, keys, ar_T):

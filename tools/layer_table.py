@@ -13,10 +13,15 @@ from human_dynamics_amd import assets
 from human_dynamics_amd.engine import HmmrEngine
 
 
-def layers(n, esz):
+def layers(n, esz, fused_stem=True):
     """(name, flops, bytes) per profile slot, in launch order (csrc/resnet.hip)."""
-    out = [("stem(fused)", 2.0 * n * 112 * 112 * 64 * 147, n * (224 * 224 * 3 * 4 + 56 * 56 * 64 * esz)),
-           ("-", 0, 0), ("-", 0, 0)]
+    if fused_stem:
+        out = [("stem(fused)", 2.0 * n * 112 * 112 * 64 * 147, n * (224 * 224 * 3 * 4 + 56 * 56 * 64 * esz)),
+               ("-", 0, 0), ("-", 0, 0)]
+    else:
+        out = [("stem re-pack", 0, n * (224 * 224 * 3 * 4 + 230 * 232 * 4 * esz)),
+               ("stem 7x7/2 (8 taps x 32)", 2.0 * n * 112 * 112 * 64 * 147, n * (230 * 232 * 4 + 112 * 112 * 64) * esz),
+               ("pool1 + preact", 0, n * (112 * 112 * 64 + 56 * 56 * 64) * esz)]
     h = 56
     for scope, c_in, base, depth, stride, has_sc in assets.resnet_units():
         u = scope.split("/")[1][5:] + "." + scope.split("/")[2][5:]
@@ -48,7 +53,7 @@ def main():
         _, prof = eng.resnet(x, prof=True)
         p = np.asarray(prof, dtype=np.float64)
         acc = p if acc is None else np.minimum(acc, p)
-    tab = layers(n, 2 if dt == "bf16" else 4)
+    tab = layers(n, 2 if dt == "bf16" else 4, fused_stem=(dt == "bf16"))
     tot_ms = tot_f = tot_b = 0.0
     print("%-26s %8s %8s %8s %7s" % ("layer", "ms", "TFLOP/s", "TB/s", "GB"))
     for i, (name, fl, by) in enumerate(tab):
