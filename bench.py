@@ -221,7 +221,7 @@ def roofline_leg(tester, plan, span, dtype, frames):
     _, prof = eng.resnet(span, prof=True, n_zero=1)
     eng.resnet_streams = streams_used
     mask = conv_slot_mask()
-    fused_stem = dtype == "bf16"                  # slot 0 = the fused stem kernel (an MFMA launch); else slot 1 = the stem GEMM
+    fused_stem = dtype in ("bf16", "bf16x3")      # slot 0 = the fused stem kernel (an MFMA launch); else slot 1 = the stem GEMM
     if fused_stem:
         mask[0], mask[1] = True, False
     conv_share = float(prof[:len(mask)][mask].sum()) / float(prof[:len(mask)].sum())
@@ -230,7 +230,7 @@ def roofline_leg(tester, plan, span, dtype, frames):
     skipped = {0: 0, 1: 1, 2: 2, 3: 3, 4: 1}       # launches a fused unit saves, by hmmr_resnet_unit_t.fuse_tail
     n_tails = sum(int(eng.rw.unit[i].fuse_tail > 0) for i in range(16))
     n_conv = 53 - sum(skipped[int(eng.rw.unit[i].fuse_tail)] + int(bool(eng.rw.unit[i].sc_c1.w)) for i in range(16))
-    if fused_stem and os.environ.get("HMMR_STEM_C1", "1") != "0":
+    if dtype == "bf16" and os.environ.get("HMMR_STEM_C1", "1") != "0":
         n_conv -= 1                                   # block1/unit_1's conv1 runs inside the fused stem launch
     flops_per_launch = RESNET_FLOPS_PER_FRAME * n_enc / n_conv
     avg_launch_s = conv_ms * 1e-3 / n_conv
@@ -249,7 +249,7 @@ def roofline_leg(tester, plan, span, dtype, frames):
             break
     return {"bound": "mfma",
             "kernel": "conv_gemm_kernel%s (ResNet-v2-50, %s operands: %d MFMA launches/pass, %d of them fused bottleneck units)"
-                      % (" / bottleneck_tail_kernel / stem_fused_kernel" if dtype == "bf16" else "", dtype, n_conv, n_tails),
+                      % ({"bf16": " / bottleneck_tail_kernel / stem_fused_kernel", "bf16x3": " / stem_fused_split_kernel"}.get(dtype, ""), dtype, n_conv, n_tails),
             "achieved": round(achieved / 1e12, 2), "peak": round(peak / 1e12, 1), "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4),
             "peak_note": {"bf16": "dense bf16 MFMA", "f32": "fp32 MFMA",

@@ -52,7 +52,17 @@ struct ConvArgs {
     int relu, tiles_n, n_tiles;
     int kt_per_slice;                 // K steps per split-K slice (blockIdx.y); == all of them without split-K
     long long out_slice_stride;       // elements between the partial-sum planes of consecutive slices
+    int probe;                        // always 0 in the product build (see HMMR_GEMM_PROBE below)
 };
+
+// Development build only (-DHMMR_GEMM_PROBE, tools/probe_build.sh -> libhmmr_hip_probe.so): the K loop can drop its
+// MFMAs (1), its operand loads after the first stage (2) or its barriers (4), to measure which of the three bounds
+// a shape.  Results are garbage in those modes.  The product build compiles the switches away.
+#ifdef HMMR_GEMM_PROBE
+#define HMMR_PROBE(a, bit) (((a).probe & (bit)) != 0)
+#else
+#define HMMR_PROBE(a, bit) false
+#endif
 
 template <typename TA> struct Frag;
 template <> struct Frag<float>  { typedef f32x4 type; };
@@ -169,9 +179,17 @@ __device__ __forceinline__ u32x4 preact_slot_split(const u32x4& v, const f32x4* 
 //         ResNet shape, with 4-wave 128x128, 8-wave 128x128 and 8-wave 256x128 tiles alike: it
 //         halves the resident workgroups per CU, and resident waves are what hides latency in this
 //         structure.
+// s_waitcnt with vmcnt = N, lgkmcnt = 0 (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14])
+template <int N> __device__ __forceinline__ void wait_vm_lgkm0() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (0 << 8) | ((N >> 4) << 14));
+}
+
 template <typename TA, typename TO, int BM, int BN, int WGM, int WGN, bool PRO, bool UTAP, int NSTAGE>
-__global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 1) void conv_gemm_kernel(const ConvArgs a) {
-    static_assert(NSTAGE == 2, "only the 2-stage pipeline is kept");
+__global__ __launch_bounds__(WGM * WGN * 64, NSTAGE >= 3 ? (WGM * WGN) / 4 : ((WGM * WGN == 8) ? 4 : 1))
+void conv_gemm_kernel(const ConvArgs a) {
+    static_assert(NSTAGE >= 2 && NSTAGE <= 4, "2 stages (two workgroups per CU) or a 3/4-stage ring (one workgroup per CU)");
+    static_assert(NSTAGE == 2 || WGM * WGN == 8, "the deep ring is written for 8-wave workgroups");
     static_assert(!PRO || UTAP, "the fused pre-activation needs one tap per K step");
     constexpr int NT = WGM * WGN * 64;            // threads per workgroup (4 or 8 waves)
     constexpr int RPP = NT / 8;                   // tile rows staged per pass (8 lanes per row)
@@ -247,6 +265,18 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 1) void conv
             const bool ok = (amask[p] >> tap) & 1u;
             const void* src = ok ? (const void*)(aptr[p] + koff) : (const void*)g_zero_page;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + p * (RPP * 128)), 16, 0, 0);
+        }
+    };
+    // one LDS-DMA instruction of the pair above: q < PA -> A pass q, else B pass q - PA (deep ring: issued between MFMA groups)
+    auto glds_one = [&](int kt, int buf, int q, int koff, int tap) {
+        if (q < PA) {
+            const bool ok = (amask[q] >> tap) & 1u;
+            const void* src = ok ? (const void*)(aptr[q] + koff) : (const void*)g_zero_page;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + buf * STAGE + wave * 1024 + q * (RPP * 128)), 16, 0, 0);
+        } else {
+            const int p = q - PA;
+            __builtin_amdgcn_global_load_lds((gptr_t)(wptr + (long long)(RPP * p) * a.K + kt * BKE),
+                                             (lptr_t)(smem + buf * STAGE + A_BYTES + wave * 1024 + p * (RPP * 128)), 16, 0, 0);
         }
     };
     // B operand of K step kt, always LDS-DMA
@@ -346,11 +376,12 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 1) void conv
     const int nk = a.K / BKE;
     // one K step of MFMAs out of LDS stage `sbuf`; fragments of 32-B chunk c+1 are fetched before
     // the MFMAs of chunk c issue
-    auto compute_stage = [&](const char* sbuf) {
+    // `between(slot)` runs after the MFMAs of each (chunk, row fragment): NCHK * FM slots per stage (deep ring: DMA issue)
+    auto compute_stage = [&](const char* sbuf, auto&& between) {
         constexpr int NCHK = FragIO<TA>::CHUNKS;
         // split fragments are twice as wide: 8-wave 128x128 tiles keep ONE fragment set (the 128-VGPR budget of
         // two workgroups per CU has no room for a second one next to the prefetched residual)
-        constexpr bool DBUF = !(std::is_same<TA, bsplit_t>::value && WGM * WGN == 8 && FM * FN >= 2);
+        constexpr bool DBUF = NSTAGE >= 3 || !(std::is_same<TA, bsplit_t>::value && WGM * WGN == 8 && FM * FN >= 2);
         frag_t fa[DBUF ? 2 : 1][FM], fb[DBUF ? 2 : 1][FN];
         auto read_frags = [&](int c, int slot_) {
 #pragma unroll
@@ -365,25 +396,112 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 1) void conv
                 if (c + 1 < NCHK) read_frags(c + 1, (c + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of this chunk's MFMAs
 #pragma unroll
-                for (int i = 0; i < FM; ++i)
+                for (int i = 0; i < FM; ++i) {
 #pragma unroll
                     for (int j = 0; j < FN; ++j) acc[i][j] = mma(fa[c & 1][i], fb[c & 1][j], acc[i][j]);
+                    between(c * FM + i);
+                }
             }
         } else {
 #pragma unroll
             for (int c = 0; c < NCHK; ++c) {
                 read_frags(c, 0);
 #pragma unroll
-                for (int i = 0; i < FM; ++i)
+                for (int i = 0; i < FM; ++i) {
 #pragma unroll
                     for (int j = 0; j < FN; ++j) acc[i][j] = mma(fa[0][i], fb[0][j], acc[i][j]);
+                    between(c * FM + i);
+                }
             }
         }
     };
+    auto no_between = [](int) {};
     // split-K: slice blockIdx.y owns K steps [kt0, kt1) and writes a raw fp32 partial plane
     const int kt0 = blockIdx.y * a.kt_per_slice;
     const int kt1 = min(nk, kt0 + a.kt_per_slice);
-    if constexpr (PRO) {
+    if constexpr (NSTAGE >= 3) {
+        // ---- deep ring, ONE workgroup per CU: the LDS-DMA of K step kt + NSTAGE - 1 is issued at the top of step kt,
+        // so NSTAGE - 1 stages (the stage being awaited and NSTAGE - 2 behind it) are in flight while step kt's MFMAs
+        // run.  Waits are counted (the newest stages stay outstanding) and the barrier is a bare s_barrier: a
+        // __syncthreads() fence would drain vmcnt(0) every step, which is what serialises loads against MFMAs in
+        // the 2-stage loop (measured with the HMMR_GEMM_PROBE build: loads-only + MFMA-only ~ the full kernel).
+        // PRO: the pre-activation is applied IN LDS by the lane that DMA'd the slot, after its own wait and before
+        // the barrier that publishes the stage (constants live in LDS behind the ring).
+        constexpr int LPW = PA + PB;                              // LDS-DMA instructions per wave per stage
+        static_assert(LPW * (NSTAGE - 2) < 64, "vmcnt range");
+        [[maybe_unused]] float* s_pro = (float*)(smem + NSTAGE * STAGE);      // [2][K]: scale, shift
+        if constexpr (PRO) {
+            for (int i = tid; i < a.K; i += NT) { s_pro[i] = a.pro_scale[i]; s_pro[a.K + i] = a.pro_shift[i]; }
+        }
+        auto transform = [&](int kt, int buf) {
+            if constexpr (PRO) {
+                const int ci = ((kt * BKE) & cin_mask) + (SPLIT ? (lslot >> 1) * 8 : lslot * EPS);
+                f32x4 sc_[PCH / 4], sh_[PCH / 4];
+#pragma unroll
+                for (int q = 0; q < PCH / 4; ++q) {
+                    sc_[q] = *(const f32x4*)(s_pro + ci + 4 * q);
+                    sh_[q] = *(const f32x4*)(s_pro + a.K + ci + 4 * q);
+                }
+                char* sa = smem + buf * STAGE + r0 * 128 + pslot * 16;
+#pragma unroll
+                for (int p = 0; p < PA; ++p) {
+                    u32x4* q = (u32x4*)(sa + p * (RPP * 128));
+                    if constexpr (SPLIT) *q = preact_slot_split(*q, sc_, sh_, lslot & 1);
+                    else *q = preact_slot<TA>(*q, sc_, sh_);
+                }
+            }
+        };
+        // wait until at most `ahead` whole stages of this wave's DMA are outstanding (+ all LDS traffic), then barrier
+        auto wait_ahead = [&](int ahead) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (ahead >= 2) { if constexpr (NSTAGE >= 4) wait_vm_lgkm0<2 * LPW>(); }
+            else if (ahead == 1) wait_vm_lgkm0<LPW>();
+            else wait_vm_lgkm0<0>();
+        };
+        const int nloc = kt1 - kt0;
+#pragma unroll
+        for (int s_ = 0; s_ < NSTAGE - 1; ++s_)
+            if (s_ < nloc && !HMMR_PROBE(a, 8)) { glds_a(kt0 + s_, s_); glds_b(kt0 + s_, s_); }
+        if constexpr (PRO) {                                      // the constants are visible to every wave (no vmcnt drain)
+            wait_vm_lgkm0<63>();
+            __builtin_amdgcn_s_barrier();
+        }
+        wait_ahead(min(NSTAGE - 2, nloc - 1));
+        transform(kt0, 0);
+        wait_vm_lgkm0<63>();                                      // (lgkmcnt(0): the transformed slots are written)
+        __builtin_amdgcn_s_barrier();
+        int cur = 0, nxt = NSTAGE - 1;                            // ring positions of step kt and of the stage to fill
+        for (int kt = kt0; kt < kt1; ++kt) {
+            // the stage's LPW DMA instructions are issued BETWEEN the MFMA groups of this step: a burst of them at the top
+            // holds every wave of the workgroup in the texture-address queue while the matrix pipes idle
+            const bool fill = kt + NSTAGE - 1 < kt1 && !HMMR_PROBE(a, 2);
+            int tapn = 0, koffn = 0;
+            if (fill) koffn = UTAP ? tap_of((kt + NSTAGE - 1) * BKE, tapn) : 0;
+            constexpr int SLOTS = FragIO<TA>::CHUNKS * FM;
+            auto between = [&](int slot) {
+                if constexpr (UTAP) {
+#pragma unroll
+                    for (int q = 0; q < LPW; ++q)
+                        if (q * SLOTS / LPW == slot && fill) {
+                            glds_one(kt + NSTAGE - 1, nxt, q, koffn, tapn);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                }
+            };
+            if constexpr (!UTAP) { if (fill) { glds_a(kt + NSTAGE - 1, nxt); glds_b(kt + NSTAGE - 1, nxt); } }
+            if (!HMMR_PROBE(a, 1)) compute_stage(smem + cur * STAGE, between);
+            else if (fill && UTAP) { glds_a(kt + NSTAGE - 1, nxt); glds_b(kt + NSTAGE - 1, nxt); }
+            const int c1 = (cur + 1 == NSTAGE) ? 0 : cur + 1;
+            if (kt + 1 < kt1) {
+                wait_ahead(min(NSTAGE - 2, kt1 - 2 - kt));
+                transform(kt + 1, c1);
+            }
+            wait_vm_lgkm0<63>();
+            __builtin_amdgcn_sched_barrier(0);
+            if (!HMMR_PROBE(a, 4)) __builtin_amdgcn_s_barrier();
+            nxt = cur; cur = c1;
+        }
+    } else if constexpr (PRO) {
         // tile kt+1 was fetched into VGPRs a whole K step earlier, so pre-activating and writing it
         // at the TOP of step kt never waits for HBM; its registers are then free for tile kt+2.
         load_regs(kt0);
@@ -392,10 +510,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 1) void conv
         __syncthreads();
         for (int kt = kt0; kt < kt1; ++kt) {
             const int cur = (kt - kt0) & 1;
-            if (kt + 1 < kt1) store_regs(cur ^ 1);
-            if (kt + 2 < kt1) load_regs(kt + 2);
-            compute_stage(smem + cur * STAGE);
-            __syncthreads();
+            if (kt + 1 < kt1 && !HMMR_PROBE(a, 2)) store_regs(cur ^ 1);
+            if (kt + 2 < kt1 && !HMMR_PROBE(a, 2)) load_regs(kt + 2);
+            if (!HMMR_PROBE(a, 1)) compute_stage(smem + cur * STAGE, no_between);
+            if (!HMMR_PROBE(a, 4)) __syncthreads();
         }
     } else {
         glds_a(kt0, 0);
@@ -403,9 +521,9 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 1) void conv
         __syncthreads();
         for (int kt = kt0; kt < kt1; ++kt) {
             const int cur = (kt - kt0) & 1;
-            if (kt + 1 < kt1) { glds_a(kt + 1, cur ^ 1); glds_b(kt + 1, cur ^ 1); }
-            compute_stage(smem + cur * STAGE);
-            __syncthreads();
+            if (kt + 1 < kt1 && !HMMR_PROBE(a, 2)) { glds_a(kt + 1, cur ^ 1); glds_b(kt + 1, cur ^ 1); }
+            if (!HMMR_PROBE(a, 1)) compute_stage(smem + cur * STAGE, no_between);
+            if (!HMMR_PROBE(a, 4)) __syncthreads();
         }
     }
 
@@ -494,12 +612,15 @@ static int launch_cfg(const ConvArgs& base, int slices, hipStream_t stream) {
     const int tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.cout + BN - 1) / BN;
     a.n_tiles = tiles_m * a.tiles_n;
-    constexpr int kloop = NSTAGE * (BM + BN) * 128, epi = BM * BN * 4;
-    constexpr int lds = kloop > epi ? kloop : epi;
+    constexpr int kring = NSTAGE * (BM + BN) * 128, epi = BM * BN * 4;
+    const int kloop = kring + ((PRO && NSTAGE >= 3) ? 8 * a.K : 0);      // deep PRO: [2][K] fp32 constants behind the ring
+    const int lds = kloop > epi ? kloop : epi;
+    if (lds > 160 * 1024) { hmmr_set_error("hmmr_conv_gemm: tile needs %d B of LDS (K = %d)", lds, a.K); return -1; }
     auto kern = conv_gemm_kernel<TA, TO, BM, BN, WGM, WGN, PRO, UTAP, NSTAGE>;
     static DeviceOnce once;              // per kernel instantiation, per device
     if (const unsigned long long bit = once.due()) {
-        HMMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HMMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           NSTAGE >= 3 ? 160 * 1024 : lds));
         once.mark(bit);
     }
     constexpr int BKE_ = 8 * elem_traits<TA>::EPS;
@@ -518,6 +639,10 @@ static int launch_tiled(const ConvArgs& a, int tile, int slices, hipStream_t str
         case 3: return launch_cfg<TA, TO, 64, 64, 2, 2, PRO, UTAP, 2>(a, slices, stream);     // 4 waves, 32x32 each
         case 5: return launch_cfg<TA, TO, 128, 128, 4, 2, PRO, UTAP, 2>(a, slices, stream);   // 8 waves, 32x64 each
         case 6: return launch_cfg<TA, TO, 128, 64, 4, 2, PRO, UTAP, 2>(a, slices, stream);    // 8 waves, 32x32 each
+        // deep rings, one 8-wave workgroup per CU (256 VGPRs per lane)
+        case 7: return launch_cfg<TA, TO, 256, 128, 4, 2, PRO, UTAP, 3>(a, slices, stream);   // 64x64 each, 3 x 48 KB
+        case 8: return launch_cfg<TA, TO, 128, 128, 4, 2, PRO, UTAP, 4>(a, slices, stream);   // 32x64 each, 4 x 32 KB
+        case 9: return launch_cfg<TA, TO, 256, 64, 4, 2, PRO, UTAP, 3>(a, slices, stream);    // 64x32 each, 3 x 40 KB
         default: hmmr_set_error("hmmr_conv_gemm: bad tile %d", tile); return -1;
     }
 }
@@ -667,7 +792,10 @@ extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
     a.res_strided = d->res_strided; a.res_img_stride = d->res_img_stride;
     a.res_row_stride = d->res_row_stride; a.res_px_stride = d->res_px_stride;
     a.relu = d->relu; a.tiles_n = 0; a.n_tiles = 0;
-    a.kt_per_slice = 0; a.out_slice_stride = 0;
+    a.kt_per_slice = 0; a.out_slice_stride = 0; a.probe = 0;
+#ifdef HMMR_GEMM_PROBE
+    if (const char* e = getenv("HMMR_GEMM_PROBE")) a.probe = atoi(e);
+#endif
     if (a.M <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const bool in16 = d->in_dtype == HMMR_BF16, in32 = d->in_dtype == HMMR_F32, inx3 = d->in_dtype == HMMR_BF16X3;

@@ -215,10 +215,10 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
     // Default: ONE fused kernel (csrc/stem.hip).  HMMR_STEM=unfused keeps the three-kernel route
     // (re-pack, implicit GEMM, pool) for A/B measurements.
     // In fp32-operand mode the fused kernel needs 104 KB of LDS (one workgroup per CU) and measures
-    // ~1 % slower than the three-kernel route, which therefore stays the fp32 default.
+    // ~1 % slower than the three-kernel route, which therefore stays the fp32 default.  bf16x3 has its own
+    // fused kernel (stem_fused_split_kernel: hi/lo planes, 32 output channels per workgroup).
     const hmmr_debug_t* dbg = hmmr_debug_state();
-    HMMR_REQUIRE(!(dbg->stem_route == 2 && w->dtype == HMMR_BF16X3), "resnet: there is no fused stem kernel for bf16x3 tensors");
-    const bool unfused = dbg->stem_route == 1 || (dbg->stem_route == 0 && w->dtype != HMMR_BF16);
+    const bool unfused = dbg->stem_route == 1 || (dbg->stem_route == 0 && w->dtype == HMMR_F32);
     bool stem_c1 = false;
     if (!unfused) {
         // bf16: block1/unit_1's conv1 is computed on each pooled tile inside the same launch (-> T1)

@@ -241,13 +241,173 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const float* __restrict
 }
 }  // namespace
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// bf16x3 (split) operands: the same tile geometry with hi and lo PLANES of the patch and of the filters in LDS and
+// three MFMAs per product (act.lo*w.hi, act.hi*w.lo, act.hi*w.hi -- the order of gemm_conv.hip's mma(split, split)).
+// A workgroup (5 waves, two MFMA row tiles each) computes 32 of the 64 output channels (blockIdx.z), which keeps
+// patch planes + filter planes / fp32 pooling stage at 66 KB: two workgroups per CU.  Rounding points are those of
+// the three-kernel route (conv + bias -> split storage -> max pool -> fma + ReLU -> split storage), K order is tap
+// by tap, 16 elements at a time, so the result is that route's, bit for bit (tests/test_gpu_sizes.py).
+namespace {
+constexpr int X3_NT = 320, X3_CO = 32;
+constexpr int X3_PLANE = IP * IPW * 8;                       // one bf16 RGBX plane of the patch
+constexpr int X3_WROW = 7 * TAPK * 2 + 16;                   // padded filter row of one plane (464 B: conflict-free b128 reads)
+constexpr int X3_WPLANE = X3_CO * X3_WROW;
+constexpr int X3_STAGE = MT * 32 * X3_CO * 4;                // conv + bias as fp32 [pixel][32] (overlaps the filters)
+constexpr int X3_LDS = 2 * X3_PLANE + (2 * X3_WPLANE > X3_STAGE ? 2 * X3_WPLANE : X3_STAGE);
+
+__global__ __launch_bounds__(X3_NT) void stem_fused_split_kernel(const float* __restrict__ img, const bsplit_t* __restrict__ wts,
+                                                                 const float* __restrict__ bias, const float* __restrict__ pscale,
+                                                                 const float* __restrict__ pshift, bsplit_t* __restrict__ out,
+                                                                 int n_real) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_ph = smem;                            // patch, hi plane
+    char* s_pl = smem + X3_PLANE;                 // patch, lo plane
+    char* s_wh = smem + 2 * X3_PLANE;             // filters, hi plane
+    char* s_wl = s_wh + X3_WPLANE;
+    float* s_c = (float*)(smem + 2 * X3_PLANE);   // reuses the filter region after the MFMAs
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ty = blockIdx.x / (POOL / PT), tx = blockIdx.x % (POOL / PT);
+    const int n = blockIdx.y, ch0 = blockIdx.z * X3_CO;
+    const int cy0 = 2 * PT * ty, cx0 = 2 * PT * tx;
+    const int iy0 = 2 * cy0 - 3, ix0 = 2 * cx0 - 3;
+
+    // ---- 1. input patch -> two bf16 RGBX planes (hi = bf16(x), lo = bf16(x - hi): stem_repack_split_kernel's values)
+    const float* im = img + (long long)n * IMG * IMG * 3;
+    for (int i = tid; i < IP * 11; i += X3_NT) {
+        const int py = i / 11, q = i - py * 11;
+        const int gy = iy0 + py, gx = ix0 - 1 + 4 * q;
+        float f[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) f[e] = 0.f;
+        if (n < n_real && (unsigned)gy < (unsigned)IMG && (unsigned)gx < (unsigned)IMG) {
+            const f32x4* p = (const f32x4*)(im + (gy * IMG + gx) * 3);
+            const f32x4 v0 = p[0], v1 = p[1], v2 = p[2];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { f[e] = v0[e]; f[4 + e] = v1[e]; f[8 + e] = v2[e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int px = 4 * q - 1 + e;
+            if ((unsigned)px < (unsigned)IPW) {
+                typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+                bf16x4 h, l;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    h[c] = (bf16_t)f[3 * e + c];
+                    l[c] = (bf16_t)(f[3 * e + c] - (float)h[c]);
+                }
+                h[3] = (bf16_t)0.f; l[3] = (bf16_t)0.f;
+                *(bf16x4*)(s_ph + (py * IPW + px) * 8) = h;
+                *(bf16x4*)(s_pl + (py * IPW + px) * 8) = l;
+            }
+        }
+    }
+    // ---- 2. this workgroup's 32 filters -> LDS planes.  HBM rows are [32 groups][hi 16 B | lo 16 B]; groups 0..27 = taps 0..6
+    for (int i = tid; i < X3_CO * 28; i += X3_NT) {
+        const int row = i / 28, g = i - row * 28;
+        const u32x4* src = (const u32x4*)((const char*)wts + (long long)(ch0 + row) * (WK * 4) + g * 32);
+        *(u32x4*)(s_wh + row * X3_WROW + g * 16) = src[0];
+        *(u32x4*)(s_wl + row * X3_WROW + g * 16) = src[1];
+    }
+    __syncthreads();
+
+    // ---- 3. implicit GEMM: wave w owns row tiles w and w + 5
+    const int lr = lane & 31, lh = lane >> 5;
+    constexpr int MPW = MT / 5;
+    static_assert(MPW * 5 == MT, "10 row tiles over 5 waves");
+    f32x16 acc[MPW];
+#pragma unroll
+    for (int i = 0; i < MPW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    int abase[MPW];
+#pragma unroll
+    for (int i = 0; i < MPW; ++i) {
+        int p = (wave + 5 * i) * 32 + lr;
+        if (p >= NPIX) p = 0;                     // padding rows of the last tile: computed, never used
+        const int cy = p / CT, cx = p - cy * CT;
+        abase[i] = ((2 * cy) * IPW + 2 * cx) * 8 + lh * 16;
+    }
+    const int bbase = lr * X3_WROW + lh * 16;
+#pragma unroll 1
+    for (int ky = 0; ky < 7; ++ky) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const bf16x8 bh = *(const bf16x8*)(s_wh + bbase + ky * 64 + c * 32);
+            const bf16x8 bl = *(const bf16x8*)(s_wl + bbase + ky * 64 + c * 32);
+#pragma unroll
+            for (int i = 0; i < MPW; ++i) {
+                const bf16x8 ah = *(const bf16x8*)(s_ph + abase[i] + ky * IPW * 8 + c * 32);
+                const bf16x8 al = *(const bf16x8*)(s_pl + abase[i] + ky * IPW * 8 + c * 32);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();                              // every wave is done with the filters: reuse as staging
+
+    // ---- 4a. conv + bias, rounded to what split storage holds, -> LDS fp32 [pixel][32]
+    {
+        const float bch = bias[ch0 + lr];
+#pragma unroll
+        for (int i = 0; i < MPW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = (wave + 5 * i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                s_c[p * X3_CO + lr] = stored_value<bsplit_t>(acc[i][r] + bch);
+            }
+    }
+    __syncthreads();
+
+    // ---- 4b. 3x3/2 max pool (TF SAME) + preact BN + ReLU -> split storage
+    for (int it = tid; it < PT * PT * (X3_CO / 8); it += X3_NT) {
+        const int v8 = it & 3, pp = it >> 2;
+        const int py = pp / PT, px = pp - py * PT;
+        float m[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = -3.0e38f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            if (cy0 + 2 * py + dy >= CONV) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                if (cx0 + 2 * px + dx >= CONV) continue;
+                float v[8];
+                load8(s_c + ((2 * py + dy) * CT + 2 * px + dx) * X3_CO + v8 * 8, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], v[j]);
+            }
+        }
+        float sc[8], sh[8];
+        load8(pscale + ch0 + v8 * 8, sc); load8(pshift + ch0 + v8 * 8, sh);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = fmaxf(fmaf(m[j], sc[j], sh[j]), 0.f);   // one explicit fma: = maxpool_bn_relu_kernel
+        store8(out + (((long long)n * POOL + PT * ty + py) * POOL + PT * tx + px) * CO + ch0 + v8 * 8, m);
+    }
+}
+}  // namespace
+
 // images [n_real,224,224,3] fp32 (+ n - n_real implicit zero images) -> out [n,56,56,64] (dtype)
 // w1 / s1 / b1 / out_h1 (bf16 only, may be NULL): block1/unit_1's conv1 [64][64] + folded BN, computed on the
 // pooled tile in the same launch -> out_h1 [n,56,56,64]
 int hmmr_stem_fused(const float* images, int n_real, int n, const void* wts, const float* bias,
                     const float* pscale, const float* pshift, void* out, int dtype, hipStream_t s,
                     const void* w1, const float* s1, const float* b1, void* out_h1) {
-    if (dtype == HMMR_BF16) {
+    if (dtype == HMMR_BF16X3) {
+        auto kern = stem_fused_split_kernel;
+        static DeviceOnce oncex3;
+        if (const unsigned long long bit = oncex3.due()) {
+            HMMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS));
+            oncex3.mark(bit);
+        }
+        hipLaunchKernelGGL(kern, dim3((POOL / PT) * (POOL / PT), n, CO / X3_CO), dim3(X3_NT), X3_LDS, s, images,
+                           (const bsplit_t*)wts, bias, pscale, pshift, (bsplit_t*)out, n_real);
+    } else if (dtype == HMMR_BF16) {
         auto kern = stem_fused_kernel<bf16_t>;
         static DeviceOnce once16;
         if (const unsigned long long bit = once16.due()) {

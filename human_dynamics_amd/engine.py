@@ -170,7 +170,7 @@ class HmmrEngine(object):
             for slot, u, nm in layers:
                 lay = getattr(self.rw.unit[u], nm)
                 cout = self.rw.unit[u].base if nm in ("conv1", "conv2") else self.rw.unit[u].depth
-                lay.tile = cand if (cand not in (1, 5) or cout % 128 == 0) else 0
+                lay.tile = cand if (cand not in (1, 5, 7, 8) or cout % 128 == 0) else 0
             t = None
             for rep in range(3):
                 pm = (C.c_float * L.RESNET_PROF_SLOTS)()

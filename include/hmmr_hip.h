@@ -44,8 +44,8 @@ const char* hmmr_last_error(void);
 /* Development switches for A/B measurements and tests.  Process-wide; all zero = the product defaults.  No
  * switch changes a result beyond what its comment says; the library never reads the environment. */
 typedef struct hmmr_debug_s {
-    int stem_route;        /* 0: default (fused stem kernel for bf16, re-pack + GEMM + pool otherwise);
-                              1: always the three-kernel route; 2: always the fused kernel (not for bf16x3) */
+    int stem_route;        /* 0: default (fused stem kernel for bf16 / bf16x3, re-pack + GEMM + pool for f32);
+                              1: always the three-kernel route; 2: always the fused kernel */
     int stem_no_conv1;     /* 1: the fused bf16 stem leaves block1/unit_1's conv1 to its own launch */
     int reserved[6];
 } hmmr_debug_t;

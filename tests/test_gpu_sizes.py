@@ -154,7 +154,7 @@ def test_bf16_mode_against_its_emulation(weights, smpl_consts, gpu_device):
 
 
 # --------------------------------------------------------------------------- fused stem
-@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("dt", ["bf16", "bf16x3", "f32"])
 def test_fused_stem_equals_three_kernel_route(weights, gpu_device, dt):
     """stem.hip (7x7/2 conv + bias + pool1 + unit_1 preact [+ unit_1 conv1] in one launch) against the
     re-pack + implicit-GEMM + pool route, through the whole ResNet: image-edge tiles, interior tiles

@@ -13,7 +13,11 @@ sys.path.insert(0, ".")
 from human_dynamics_amd import _lib as L
 from human_dynamics_amd import packing
 
-DT = {"bf16": (L.HMMR_BF16, torch.bfloat16), "f32": (L.HMMR_F32, torch.float32)}
+DT = {"bf16": (L.HMMR_BF16, torch.bfloat16), "f32": (L.HMMR_F32, torch.float32), "bf16x3": (L.HMMR_BF16X3, packing.SPLIT)}
+
+
+def cast(t, tdt):
+    return packing.to_split(t) if tdt is packing.SPLIT else t.to(tdt)
 
 
 def run(lib, name, n, h, cin, cout, k, stride, kind, dt, tile, iters=20):
@@ -21,13 +25,13 @@ def run(lib, name, n, h, cin, cout, k, stride, kind, dt, tile, iters=20):
     dev = "cuda"
     pad = 1 if k == 3 else 0
     ho = (h + 2 * pad - k) // stride + 1
-    x = (torch.randn((n, h, h, cin), device=dev) * 0.5).to(tdt)
-    w = (torch.randn((max(cout, 128) if cout % 128 else cout, k * k * cin), device=dev) / (k * k * cin) ** 0.5).to(tdt)
+    x = cast(torch.randn((n, h, h, cin), device=dev) * 0.5, tdt)
+    w = cast(torch.randn((max(cout, 128) if cout % 128 else cout, k * k * cin), device=dev) / (k * k * cin) ** 0.5, tdt)
     if w.shape[0] % 128:
         w = torch.cat([w, torch.zeros((128 - w.shape[0] % 128, w.shape[1]), device=dev, dtype=tdt)])
     sc = torch.rand(w.shape[0], device=dev) + 0.5
     sh = torch.randn(w.shape[0], device=dev)
-    out = torch.empty((n, ho, ho, cout), device=dev, dtype=tdt)
+    out = packing.empty_act((n, ho, ho, cout), code, dev)
     d = L.ConvDesc()
     d.in_, d.w, d.out = x.data_ptr(), w.data_ptr(), out.data_ptr()
     d.in_dtype = d.out_dtype = code
@@ -47,12 +51,12 @@ def run(lib, name, n, h, cin, cout, k, stride, kind, dt, tile, iters=20):
     elif kind == "bias":
         d.shift = sh.data_ptr()
     elif kind == "res":                       # conv3: bias + residual
-        res = torch.randn_like(out)
+        res = cast(torch.randn((n, ho, ho, cout), device=dev), tdt)
         d.shift, d.res, d.ldr = sh.data_ptr(), res.data_ptr(), cout
         keep += [res]
         nbytes += out.numel() * out.element_size()
     elif kind == "res2":                      # conv3: bias + residual + second output
-        res = torch.randn_like(out)
+        res = cast(torch.randn((n, ho, ho, cout), device=dev), tdt)
         out2 = torch.empty_like(out)
         d.shift, d.res, d.ldr = sh.data_ptr(), res.data_ptr(), cout
         d.out2, d.scale2, d.shift2 = out2.data_ptr(), sc.data_ptr(), sh.data_ptr()
@@ -97,13 +101,16 @@ def main():
     global TILES
     if len(sys.argv) > 3:
         TILES = tuple(int(t) for t in sys.argv[3].split(','))
+    only = sys.argv[4].split(',') if len(sys.argv) > 4 else None
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     dt = sys.argv[2] if len(sys.argv) > 2 else "bf16"
     lib = L.load()
     rows = []
     for name, h, cin, cout, k, stride, kind in SHAPES:
+        if only and not any(o in name for o in only):
+            continue
         for tile in TILES:
-            if tile in (1, 5) and cout % 128:
+            if tile in (1, 5, 7, 8) and cout % 128:
                 continue
             rows.append(run(lib, name, n, h, cin, cout, k, stride, kind, dt, tile))
             print(json.dumps(rows[-1]), flush=True)

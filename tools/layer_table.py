@@ -53,7 +53,7 @@ def main():
         _, prof = eng.resnet(x, prof=True)
         p = np.asarray(prof, dtype=np.float64)
         acc = p if acc is None else np.minimum(acc, p)
-    tab = layers(n, 2 if dt == "bf16" else 4, fused_stem=(dt == "bf16"))
+    tab = layers(n, 2 if dt == "bf16" else 4, fused_stem=(dt != "f32"))
     tot_ms = tot_f = tot_b = 0.0
     print("%-26s %8s %8s %8s %7s" % ("layer", "ms", "TFLOP/s", "TB/s", "GB"))
     for i, (name, fl, by) in enumerate(tab):
