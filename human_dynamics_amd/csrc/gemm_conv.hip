@@ -140,29 +140,35 @@ template <> __device__ __forceinline__ u32x4 preact_slot<bf16_t>(const u32x4& v,
 }
 
 // split tensors keep the hi and the lo half of an 8-channel group in neighbouring slots, i.e. in neighbouring lanes of
-// the staging geometry (lslot ^ 1 <-> lane ^ 1): the two lanes swap their raw slots (DPP quad_perm [1,0,3,2]), both
-// rebuild x = hi + lo, apply relu(x*s + b) and split the result again; each keeps the half its own slot stores.
-// Value for value this is store8<bsplit_t>(relu(fma(load8<bsplit_t>(x), s, b))), the producer-side `out2` of the epilogue.
-__device__ __forceinline__ u32x4 preact_slot_split(const u32x4& v, const f32x4* sc, const f32x4* sh, bool is_lo) {
-    u32x4 other, o;
+// the staging geometry (lslot ^ 1 <-> lane ^ 1).  The two lanes share the work: the lane holding the hi slot
+// pre-activates channels 0-3 of the group, the lane holding the lo slot channels 4-7 (each needs two dwords of its
+// partner: DPP quad_perm [1,0,3,2]), both split their four results, and a second exchange completes each lane's own
+// slot.  sc / sh: scale and shift of THIS lane's four channels.  Value for value this is
+// store8<bsplit_t>(relu(fma(load8<bsplit_t>(x), s, b))), the producer-side `out2` of the epilogue.
+__device__ __forceinline__ unsigned dpp_swap(unsigned v) {
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
+}
+__device__ __forceinline__ u32x4 preact_slot_split(const u32x4& v, const f32x4& sc, const f32x4& sh, bool is_lo) {
+    // what the partner needs from this lane: hi lane -> its hi[4..7] (dwords 2, 3); lo lane -> its lo[0..3] (dwords 0, 1)
+    const unsigned r0 = dpp_swap(is_lo ? v[0] : v[2]), r1 = dpp_swap(is_lo ? v[1] : v[3]);
+    const unsigned h0 = is_lo ? r0 : v[0], h1 = is_lo ? r1 : v[1];       // hi halves of this lane's four channels
+    const unsigned l0 = is_lo ? v[2] : r0, l1 = is_lo ? v[3] : r1;       // lo halves
+    float y[4];
+    y[0] = fmaxf(fmaf(__uint_as_float(h0 << 16) + __uint_as_float(l0 << 16), sc[0], sh[0]), 0.f);
+    y[1] = fmaxf(fmaf(__uint_as_float(h0 & 0xffff0000u) + __uint_as_float(l0 & 0xffff0000u), sc[1], sh[1]), 0.f);
+    y[2] = fmaxf(fmaf(__uint_as_float(h1 << 16) + __uint_as_float(l1 << 16), sc[2], sh[2]), 0.f);
+    y[3] = fmaxf(fmaf(__uint_as_float(h1 & 0xffff0000u) + __uint_as_float(l1 & 0xffff0000u), sc[3], sh[3]), 0.f);
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    unsigned ph[2], pl[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) other[i] = (unsigned)__builtin_amdgcn_mov_dpp((int)v[i], 0xB1, 0xF, 0xF, true);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const unsigned h = is_lo ? other[i] : v[i], l = is_lo ? v[i] : other[i];
-        const float x0 = __uint_as_float(h << 16) + __uint_as_float(l << 16);
-        const float x1 = __uint_as_float(h & 0xffff0000u) + __uint_as_float(l & 0xffff0000u);
-        const int e = 2 * i;
-        const float a = fmaxf(fmaf(x0, sc[e >> 2][e & 3], sh[e >> 2][e & 3]), 0.f);
-        const float b = fmaxf(fmaf(x1, sc[(e + 1) >> 2][(e + 1) & 3], sh[(e + 1) >> 2][(e + 1) & 3]), 0.f);
-        const bf16_t ah = (bf16_t)a, bh = (bf16_t)b;
-        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-        bf16x2 pk;
-        if (is_lo) pk = bf16x2{(bf16_t)(a - (float)ah), (bf16_t)(b - (float)bh)};
-        else pk = bf16x2{ah, bh};
-        o[i] = __builtin_bit_cast(unsigned, pk);
+    for (int i = 0; i < 2; ++i) {
+        const bf16_t a = (bf16_t)y[2 * i], b = (bf16_t)y[2 * i + 1];
+        ph[i] = __builtin_bit_cast(unsigned, bf16x2{a, b});
+        pl[i] = __builtin_bit_cast(unsigned, bf16x2{(bf16_t)(y[2 * i] - (float)a), (bf16_t)(y[2 * i + 1] - (float)b)});
     }
-    return o;
+    // the partner's slot needs this lane's OTHER half: hi lane sends its lo[0..3], lo lane sends its hi[4..7]
+    const unsigned s0 = dpp_swap(is_lo ? ph[0] : pl[0]), s1 = dpp_swap(is_lo ? ph[1] : pl[1]);
+    return is_lo ? u32x4{s0, s1, pl[0], pl[1]} : u32x4{ph[0], ph[1], s0, s1};
 }
 
 // Operands go HBM -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave instruction, LDS image
@@ -252,7 +258,7 @@ void conv_gemm_kernel(const ConvArgs a) {
     };
 
     constexpr bool SPLIT = std::is_same<TA, bsplit_t>::value;
-    constexpr int PCH = SPLIT ? 8 : EPS;                      // channels whose preact constants this lane needs
+    constexpr int PCH = EPS;                                  // channels whose preact constants this lane needs (split: 4 of the group's 8)
     u32x4 ra[PRO ? PA : 1];
     f32x4 psc[PRO ? PCH / 4 : 1], psh[PRO ? PCH / 4 : 1];     // scale/shift of this lane's channels
     // A operand of K step kt, LDS-DMA route (non-PRO)
@@ -265,18 +271,6 @@ void conv_gemm_kernel(const ConvArgs a) {
             const bool ok = (amask[p] >> tap) & 1u;
             const void* src = ok ? (const void*)(aptr[p] + koff) : (const void*)g_zero_page;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + p * (RPP * 128)), 16, 0, 0);
-        }
-    };
-    // one LDS-DMA instruction of the pair above: q < PA -> A pass q, else B pass q - PA (deep ring: issued between MFMA groups)
-    auto glds_one = [&](int kt, int buf, int q, int koff, int tap) {
-        if (q < PA) {
-            const bool ok = (amask[q] >> tap) & 1u;
-            const void* src = ok ? (const void*)(aptr[q] + koff) : (const void*)g_zero_page;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + buf * STAGE + wave * 1024 + q * (RPP * 128)), 16, 0, 0);
-        } else {
-            const int p = q - PA;
-            __builtin_amdgcn_global_load_lds((gptr_t)(wptr + (long long)(RPP * p) * a.K + kt * BKE),
-                                             (lptr_t)(smem + buf * STAGE + A_BYTES + wave * 1024 + p * (RPP * 128)), 16, 0, 0);
         }
     };
     // B operand of K step kt, always LDS-DMA
@@ -298,8 +292,8 @@ void conv_gemm_kernel(const ConvArgs a) {
         if constexpr (PRO) {
             int tap;
             const int koff = tap_of(kt * BKE, tap);
-            // (split: the 8 channels of the group this lane holds the hi or the lo half of)
-            const int ci = ((kt * BKE) & cin_mask) + (SPLIT ? (lslot >> 1) * 8 : lslot * EPS);
+            // (split: channels 0-3 of the group for the lane holding its hi slot, 4-7 for the lane holding the lo slot)
+            const int ci = ((kt * BKE) & cin_mask) + lslot * EPS;
 #pragma unroll
             for (int q = 0; q < PCH / 4; ++q) {
                 psc[q] = *(const f32x4*)(a.pro_scale + ci + 4 * q);
@@ -317,7 +311,7 @@ void conv_gemm_kernel(const ConvArgs a) {
             char* sa = smem + buf * STAGE + r0 * 128 + pslot * 16;
 #pragma unroll
             for (int p = 0; p < PA; ++p) {
-                if constexpr (SPLIT) *(u32x4*)(sa + p * (RPP * 128)) = preact_slot_split(ra[p], psc, psh, lslot & 1);
+                if constexpr (SPLIT) *(u32x4*)(sa + p * (RPP * 128)) = preact_slot_split(ra[p], psc[0], psh[0], lslot & 1);
                 else *(u32x4*)(sa + p * (RPP * 128)) = preact_slot<TA>(ra[p], psc, psh);
             }
 #pragma unroll
@@ -376,8 +370,7 @@ void conv_gemm_kernel(const ConvArgs a) {
     const int nk = a.K / BKE;
     // one K step of MFMAs out of LDS stage `sbuf`; fragments of 32-B chunk c+1 are fetched before
     // the MFMAs of chunk c issue
-    // `between(slot)` runs after the MFMAs of each (chunk, row fragment): NCHK * FM slots per stage (deep ring: DMA issue)
-    auto compute_stage = [&](const char* sbuf, auto&& between) {
+    auto compute_stage = [&](const char* sbuf) {
         constexpr int NCHK = FragIO<TA>::CHUNKS;
         // split fragments are twice as wide: 8-wave 128x128 tiles keep ONE fragment set (the 128-VGPR budget of
         // two workgroups per CU has no room for a second one next to the prefetched residual)
@@ -396,31 +389,26 @@ void conv_gemm_kernel(const ConvArgs a) {
                 if (c + 1 < NCHK) read_frags(c + 1, (c + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of this chunk's MFMAs
 #pragma unroll
-                for (int i = 0; i < FM; ++i) {
+                for (int i = 0; i < FM; ++i)
 #pragma unroll
                     for (int j = 0; j < FN; ++j) acc[i][j] = mma(fa[c & 1][i], fb[c & 1][j], acc[i][j]);
-                    between(c * FM + i);
-                }
             }
         } else {
 #pragma unroll
             for (int c = 0; c < NCHK; ++c) {
                 read_frags(c, 0);
 #pragma unroll
-                for (int i = 0; i < FM; ++i) {
+                for (int i = 0; i < FM; ++i)
 #pragma unroll
                     for (int j = 0; j < FN; ++j) acc[i][j] = mma(fa[0][i], fb[0][j], acc[i][j]);
-                    between(c * FM + i);
-                }
             }
         }
     };
-    auto no_between = [](int) {};
     // split-K: slice blockIdx.y owns K steps [kt0, kt1) and writes a raw fp32 partial plane
     const int kt0 = blockIdx.y * a.kt_per_slice;
     const int kt1 = min(nk, kt0 + a.kt_per_slice);
     if constexpr (NSTAGE >= 3) {
-        // ---- deep ring, ONE workgroup per CU: the LDS-DMA of K step kt + NSTAGE - 1 is issued at the top of step kt,
+        // ---- deep ring, ONE workgroup per CU: the LDS-DMA of K step kt + NSTAGE - 1 is issued during step kt,
         // so NSTAGE - 1 stages (the stage being awaited and NSTAGE - 2 behind it) are in flight while step kt's MFMAs
         // run.  Waits are counted (the newest stages stay outstanding) and the barrier is a bare s_barrier: a
         // __syncthreads() fence would drain vmcnt(0) every step, which is what serialises loads against MFMAs in
@@ -435,7 +423,7 @@ void conv_gemm_kernel(const ConvArgs a) {
         }
         auto transform = [&](int kt, int buf) {
             if constexpr (PRO) {
-                const int ci = ((kt * BKE) & cin_mask) + (SPLIT ? (lslot >> 1) * 8 : lslot * EPS);
+                const int ci = ((kt * BKE) & cin_mask) + lslot * EPS;
                 f32x4 sc_[PCH / 4], sh_[PCH / 4];
 #pragma unroll
                 for (int q = 0; q < PCH / 4; ++q) {
@@ -446,7 +434,7 @@ void conv_gemm_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int p = 0; p < PA; ++p) {
                     u32x4* q = (u32x4*)(sa + p * (RPP * 128));
-                    if constexpr (SPLIT) *q = preact_slot_split(*q, sc_, sh_, lslot & 1);
+                    if constexpr (SPLIT) *q = preact_slot_split(*q, sc_[0], sh_[0], lslot & 1);
                     else *q = preact_slot<TA>(*q, sc_, sh_);
                 }
             }
@@ -470,37 +458,64 @@ void conv_gemm_kernel(const ConvArgs a) {
         transform(kt0, 0);
         wait_vm_lgkm0<63>();                                      // (lgkmcnt(0): the transformed slots are written)
         __builtin_amdgcn_s_barrier();
+        // ---- ping-pong: waves 0-3 (group 0) and waves 4-7 (group 1) share the four SIMDs pairwise.  Each group
+        // alternates a LOAD segment (all fragments of its stage -> VGPRs, the DMA of stage kt + NSTAGE - 1) with a
+        // COMPUTE segment (the stage's MFMAs), one bare s_barrier between segments, and group 1 runs ONE segment
+        // behind group 0: while one wave of a SIMD feeds the matrix pipe its partner is in LDS / the address queue.
+        //   interval 2k  : group 0 LOAD(k)     | group 1 COMPUTE(k-1)
+        //   interval 2k+1: group 0 COMPUTE(k)  | group 1 LOAD(k)
+        // RAW: stage k is read first in interval 2k; every wave retires its own DMA of stage k (counted vmcnt) before
+        // the barrier that ends interval 2k-1 (group 0 at the end of COMPUTE(k-1), group 1 at the end of LOAD(k-1)).
+        // WAR: the DMA of stage k + NSTAGE - 1 lands in the buffer of stage k-1, whose last reads (group 1, LOAD(k-1),
+        // interval 2k-1) are retired by the lgkmcnt(0) in front of that interval's barrier.
+        constexpr int NCHK = FragIO<TA>::CHUNKS;
+        const int grp = wave >> 2;
         int cur = 0, nxt = NSTAGE - 1;                            // ring positions of step kt and of the stage to fill
+        if (grp == 1) __builtin_amdgcn_s_barrier();
         for (int kt = kt0; kt < kt1; ++kt) {
-            // the stage's LPW DMA instructions are issued BETWEEN the MFMA groups of this step: a burst of them at the top
-            // holds every wave of the workgroup in the texture-address queue while the matrix pipes idle
-            const bool fill = kt + NSTAGE - 1 < kt1 && !HMMR_PROBE(a, 2);
-            int tapn = 0, koffn = 0;
-            if (fill) koffn = UTAP ? tap_of((kt + NSTAGE - 1) * BKE, tapn) : 0;
-            constexpr int SLOTS = FragIO<TA>::CHUNKS * FM;
-            auto between = [&](int slot) {
-                if constexpr (UTAP) {
-#pragma unroll
-                    for (int q = 0; q < LPW; ++q)
-                        if (q * SLOTS / LPW == slot && fill) {
-                            glds_one(kt + NSTAGE - 1, nxt, q, koffn, tapn);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                }
-            };
-            if constexpr (!UTAP) { if (fill) { glds_a(kt + NSTAGE - 1, nxt); glds_b(kt + NSTAGE - 1, nxt); } }
-            if (!HMMR_PROBE(a, 1)) compute_stage(smem + cur * STAGE, between);
-            else if (fill && UTAP) { glds_a(kt + NSTAGE - 1, nxt); glds_b(kt + NSTAGE - 1, nxt); }
+            const char* sbuf = smem + cur * STAGE;
             const int c1 = (cur + 1 == NSTAGE) ? 0 : cur + 1;
-            if (kt + 1 < kt1) {
+            const bool fill = kt + NSTAGE - 1 < kt1 && !HMMR_PROBE(a, 2);
+            // ---- LOAD segment
+            frag_t fa[NCHK][FM], fb[NCHK][FN];
+#pragma unroll
+            for (int c = 0; c < NCHK; ++c) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i) fa[c][i] = FragIO<TA>::read(sbuf + a_row_off + i * 32 * 128, c, lh, fsw);
+#pragma unroll
+                for (int j = 0; j < FN; ++j) fb[c][j] = FragIO<TA>::read(sbuf + b_row_off + j * 32 * 128, c, lh, fsw);
+            }
+            if (fill) { glds_a(kt + NSTAGE - 1, nxt); glds_b(kt + NSTAGE - 1, nxt); }
+            if (grp == 1 && kt + 1 < kt1) {
                 wait_ahead(min(NSTAGE - 2, kt1 - 2 - kt));
                 transform(kt + 1, c1);
             }
             wait_vm_lgkm0<63>();
             __builtin_amdgcn_sched_barrier(0);
-            if (!HMMR_PROBE(a, 4)) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- COMPUTE segment
+            if (!HMMR_PROBE(a, 1)) {
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int c = 0; c < NCHK; ++c)
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int j = 0; j < FN; ++j) acc[i][j] = mma(fa[c][i], fb[c][j], acc[i][j]);
+                __builtin_amdgcn_s_setprio(0);
+            }
+            if (grp == 0 && kt + 1 < kt1) {
+                wait_ahead(min(NSTAGE - 2, kt1 - 2 - kt));
+                transform(kt + 1, c1);
+                wait_vm_lgkm0<63>();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
             nxt = cur; cur = c1;
         }
+        if (grp == 0) __builtin_amdgcn_s_barrier();
     } else if constexpr (PRO) {
         // tile kt+1 was fetched into VGPRs a whole K step earlier, so pre-activating and writing it
         // at the TOP of step kt never waits for HBM; its registers are then free for tile kt+2.
@@ -512,7 +527,7 @@ void conv_gemm_kernel(const ConvArgs a) {
             const int cur = (kt - kt0) & 1;
             if (kt + 1 < kt1 && !HMMR_PROBE(a, 2)) store_regs(cur ^ 1);
             if (kt + 2 < kt1 && !HMMR_PROBE(a, 2)) load_regs(kt + 2);
-            if (!HMMR_PROBE(a, 1)) compute_stage(smem + cur * STAGE, no_between);
+            if (!HMMR_PROBE(a, 1)) compute_stage(smem + cur * STAGE);
             if (!HMMR_PROBE(a, 4)) __syncthreads();
         }
     } else {
@@ -522,7 +537,7 @@ void conv_gemm_kernel(const ConvArgs a) {
         for (int kt = kt0; kt < kt1; ++kt) {
             const int cur = (kt - kt0) & 1;
             if (kt + 1 < kt1 && !HMMR_PROBE(a, 2)) { glds_a(kt + 1, cur ^ 1); glds_b(kt + 1, cur ^ 1); }
-            if (!HMMR_PROBE(a, 1)) compute_stage(smem + cur * STAGE, no_between);
+            if (!HMMR_PROBE(a, 1)) compute_stage(smem + cur * STAGE);
             if (!HMMR_PROBE(a, 4)) __syncthreads();
         }
     }
@@ -639,10 +654,9 @@ static int launch_tiled(const ConvArgs& a, int tile, int slices, hipStream_t str
         case 3: return launch_cfg<TA, TO, 64, 64, 2, 2, PRO, UTAP, 2>(a, slices, stream);     // 4 waves, 32x32 each
         case 5: return launch_cfg<TA, TO, 128, 128, 4, 2, PRO, UTAP, 2>(a, slices, stream);   // 8 waves, 32x64 each
         case 6: return launch_cfg<TA, TO, 128, 64, 4, 2, PRO, UTAP, 2>(a, slices, stream);    // 8 waves, 32x32 each
-        // deep rings, one 8-wave workgroup per CU (256 VGPRs per lane)
+        // deep ring + ping-pong wave groups, one 8-wave workgroup per CU (256 VGPRs per lane).  128x128 and 256x64 variants
+        // of this structure were measured 15-40 % slower than tiles 5 / 6 on every ResNet shape and are not instantiated.
         case 7: return launch_cfg<TA, TO, 256, 128, 4, 2, PRO, UTAP, 3>(a, slices, stream);   // 64x64 each, 3 x 48 KB
-        case 8: return launch_cfg<TA, TO, 128, 128, 4, 2, PRO, UTAP, 4>(a, slices, stream);   // 32x64 each, 4 x 32 KB
-        case 9: return launch_cfg<TA, TO, 256, 64, 4, 2, PRO, UTAP, 3>(a, slices, stream);    // 64x32 each, 3 x 40 KB
         default: hmmr_set_error("hmmr_conv_gemm: bad tile %d", tile); return -1;
     }
 }
