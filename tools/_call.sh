@@ -1,4 +1,7 @@
-mkdir -p gpurun_out/r02b
-( time python -m pytest tests -m gpu -x -q ) > gpurun_out/r02b/pytest.log 2>&1; tail -5 gpurun_out/r02b/pytest.log
-bash tools/profile_round.sh r02b bf16x3 > gpurun_out/r02b/profile.log 2>&1
-tail -75 gpurun_out/r02b/profile.log
+B="python bench.py --only-main --no-cpu-baseline --no-pcie --steps 10"
+pick() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(sys.argv[1], d['value'], d['ms_per_step'], d['roofline']['resnet_pass_ms'])" "$1"; }
+$B | pick default
+HMMR_FUSE_SC=all $B | pick fuse_sc_all
+HMMR_FUSE_SC=0 $B | pick fuse_sc_0
+HMMR_TAIL_PRIORITY=-1 $B | pick tailprio
+HMMR_RESNET_PRIORITY=0 $B | pick resprio0
