@@ -354,19 +354,26 @@ def main():
             modes[args.dtype] = dict(fps=round(value, 1), ms_per_step=round(ms_per_step, 3), **e2e_errors(out, tester, ref))
 
         # ---- PCIe-inclusive rate (host frames in, host dict out: the reference's call surface), 1 GPU only, untimed extra
-        def pcie_rate(t):
-            t.predict_all_images(span_host[:64])
-            t1 = time.perf_counter()
-            res = t.predict_all_images(span_host)
-            r = round(len(span_host) / (time.perf_counter() - t1), 1)
-            del res
-            t2 = time.perf_counter()
-            t.predict_all_images(span_host, want=("joints", "omegas", "cams"))
-            r2 = round(len(span_host) / (time.perf_counter() - t2), 1)
+        def pcie_rate(t, video=None):
+            """host float32 frames in -> host dict out, through Tester.predict_all_images (the reference's call surface);
+            one warm-up call of the same size (pinned output buffers, staging buffers), then the best of two calls."""
+            video = span_host if video is None else video
+            def once(**kw):
+                t1 = time.perf_counter()
+                res = t.predict_all_images(video, **kw)
+                dt = time.perf_counter() - t1
+                del res
+                return dt
+            once()
+            r = round(len(video) / min(once(), once()), 1)
+            r2 = round(len(video) / min(once(want=("joints", "omegas", "cams")), once(want=("joints", "omegas", "cams"))), 1)
             return r, r2
         pcie_fps = pcie_nov = None
+        pcie_long = None
         if single and not args.no_pcie:
             pcie_fps, pcie_nov = pcie_rate(tester)
+            if len(span_host) >= 256:            # a 4-chunk video: the streamed steady state (copies under the kernels)
+                pcie_long = pcie_rate(tester, np.concatenate([span_host[:256]] * 4))[0]
         # ---- the other operand modes, same workload, fewer steps (extras: never the headline)
         pcie_other = {}
         if single and not args.only_main:
@@ -416,6 +423,7 @@ def main():
             "scaling_efficiency": None,        # computed by the driver from the per-N lines (tools/scale_table.py does the same)
             "roofline": roofline,
             "pcie_inclusive_fps": pcie_fps, "pcie_inclusive_fps_without_verts": pcie_nov,
+            "pcie_inclusive_fps_1024_frame_video": pcie_long,
         }
         if modes:
             result["modes"] = modes

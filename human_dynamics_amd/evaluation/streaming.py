@@ -5,14 +5,15 @@ The reference contract is host ndarray in, dict of host ndarrays out (src/evalua
 path is bound by PCIe and host copies unless they overlap the kernels, so the video is cut into
 chunks of `chunk` frames and three HIP streams run side by side:
 
-    copy-in stream   chunk k+1: pinned staging buffer -> HBM        (hipMemcpyAsync, double-buffered)
+    copy-in stream   chunk k+1: the caller's array -> HBM (double-buffered device side; straight from the pageable
+                                array, which moves at the pinned rate on this platform, or via pinned staging buffers)
     compute stream   chunk k  : [uint8 -> float crop] -> ResNet -> phi
     tail stream      chunk k-1: the per-window tail (f_movie, IEF, 3 x SMPL), whose halo is encoded by now,
                                 underneath the ResNet of chunk k+1
     copy-out stream  chunk k-2: record fields -> one pinned host array per output key
 
-Only the host-side staging copy (pageable user array -> pinned buffer) occupies the Python thread,
-while the GPU works on the previous chunk.  Every kernel sees exactly the operands it sees in the
+Only the copy-in call occupies the Python thread (2.8 ms per 256 float32 frames), while the GPU works on the
+previous chunk.  Every kernel sees exactly the operands it sees in the
 one-shot path (per-frame ResNet, per-window tail), so the result is byte-identical to
 `Tester.predict_all_images(..., stream=False)`; tested on the GPU.
 
@@ -33,8 +34,13 @@ OUTPUT_KEYS = ("cams", "joints", "kps", "poses", "shapes", "verts", "omegas")
 class HostStreamer(object):
     """Re-usable pinned staging buffers and copy streams of one Tester."""
 
-    def __init__(self, tester, chunk=256):
+    def __init__(self, tester, chunk=256, staged="auto"):
         self.t = tester
+        # How a chunk of the caller's (pageable) frames reaches HBM.  False: copied straight from the array -- on MI355X /
+        # ROCm 7 at the pinned rate (55 GB/s, tools/pcie_probe.py), but the copy does not overlap running kernels; True:
+        # through pinned staging buffers (a host memcpy on the private pool, then an async DMA under the kernels).
+        # "auto": chunk 0 straight (nothing runs yet), later chunks staged -- best for one-chunk and for long videos.
+        self.staged = staged
         self.eng = tester.engine
         self.dev = self.eng.device
         self.margin = (tester.fov - 1) // 2
@@ -64,7 +70,7 @@ class HostStreamer(object):
     def _staging(self, dtype):
         if dtype not in self._pin:
             shape = (self.chunk, 224, 224, 3)
-            self._pin[dtype] = [torch.empty(shape, dtype=dtype, pin_memory=True) for _ in range(2)]
+            self._pin[dtype] = [torch.empty(shape, dtype=dtype, pin_memory=True) for _ in range(2)] if self.staged else [None, None]   # ("auto" is truthy)
             self._dev_in[dtype] = [torch.empty(shape, dtype=dtype, device=self.dev) for _ in range(2)]
         return self._pin[dtype], self._dev_in[dtype]
 
@@ -94,6 +100,8 @@ class HostStreamer(object):
             src = src if src.dtype == np.float32 else src.astype(np.float32)
         assert src.shape[1:] == (224, 224, 3), src.shape
         tdt = torch.uint8 if src.dtype == np.uint8 else torch.float32
+        if not src.flags.c_contiguous:
+            src = np.ascontiguousarray(src)
         pin, dev_in = self._staging(tdt)
         C, g, margin, T = self.chunk, self.g, self.margin, t.sequence_length
         n_chunks = (N + C - 1) // C
@@ -116,10 +124,16 @@ class HostStreamer(object):
                 if in_free[slot] is not None:
                     in_free[slot].synchronize()                      # the staging pair is free again (chunk k-2 is encoded)
                 tr(" waited")
-                self._stage(pin[slot], src[lo:hi])                   # the only host-side work of the loop
-                tr(" staged")
+                staged = (k > 0) if self.staged == "auto" else bool(self.staged)
+                if staged:
+                    self._stage(pin[slot], src[lo:hi])               # pageable -> pinned on the memcpy pool, then an async H2D
+                    tr(" staged")
                 with torch.cuda.stream(self.s_in):
-                    dev_in[slot][:n].copy_(pin[slot][:n], non_blocking=True)
+                    if staged:
+                        dev_in[slot][:n].copy_(pin[slot][:n], non_blocking=True)
+                    else:
+                        # straight from the caller's array; the call returns when the bytes have left it
+                        dev_in[slot][:n].copy_(torch.from_numpy(src[lo:hi]), non_blocking=True)
                     landed = torch.cuda.Event()
                     landed.record(self.s_in)
                 cur.wait_event(landed)

@@ -43,8 +43,9 @@ def main():
     te = Tester(Cfg(), weights=w, smpl=s, dtype=dt, device="cuda:0")
     for n in (256, 1024):
         xs = np.concatenate([x] * (n // 256))
-        for chunk in (64, 128, 256):
-            te._streamer = HostStreamer(te, chunk=chunk)
+        for chunk, staged in ((256, False), (256, True), (256, "auto")):
+            te._streamer = HostStreamer(te, chunk=chunk, staged=staged)
+            print("staged=%s" % (staged,), end=" ")
             ms = t(lambda: te.predict_all_images(xs), 2)
             ms2 = t(lambda: te.predict_all_images(xs, want=("joints", "omegas", "cams")), 2)
             print("%s N=%d chunk=%d: %.1f ms = %.0f fps; without verts %.1f ms = %.0f fps" % (dt, n, chunk, ms, n / ms * 1e3, ms2, n / ms2 * 1e3))
