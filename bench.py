@@ -189,10 +189,10 @@ def run_mode(dtype, args, world, rank, device, weights, smpl, span, n_total, ste
     return timing, tester, predictor, out
 
 
-def e2e_errors(out, tester, ref):
+def e2e_errors(out, tester, ref, sliced=False):
     from human_dynamics_amd import dist as hd
     layout, _ = hd.record_layout(len(tester.delta_t_values))
-    rec = hd.unpack_outputs(out[ERR_WINDOW_START:ERR_WINDOW_START + 8], layout)
+    rec = hd.unpack_outputs(out if sliced else out[ERR_WINDOW_START:ERR_WINDOW_START + 8], layout)
     return {"e2e_%s_max_abs_err" % k: float(np.abs(rec[k].cpu().numpy() - ref[k]).max()) for k in ("verts", "joints", "omegas")}
 
 
@@ -346,12 +346,27 @@ def main():
     if rank == 0:
         roofline = roofline_leg(tester, plan, span, args.dtype, args.frames if not strong else -1)
         single = world == 1
+        # ---- the other operand modes, same workload, same steps (extras: never the headline).  Timed BEFORE any host-side
+        # work of this script (oracle, PCIe legs): under the container's CPU quota the oracle's thread pool slows the launch
+        # thread down afterwards, and the 190-launch bf16 step is the first thing to become host-bound.
+        others, modes = {}, {}
+        if single and not args.only_main:
+            for other in [m for m in ("bf16x3", "bf16", "f32") if m != args.dtype]:
+                tm, t_o, pred_o, out_o = run_mode(other, args, world, rank, device, weights, smpl, span, n_total,
+                                                  args.steps, args.warmup)
+                modes[other] = dict(fps=round(tm["fps"], 1), ms_per_step=round(tm["ms_per_step"], 3))
+                others[other] = (t_o, out_o[ERR_WINDOW_START:ERR_WINDOW_START + 8].clone())
+                del pred_o, out_o
+                torch.cuda.empty_cache()
         span_host = span.cpu().numpy() if single else None
         ref = None
-        modes = {}
         if single and not args.no_cpu_baseline and n_total >= ERR_WINDOW_START + 14:
             ref = oracle_window(span_host, plan.f0, n_total, weights, smpl)
             modes[args.dtype] = dict(fps=round(value, 1), ms_per_step=round(ms_per_step, 3), **e2e_errors(out, tester, ref))
+            for other, (t_o, rows) in others.items():
+                modes[other].update(e2e_errors(rows, t_o, ref, sliced=True))
+        elif modes:
+            modes[args.dtype] = dict(fps=round(value, 1), ms_per_step=round(ms_per_step, 3))
 
         # ---- PCIe-inclusive rate (host frames in, host dict out: the reference's call surface), 1 GPU only, untimed extra
         def pcie_rate(t, video=None):
@@ -370,25 +385,13 @@ def main():
             return r, r2
         pcie_fps = pcie_nov = None
         pcie_long = None
+        pcie_other = {}
         if single and not args.no_pcie:
             pcie_fps, pcie_nov = pcie_rate(tester)
             if len(span_host) >= 256:            # a 4-chunk video: the streamed steady state (copies under the kernels)
                 pcie_long = pcie_rate(tester, np.concatenate([span_host[:256]] * 4))[0]
-        # ---- the other operand modes, same workload, fewer steps (extras: never the headline)
-        pcie_other = {}
-        if single and not args.only_main:
-            del predictor, out
-            for other in [m for m in ("bf16x3", "bf16", "f32") if m != args.dtype]:
-                tester = None
-                torch.cuda.empty_cache()
-                tm, tester, pred_o, out_o = run_mode(other, args, world, rank, device, weights, smpl, span, n_total,
-                                                     max(3, args.steps // 2), min(args.warmup, 2))
-                modes[other] = dict(fps=round(tm["fps"], 1), ms_per_step=round(tm["ms_per_step"], 3))
-                if ref is not None:
-                    modes[other].update(e2e_errors(out_o, tester, ref))
-                if other == "bf16" and not args.no_pcie:
-                    pcie_other["bf16"] = pcie_rate(tester)[0]
-                del pred_o, out_o
+            if "bf16" in others:
+                pcie_other["bf16"] = pcie_rate(others["bf16"][0])[0]
         tol = 1e-4
         result = {
             "metric": "frames/sec/GPU (ResNet+temporal+SMPL, 224x224); SMPL verts max-abs-err",

@@ -1,2 +1,6 @@
-python tools/pcie_probe.py bf16x3 2>&1 | grep -v amdgpu.ids | grep "N="
-python -m pytest tests/test_gpu_pipeline.py -m gpu -x -q -k "stream or host" 2>&1 | tail -3
+python bench.py --steps 20 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print(d['value'], d['ms_per_step'], d['roofline']['frac'])
+print(json.dumps(d['modes'], indent=0))
+print({k:v for k,v in d.items() if 'pcie' in k}); print(d['cpu_baseline']['value'], d['value_meets_tolerance'])"
