@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HMMR_LIB_PATH") or os.path.join(HERE, "libhmmr_hip.so")
 
 HMMR_F32, HMMR_BF16, HMMR_BF16X3 = 0, 1, 2
-ABI_VERSION = 8
+ABI_VERSION = 9
 RESNET_UNITS = 16
 RESNET_PROF_SLOTS = 64
 MAX_TEMPORAL_BLOCKS = 8
@@ -38,6 +38,7 @@ class ConvDesc(C.Structure):
         ("split_k", C.c_int), ("ws", _vp), ("ws_bytes", C.c_size_t),
         ("pro_scale", _fp), ("pro_shift", _fp),
         ("out_b", _vp), ("ldo_b", C.c_int), ("n_split", C.c_int), ("relu_b", C.c_int),
+        ("in2", _vp), ("cin2", C.c_int),
     ]
 
 
@@ -66,7 +67,7 @@ class Layer(C.Structure):
 
 
 class ResnetUnit(C.Structure):
-    _fields_ = [("conv1", Layer), ("conv2", Layer), ("conv3", Layer), ("shortcut", Layer), ("sc_c1", Layer),
+    _fields_ = [("conv1", Layer), ("conv2", Layer), ("conv3", Layer), ("shortcut", Layer), ("c3sc", Layer), ("sc_c1", Layer),
                 ("pre_scale", _fp), ("pre_shift", _fp),
                 ("c_in", C.c_int), ("base", C.c_int), ("depth", C.c_int), ("stride", C.c_int),
                 ("fuse_preact", C.c_int), ("fuse_tail", C.c_int)]

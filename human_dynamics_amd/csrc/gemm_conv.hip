@@ -53,6 +53,7 @@ struct ConvArgs {
     int kt_per_slice;                 // K steps per split-K slice (blockIdx.y); == all of them without split-K
     long long out_slice_stride;       // elements between the partial-sum planes of consecutive slices
     int probe;                        // always 0 in the product build (see HMMR_GEMM_PROBE below)
+    const void* in2; int cin2, kt_split;   // second operand source: K steps >= kt_split read rows of in2 [M][cin2]
 };
 
 // Development build only (-DHMMR_GEMM_PROBE, tools/probe_build.sh -> libhmmr_hip_probe.so): the K loop can drop its
@@ -266,6 +267,17 @@ void conv_gemm_kernel(const ConvArgs a) {
         int tap;
         const int koff = UTAP ? tap_of(kt * BKE, tap) : tap_of(kt * BKE + lslot * EPS, tap) - lslot * EPS;
         char* sa = smem + buf * STAGE + wave * 1024;
+        if (a.in2 && kt >= a.kt_split) {
+            // second source (dense rows of cin2 elements): the address is rebuilt per instruction, nothing stays live
+            const TA* in2 = (const TA*)a.in2 + (kt - a.kt_split) * BKE + lslot * EPS;
+#pragma unroll
+            for (int p = 0; p < PA; ++p) {
+                const void* src = (amask[p] & 1u) ? (const void*)(in2 + (long long)(m0 + r0 + RPP * p) * a.cin2)
+                                                  : (const void*)g_zero_page;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sa + p * (RPP * 128)), 16, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
             const bool ok = (amask[p] >> tap) & 1u;
@@ -770,7 +782,7 @@ extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
     const int eps = d->in_dtype == HMMR_BF16X3 ? 8 : 16 / esz;
     const int cl2 = ilog2_exact(d->cin);
     HMMR_REQUIRE(cl2 >= 0 && d->cin % eps == 0, "hmmr_conv_gemm: cin=%d must be a power of two >= %d", d->cin, eps);
-    const int K = d->kh * d->kw * d->cin;
+    const int K = d->kh * d->kw * d->cin + (d->in2 ? d->cin2 : 0);      // (in2: a second 1x1 source appended along K)
     HMMR_REQUIRE(d->kh * d->kw <= 32, "hmmr_conv_gemm: at most 32 filter taps");
     const int bke = 128 / esz;             // elements per 128-byte K step
     HMMR_REQUIRE(K % bke == 0, "hmmr_conv_gemm: K=%d must be a multiple of %d", K, bke);
@@ -794,6 +806,12 @@ extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
     HMMR_REQUIRE(!d->pro_scale || !d->res, "hmmr_conv_gemm: a fused pre-activation (pro_*) cannot be combined with a residual");
     HMMR_REQUIRE(!d->pro_scale || (d->py == 0 && d->px == 0 && d->kh == 1 && d->kw == 1),
                  "hmmr_conv_gemm: the fused pre-activation is for un-padded 1x1 gathers (padding must stay zero)");
+    HMMR_REQUIRE(!d->in2 || (d->kh == 1 && d->kw == 1 && d->py == 0 && d->px == 0 && d->sy == 1 && d->sx == 1 && !d->pro_scale &&
+                             d->split_k <= 1 && d->cin2 > 0 && d->cin % bke == 0 && d->cin2 % bke == 0 &&
+                             d->in_px_stride == d->cin && d->in_row_stride == d->win * d->cin &&
+                             d->in_img_stride == (int64_t)d->hin * d->win * d->cin && d->ho == d->hin && d->wo == d->win),
+                 "hmmr_conv_gemm: a second operand source (in2) needs a dense 1x1 stride-1 un-padded GEMM, cin and cin2 "
+                 "multiples of the 128-byte K step, no pro_scale, no split_k");
     ConvArgs a;
     a.in = d->in; a.w = d->w; a.scale = d->scale; a.shift = d->shift; a.res = d->res;
     a.out = d->out; a.out2 = d->out2; a.scale2 = d->scale2; a.shift2 = d->shift2;
@@ -807,6 +825,7 @@ extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
     a.res_row_stride = d->res_row_stride; a.res_px_stride = d->res_px_stride;
     a.relu = d->relu; a.tiles_n = 0; a.n_tiles = 0;
     a.kt_per_slice = 0; a.out_slice_stride = 0; a.probe = 0;
+    a.in2 = d->in2; a.cin2 = d->in2 ? d->cin2 : 0; a.kt_split = d->cin / bke;
 #ifdef HMMR_GEMM_PROBE
     if (const char* e = getenv("HMMR_GEMM_PROBE")) a.probe = atoi(e);
 #endif

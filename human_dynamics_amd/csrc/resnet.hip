@@ -289,7 +289,14 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
         hmmr_conv_desc_t d;
         const bool sc_c1 = U.shortcut.w && U.sc_c1.w && !h1_ready && U.stride == 1;
         const bool sc_in_tail = U.fuse_tail == 3;        // the conv shortcut is computed inside the fused tail
-        if (sc_in_tail) {
+        // the conv shortcut is folded into conv3: ONE GEMM over {h2, preact} with [W3 | Wsc] (hmmr_conv_desc_t.in2);
+        // the shortcut tensor (the widest tensor of the unit) is neither written nor read back
+        const bool sc_in_c3 = U.c3sc.w != nullptr;
+        HMMR_REQUIRE(!sc_in_c3 || (U.shortcut.w && !fused && U.stride == 1 && !U.fuse_tail && !U.sc_c1.w),
+                     "resnet: unit %d cannot fold its shortcut into conv3", u);
+        if (sc_in_c3) {
+            if (prof_mark(pf)) return -2;
+        } else if (sc_in_tail) {
             HMMR_REQUIRE(U.shortcut.w && !U.shortcut.scale && !fused && U.c_in == 64 && U.stride == 1,
                          "resnet: unit %d cannot compute its shortcut inside the tail", u);
             if (prof_mark(pf)) return -2;
@@ -341,7 +348,8 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
         d.n_img = n; d.hin = Ho; d.win = Ho; d.cin = U.base;
         d.in_img_stride = (int64_t)Ho * Ho * U.base; d.in_row_stride = Ho * U.base; d.in_px_stride = U.base;
         d.kh = d.kw = 1; d.sy = d.sx = 1; d.ho = d.wo = Ho; d.cout = U.depth; d.ldo = U.depth;
-        if (U.shortcut.w) { d.res = xn; d.ldr = U.depth; }
+        if (sc_in_c3) { d.w = U.c3sc.w; d.scale = U.c3sc.scale; d.shift = U.c3sc.shift; d.tile = U.c3sc.tile; d.in2 = xin; d.cin2 = U.c_in; }
+        else if (U.shortcut.w) { d.res = xn; d.ldr = U.depth; }
         else if (U.stride == 1) { d.res = X[cur]; d.ldr = U.depth; }
         else {                        // max_pool2d(x, [1,1], stride) = x[:, ::s, ::s] of the RAW input
             d.res = X[cur]; d.res_strided = 1;

@@ -69,7 +69,7 @@ class HmmrEngine(object):
 
     def __init__(self, weights, smpl, dtype=DEFAULT_DTYPE, device="cuda:0", num_conv_layers=3,
                  delta_t_values=(-5, 5), joint_type="cocoplus", resnet_chunk=0,
-                 temporal_dtype=None, ief_dtype=None, autotune=True):
+                 temporal_dtype=None, ief_dtype=None, autotune=True, fold_sc=None):
         self.lib = L.load()
         _debug_from_env()
         if not torch.cuda.is_available():
@@ -87,11 +87,12 @@ class HmmrEngine(object):
         tail = {"0": False, "1": True}.get(os.environ.get("HMMR_FUSE_TAIL", "1"), os.environ.get("HMMR_FUSE_TAIL"))   # dev A/B switch: 0, 1, "block1", "noconv2", "conv2b1", "nosc", "nostride2"
         fsc = {"0": False, "1": True}.get(os.environ.get("HMMR_FUSE_SC", "1"), "all")               # dev A/B switch: 0, 1, all
         pfirst = os.environ.get("HMMR_PREACT_FIRST", "0") != "0"                                    # dev A/B switch
+        fold = {"0": False, "1": True}.get(os.environ.get("HMMR_FOLD_SC", ""), None) if fold_sc is None else fold_sc   # dev A/B switch
         # every stage is packed only when its variables exist: a ResNet-only checkpoint (hmr_noS5.ckpt-642561, what
         # FeatureExtractor is given: src/datasets/resnet_extractor.py:31-40) has no AZ_FC_* / single_view_ief* names
         w = weights if weights is not None else {}
         self.rw = (packing.pack_resnet(w, self.dtype, self.store, fuse_preact_blocks=fuse, fuse_tail=tail, fuse_sc=fsc,
-                                       fuse_preact_first=pfirst)
+                                       fuse_preact_first=pfirst, fold_sc=fold)
                    if "resnet_v2_50/conv1/weights" in w else None)
         self.tw = (packing.pack_temporal(w, self.temporal_dtype, self.store, num_conv_layers)
                    if assets.temporal_scopes(0)[1] + "/weights" in w else None)
@@ -149,9 +150,16 @@ class HmmrEngine(object):
                 slot += 1
         return out
 
+    def _layer_of(self, u, nm):
+        """the hmmr_layer_t whose .tile the launch of (unit, layer name) reads (csrc/resnet.hip)"""
+        U = self.rw.unit[u]
+        if nm == "conv3" and U.c3sc.w:
+            return U.c3sc
+        return getattr(U, nm)
+
     def _set_tiles(self, table):
         for (u, nm), t in table.items():
-            getattr(self.rw.unit[u], nm).tile = int(t)
+            self._layer_of(u, nm).tile = int(t)
 
     def _tune_resnet(self, images, n, n_zero):
         """Pick hmmr_layer_t.tile for every ResNet conv at this batch size: one instrumented pass per
@@ -168,7 +176,7 @@ class HmmrEngine(object):
         best = {}
         for cand in (0,) + self._TUNE_TILES:
             for slot, u, nm in layers:
-                lay = getattr(self.rw.unit[u], nm)
+                lay = self._layer_of(u, nm)
                 cout = self.rw.unit[u].base if nm in ("conv1", "conv2") else self.rw.unit[u].depth
                 lay.tile = cand if (cand not in (1, 5, 7) or cout % 128 == 0) else 0
             t = None
@@ -179,7 +187,7 @@ class HmmrEngine(object):
                 cur = np.frombuffer(pm, dtype=np.float32).copy()
                 t = cur if (t is None or rep == 0) else np.minimum(t, cur)      # rep 0 is the warm-up
             for slot, u, nm in layers:
-                tile = getattr(self.rw.unit[u], nm).tile
+                tile = self._layer_of(u, nm).tile
                 if (u, nm) not in best or t[slot] < best[(u, nm)][0] * 0.98:    # 2 % hysteresis towards the heuristic
                     best[(u, nm)] = (float(t[slot]), tile)
         table = {k: v[1] for k, v in best.items()}
@@ -363,7 +371,7 @@ class HmmrEngine(object):
 
 def conv_gemm(x, w_hwio, stride=1, pad=0, scale=None, shift=None, res=None, relu=False,
               scale2=None, shift2=None, in_dtype=L.HMMR_F32, out_dtype=L.HMMR_F32, tile=0,
-              device="cuda:0", res_stride=1, split_k=0, pro=None, raw=False):
+              device="cuda:0", res_stride=1, split_k=0, pro=None, raw=False, second=None):
     """Test/utility entry: run one NHWC convolution through hmmr_conv_gemm.
     x [n,h,w,cin] (numpy/torch), w_hwio [kh,kw,cin,cout].  Returns (out, out2) as float32 arrays, or with
     raw=True the device tensors in their storage type; x may itself be such a device tensor."""
@@ -379,11 +387,17 @@ def conv_gemm(x, w_hwio, stride=1, pad=0, scale=None, shift=None, res=None, relu
     py, px = (pad, pad) if isinstance(pad, int) else pad
     ho = (h + 2 * py - kh) // stride + 1
     wo = (w_ + 2 * px - kw) // stride + 1
+    x2 = None
+    if second is not None:          # (x2 [n,h,w,cin2], w2 [1,1,cin2,cout]): a second 1x1 source appended along K (hmmr_conv_desc_t.in2)
+        x2 = store.put(np.asarray(second[0], np.float32), packing.TORCH_DT[in_dtype])
+        w_hwio = np.concatenate([np.asarray(w_hwio, np.float32), np.asarray(second[1], np.float32)], axis=2)
     wt = store.put(packing.pack_conv_weight(np.asarray(w_hwio, np.float32)), packing.TORCH_DT[in_dtype])
     ldo = (cout + 7) // 8 * 8
     out = packing.empty_act((n, ho, wo, ldo), out_dtype, dev, zero=True)
     d = L.ConvDesc()
     d.in_, d.w, d.out = xt.data_ptr(), wt.data_ptr(), out.data_ptr()
+    if x2 is not None:
+        d.in2, d.cin2 = x2.data_ptr(), x2.shape[-1]
     d.scale = store.vec(scale).data_ptr() if scale is not None else None
     d.shift = store.vec(shift).data_ptr() if shift is not None else None
     out2 = None

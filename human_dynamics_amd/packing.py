@@ -111,12 +111,18 @@ def _layer(store, w_packed, dtype, scale=None, shift=None):
 
 
 def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3", "block4"), fuse_tail=True,
-                fuse_sc=True, fuse_preact_first=False):
+                fuse_sc=True, fuse_preact_first=False, fold_sc=None):
     """fuse_preact_blocks: blocks whose units apply their `preact` BN+ReLU inside the operand
     staging of conv1/shortcut instead of reading a materialised preact tensor (csrc/resnet.hip;
     measured at batch 256: -4.5 % ResNet time with blocks 1-2 fused, neutral for blocks 3-4).
     fuse_tail: mark the units whose conv3 + add runs with the next unit's preact + conv1 as one
     hmmr_bottleneck_tail launch (bf16; the stride-1 units of block1 and block2)."""
+    if fold_sc is None:
+        # fold every conv shortcut into its unit's conv3 (one GEMM over {h2, preact}: hmmr_resnet_unit_t.c3sc).  Default in
+        # the bf16x3 mode, where it removes the widest tensor of the unit (4 B/element) from HBM; the bf16 mode has its own
+        # fused units, and in f32 mode it would move the accumulation order away from the layer-per-launch schedule.
+        fold_sc = dtype == L.HMMR_BF16X3
+    bke = 64 if dtype == L.HMMR_BF16 else 32
     rw = L.ResnetWeights()
     rw.dtype = dtype
     rw.stem = _layer(store, pack_stem_weight(w["resnet_v2_50/conv1/weights"]), dtype,
@@ -141,7 +147,13 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
         if has_sc:
             u.shortcut = _layer(store, pack_conv_weight(w[scope + "/shortcut/weights"]), dtype,
                                 shift=w[scope + "/shortcut/biases"])
-            if fuse_sc and stride == 1 and (c_in >= 512 or fuse_sc == "all"):   # measured: pays in blocks 3-4 only
+            folded = bool(fold_sc) and stride == 1 and not u.fuse_preact and base % bke == 0 and c_in % bke == 0
+            if folded:
+                both = np.concatenate([w[scope + "/conv3/weights"], w[scope + "/shortcut/weights"]], axis=2)   # along K
+                bias = (np.asarray(w[scope + "/conv3/biases"], np.float64) +
+                        np.asarray(w[scope + "/shortcut/biases"], np.float64)).astype(np.float32)
+                u.c3sc = _layer(store, pack_conv_weight(both), dtype, shift=bias)
+            if not folded and fuse_sc and stride == 1 and (c_in >= 512 or fuse_sc == "all"):   # measured: pays in blocks 3-4 only
                 # shortcut and conv1 read the same operand: one [depth + base][c_in] filter bank, conv1's columns
                 # after the shortcut's; scale 1 on the shortcut columns (fma(v, 1, b) == v + b exactly)
                 both = np.concatenate([w[scope + "/shortcut/weights"], w[scope + "/conv1/weights"]], axis=3)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HMMR_ABI_VERSION 8
+#define HMMR_ABI_VERSION 9
 
 /* HMMR_BF16X3: "split" tensors -- every group of 8 consecutive channels is 32 bytes, [hi x8][lo x8] with
  * hi = bf16(x), lo = bf16(x - hi) (4 bytes per element, ~16 mantissa bits); GEMMs on them issue three bf16
@@ -111,6 +111,13 @@ typedef struct {
      * with out2, res or split_k.  out_b == NULL: off. */
     void* out_b;
     int ldo_b, n_split, relu_b;
+    /* second operand source: K = cin + cin2, the first cin elements of a row of A come from `in`, the next cin2 from
+     * `in2` -- two 1x1 convolutions over two tensors of the same pixel grid summed in ONE accumulator (a unit's conv3
+     * and its conv shortcut: `w` = [W3 | Wsc] along K, `shift` = the sum of the two biases; the shortcut tensor is
+     * never stored).  Both tensors dense [M][cin] / [M][cin2] (1x1, stride 1, no padding), cin and cin2 multiples of
+     * the 128-byte K step, no pro_scale, no split_k.  in2 == NULL: off. */
+    const void* in2;
+    int cin2;
 } hmmr_conv_desc_t;
 
 int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream);
@@ -133,6 +140,9 @@ typedef struct {
 
 typedef struct {
     hmmr_layer_t conv1, conv2, conv3, shortcut;   /* shortcut.w == NULL: identity / subsample */
+    hmmr_layer_t c3sc;         /* optional (stride-1 units with a conv shortcut): [W3 | Wsc] as one [depth][base + c_in]
+                                  filter bank, shift = conv3 bias + shortcut bias: conv3 and the shortcut as ONE GEMM over
+                                  {h2, preact} (hmmr_conv_desc_t.in2); needs fuse_preact == 0.  w == NULL: separate launches */
     hmmr_layer_t sc_c1;        /* optional: rows [shortcut (depth); conv1 (base)] of one [depth+base][c_in] filter
                                   bank with scale = [1..1; BN scale], shift = [bias; BN shift]: both convs as
                                   one column-split GEMM.  w == NULL: two launches. */

@@ -97,7 +97,7 @@ def _fold_bn32(w, prefix):
     return scale.astype(np.float32), (b - m * scale).astype(np.float32)
 
 
-def resnet_v2_50_emulated(images_nhwc, w, emulate):
+def resnet_v2_50_emulated(images_nhwc, w, emulate, fold_shortcut=None):
     """resnet_v2_50 below with the rounding points of csrc/resnet.hip in mode `emulate`: image and
     filters as operands, and every tensor the launch sequence stores (stem conv + bias, each unit's
     pre-activation, h1, h2, conv shortcut, trunk).  Arithmetic between rounding points is float64
@@ -105,6 +105,8 @@ def resnet_v2_50_emulated(images_nhwc, w, emulate):
     such a difference tips over a rounding boundary)."""
     dt = torch.float64
     q = lambda t: quantize(t, emulate)
+    if fold_shortcut is None:      # bf16x3: the conv shortcut of a stride-1 unit is accumulated inside conv3's GEMM, never stored
+        fold_shortcut = emulate == "bf16x3"
 
     def conv(x, name, stride=1, pad=0):
         wt = q(_t(w[name], dt)).permute(3, 2, 0, 1).contiguous()
@@ -126,8 +128,10 @@ def resnet_v2_50_emulated(images_nhwc, w, emulate):
             if c_in == depth:
                 shortcut = raw if stride == 1 else raw[:, :, ::stride, ::stride]
             else:
-                shortcut = q(conv(preact, sc + "/shortcut/weights", stride)
-                             + _t(w[sc + "/shortcut/biases"], dt).view(1, -1, 1, 1))
+                shortcut = (conv(preact, sc + "/shortcut/weights", stride)
+                            + _t(w[sc + "/shortcut/biases"], dt).view(1, -1, 1, 1))
+                if not (fold_shortcut and stride == 1):
+                    shortcut = q(shortcut)
             r = q(torch.relu(affine(conv(preact, sc + "/conv1/weights"), *_fold_bn32(w, sc + "/conv1/BatchNorm"))))
             r = q(torch.relu(affine(conv(r, sc + "/conv2/weights", stride, 1), *_fold_bn32(w, sc + "/conv2/BatchNorm"))))
             r = conv(r, sc + "/conv3/weights") + _t(w[sc + "/conv3/biases"], dt).view(1, -1, 1, 1)

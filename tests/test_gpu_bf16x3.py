@@ -222,3 +222,53 @@ def test_predict_all_images_split_matches_golden_video(weights, smpl_consts, gpu
                  dedup=False).predict_all_images(frames)
     for k in res:
         assert np.array_equal(res[k], lit[k]), k
+
+
+@pytest.mark.parametrize("tile", [0, 5, 6, 7, 3])
+@pytest.mark.parametrize("dt", ["x3", "bf16", "f32"])
+def test_conv_gemm_second_operand_source(tile, dt, gpu_device):
+    """hmmr_conv_desc_t.in2: K = cin + cin2 over two tensors of the same pixel grid in ONE accumulator (a unit's conv3
+    + its conv shortcut) against the two convolutions evaluated separately in float64 on the same (rounded) operands."""
+    from human_dynamics_amd.engine import conv_gemm
+    from human_dynamics_amd.packing import from_split, to_split
+    rng = np.random.default_rng(11)
+    n, h, c1, c2, cout = 3, 13, 64, 256, 256            # 507 pixels: M tail inside the last tile
+    x1 = rng.normal(size=(n, h, h, c1)).astype(np.float32)
+    x2 = np.maximum(rng.normal(size=(n, h, h, c2)), 0).astype(np.float32)
+    w1 = (rng.normal(size=(1, 1, c1, cout)) / 8).astype(np.float32)
+    w2 = (rng.normal(size=(1, 1, c2, cout)) / 16).astype(np.float32)
+    b = rng.normal(size=cout).astype(np.float32)
+    code = {"x3": X3, "bf16": L.HMMR_BF16, "f32": L.HMMR_F32}[dt]
+    out, _ = conv_gemm(x1, w1, 1, 0, None, b, None, False, in_dtype=code, out_dtype=L.HMMR_F32, tile=tile,
+                       device=gpu_device, second=(x2, w2))
+    def rnd(a):
+        t = torch.from_numpy(a)
+        if dt == "x3":
+            return from_split(to_split(t)).double().numpy()
+        return (t.to(torch.bfloat16) if dt == "bf16" else t).double().numpy()
+    ref = rnd(x1).reshape(-1, c1) @ rnd(w1).reshape(c1, cout) + rnd(x2).reshape(-1, c2) @ rnd(w2).reshape(c2, cout) + b
+    err = np.abs(out.reshape(-1, cout) - ref).max()
+    assert err < 2e-5 * max(1.0, np.abs(ref).max()), err
+
+
+def test_resnet_folded_shortcut_is_the_separate_shortcut_up_to_its_rounding(weights, gpu_device):
+    """bf16x3 default: the conv shortcut of every block's first unit is accumulated inside conv3's GEMM instead of being
+    stored (rounded to 16 bits) and added back.  Against the launch-per-layer schedule the features move by that one
+    rounding; against the float64 oracle both stay inside the mode's bound."""
+    from human_dynamics_amd.engine import HmmrEngine
+    from oracle import hmmr_oracle as O
+    frames = assets.make_synthetic_frames(5, seed=9)
+    folded = HmmrEngine(weights, None, dtype="bf16x3", device=gpu_device, autotune=False)
+    assert [i for i in range(16) if folded.rw.unit[i].c3sc.w] == [0, 3, 7, 13]
+    plain = HmmrEngine(weights, None, dtype="bf16x3", device=gpu_device, autotune=False, fold_sc=False)
+    assert not any(plain.rw.unit[i].c3sc.w for i in range(16))
+    a, b = folded.resnet(frames, n_zero=1).cpu().numpy(), plain.resnet(frames, n_zero=1).cpu().numpy()
+    ref = O.resnet_v2_50(np.concatenate([frames, np.zeros_like(frames[:1])]), weights, torch.float64).numpy()
+    n = np.linalg.norm(ref)
+    ea, eb, d = np.linalg.norm(a - ref) / n, np.linalg.norm(b - ref) / n, np.linalg.norm(a - b) / n
+    print("folded shortcut: rel-L2 vs f64 %.2e (separate launches %.2e), folded vs separate %.2e" % (ea, eb, d))
+    assert ea < 5e-5 and eb < 5e-5 and d < 2e-5
+    emu = O.resnet_v2_50_emulated(frames[:2], weights, "bf16x3").numpy()
+    emu_sep = O.resnet_v2_50_emulated(frames[:2], weights, "bf16x3", fold_shortcut=False).numpy()
+    assert np.linalg.norm(a[:2] - emu) / np.linalg.norm(emu) < 5e-6
+    assert np.linalg.norm(b[:2] - emu_sep) / np.linalg.norm(emu_sep) < 5e-6
