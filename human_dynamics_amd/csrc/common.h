@@ -155,3 +155,35 @@ template <> __device__ __forceinline__ void unpack8<bsplit_t>(const u32x4 (&r)[2
         v[2 * i + 1] = __uint_as_float(r[0][i] & 0xffff0000u) + __uint_as_float(r[1][i] & 0xffff0000u);
     }
 }
+
+// split tensors keep the hi and the lo half of an 8-channel group in neighbouring slots, i.e. in neighbouring lanes of
+// the staging geometry (lslot ^ 1 <-> lane ^ 1).  The two lanes share the work: the lane holding the hi slot
+// pre-activates channels 0-3 of the group, the lane holding the lo slot channels 4-7 (each needs two dwords of its
+// partner: DPP quad_perm [1,0,3,2]), both split their four results, and a second exchange completes each lane's own
+// slot.  sc / sh: scale and shift of THIS lane's four channels.  Value for value this is
+// store8<bsplit_t>(relu(fma(load8<bsplit_t>(x), s, b))), the producer-side `out2` of the epilogue.
+__device__ __forceinline__ unsigned dpp_swap(unsigned v) {
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
+}
+__device__ __forceinline__ u32x4 preact_slot_split(const u32x4& v, const f32x4& sc, const f32x4& sh, bool is_lo) {
+    // what the partner needs from this lane: hi lane -> its hi[4..7] (dwords 2, 3); lo lane -> its lo[0..3] (dwords 0, 1)
+    const unsigned r0 = dpp_swap(is_lo ? v[0] : v[2]), r1 = dpp_swap(is_lo ? v[1] : v[3]);
+    const unsigned h0 = is_lo ? r0 : v[0], h1 = is_lo ? r1 : v[1];       // hi halves of this lane's four channels
+    const unsigned l0 = is_lo ? v[2] : r0, l1 = is_lo ? v[3] : r1;       // lo halves
+    float y[4];
+    y[0] = fmaxf(fmaf(__uint_as_float(h0 << 16) + __uint_as_float(l0 << 16), sc[0], sh[0]), 0.f);
+    y[1] = fmaxf(fmaf(__uint_as_float(h0 & 0xffff0000u) + __uint_as_float(l0 & 0xffff0000u), sc[1], sh[1]), 0.f);
+    y[2] = fmaxf(fmaf(__uint_as_float(h1 << 16) + __uint_as_float(l1 << 16), sc[2], sh[2]), 0.f);
+    y[3] = fmaxf(fmaf(__uint_as_float(h1 & 0xffff0000u) + __uint_as_float(l1 & 0xffff0000u), sc[3], sh[3]), 0.f);
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    unsigned ph[2], pl[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const bf16_t a = (bf16_t)y[2 * i], b = (bf16_t)y[2 * i + 1];
+        ph[i] = __builtin_bit_cast(unsigned, bf16x2{a, b});
+        pl[i] = __builtin_bit_cast(unsigned, bf16x2{(bf16_t)(y[2 * i] - (float)a), (bf16_t)(y[2 * i + 1] - (float)b)});
+    }
+    // the partner's slot needs this lane's OTHER half: hi lane sends its lo[0..3], lo lane sends its hi[4..7]
+    const unsigned s0 = dpp_swap(is_lo ? ph[0] : pl[0]), s1 = dpp_swap(is_lo ? ph[1] : pl[1]);
+    return is_lo ? u32x4{s0, s1, pl[0], pl[1]} : u32x4{ph[0], ph[1], s0, s1};
+}

@@ -292,7 +292,7 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
         // the conv shortcut is folded into conv3: ONE GEMM over {h2, preact} with [W3 | Wsc] (hmmr_conv_desc_t.in2);
         // the shortcut tensor (the widest tensor of the unit) is neither written nor read back
         const bool sc_in_c3 = U.c3sc.w != nullptr;
-        HMMR_REQUIRE(!sc_in_c3 || (U.shortcut.w && !fused && U.stride == 1 && !U.fuse_tail && !U.sc_c1.w),
+        HMMR_REQUIRE(!sc_in_c3 || (U.shortcut.w && !fused && U.stride == 1 && U.fuse_tail <= 1 && !U.sc_c1.w),
                      "resnet: unit %d cannot fold its shortcut into conv3", u);
         if (sc_in_c3) {
             if (prof_mark(pf)) return -2;
@@ -376,7 +376,8 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
             t.out = d.out; t.out_pre = d.out2; t.pre_scale = d.scale2; t.pre_shift = d.shift2;
             if (hmmr_bottleneck_tail(&t, s)) return -2;
         } else if (U.fuse_tail) {     // conv3 + add + the next unit's preact + conv1 in one launch (csrc/bottleneck.hip)
-            HMMR_REQUIRE(!last && w->dtype == HMMR_BF16 && U.stride == 1 && write_raw && !write_pre && next_fused &&
+            HMMR_REQUIRE(!last && (w->dtype == HMMR_BF16 || (w->dtype == HMMR_BF16X3 && U.fuse_tail == 1 && U.w3_frag && U.w1n_frag)) &&
+                         U.stride == 1 && write_raw && !write_pre && next_fused &&
                          next_identity && w->unit[u + 1].base == U.base && w->unit[u + 1].c_in == U.depth &&
                          ((U.base == 64 && U.depth == 256) || (U.base == 128 && U.depth == 512)),
                          "resnet: unit %d cannot fuse its tail", u);
@@ -391,7 +392,12 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
                 t.h2 = T2;
             }
             t.w3 = U.conv3.w; t.scale3 = U.conv3.scale; t.shift3 = U.conv3.shift;
-            if (sc_in_tail) {
+            if (w->dtype == HMMR_BF16X3) {            // fragment-major filters; a folded shortcut rides in conv3's K
+                t.w3 = U.w3_frag;
+                if (sc_in_c3) { t.scale3 = U.c3sc.scale; t.shift3 = U.c3sc.shift; t.xp = xin; }
+            }
+            if (sc_in_c3) {
+            } else if (sc_in_tail) {
                 t.xp = xin; t.wsc = U.shortcut.w; t.shift_sc = U.shortcut.shift;
             } else {
                 t.res = d.res; t.ldr = d.ldr; t.res_strided = d.res_strided; t.res_img_stride = d.res_img_stride;
@@ -399,7 +405,8 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
             }
             t.ho = Ho; t.wo = Ho;
             t.out = xn; t.pre_scale = N.pre_scale; t.pre_shift = N.pre_shift;
-            t.w1 = N.conv1.w; t.scale1 = N.conv1.scale; t.shift1 = N.conv1.shift; t.relu1 = 1; t.n2 = N.base;
+            t.w1 = w->dtype == HMMR_BF16X3 ? U.w1n_frag : N.conv1.w;
+            t.scale1 = N.conv1.scale; t.shift1 = N.conv1.shift; t.relu1 = 1; t.n2 = N.base;
             t.out_h1 = conv2_in_tail ? T2 : T1;
             if (hmmr_bottleneck_tail(&t, s)) return -2;
             if (conv2_in_tail) { T* tmp = T1; T1 = T2; T2 = tmp; }

@@ -69,7 +69,7 @@ class HmmrEngine(object):
 
     def __init__(self, weights, smpl, dtype=DEFAULT_DTYPE, device="cuda:0", num_conv_layers=3,
                  delta_t_values=(-5, 5), joint_type="cocoplus", resnet_chunk=0,
-                 temporal_dtype=None, ief_dtype=None, autotune=True, fold_sc=None):
+                 temporal_dtype=None, ief_dtype=None, autotune=True, fold_sc=None, fuse_tail=None):
         self.lib = L.load()
         _debug_from_env()
         if not torch.cuda.is_available():
@@ -85,6 +85,8 @@ class HmmrEngine(object):
         self.delta_keys = sorted(int(d) for d in delta_t_values)
         fuse = tuple(b for b in os.environ.get("HMMR_FUSE_PREACT", "block1,block2,block3,block4").split(",") if b)   # dev A/B switch
         tail = {"0": False, "1": True}.get(os.environ.get("HMMR_FUSE_TAIL", "1"), os.environ.get("HMMR_FUSE_TAIL"))   # dev A/B switch: 0, 1, "block1", "noconv2", "conv2b1", "nosc", "nostride2"
+        if fuse_tail is not None:
+            tail = fuse_tail
         fsc = {"0": False, "1": True}.get(os.environ.get("HMMR_FUSE_SC", "1"), "all")               # dev A/B switch: 0, 1, all
         pfirst = os.environ.get("HMMR_PREACT_FIRST", "0") != "0"                                    # dev A/B switch
         fold = {"0": False, "1": True}.get(os.environ.get("HMMR_FOLD_SC", ""), None) if fold_sc is None else fold_sc   # dev A/B switch

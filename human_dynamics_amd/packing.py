@@ -75,6 +75,22 @@ def pack_conv_weight(w_hwio):
     return _pad_rows(np.ascontiguousarray(w_hwio.reshape(kh * kw * cin, cout).T))
 
 
+def pack_frag_major(w_nk):
+    """[n_out][K] fp32 -> bf16 [n_out / 32][K / 16][64 lanes][2 (hi, lo)][8]: the MFMA A-operand fragments of a split
+    filter bank, one coalesced 2 KB read per (32-row block, 16-wide K chunk); lane = 32 * (k half) + row
+    (hmmr_tail_desc_t, csrc/bottleneck_split.hip)."""
+    t = torch.from_numpy(np.ascontiguousarray(w_nk, dtype=np.float32))
+    n, K = t.shape
+    assert n % 32 == 0 and K % 16 == 0, (n, K)
+    hi = t.to(torch.bfloat16)
+    lo = (t - hi.to(torch.float32)).to(torch.bfloat16)
+
+    def frag(x):
+        x = x.reshape(n // 32, 32, K // 16, 2, 8)                # rb, row, kc, half, e
+        return x.permute(0, 2, 3, 1, 4).reshape(n // 32, K // 16, 64, 8)
+    return torch.stack([frag(hi), frag(lo)], dim=3).contiguous()   # [rb, kc, lane, 2, 8]
+
+
 def pack_stem_weight(w_hwio):
     """[7,7,3,64] -> [128][8*32]: k = ky*32 + kx*4 + c (kx = 7, c = 3 and ky = 7 are zero)."""
     out = np.zeros((64, 8, 8, 4), np.float32)
@@ -95,6 +111,12 @@ class DeviceStore(object):
             t = to_split(t)
         elif t.dtype != dtype:
             t = t.to(dtype)
+        self.tensors.append(t)
+        return t
+
+    def put_tensor(self, t):
+        """a host tensor that is already in its device layout"""
+        t = t.to(self.device)
         self.tensors.append(t)
         return t
 
@@ -163,9 +185,31 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
                                  np.concatenate([np.asarray(w[scope + "/shortcut/biases"], np.float32), b1]))
         s, b = fold_bn(w, scope + "/preact")
         u.pre_scale, u.pre_shift = store.vec(s).data_ptr(), store.vec(b).data_ptr()
+    if dtype == L.HMMR_BF16X3 and fuse_tail:
+        # bf16x3: conv3 + add + the next unit's preact + conv1 as one launch (csrc/bottleneck_split.hip) for the stride-1
+        # units of blocks 1-2 whose successor has an identity shortcut; filters fragment-major, a folded shortcut
+        # (c3sc) only with a 64-channel unit input (block1/unit_1)
+        for i, (scope, c_in, base, depth, stride, has_sc) in enumerate(units[:-1]):
+            u, nx = rw.unit[i], rw.unit[i + 1]
+            nscope = units[i + 1][0]
+            ok = (stride == 1 and (base, depth) in ((64, 256), (128, 512)) and nx.c_in == depth and nx.base == base and
+                  nx.fuse_preact == 1 and not nx.shortcut.w and (not has_sc or (u.c3sc.w and c_in == 64 and base == 64)))
+            if fuse_tail in ("block1",) and base != 64:
+                ok = False
+            if not ok:
+                continue
+            w3 = np.asarray(w[scope + "/conv3/weights"], np.float32)[0, 0]              # [K][depth]
+            if u.c3sc.w:
+                w3 = np.concatenate([w3, np.asarray(w[scope + "/shortcut/weights"], np.float32)[0, 0]], axis=0)
+            w1n = np.asarray(w[nscope + "/conv1/weights"], np.float32)[0, 0]            # [depth][base]
+            u.w3_frag = store.put_tensor(pack_frag_major(w3.T)).data_ptr()
+            u.w1n_frag = store.put_tensor(pack_frag_major(w1n.T)).data_ptr()
+            u.fuse_tail = 1
     for i in range(L.RESNET_UNITS - 1):
         u, nx = rw.unit[i], rw.unit[i + 1]
         shapes = ((64, 256),) if fuse_tail == "block1" else ((64, 256), (128, 512))
+        if dtype == L.HMMR_BF16X3:
+            break
         u.fuse_tail = int(bool(fuse_tail) and dtype == L.HMMR_BF16 and u.stride == 1 and
                           (u.base, u.depth) in shapes and nx.c_in == u.depth and nx.base == u.base and
                           nx.fuse_preact == 1 and not nx.shortcut.w)
