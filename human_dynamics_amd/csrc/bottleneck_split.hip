@@ -34,6 +34,10 @@ struct SplitTailArgs {
     const float* scale1; const float* shift1; int relu1;
     bsplit_t* out_h1;                           // [M][N2]
     int M;
+    // CONV2: the unit's 3x3 conv2 (stride 1, SAME) runs in front, over h1 [n][H][W][64]; src[0] is not read
+    const bsplit_t* h1; int H, W;               // H, W multiples of 8: a workgroup owns an 8 x 8 pixel tile
+    const char* w2f;                            // fragment-major [2][9 taps x 4][64 lanes][32 B], K = (ky, kx, ci)
+    const float* scale2; const float* shift2;
 };
 
 struct wfrag { bf16x8 hi, lo; };
@@ -64,13 +68,18 @@ __device__ __forceinline__ void split4(const float (&v)[4], unsigned long long& 
 // NCH = depth / 64, N2 = conv1' output channels, RES: a shortcut tensor is added (false: it is folded into conv3's K)
 // Block 1 (NCH 4) fits the 168-VGPR budget of three workgroups per CU (0.45 -> 0.38 ms per launch); block 2's longer K and two
 // conv1' blocks per wave do not (spills, 0.32 -> 0.41 ms), so it runs two per CU.
-template <int KS, int NCH, int N2, bool RES>
+// CONV2 (block 1): the workgroup's 64 pixels are an 8 x 8 tile of one image; its 10 x 10 h1 patch (zeros outside the
+// image) sits in the P region while conv2 runs (9 taps read as shifted fragments of the patch, filters fragment-major from
+// L2), and conv2's BN + ReLU output becomes the H2 tile: h2 never exists in HBM.
+template <int KS, int NCH, int N2, bool RES, bool CONV2>
 __global__ __launch_bounds__(256, NCH > 4 ? 2 : 3) void tail_split_kernel(const SplitTailArgs a) {
     constexpr int BM = 64, NT = 256, depth = NCH * 64;
     constexpr int PLANE = BM * 128;                  // one bf16 plane of a [64 rows][64 channels] tile
+    constexpr int PPLANE = 104 * 128;                // one plane of the 10 x 10 pixel patch (CONV2)
     constexpr int OFF_H2 = 0;                        // KS tiles x (hi, lo); later the conv1' output tiles
-    constexpr int OFF_P = OFF_H2 + KS * 2 * PLANE;   // the trunk chunk (hi, lo)
-    constexpr int OFF_C = OFF_P + 2 * PLANE;         // 4 x depth floats
+    constexpr int OFF_P = OFF_H2 + KS * 2 * PLANE;   // the trunk chunk (hi, lo); CONV2: first the h1 patch
+    constexpr int OFF_C = OFF_P + (CONV2 ? 2 * PPLANE : 2 * PLANE);         // 4 x depth floats
+    static_assert(!CONV2 || N2 == 64, "conv2 in front is written for block 1");
     constexpr int J2 = N2 / 64;                      // conv1' 32-row blocks per wave
     static_assert(J2 <= KS, "the conv1' output tiles reuse the H2 region");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -85,10 +94,19 @@ __global__ __launch_bounds__(256, NCH > 4 ? 2 : 3) void tail_split_kernel(const 
     auto slot_of = [&](int tile_off, int row) -> char* {
         return smem + tile_off + plane * PLANE + row * 128 + ((L ^ ((row >> 1) & 7)) << 4);
     };
+    // tile pixel p -> row of the [M][..] tensors: 64 consecutive rows, or (CONV2) pixel (p >> 3, p & 7) of an 8 x 8 image tile
+    int img = 0, ty = 0, tx = 0;
+    if constexpr (CONV2) {
+        const int tw = a.W >> 3, tpi = (a.H >> 3) * tw;
+        img = blockIdx.x / tpi;
+        const int t = blockIdx.x - img * tpi;
+        ty = t / tw; tx = t - ty * tw;
+    }
     bool rok[4]; long long grow[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        const int m = m0 + rr + 16 * p;
+        const int pix = rr + 16 * p;
+        const int m = CONV2 ? ((img * a.H + 8 * ty + (pix >> 3)) * a.W + 8 * tx + (pix & 7)) : m0 + pix;
         rok[p] = m < a.M;
         grow[p] = rok[p] ? m : 0;                    // tail rows read row 0 and are never stored
     }
@@ -137,12 +155,71 @@ __global__ __launch_bounds__(256, NCH > 4 ? 2 : 3) void tail_split_kernel(const 
     };
 
     // ---- prologue
-    load_w3(0, 0);
-    load_w1(0, 0);
     load_res(0, rres[0]);
     if (AHEAD > 1 && NCH > 1) load_res(1, rres[AHEAD - 1]);
+    if constexpr (CONV2) {
+        // the 10 x 10 h1 patch -> LDS planes (16 lanes per pixel, 7 passes; zeros outside the image)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
+        for (int pass = 0; pass < 7; ++pass) {
+            const int pix = rr + 16 * pass;
+            if (pix < 100) {
+                const int py = pix / 10, px = pix - 10 * py;
+                const int iy = 8 * ty - 1 + py, ix = 8 * tx - 1 + px;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                    v = *(const u32x4*)(a.h1 + ((long long)(img * a.H + iy) * a.W + ix) * 64 + s * 4);
+                *(u32x4*)(smem + OFF_P + plane * PPLANE + pix * 128 + ((L ^ ((pix >> 1) & 7)) << 4)) = v;
+            }
+        }
+        wfrag w2[2][4];
+        auto load_w2 = [&](int tap, wfrag (&w)[4]) {
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                const bf16x8* p = (const bf16x8*)(a.w2f + ((long long)(wn * 36 + tap * 4 + kc) * 64 + lane) * 32);
+                w[kc].hi = p[0]; w[kc].lo = p[1];
+            }
+        };
+        load_w2(0, w2[0]);
+        __syncthreads();
+        const int pq = wm * 32 + lr;                                  // this lane's pixel of the tile
+        const int brow = (pq >> 3) * 10 + (pq & 7);                   // its patch row for tap (0, 0)
+        f32x16 acc0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap + 1 < 9) load_w2(tap + 1, w2[(tap + 1) & 1]);
+            const int row = brow + (tap / 3) * 10 + tap % 3;
+            const char* ph = smem + OFF_P + row * 128;
+            const int sw = (row >> 1) & 7;
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                const bf16x8 xh = *(const bf16x8*)(ph + (((2 * kc + lh) ^ sw) << 4));
+                const bf16x8 xl = *(const bf16x8*)(ph + PPLANE + (((2 * kc + lh) ^ sw) << 4));
+                acc0 = mma3(w2[tap & 1][kc], xh, xl, acc0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // BN + ReLU, split -> the H2 tile (lane: 4 consecutive channels x 4 groups of its pixel)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = wn * 32 + 8 * g + 4 * lh;
+            const f32x4 s4 = *(const f32x4*)(a.scale2 + n), b4 = *(const f32x4*)(a.shift2 + n);
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(acc0[4 * g + j], s4[j], b4[j]), 0.f);
+            char* q = smem + OFF_H2 + prow + (((n >> 3) ^ fsw) << 4) + 8 * lh;
+            unsigned long long oh, ol;
+            split4(v, oh, ol);
+            *(unsigned long long*)q = oh;
+            *(unsigned long long*)(q + PLANE) = ol;
+        }
+        __syncthreads();                                              // every wave is done with the patch: P is free
+    }
+    load_w3(0, 0);
+    load_w1(0, 0);
+#pragma unroll
+    for (int ks = CONV2 ? 1 : 0; ks < KS; ++ks) {
         u32x4 v[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) v[p] = *(const u32x4*)(a.src[ks] + grow[p] * a.src_ld[ks] + s * 4);
@@ -253,16 +330,16 @@ __global__ __launch_bounds__(256, NCH > 4 ? 2 : 3) void tail_split_kernel(const 
                 *(u32x4*)(a.out_h1 + grow[p] * N2 + t * 64 + s * 4) = *(const u32x4*)slot_of(OFF_H2 + t * 2 * PLANE, rr + 16 * p);
 }
 
-template <int KS, int NCH, int N2, bool RES>
+template <int KS, int NCH, int N2, bool RES, bool CONV2 = false>
 int launch_split_tail(const SplitTailArgs& a, hipStream_t stream) {
-    constexpr int lds = (KS * 2 + 2) * 64 * 128 + 4 * NCH * 64 * (int)sizeof(float);
-    auto kern = tail_split_kernel<KS, NCH, N2, RES>;
+    constexpr int lds = KS * 2 * 64 * 128 + (CONV2 ? 2 * 104 * 128 : 2 * 64 * 128) + 4 * NCH * 64 * (int)sizeof(float);
+    auto kern = tail_split_kernel<KS, NCH, N2, RES, CONV2>;
     static DeviceOnce once;
     if (const unsigned long long bit = once.due()) {
         HMMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         once.mark(bit);
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)((a.M + 63) / 64)), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((a.M + 63) / 64)), dim3(256), lds, stream, a);     // (CONV2: M = images x H x W, 64 | H W)
     HMMR_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -271,9 +348,14 @@ int launch_split_tail(const SplitTailArgs& a, hipStream_t stream) {
 
 // hmmr_bottleneck_tail for HMMR_BF16X3 (called from bottleneck.hip).  w3 / w1 are FRAGMENT-MAJOR here (hmmr_hip.h).
 int hmmr_bottleneck_tail_split(const hmmr_tail_desc_t* d, hipStream_t stream) {
-    HMMR_REQUIRE(d->h2 && !d->h1 && d->w1 && d->out && d->out_h1 && d->pre_scale && d->pre_shift && d->scale1 && d->shift1 &&
-                 !d->out_pre && !d->res_strided,
-                 "hmmr_bottleneck_tail (bf16x3): needs h2 (no conv2 in front), the next conv1, out, out_h1 and a dense shortcut");
+    HMMR_REQUIRE((d->h2 != nullptr) != (d->h1 != nullptr) && d->w1 && d->out && d->out_h1 && d->pre_scale && d->pre_shift && d->scale1 &&
+                 d->shift1 && !d->out_pre && !d->res_strided,
+                 "hmmr_bottleneck_tail (bf16x3): needs h2 or h1 (conv2 in front), the next conv1, out, out_h1 and a dense shortcut");
+    const bool conv2 = d->h1 != nullptr;
+    HMMR_REQUIRE(!conv2 || (d->w2 && d->scale2 && d->shift2 && d->conv2_stride <= 1 && d->hin > 0 && d->win > 0 && d->hin % 8 == 0 &&
+                            d->win % 8 == 0 && d->m % (d->hin * d->win) == 0 && d->c_mid == 64 && d->depth == 256 && d->n2 == 64),
+                 "hmmr_bottleneck_tail (bf16x3): conv2 in front needs the 64 -> 256 -> 64 shape, stride 1, w2 (fragment-major), "
+                 "scale2, shift2 and an image grid that is a multiple of 8 x 8");
     const bool folded = d->xp != nullptr;             // {h2, xp} x [W3 | Wsc]: the conv shortcut inside conv3's K
     HMMR_REQUIRE(folded != (d->res != nullptr), "hmmr_bottleneck_tail (bf16x3): either a shortcut tensor (res) or a folded one (xp)");
     SplitTailArgs a = {};
@@ -286,11 +368,13 @@ int hmmr_bottleneck_tail_split(const hmmr_tail_desc_t* d, hipStream_t stream) {
     HMMR_REQUIRE(folded || d->ldr >= d->depth, "hmmr_bottleneck_tail: residual row stride < depth");
     if (d->c_mid == 64 && d->depth == 256 && d->n2 == 64) {
         a.src[0] = (const bsplit_t*)d->h2; a.src_ld[0] = 64;
+        a.h1 = (const bsplit_t*)d->h1; a.H = d->hin; a.W = d->win; a.w2f = (const char*)d->w2; a.scale2 = d->scale2; a.shift2 = d->shift2;
         if (folded) {
             a.src[1] = (const bsplit_t*)d->xp; a.src_ld[1] = 64;
+            HMMR_REQUIRE(!conv2, "hmmr_bottleneck_tail (bf16x3): conv2 in front is not built for the folded-shortcut form");
             return launch_split_tail<2, 4, 64, false>(a, stream);
         }
-        return launch_split_tail<1, 4, 64, true>(a, stream);
+        return conv2 ? launch_split_tail<1, 4, 64, true, true>(a, stream) : launch_split_tail<1, 4, 64, true>(a, stream);
     }
     if (d->c_mid == 128 && d->depth == 512 && d->n2 == 128 && !folded) {
         a.src[0] = (const bsplit_t*)d->h2; a.src_ld[0] = 128;

@@ -292,7 +292,7 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
         // the conv shortcut is folded into conv3: ONE GEMM over {h2, preact} with [W3 | Wsc] (hmmr_conv_desc_t.in2);
         // the shortcut tensor (the widest tensor of the unit) is neither written nor read back
         const bool sc_in_c3 = U.c3sc.w != nullptr;
-        HMMR_REQUIRE(!sc_in_c3 || (U.shortcut.w && !fused && U.stride == 1 && U.fuse_tail <= 1 && !U.sc_c1.w),
+        HMMR_REQUIRE(!sc_in_c3 || (U.shortcut.w && !fused && U.stride == 1 && U.fuse_tail <= 2 && !U.sc_c1.w),
                      "resnet: unit %d cannot fold its shortcut into conv3", u);
         if (sc_in_c3) {
             if (prof_mark(pf)) return -2;
@@ -376,7 +376,7 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
             t.out = d.out; t.out_pre = d.out2; t.pre_scale = d.scale2; t.pre_shift = d.shift2;
             if (hmmr_bottleneck_tail(&t, s)) return -2;
         } else if (U.fuse_tail) {     // conv3 + add + the next unit's preact + conv1 in one launch (csrc/bottleneck.hip)
-            HMMR_REQUIRE(!last && (w->dtype == HMMR_BF16 || (w->dtype == HMMR_BF16X3 && U.fuse_tail == 1 && U.w3_frag && U.w1n_frag)) &&
+            HMMR_REQUIRE(!last && (w->dtype == HMMR_BF16 || (w->dtype == HMMR_BF16X3 && U.w3_frag && U.w1n_frag && (U.fuse_tail == 1 || (U.fuse_tail == 2 && U.w2_frag)))) &&
                          U.stride == 1 && write_raw && !write_pre && next_fused &&
                          next_identity && w->unit[u + 1].base == U.base && w->unit[u + 1].c_in == U.depth &&
                          ((U.base == 64 && U.depth == 256) || (U.base == 128 && U.depth == 512)),
@@ -387,7 +387,8 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
             if (conv2_in_tail) {      // h2 never exists in HBM; the conv1' output goes to T2 (T1 is still being read
                                       // by neighbouring tiles' halos), and the two buffers swap roles afterwards
                 HMMR_REQUIRE(U.conv2.scale && U.conv2.shift, "resnet: unit %d cannot fuse its conv2", u);
-                t.h1 = T1; t.hin = H; t.win = H; t.w2 = U.conv2.w; t.scale2 = U.conv2.scale; t.shift2 = U.conv2.shift;
+                t.h1 = T1; t.hin = H; t.win = H; t.w2 = w->dtype == HMMR_BF16X3 ? U.w2_frag : U.conv2.w;
+                t.scale2 = U.conv2.scale; t.shift2 = U.conv2.shift;
             } else {
                 t.h2 = T2;
             }
