@@ -36,7 +36,7 @@ def agg(root, tag, counter):
 
 def resnet_kernel(k, dtype):
     """The ResNet's MFMA launches of one operand mode (the IEF GEMMs of the same instantiation ride along: < 1 % of the bytes)."""
-    if "stem_fused" in k or "bottleneck_tail_kernel" in k or "unit_fused_kernel" in k:
+    if "stem_fused" in k or "bottleneck_tail_kernel" in k or "tail_split_kernel" in k:
         return True
     if "conv_gemm_kernel" not in k:
         return False
