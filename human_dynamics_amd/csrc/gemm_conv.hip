@@ -635,8 +635,9 @@ static int launch_tiled(const ConvArgs& a, int tile, int slices, hipStream_t str
         case 5: return launch_cfg<TA, TO, 128, 128, 4, 2, PRO, UTAP, 2>(a, slices, stream);   // 8 waves, 32x64 each
         case 6: return launch_cfg<TA, TO, 128, 64, 4, 2, PRO, UTAP, 2>(a, slices, stream);    // 8 waves, 32x32 each
         // deep ring + ping-pong wave groups, one 8-wave workgroup per CU (256 VGPRs per lane).  128x128 and 256x64 variants
-        // of this structure were measured 15-40 % slower than tiles 5 / 6 on every ResNet shape and are not instantiated.
+        // of this structure were measured 15-40 % slower than tiles 5 / 6 on every ResNet shape and are not instantiated; 128x256 (tile 8) is the faster 3x3 tile.
         case 7: return launch_cfg<TA, TO, 256, 128, 4, 2, PRO, UTAP, 3>(a, slices, stream);   // 64x64 each, 3 x 48 KB
+        case 8: return launch_cfg<TA, TO, 128, 256, 2, 4, PRO, UTAP, 3>(a, slices, stream);   // 64x64 each; half the A rows: half the fused-preact work per MFMA
         default: hmmr_set_error("hmmr_conv_gemm: bad tile %d", tile); return -1;
     }
 }
@@ -774,6 +775,7 @@ extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
     HMMR_REQUIRE(!d->pro_scale || !d->res, "hmmr_conv_gemm: a fused pre-activation (pro_*) cannot be combined with a residual");
     HMMR_REQUIRE(!d->pro_scale || (d->py == 0 && d->px == 0 && d->kh == 1 && d->kw == 1),
                  "hmmr_conv_gemm: the fused pre-activation is for un-padded 1x1 gathers (padding must stay zero)");
+    HMMR_REQUIRE(d->tile != 8 || d->cout % 256 == 0, "hmmr_conv_gemm: tile 8 (128x256) needs cout %% 256 == 0 (filter rows are padded to 128)");
     HMMR_REQUIRE(!d->in2 || (d->kh == 1 && d->kw == 1 && d->py == 0 && d->px == 0 && d->sy == 1 && d->sx == 1 && !d->pro_scale &&
                              d->split_k <= 1 && d->cin2 > 0 && d->cin % bke == 0 && d->cin2 % bke == 0 &&
                              d->in_px_stride == d->cin && d->in_row_stride == d->win * d->cin &&

@@ -138,7 +138,7 @@ class HmmrEngine(object):
         return torch.from_numpy(np.ascontiguousarray(a)).to(self.device).to(dtype).contiguous()
 
     # -- ResNet launch tuning ----------------------------------------------------
-    _TUNE_TILES = tuple(int(t) for t in os.environ.get("HMMR_TUNE_TILES", "5,6,3,1,2,7").split(","))   # hmmr_conv_desc_t.tile candidates (8-wave 128x128 / 128x64, 4-wave 64x64 / 128x128 / 128x64, 8-wave ping-pong 256x128)
+    _TUNE_TILES = tuple(int(t) for t in os.environ.get("HMMR_TUNE_TILES", "5,6,3,1,2,7,8").split(","))   # hmmr_conv_desc_t.tile candidates (8-wave 128x128 / 128x64, 4-wave 64x64 / 128x128 / 128x64, 8-wave ping-pong 256x128 / 128x256)
     _TUNE_MIN_FRAMES = 32
     _SPLIT_MIN_FRAMES = 128
 
@@ -180,7 +180,7 @@ class HmmrEngine(object):
             for slot, u, nm in layers:
                 lay = self._layer_of(u, nm)
                 cout = self.rw.unit[u].base if nm in ("conv1", "conv2") else self.rw.unit[u].depth
-                lay.tile = cand if (cand not in (1, 5, 7) or cout % 128 == 0) else 0
+                lay.tile = cand if ((cand not in (1, 5, 7) or cout % 128 == 0) and (cand != 8 or cout % 256 == 0)) else 0
             t = None
             for rep in range(3):
                 pm = (C.c_float * L.RESNET_PROF_SLOTS)()

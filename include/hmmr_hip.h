@@ -92,7 +92,7 @@ typedef struct {
     int relu;              /* ReLU on `out` after the residual add */
     int tile;              /* 0 = auto; 4-wave tiles: 1 = 128x128, 2 = 128x64, 3 = 64x64;
                               8-wave tiles: 5 = 128x128, 6 = 128x64 (two workgroups per CU, 2 LDS stages);
-                              7 = 256x128 (one workgroup per CU: 3-stage LDS ring, ping-pong wave groups) */
+                              7 = 256x128, 8 = 128x256 (one workgroup per CU: 3-stage LDS ring, ping-pong wave groups) */
     /* split-K (for GEMMs with few output tiles and a long K): split_k > 1 slices K into that many
      * contiguous ranges, each range leaves an fp32 partial plane in `ws`, and a second launch adds the
      * planes IN SLICE ORDER and applies the epilogue.  The caller fixes split_k per layer (never from

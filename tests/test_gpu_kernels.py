@@ -53,13 +53,13 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 5, 6, 7])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 5, 6, 7, 8])
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_conv_gemm(case, tile, dt, gpu_device):
     from human_dynamics_amd.engine import conv_gemm
     name, n, h, w_, cin, cout, k, stride, pad, flags = case
-    if tile in (1, 5, 7) and cout % 128:
-        pytest.skip("128-wide tiles are only selected for cout % 128 == 0")
+    if (tile in (1, 5, 7) and cout % 128) or (tile == 8 and cout % 256):
+        pytest.skip("128- / 256-wide tiles are only selected for cout % 128 / 256 == 0")
     import zlib
     rng = np.random.default_rng(zlib.crc32(name.encode()) % 1000)
     x = rng.normal(size=(n, h, w_, cin)).astype(np.float32)
@@ -317,11 +317,11 @@ def test_resnet_tile_choice_never_changes_a_bit(dt, weights, gpu_device):
     x = torch.from_numpy(assets.make_synthetic_frames(40, seed=3)).to(gpu_device)
     ref = eng.resnet(x, n_zero=1).clone()
     layers = eng._resnet_layers()
-    for tile in (3, 6, 5, 2, 1, 7):
+    for tile in (3, 6, 5, 2, 1, 7, 8):
         table = {}
         for _, u, nm in layers:
             cout = eng.rw.unit[u].base if nm in ("conv1", "conv2") else eng.rw.unit[u].depth
-            table[(u, nm)] = tile if (tile not in (1, 5, 7) or cout % 128 == 0) else 6
+            table[(u, nm)] = tile if ((tile not in (1, 5, 7) or cout % 128 == 0) and (tile != 8 or cout % 256 == 0)) else 6
         eng._set_tiles(table)
         assert torch.equal(eng.resnet(x, n_zero=1), ref), tile
     tuned = HmmrEngine(weights, None, dtype=dt, device=gpu_device, autotune=True)

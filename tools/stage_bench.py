@@ -21,3 +21,8 @@ th = torch.randn((256, 72), device="cuda") * 0.3; be = torch.randn((256, 10), de
 out = {"resnet257_ms": timed(lambda: eng.resnet(x, n_zero=1), 10), "temporal32x20_ms": timed(lambda: eng.temporal(phi)),
        "ief256_ms": timed(lambda: eng.ief(st)), "smpl256_ms(x1 of 3)": timed(lambda: eng.smpl(th, be, cm))}
 print(json.dumps(out))
+if len(sys.argv) > 2:       # temporal tiles
+    for t in (0, 5, 6, 1, 7):
+        for i in range(3):
+            eng.tw.block[i].conv1.tile = eng.tw.block[i].conv2.tile = t
+        print("temporal tile", t, timed(lambda: eng.temporal(phi)))
