@@ -110,6 +110,11 @@ class Tester(object):
         self.f_hal = get_hallucinator_model()
         self.f_image_enc = get_image_encoder()
         self.f_temporal_enc = get_temporal_encoder()
+        if "mean_param" not in weights:
+            # the reference initialises this variable from neutral_smpl_meanwjoints.h5 (tester.py:118-141) and then restores
+            # it from the checkpoint (tester.py:114-116); the h5 (deepdish / blosc) is not read here -- see DESIGN.md section 7
+            raise KeyError("the loaded weights have no 'mean_param' variable (the 1 x 85 mean theta both published "
+                           "checkpoints carry); add it to the .npz, or load a checkpoint that was saved by the reference")
         self.theta_mean = np.asarray(weights["mean_param"], np.float32).reshape(1, 85)
         self._streamer = None
 
