@@ -130,20 +130,34 @@ __global__ __launch_bounds__(256, NCH > 4 ? 2 : 3) void tail_split_kernel(const 
     auto xfrag = [&](int plane_off, int kc) {
         return *(const bf16x8*)(smem + plane_off + prow + (((2 * kc + lh) ^ fsw) << 4));
     };
-    wfrag w3[4], w1[4];
+    // Filter fragments straight from L2, requested a whole chunk before their use.  ALLW (block 2: 256-VGPR budget of two
+    // workgroups per CU): every fragment of a chunk (KS x 4 of conv3, J2 x 4 of conv1') is held at once; otherwise four of
+    // each, and the second K tile / row block is requested mid-chunk (an exposed L2 round trip that three workgroups per
+    // CU cover in block 1 -- and that took 17 k cycles per chunk in block 2 before ALLW).
+    constexpr bool ALLW = NCH > 4;
+    constexpr int G3 = ALLW ? KS : 1, G1 = ALLW ? J2 : 1;
+    wfrag w3[G3 * 4], w1[G1 * 4];
     auto load_w3 = [&](int nc, int ks) {             // row block 2 nc + wn, K chunks 4 ks .. 4 ks + 3
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
             const bf16x8* p = (const bf16x8*)(a.w3f + ((long long)((2 * nc + wn) * (KS * 4) + ks * 4 + kc) * 64 + lane) * 32);
-            w3[kc].hi = p[0]; w3[kc].lo = p[1];
+            w3[(ALLW ? ks * 4 : 0) + kc].hi = p[0]; w3[(ALLW ? ks * 4 : 0) + kc].lo = p[1];
         }
     };
     auto load_w1 = [&](int nc, int j) {              // row block wn * J2 + j, K chunks 4 nc .. 4 nc + 3
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
             const bf16x8* p = (const bf16x8*)(a.w1f + ((long long)((wn * J2 + j) * (depth / 16) + 4 * nc + kc) * 64 + lane) * 32);
-            w1[kc].hi = p[0]; w1[kc].lo = p[1];
+            w1[(ALLW ? j * 4 : 0) + kc].hi = p[0]; w1[(ALLW ? j * 4 : 0) + kc].lo = p[1];
         }
+    };
+    auto load_w3_chunk = [&](int nc) {
+#pragma unroll
+        for (int ks = 0; ks < G3; ++ks) load_w3(nc, ks);
+    };
+    auto load_w1_chunk = [&](int nc) {
+#pragma unroll
+        for (int j = 0; j < G1; ++j) load_w1(nc, j);
     };
     constexpr int AHEAD = 2;                         // shortcut chunks in flight
     u32x4 rres[AHEAD][RES ? 4 : 1];
@@ -216,8 +230,8 @@ __global__ __launch_bounds__(256, NCH > 4 ? 2 : 3) void tail_split_kernel(const 
         }
         __syncthreads();                                              // every wave is done with the patch: P is free
     }
-    load_w3(0, 0);
-    load_w1(0, 0);
+    load_w3_chunk(0);
+    load_w1_chunk(0);
 #pragma unroll
     for (int ks = CONV2 ? 1 : 0; ks < KS; ++ks) {
         u32x4 v[4];
@@ -248,13 +262,13 @@ __global__ __launch_bounds__(256, NCH > 4 ? 2 : 3) void tail_split_kernel(const 
         for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            if (ks > 0) { __builtin_amdgcn_sched_barrier(0); load_w3(nc, ks); }
+            if (!ALLW && ks > 0) { __builtin_amdgcn_sched_barrier(0); load_w3(nc, ks); }
 #pragma unroll
             for (int kc = 0; kc < 4; ++kc)
-                acc1 = mma3(w3[kc], xfrag(OFF_H2 + ks * 2 * PLANE, kc), xfrag(OFF_H2 + ks * 2 * PLANE + PLANE, kc), acc1);
+                acc1 = mma3(w3[(ALLW ? ks * 4 : 0) + kc], xfrag(OFF_H2 + ks * 2 * PLANE, kc), xfrag(OFF_H2 + ks * 2 * PLANE + PLANE, kc), acc1);
         }
         __builtin_amdgcn_sched_barrier(0);               // (the reload must not be hoisted above the MFMAs: it would double the live fragment registers)
-        if (nc + 1 < NCH) load_w3(nc + 1, 0);
+        if (nc + 1 < NCH) load_w3_chunk(nc + 1);
         // + bias (+ shortcut), split, in place: a lane owns 4 consecutive channels x 4 groups of its pixel
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -293,12 +307,12 @@ __global__ __launch_bounds__(256, NCH > 4 ? 2 : 3) void tail_split_kernel(const 
         // (4) conv1' K step `nc`
 #pragma unroll
         for (int j = 0; j < J2; ++j) {
-            if (j > 0) { __builtin_amdgcn_sched_barrier(0); load_w1(nc, j); }
+            if (!ALLW && j > 0) { __builtin_amdgcn_sched_barrier(0); load_w1(nc, j); }
 #pragma unroll
-            for (int kc = 0; kc < 4; ++kc) acc2[j] = mma3(w1[kc], xfrag(OFF_P, kc), xfrag(OFF_P + PLANE, kc), acc2[j]);
+            for (int kc = 0; kc < 4; ++kc) acc2[j] = mma3(w1[(ALLW ? j * 4 : 0) + kc], xfrag(OFF_P, kc), xfrag(OFF_P + PLANE, kc), acc2[j]);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (nc + 1 < NCH) load_w1(nc + 1, 0);
+        if (nc + 1 < NCH) load_w1_chunk(nc + 1);
         __syncthreads();                                             // P is free for the next chunk's pre-fill
     }
 
