@@ -1,5 +1,4 @@
-B="python bench.py --only-main --no-cpu-baseline --no-pcie --steps 20"
-pick() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(sys.argv[1], d['value'], d['ms_per_step'])" "$1"; }
-$B | pick default
-HMMR_RESNET_NOJOIN=1 $B | pick nojoin
-for o in 2 5 10 20; do HMMR_RESNET_NOJOIN=1 HMMR_RESNET_OFFSET_MCYC=$o $B | pick nojoin_off$o; done
+bash tools/pmc_conv_study.sh 257 5,7,8 bf16x3
+python tools/pmc_conv_study.py gpurun_out > gpurun_out/r02c_conv_pmc_bf16x3.log 2>&1
+cat gpurun_out/r02c_conv_pmc_bf16x3.log
+find gpurun_out/cs_* -name "*.csv" -size +1M -delete
