@@ -425,6 +425,8 @@ def main():
             "all_gather_ms": all_gather_ms, "all_gather_bytes": gather_bytes,
             "scaling_efficiency": None,        # computed by the driver from the per-N lines (tools/scale_table.py does the same)
             "roofline": roofline,
+            "init_untimed": {"conv_tile_tuning_ms_by_batch": {str(n_): ms_ for n_, ms_ in tester.engine.tune_log},
+                             "note": "one pass per candidate tile and batch size on the first call, before the warm-up steps"},
             "pcie_inclusive_fps": pcie_fps, "pcie_inclusive_fps_without_verts": pcie_nov,
             "pcie_inclusive_fps_1024_frame_video": pcie_long,
         }

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import time
 
 import numpy as np
 import torch
@@ -110,6 +111,7 @@ class HmmrEngine(object):
         # per-layer conv tiles of the ResNet, tuned per batch size on first use (see _tune_resnet)
         self.autotune = bool(autotune) and os.environ.get("HMMR_AUTOTUNE", "1") != "0"
         self._tiles = {}
+        self.tune_log = []       # [(frames, ms)] of every tuning pass run by this engine (HMMR_AUTOTUNE=0 / autotune=False: none)
         # optional on-disk copy of the tuned tables (HMMR_TILE_CACHE=file.json): profiling runs load it so
         # that no tuning pass ends up inside the rocprofv3 trace
         self._tile_cache = os.environ.get("HMMR_TILE_CACHE", "")
@@ -170,6 +172,7 @@ class HmmrEngine(object):
         only moves the balance between tile-count quantisation, occupancy and operand reuse, which
         flips between layers as the batch grows.  ~90 ms once per batch size."""
         layers = self._resnet_layers()
+        t_start = time.perf_counter()
         nt = n + n_zero
         nbytes = self.lib.hmmr_resnet50_workspace_bytes(nt, self.dtype)
         ws = self._ws["resnet"].get(nbytes)
@@ -193,6 +196,7 @@ class HmmrEngine(object):
                 if (u, nm) not in best or t[slot] < best[(u, nm)][0] * 0.98:    # 2 % hysteresis towards the heuristic
                     best[(u, nm)] = (float(t[slot]), tile)
         table = {k: v[1] for k, v in best.items()}
+        self.tune_log.append((nt, round((time.perf_counter() - t_start) * 1e3, 1)))     # (frames, ms): never silent
         if self._tile_cache:
             import json
             old = json.load(open(self._tile_cache)) if os.path.exists(self._tile_cache) else {}

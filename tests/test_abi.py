@@ -65,6 +65,62 @@ def test_argument_validation_reports_errors():
         _lib.check(rc, "hmmr_conv_gemm")
 
 
+def _dense_1x1(m=256, cin=64, cout=256, dtype=_lib.HMMR_BF16X3):
+    """a syntactically valid 1x1 descriptor with dummy (never dereferenced) pointers: validation runs before any launch"""
+    d = _lib.ConvDesc()
+    d.in_, d.w, d.out = 0x1000, 0x2000, 0x3000
+    d.in_dtype = d.out_dtype = dtype
+    d.n_img, d.hin, d.win, d.cin = 1, m, 1, cin
+    d.in_img_stride, d.in_row_stride, d.in_px_stride = m * cin, cin, cin
+    d.kh = d.kw = d.sy = d.sx = 1
+    d.ho, d.wo, d.cout, d.ldo = m, 1, cout, cout
+    return d
+
+
+def test_conv_desc_validation_of_the_round_2_fields():
+    """hmmr_conv_desc_t.in2 (a second operand source appended along K) and the 128x256 tile are refused with a message
+    where the kernel could not honour them -- before anything is launched, so this runs without a GPU."""
+    lib = _lib.load()
+    d = _dense_1x1()
+    d.in2, d.cin2 = 0x4000, 48                       # not a multiple of the 128-byte K step (32 split elements)
+    assert lib.hmmr_conv_gemm(d, None) != 0 and b"multiple of 32" in lib.hmmr_last_error()
+    d = _dense_1x1()
+    d.in2, d.cin2, d.sy, d.sx, d.ho = 0x4000, 64, 2, 2, 128       # strided: the two sources would not share a pixel grid
+    assert lib.hmmr_conv_gemm(d, None) != 0 and b"second operand source" in lib.hmmr_last_error()
+    d = _dense_1x1()
+    d.in2, d.cin2 = 0x4000, 64
+    d.pro_scale = d.pro_shift = 0x5000               # the fused pre-activation takes the register route: no second source there
+    assert lib.hmmr_conv_gemm(d, None) != 0
+    d = _dense_1x1(cout=128)
+    d.tile = 8
+    assert lib.hmmr_conv_gemm(d, None) != 0 and b"tile 8" in lib.hmmr_last_error()
+    t = _lib.TailDesc()
+    t.dtype, t.h2, t.w3, t.res, t.m, t.c_mid, t.depth, t.n2 = _lib.HMMR_BF16X3, 0x1000, 0x2000, 0x3000, 64, 256, 1024, 256
+    t.w1 = t.out = t.out_h1 = t.pre_scale = t.pre_shift = t.scale1 = t.shift1 = 0x4000
+    t.ldr = 1024
+    assert lib.hmmr_bottleneck_tail(t, None) != 0 and b"supported shapes" in lib.hmmr_last_error()
+
+
+def test_fragment_major_packing_layout():
+    """packing.pack_frag_major: [n][K] -> [n / 32][K / 16][64 lanes][hi, lo][8]; lane = 32 * (k half) + row, i.e. the 16 bytes a
+    lane feeds v_mfma_f32_32x32x16_bf16 as its A operand (csrc/bottleneck_split.hip reads them straight from L2)."""
+    import numpy as np
+    import torch
+    from human_dynamics_amd import packing
+    rng = np.random.default_rng(0)
+    w = rng.normal(size=(64, 48)).astype(np.float32)
+    f = packing.pack_frag_major(w)
+    assert tuple(f.shape) == (2, 3, 64, 2, 8) and f.dtype == torch.bfloat16
+    hi = torch.from_numpy(w).to(torch.bfloat16)
+    lo = (torch.from_numpy(w) - hi.float()).to(torch.bfloat16)
+    for rb, kc, lane in ((0, 0, 0), (1, 2, 63), (0, 1, 37), (1, 0, 31)):
+        row, half = rb * 32 + lane % 32, lane // 32
+        k0 = kc * 16 + 8 * half
+        assert torch.equal(f[rb, kc, lane, 0], hi[row, k0:k0 + 8]) and torch.equal(f[rb, kc, lane, 1], lo[row, k0:k0 + 8])
+    back = (f[:, :, :, 0].float() + f[:, :, :, 1].float()).reshape(2, 3, 2, 32, 8).permute(0, 3, 1, 2, 4).reshape(64, 48)
+    assert float((back - torch.from_numpy(w)).abs().max()) < 2.0 ** -15
+
+
 def test_engine_refuses_to_run_without_a_gpu():
     import torch
     if torch.cuda.is_available():
