@@ -57,6 +57,9 @@ class HostStreamer(object):
         from concurrent.futures import ThreadPoolExecutor
         self._copy_workers = 8
         self._pool = ThreadPoolExecutor(max_workers=self._copy_workers)
+        # ... and are started one chunk AHEAD by a stager thread (it waits for the staging pair to be free, then fans the
+        # memcpy out), so the Python thread keeps enqueueing kernels instead of waiting for 154 MB of memcpy per chunk
+        self._stager = ThreadPoolExecutor(max_workers=1)
 
     def _stage(self, dst_pinned, src):
         """src (ndarray [n,...]) -> the first n rows of the pinned staging tensor."""
@@ -66,6 +69,11 @@ class HostStreamer(object):
         futs = [self._pool.submit(np.copyto, dst[i:i + step], src[i:i + step]) for i in range(0, n, step)]
         for f in futs:
             f.result()
+
+    def _stage_when_free(self, dst_pinned, src, free_event):
+        if free_event is not None:
+            free_event.synchronize()                               # chunk k-2 has been encoded: its staging pair is free
+        self._stage(dst_pinned, src)
 
     def _staging(self, dtype):
         if dtype not in self._pin:
@@ -116,18 +124,27 @@ class HostStreamer(object):
         import os as _os, time as _time
         trace = [] if _os.environ.get("HMMR_STREAM_TRACE") else None
         tr = (lambda tag: trace.append((tag, _time.perf_counter()))) if trace is not None else (lambda tag: None)
+        is_staged = lambda k_: (k_ > 0) if self.staged == "auto" else bool(self.staged)
+        ahead = None                                                 # the stager's future for the chunk about to be consumed
+
+        def stage_ahead(k_):
+            if k_ >= n_chunks or not is_staged(k_):
+                return None
+            lo_, hi_ = k_ * C, min(N, (k_ + 1) * C)
+            return self._stager.submit(self._stage_when_free, pin[k_ % 2], src[lo_:hi_], in_free[k_ % 2])
+        if is_staged(0):
+            ahead = stage_ahead(0)
         for k in range(n_chunks + 1):
             tr("chunk %d" % k)
             if k < n_chunks:
                 lo, hi = k * C, min(N, (k + 1) * C)
                 n, slot = hi - lo, k % 2
-                if in_free[slot] is not None:
-                    in_free[slot].synchronize()                      # the staging pair is free again (chunk k-2 is encoded)
-                tr(" waited")
-                staged = (k > 0) if self.staged == "auto" else bool(self.staged)
+                staged = is_staged(k)
                 if staged:
-                    self._stage(pin[slot], src[lo:hi])               # pageable -> pinned on the memcpy pool, then an async H2D
+                    ahead.result()                                   # pageable -> pinned, done one chunk ahead
                     tr(" staged")
+                elif in_free[slot] is not None:
+                    in_free[slot].synchronize()                      # the device-side pair is free again (chunk k-2 is encoded)
                 with torch.cuda.stream(self.s_in):
                     if staged:
                         dev_in[slot][:n].copy_(pin[slot][:n], non_blocking=True)
@@ -145,6 +162,7 @@ class HostStreamer(object):
                 tr(" resnet queued")
                 in_free[slot] = torch.cuda.Event()
                 in_free[slot].record(cur)
+                ahead = stage_ahead(k + 1)                           # runs while this chunk's kernels are enqueued and executed
             if k >= 1:
                 # tail of output frames [o0, o1): their windows reach margin frames into chunk k, encoded just above
                 encoded = torch.cuda.Event()
