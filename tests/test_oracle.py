@@ -177,3 +177,16 @@ def test_storage_emulating_resnet(weights):
     finally:
         O.quantize = orig
     assert rel(nudged, e16) > 0.2 * rel(e16, exact)
+
+
+def test_emulated_resnet_with_folded_shortcut_differs_by_one_rounding(weights):
+    """bf16x3 emulation: accumulating the conv shortcut inside conv3 (what the HIP path does, csrc/gemm_conv.hip in2) instead
+    of storing it first removes ONE 16-bit rounding of the shortcut tensor in four units -- the features move by ~1e-6
+    relative, and both stay within the mode's distance of the unrounded graph."""
+    frames = assets.make_synthetic_frames(1, seed=4)
+    a = O.resnet_v2_50_emulated(frames, weights, "bf16x3").numpy()
+    b = O.resnet_v2_50_emulated(frames, weights, "bf16x3", fold_shortcut=False).numpy()
+    ref = O.resnet_v2_50(frames, weights, torch.float64).numpy()
+    n = np.linalg.norm(ref)
+    assert 0 < np.linalg.norm(a - b) / n < 2e-5
+    assert np.linalg.norm(a - ref) / n < 5e-5 and np.linalg.norm(b - ref) / n < 5e-5
