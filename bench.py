@@ -146,7 +146,7 @@ def run_mode(dtype, args, world, rank, device, weights, smpl, span, n_total, ste
         eng.resnet_streams = 1
     predictor = hd.ShardedPredictor(tester, n_total, rank, world, use_graph=args.graph,
                                      overlap_gather=not args.serial_gather, pipeline=pipeline,
-                                     gather_mode=args.gather)
+                                     gather_mode=args.gather, step_streams=not args.no_step_streams)
 
     def barrier():
         if world > 1:
@@ -185,7 +185,8 @@ def run_mode(dtype, args, world, rank, device, weights, smpl, span, n_total, ste
         elapsed = float(t.item())
     assert out.shape[0] == n_total and bool(torch.isfinite(out[:, :1000]).all())
     timing = {"fps": n_total * steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "steps": steps,
-              "pipeline": pipeline, "resnet_streams": eng.resnet_streams}
+              "pipeline": pipeline, "resnet_streams": eng.resnet_streams,
+              "step_streams": getattr(predictor, "step_streams", None) is not None}
     return timing, tester, predictor, out
 
 
@@ -283,6 +284,9 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the per-window tail on the ResNet's stream instead of a second stream "
                          "(default: tail of step k overlaps the ResNet of step k+1)")
+    ap.add_argument("--no-step-streams", action="store_true",
+                    help="pipelined mode: keep every step's ResNet on the caller's stream as two concurrent half-batch "
+                         "sequences instead of alternating whole-batch passes of consecutive steps on two streams")
     ap.add_argument("--serial", action="store_true",
                     help="one HIP stream for everything (no tail pipeline, no concurrent ResNet half-batches): the "
                          "configuration the per-kernel rocprofv3 summaries under profiles/ are taken in, so that "
@@ -411,6 +415,9 @@ def main():
                                     "bf16": "bf16 operands and activations, fp32 accumulate: OUTSIDE the 1e-4 tolerance",
                                     "f32": "exact fp32 MFMA"}[args.dtype],
                        "smpl_calls_per_frame": 3, "launch": ("hipGraph replay of the local pass" if args.graph else
+                                  "eager; the ResNet passes of consecutive steps alternate between two streams (one whole-batch "
+                                  "launch sequence each, two steps in flight); the f_movie/IEF/SMPL tail of step k runs on its "
+                                  "own stream under the ResNets of steps k+1, k+2" if timing.get("step_streams") else
                                   "eager; ResNet as %d concurrent half-batch launch sequences%s" % (
                                       timing["resnet_streams"], "; the f_movie/IEF/SMPL tail of step k runs on its own "
                                       "stream under the ResNet of step k+1" if timing["pipeline"] else "")

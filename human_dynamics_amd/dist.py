@@ -119,7 +119,7 @@ class ShardedPredictor(object):
     input and replays it afterwards.  (Measured equal to eager launches: the step is GPU-bound.)"""
 
     def __init__(self, tester, n_frames, rank=None, world_size=None, group=None, use_graph=False,
-                 overlap_gather=False, pipeline=False, gather_mode="records"):
+                 overlap_gather=False, pipeline=False, gather_mode="records", step_streams=True):
         if world_size is None:
             world_size = dist.get_world_size() if dist.is_initialized() else 1
         if rank is None:
@@ -150,6 +150,13 @@ class ShardedPredictor(object):
         nbuf = 2 if (self.overlap or self.pipeline) else 1
         self.s_tail = (torch.cuda.Stream(device=eng.device, priority=int(os.environ.get("HMMR_TAIL_PRIORITY", "0")))
                        if self.pipeline else None)     # env: dev A/B switch
+        # pipeline + step_streams: consecutive calls encode on ALTERNATING high-priority streams, each as ONE whole-batch
+        # launch sequence with its own workspace, so two ResNet passes (of steps k and k+1) are in flight instead of the two
+        # half-batch sequences of one step: twice the tiles per launch against the same gap filling (measured 8.28 -> 7.87 ms
+        # per 256-frame step).  Same kernels on the same per-frame operands => the same bits.  The caller must not overwrite
+        # a `frames` tensor before `ready()` of that call's result (the encode stream reads it after run() has returned).
+        self.step_streams = ([torch.cuda.Stream(device=eng.device, priority=-1) for _ in range(nbuf)]
+                             if (self.pipeline and step_streams and os.environ.get("HMMR_STEP_STREAMS", "1") != "0") else None)
         self.done = [None] * nbuf
         self.n_reg = 1 + len(tester.delta_t_values)
         self.locals = [torch.zeros((p.out_per_rank, self.n_reg * 85 if self.theta else self.rec_len),
@@ -214,14 +221,24 @@ class ShardedPredictor(object):
         return self.locals[0]
 
     def _run_pipelined(self, frames, slot, gather):
-        """ResNet on the caller's stream, everything after it on `s_tail`."""
+        """ResNet on the caller's stream (or on this step's encode stream), everything after it on `s_tail`."""
         eng, p = self.tester.engine, self.plan
         enc = torch.cuda.current_stream(eng.device)
         if not (isinstance(frames, torch.Tensor) and frames.device.type == eng.device.type):
             frames = eng.to_device(frames)
-        phi_all = self.tester.features(frames, n_zero=1)
-        handoff = torch.cuda.Event()
-        handoff.record(enc)
+        n_local = frames.shape[0]
+        if self.step_streams is not None and n_local <= self.tester.MAX_DEVICE_FRAMES:
+            se = self.step_streams[slot]
+            se.wait_stream(enc)                               # the frames are ready on the caller's stream
+            with torch.cuda.stream(se):
+                phi_all = eng.resnet(frames, n_zero=1, ws_key="resnet_step%d" % slot, parts=1)
+                handoff = torch.cuda.Event()
+                handoff.record(se)
+            frames.record_stream(se)
+        else:
+            phi_all = self.tester.features(frames, n_zero=1)
+            handoff = torch.cuda.Event()
+            handoff.record(enc)
         out = self.locals[slot]
         with torch.cuda.stream(self.s_tail):
             self.s_tail.wait_event(handoff)

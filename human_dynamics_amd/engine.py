@@ -227,7 +227,7 @@ class HmmrEngine(object):
                 "hmmr_resnet50_fwd")
         return np.frombuffer(pm, dtype=np.float32).astype(np.float64) if prof else None
 
-    def resnet(self, images, prof=False, n_zero=0, out=None):
+    def resnet(self, images, prof=False, n_zero=0, out=None, ws_key="resnet", parts=None):
         """images [n,224,224,3] fp32 (device) -> phi [n + n_zero,2048] fp32; the last
         n_zero rows are the features of all-zero images (the padding frames of
         predict_all_images), encoded in the same pass.  encoder_resnet, src/models.py:50-77.
@@ -235,7 +235,9 @@ class HmmrEngine(object):
         Large batches run as `resnet_streams` (default 2) contiguous parts on concurrent HIP streams:
         every layer launch ends in a partial round of workgroups (tile-count quantisation, worst in
         blocks 3-4 where a 256-frame batch is only 1.5-3 rounds), and a second, independent launch
-        sequence fills those tails.  Per-frame independent => bit-identical; measured -4 %."""
+        sequence fills those tails.  Per-frame independent => bit-identical; measured -4 %.
+        parts: overrides `resnet_streams` for this call (1 = one launch sequence on the current stream, whose
+        workspace is `ws_key`: a caller that keeps several passes in flight gives each its own)."""
         self._need(self.rw, "resnet_v2_50/*")
         images = self.to_device(images)
         n = images.shape[0]
@@ -256,9 +258,9 @@ class HmmrEngine(object):
                     prof_tot += pm
                 i += c_real + c_zero
             return (phi, prof_tot) if prof else phi
-        parts = self.resnet_streams
+        parts = self.resnet_streams if parts is None else int(parts)
         if prof or parts < 2 or n < self._SPLIT_MIN_FRAMES or torch.cuda.is_current_stream_capturing():
-            pm = self._resnet_pass(images, n, n_zero, phi, "resnet", prof)
+            pm = self._resnet_pass(images, n, n_zero, phi, ws_key, prof)
             return (phi, pm) if prof else phi
         cur = torch.cuda.current_stream(self.device)
         while len(self._side_streams) < parts:

@@ -174,17 +174,19 @@ def test_sharded_predictor_graph_replay_equals_eager(weights, smpl_consts, gpu_d
     assert torch.equal(torch.cat(parts, 0), eager)
 
 
-def test_sharded_predictor_two_stream_pipeline_equals_serial(weights, smpl_consts, gpu_device):
-    """pipeline=True (the tail of call k on a second stream under the ResNet of call k+1)
-    returns bit-identical records for a stream of different inputs."""
+@pytest.mark.parametrize("dt,step_streams", [("bf16", False), ("bf16", True), ("bf16x3", True)])
+def test_sharded_predictor_two_stream_pipeline_equals_serial(weights, smpl_consts, gpu_device, dt, step_streams):
+    """pipeline=True (the tail of call k on a second stream under the ResNet of call k+1; step_streams: the ResNet passes of
+    consecutive calls on alternating streams, two in flight) returns bit-identical records for a stream of different inputs."""
     import torch
     from human_dynamics_amd import dist as hd
     from human_dynamics_amd.evaluation.tester import Tester
-    t = Tester(Config(batch_size=2), weights=weights, smpl=smpl_consts, dtype="bf16", device=gpu_device)
+    t = Tester(Config(batch_size=2), weights=weights, smpl=smpl_consts, dtype=dt, device=gpu_device)
     clips = [torch.from_numpy(assets.make_synthetic_frames(24, seed=20 + i)).to(gpu_device) for i in range(5)]
     serial = hd.ShardedPredictor(t, 24, 0, 1)
     want = [serial.run(c).clone() for c in clips]
-    pipe = hd.ShardedPredictor(t, 24, 0, 1, pipeline=True)
+    pipe = hd.ShardedPredictor(t, 24, 0, 1, pipeline=True, step_streams=step_streams)
+    assert (pipe.step_streams is not None) == step_streams
     got, prev = [], None
     for c in clips:                          # read result k only after call k+1 has been queued
         cur = pipe.run(c)
