@@ -35,7 +35,7 @@ for d in sorted(glob.glob(root + "/cs_*")):
             r["c"][cn] = v / s["n"]
 names = [l.split('"')[3] for l in open(root + "/cs_1.log") if l.startswith("{")]
 ms = [float(l.split('"ms": ')[1].split(",")[0]) for l in open(root + "/cs_1.log") if l.startswith("{")]
-print("%-22s %7s %6s %6s %6s %6s %6s %6s %6s" % ("layer", "grid", "mfma%", "lds%", "bankc%", "valu%", "vmem%", "waitL%", "waves/cu"))
+print("%-22s %7s %6s %6s %6s %6s %6s %6s %6s %6s %6s" % ("layer", "grid", "mfma%", "lds%", "bankc%", "valu%", "issue%", "stall%", "park%", "waitL%", "waves/cu"))
 for i, r in runs.items():
     c = r["c"]
     cyc = c.get("GRBM_GUI_ACTIVE", 0) / 8.0            # per-XCD clock count
@@ -49,5 +49,9 @@ for i, r in runs.items():
     wl = c.get("SQ_WAIT_INST_LDS", 0) / wc if wc else 0
     occ = wc / (c.get("SQ_BUSY_CYCLES", 1)) if c.get("SQ_BUSY_CYCLES") else 0
     nm = names[i] if i < len(names) else "?"
-    print("%-22s %7s %6.1f %6.1f %6.1f %6.1f %6.1f %6.1f %6.2f" % (nm, int(r["grid"]) // 512 if r["grid"].isdigit() else r["grid"], 100 * mf, 100 * lds, 100 * bank, 100 * valu, 100 * vm, 100 * wl, occ))
+    # SQ_ACTIVE_INST_ANY + SQ_WAIT_INST_ANY (issue stall: MFMA RAW / pipe) + SQ_WAIT_ANY (parked on s_waitcnt / s_barrier) ~ SQ_WAVE_CYCLES
+    act = c.get("SQ_ACTIVE_INST_ANY", 0) / wc if wc else 0
+    wia = c.get("SQ_WAIT_INST_ANY", 0) / wc if wc else 0
+    wa = c.get("SQ_WAIT_ANY", 0) / wc if wc else 0
+    print("%-22s %7s %6.1f %6.1f %6.1f %6.1f %6.1f %6.1f %6.1f %6.1f %6.2f" % (nm, int(r["grid"]) // 512 if r["grid"].isdigit() else r["grid"], 100 * mf, 100 * lds, 100 * bank, 100 * valu, 100 * act, 100 * wia, 100 * wa, 100 * wl, occ))
 print({k: round(v) for k, v in runs[0]["c"].items()} if runs else "")
