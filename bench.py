@@ -96,7 +96,7 @@ def conv_slot_mask():
     return np.array([k == "conv" for k in kinds])
 
 
-def cpu_baseline(windows=32):
+def cpu_baseline(windows=16):
     """The CPU oracle on a bounded sample: `windows` 20-frame windows through the
     reference-literal predict() (ResNet on all 20 frames, 8 kept per window), on
     `cores` threads = what the container may actually use (usable_cores)."""
