@@ -36,7 +36,7 @@ struct SplitTailArgs {
     int M;
     // CONV2: the unit's 3x3 conv2 (stride 1, SAME) runs in front, over h1 [n][H][W][64]; src[0] is not read
     const bsplit_t* h1; int H, W;               // H, W multiples of 8: a workgroup owns an 8 x 8 pixel tile
-    const char* w2f;                            // fragment-major [2][9 taps x 4][64 lanes][32 B], K = (ky, kx, ci)
+    const char* w2f;                            // conv2 filters packed [64+][9 * 64] like every hmmr_layer_t.w, K = (ky, kx, ci)
     const float* scale2; const float* shift2;
 };
 
@@ -69,19 +69,24 @@ __device__ __forceinline__ void split4(const float (&v)[4], unsigned long long& 
 // Block 1 (NCH 4) fits the 168-VGPR budget of three workgroups per CU (0.45 -> 0.38 ms per launch); block 2's longer K and two
 // conv1' blocks per wave do not (spills, 0.32 -> 0.41 ms), so it runs two per CU.
 // CONV2 (block 1): the workgroup's 64 pixels are an 8 x 8 tile of one image; its 10 x 10 h1 patch (zeros outside the
-// image) sits in the P region while conv2 runs (9 taps read as shifted fragments of the patch, filters fragment-major from
-// L2), and conv2's BN + ReLU output becomes the H2 tile: h2 never exists in HBM.
+// image) sits in the P region while conv2 runs (9 taps read as shifted fragments of the patch, the tap's filters staged
+// in the H2 tile region), and conv2's BN + ReLU output becomes the H2 tile: h2 never exists in HBM.
 template <int KS, int NCH, int N2, bool RES, bool CONV2>
 __global__ __launch_bounds__(256, NCH > 4 ? 2 : 3) void tail_split_kernel(const SplitTailArgs a) {
     constexpr int BM = 64, NT = 256, depth = NCH * 64;
     constexpr int PLANE = BM * 128;                  // one bf16 plane of a [64 rows][64 channels] tile
     constexpr int PPLANE = 104 * 128;                // one plane of the 10 x 10 pixel patch (CONV2)
     constexpr int OFF_H2 = 0;                        // KS tiles x (hi, lo); later the conv1' output tiles
-    constexpr int OFF_P = OFF_H2 + KS * 2 * PLANE;   // the trunk chunk (hi, lo); CONV2: first the h1 patch
-    constexpr int OFF_C = OFF_P + (CONV2 ? 2 * PPLANE : 2 * PLANE);         // 4 x depth floats
+    // CONV2: only K tile 0 (h2, produced in the launch) sits in the H2 region -- which holds the conv2 filter tap while
+    // conv2 runs -- and a second K tile (the folded shortcut's operand) follows the P planes inside the patch region
+    constexpr int NH2 = CONV2 ? 1 : KS;
+    constexpr int OFF_P = OFF_H2 + NH2 * 2 * PLANE;  // the trunk chunk (hi, lo); CONV2: first the h1 patch
+    constexpr int XREG = CONV2 ? (2 * PPLANE > KS * 2 * PLANE ? 2 * PPLANE : KS * 2 * PLANE) : 2 * PLANE;
+    constexpr int OFF_C = OFF_P + XREG;              // 4 x depth floats
+    auto ktile = [&](int ks) { return (CONV2 && ks > 0) ? OFF_P + ks * 2 * PLANE : OFF_H2 + ks * 2 * PLANE; };
     static_assert(!CONV2 || N2 == 64, "conv2 in front is written for block 1");
     constexpr int J2 = N2 / 64;                      // conv1' 32-row blocks per wave
-    static_assert(J2 <= KS, "the conv1' output tiles reuse the H2 region");
+    static_assert(J2 <= (CONV2 ? 1 : KS), "the conv1' output tiles reuse the H2 region");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -185,34 +190,48 @@ __global__ __launch_bounds__(256, NCH > 4 ? 2 : 3) void tail_split_kernel(const 
                 *(u32x4*)(smem + OFF_P + plane * PPLANE + pix * 128 + ((L ^ ((pix >> 1) & 7)) << 4)) = v;
             }
         }
-        wfrag w2[2][4];
-        auto load_w2 = [&](int tap, wfrag (&w)[4]) {
+        // conv2's filters, one tap ([64 out][64 in] = a [64 rows][256 B] tile like every other) at a time: the tile of
+        // tap t+1 is requested into registers before the MFMAs of tap t and written to LDS behind them -- 16 KB per tap and
+        // workgroup through the address path instead of 32 KB of per-wave fragments (which made it the limiter)
+        const bsplit_t* w2 = (const bsplit_t*)a.w2f;                  // packed [64+][9 * 64], K = (ky, kx, ci)
+        u32x4 rw2[4];
+        auto load_w2 = [&](int tap) {
 #pragma unroll
-            for (int kc = 0; kc < 4; ++kc) {
-                const bf16x8* p = (const bf16x8*)(a.w2f + ((long long)(wn * 36 + tap * 4 + kc) * 64 + lane) * 32);
-                w[kc].hi = p[0]; w[kc].lo = p[1];
-            }
+            for (int p = 0; p < 4; ++p) rw2[p] = *(const u32x4*)(w2 + (long long)(rr + 16 * p) * (9 * 64) + tap * 64 + s * 4);
         };
-        load_w2(0, w2[0]);
+        auto store_w2 = [&]() {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) *(u32x4*)slot_of(OFF_H2, rr + 16 * p) = rw2[p];
+        };
+        load_w2(0);
+        store_w2();
         __syncthreads();
         const int pq = wm * 32 + lr;                                  // this lane's pixel of the tile
         const int brow = (pq >> 3) * 10 + (pq & 7);                   // its patch row for tap (0, 0)
+        const int wrow = (wn * 32 + lr) * 128;                        // this lane's filter row of the tap tile
         f32x16 acc0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            if (tap + 1 < 9) load_w2(tap + 1, w2[(tap + 1) & 1]);
+            if (tap + 1 < 9) load_w2(tap + 1);
             const int row = brow + (tap / 3) * 10 + tap % 3;
             const char* ph = smem + OFF_P + row * 128;
             const int sw = (row >> 1) & 7;
 #pragma unroll
             for (int kc = 0; kc < 4; ++kc) {
+                wfrag w;
+                w.hi = *(const bf16x8*)(smem + OFF_H2 + wrow + (((2 * kc + lh) ^ fsw) << 4));
+                w.lo = *(const bf16x8*)(smem + OFF_H2 + PLANE + wrow + (((2 * kc + lh) ^ fsw) << 4));
                 const bf16x8 xh = *(const bf16x8*)(ph + (((2 * kc + lh) ^ sw) << 4));
                 const bf16x8 xl = *(const bf16x8*)(ph + PPLANE + (((2 * kc + lh) ^ sw) << 4));
-                acc0 = mma3(w2[tap & 1][kc], xh, xl, acc0);
+                acc0 = mma3(w, xh, xl, acc0);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                                          // every wave is done with this tap's filters
+            if (tap + 1 < 9) {
+                store_w2();
+                __syncthreads();
+            }
         }
         // BN + ReLU, split -> the H2 tile (lane: 4 consecutive channels x 4 groups of its pixel)
 #pragma unroll
@@ -238,7 +257,7 @@ __global__ __launch_bounds__(256, NCH > 4 ? 2 : 3) void tail_split_kernel(const 
 #pragma unroll
         for (int p = 0; p < 4; ++p) v[p] = *(const u32x4*)(a.src[ks] + grow[p] * a.src_ld[ks] + s * 4);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) *(u32x4*)slot_of(OFF_H2 + ks * 2 * PLANE, rr + 16 * p) = v[p];
+        for (int p = 0; p < 4; ++p) *(u32x4*)slot_of(ktile(ks), rr + 16 * p) = v[p];
     }
 
     f32x16 acc2[J2];
@@ -265,7 +284,7 @@ __global__ __launch_bounds__(256, NCH > 4 ? 2 : 3) void tail_split_kernel(const 
             if (!ALLW && ks > 0) { __builtin_amdgcn_sched_barrier(0); load_w3(nc, ks); }
 #pragma unroll
             for (int kc = 0; kc < 4; ++kc)
-                acc1 = mma3(w3[(ALLW ? ks * 4 : 0) + kc], xfrag(OFF_H2 + ks * 2 * PLANE, kc), xfrag(OFF_H2 + ks * 2 * PLANE + PLANE, kc), acc1);
+                acc1 = mma3(w3[(ALLW ? ks * 4 : 0) + kc], xfrag(ktile(ks), kc), xfrag(ktile(ks) + PLANE, kc), acc1);
         }
         __builtin_amdgcn_sched_barrier(0);               // (the reload must not be hoisted above the MFMAs: it would double the live fragment registers)
         if (nc + 1 < NCH) load_w3_chunk(nc + 1);
@@ -346,7 +365,8 @@ __global__ __launch_bounds__(256, NCH > 4 ? 2 : 3) void tail_split_kernel(const 
 
 template <int KS, int NCH, int N2, bool RES, bool CONV2 = false>
 int launch_split_tail(const SplitTailArgs& a, hipStream_t stream) {
-    constexpr int lds = KS * 2 * 64 * 128 + (CONV2 ? 2 * 104 * 128 : 2 * 64 * 128) + 4 * NCH * 64 * (int)sizeof(float);
+    constexpr int xreg = CONV2 ? (2 * 104 * 128 > KS * 2 * 64 * 128 ? 2 * 104 * 128 : KS * 2 * 64 * 128) : 2 * 64 * 128;
+    constexpr int lds = (CONV2 ? 1 : KS) * 2 * 64 * 128 + xreg + 4 * NCH * 64 * (int)sizeof(float);
     auto kern = tail_split_kernel<KS, NCH, N2, RES, CONV2>;
     static DeviceOnce once;
     if (const unsigned long long bit = once.due()) {
@@ -385,8 +405,7 @@ int hmmr_bottleneck_tail_split(const hmmr_tail_desc_t* d, hipStream_t stream) {
         a.h1 = (const bsplit_t*)d->h1; a.H = d->hin; a.W = d->win; a.w2f = (const char*)d->w2; a.scale2 = d->scale2; a.shift2 = d->shift2;
         if (folded) {
             a.src[1] = (const bsplit_t*)d->xp; a.src_ld[1] = 64;
-            HMMR_REQUIRE(!conv2, "hmmr_bottleneck_tail (bf16x3): conv2 in front is not built for the folded-shortcut form");
-            return launch_split_tail<2, 4, 64, false>(a, stream);
+            return conv2 ? launch_split_tail<2, 4, 64, false, true>(a, stream) : launch_split_tail<2, 4, 64, false>(a, stream);
         }
         return conv2 ? launch_split_tail<1, 4, 64, true, true>(a, stream) : launch_split_tail<1, 4, 64, true>(a, stream);
     }

@@ -376,7 +376,7 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
             t.out = d.out; t.out_pre = d.out2; t.pre_scale = d.scale2; t.pre_shift = d.shift2;
             if (hmmr_bottleneck_tail(&t, s)) return -2;
         } else if (U.fuse_tail) {     // conv3 + add + the next unit's preact + conv1 in one launch (csrc/bottleneck.hip)
-            HMMR_REQUIRE(!last && (w->dtype == HMMR_BF16 || (w->dtype == HMMR_BF16X3 && U.w3_frag && U.w1n_frag && (U.fuse_tail == 1 || (U.fuse_tail == 2 && U.w2_frag)))) &&
+            HMMR_REQUIRE(!last && (w->dtype == HMMR_BF16 || (w->dtype == HMMR_BF16X3 && U.w3_frag && U.w1n_frag && U.fuse_tail <= 2)) &&
                          U.stride == 1 && write_raw && !write_pre && next_fused &&
                          next_identity && w->unit[u + 1].base == U.base && w->unit[u + 1].c_in == U.depth &&
                          ((U.base == 64 && U.depth == 256) || (U.base == 128 && U.depth == 512)),
@@ -387,8 +387,7 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
             if (conv2_in_tail) {      // h2 never exists in HBM; the conv1' output goes to T2 (T1 is still being read
                                       // by neighbouring tiles' halos), and the two buffers swap roles afterwards
                 HMMR_REQUIRE(U.conv2.scale && U.conv2.shift, "resnet: unit %d cannot fuse its conv2", u);
-                t.h1 = T1; t.hin = H; t.win = H; t.w2 = w->dtype == HMMR_BF16X3 ? U.w2_frag : U.conv2.w;
-                t.scale2 = U.conv2.scale; t.shift2 = U.conv2.shift;
+                t.h1 = T1; t.hin = H; t.win = H; t.w2 = U.conv2.w; t.scale2 = U.conv2.scale; t.shift2 = U.conv2.shift;
             } else {
                 t.h2 = T2;
             }

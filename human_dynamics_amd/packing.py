@@ -205,11 +205,7 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
             u.w3_frag = store.put_tensor(pack_frag_major(w3.T)).data_ptr()
             u.w1n_frag = store.put_tensor(pack_frag_major(w1n.T)).data_ptr()
             u.fuse_tail = 1
-            # block 1 (56 x 56 = 7 x 7 tiles of 8 x 8): conv2 inside as well.  Not for the unit with a folded shortcut: its two
-            # K tiles leave room for two workgroups per CU only, and the launch then loses more than the h2 round trip saves
-            # (measured: 0.72 ms against 0.25 + 0.39 ms)
-            if base == 64 and not u.c3sc.w and fuse_tail != "noconv2":
-                u.w2_frag = store.put_tensor(pack_frag_major(pack_conv_weight(w[scope + "/conv2/weights"])[:base])).data_ptr()
+            if base == 64 and fuse_tail != "noconv2":        # block 1 (56 x 56 = 7 x 7 tiles of 8 x 8): conv2 inside as well
                 u.fuse_tail = 2
     for i in range(L.RESNET_UNITS - 1):
         u, nx = rw.unit[i], rw.unit[i + 1]

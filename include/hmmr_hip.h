@@ -148,7 +148,6 @@ typedef struct {
                                   one column-split GEMM.  w == NULL: two launches. */
     const void* w3_frag;       /* bf16x3 fused tail (fuse_tail == 1): this unit's conv3 filters ([W3 | Wsc] when c3sc is set) */
     const void* w1n_frag;      /* ... and the NEXT unit's conv1 filters, both FRAGMENT-MAJOR (hmmr_tail_desc_t); else NULL */
-    const void* w2_frag;       /* bf16x3, fuse_tail == 2: this unit's conv2 filters [base][9 * base], fragment-major */
     const float* pre_scale;    /* this unit's folded `preact` BN, [c_in] */
     const float* pre_shift;
     int c_in, base, depth, stride;
@@ -182,7 +181,7 @@ typedef struct {
  * [block1] or (128, 512, 128) [block2].
  * The shortcut is read as rows of `ldr` elements, or (res_strided) as x[:, ::s, ::s] of an NHWC
  * tensor like hmmr_conv_desc_t's strided residual (ho, wo = output grid).
- * dtype HMMR_BF16X3 (csrc/bottleneck_split.hip): the next conv1 always; conv2 in front (h1, w2 fragment-major; stride 1, 8 x 8
+ * dtype HMMR_BF16X3 (csrc/bottleneck_split.hip): the next conv1 always; conv2 in front (h1; w2 packed like every filter bank; stride 1, 8 x 8
  * pixel tiles: hin, win multiples of 8) for the 64 -> 256 -> 64 shape only; w3 and w1 are
  * FRAGMENT-MAJOR: [rows / 32][K / 16][64 lanes][hi 16 B | lo 16 B], lane = 32 * (k half) + row, the 16 bytes = the 8
  * bf16 of W[32 rb + row][16 kc + 8 half .. + 7] (one coalesced 2 KB read per MFMA A operand, straight from L2).  With xp

@@ -276,12 +276,12 @@ def test_resnet_folded_shortcut_is_the_separate_shortcut_up_to_its_rounding(weig
 
 def test_resnet_split_fused_tails_equal_layer_per_launch(weights, gpu_device):
     """csrc/bottleneck_split.hip: conv3 (+ folded shortcut / + identity shortcut) + the next unit's preact + conv1 as one
-    launch for units 1.1, 1.2 (the latter with its 3x3 conv2 in front as well), 2.2, 2.3 -- the same MFMA order and rounding points as the launches it replaces, so the
+    launch for units 1.1, 1.2 (with their 3x3 conv2 in front as well), 2.2, 2.3 -- the same MFMA order and rounding points as the launches it replaces, so the
     features are bit-identical (6 images: block 2's 4704 pixels end in a half tile)."""
     from human_dynamics_amd.engine import HmmrEngine
     frames = assets.make_synthetic_frames(5, seed=17)
     fused = HmmrEngine(weights, None, dtype="bf16x3", device=gpu_device, autotune=False)
-    assert [int(fused.rw.unit[i].fuse_tail) for i in range(16)] == [1, 2, 0, 0, 1, 1, 0] + [0] * 9
+    assert [int(fused.rw.unit[i].fuse_tail) for i in range(16)] == [2, 2, 0, 0, 1, 1, 0] + [0] * 9
     plain = HmmrEngine(weights, None, dtype="bf16x3", device=gpu_device, autotune=False, fuse_tail=False)
     assert not any(plain.rw.unit[i].fuse_tail for i in range(16))
     a, b = fused.resnet(frames, n_zero=1), plain.resnet(frames, n_zero=1)

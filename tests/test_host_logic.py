@@ -121,7 +121,7 @@ def test_window_plan_matches_oracle():
 def test_ctypes_struct_sizes_are_plausible():
     # catches accidental field drift between include/hmmr_hip.h and _lib.py
     assert C.sizeof(_lib.Layer) == 32
-    assert C.sizeof(_lib.ResnetUnit) == 6 * 32 + 24 + 16 + 16 + 8
+    assert C.sizeof(_lib.ResnetUnit) == 6 * 32 + 16 + 16 + 16 + 8
     assert C.sizeof(_lib.ConvDesc) % 8 == 0
 
 
@@ -139,7 +139,7 @@ def test_packer_marks_the_fused_launches(weights):
     rwx = packing.pack_resnet(weights, _lib.HMMR_BF16X3, packing.DeviceStore("cpu"))
     assert [i for i in range(16) if rwx.unit[i].c3sc.w] == [0, 3, 7, 13] and not any(rwx.unit[i].sc_c1.w for i in range(16))
     # ... and conv3 + add + the next conv1 run as one launch for the stride-1 units of blocks 1-2 with an identity successor
-    assert [rwx.unit[i].fuse_tail for i in range(16)] == [1, 2, 0, 0, 1, 1, 0] + [0] * 9      # unit 1.2: conv2 inside as well
+    assert [rwx.unit[i].fuse_tail for i in range(16)] == [2, 2, 0, 0, 1, 1, 0] + [0] * 9      # block 1: conv2 inside as well
     assert all(bool(rwx.unit[i].w3_frag) == bool(rwx.unit[i].fuse_tail) for i in range(16))
     rw32 = packing.pack_resnet(weights, _lib.HMMR_F32, packing.DeviceStore("cpu"))
     assert sum(rw32.unit[i].fuse_tail for i in range(16)) == 0
