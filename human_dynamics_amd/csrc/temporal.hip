@@ -13,7 +13,9 @@
 // K = 3*2048 is long and M = b*t is short (640 rows for 32 windows): 4 K-slices quadruple the
 // number of workgroups.  Fixed per layer, never derived from b, so a window's result does not
 // depend on how many windows share the launch.
+#ifndef TEMPORAL_SPLIT_K
 #define TEMPORAL_SPLIT_K 4
+#endif
 
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
 #pragma unroll

@@ -263,8 +263,7 @@ class HmmrEngine(object):
             pm = self._resnet_pass(images, n, n_zero, phi, ws_key, prof)
             return (phi, pm) if prof else phi
         cur = torch.cuda.current_stream(self.device)
-        while len(self._side_streams) < parts:
-            self._side_streams.append(torch.cuda.Stream(device=self.device, priority=int(os.environ.get("HMMR_RESNET_PRIORITY", "-1"))))
+        self.side_stream(parts - 1)
         cuts = [(i * n) // parts for i in range(parts + 1)]
         if self.autotune:                                    # tune every part size before anything overlaps
             for i in range(parts):
@@ -281,6 +280,12 @@ class HmmrEngine(object):
         for i in range(parts):
             cur.wait_stream(self._side_streams[i])
         return phi
+
+    def side_stream(self, i):
+        """The i-th of the high-priority streams the ResNet parts run on (created on first use)."""
+        while len(self._side_streams) <= i:
+            self._side_streams.append(torch.cuda.Stream(device=self.device, priority=int(os.environ.get("HMMR_RESNET_PRIORITY", "-1"))))
+        return self._side_streams[i]
 
     def temporal(self, phi):
         """phi [b,t,2048] fp32 -> movie strips [b,t,2048].  az_fc2_groupnorm, src/models.py:121-141."""

@@ -49,7 +49,12 @@ class HostStreamer(object):
         self.s_in = torch.cuda.Stream(device=self.dev)
         self.s_out = torch.cuda.Stream(device=self.dev)
         self.s_tail = torch.cuda.Stream(device=self.dev)       # the ~150 small launches of a chunk's tail run under the next ResNet
-        self._pin, self._dev_in, self._geom = {}, {}, None
+        # uint8 -> float conversion of an uploaded chunk: a KERNEL, so it needs a hardware queue of its own -- ROCm multiplexes
+        # the streams of one priority onto 4 hardware queues, and on a queue shared with the tail stream the conversion of
+        # chunk k+2 sat behind the whole tail of chunk k (the ResNet starved for 8 ms per chunk).  High-priority streams
+        # (this one and the engine's two ResNet streams) have their own pool.
+        self.s_conv = self.eng.side_stream(0)
+        self._pin, self._dev_in, self._geom, self._dev_f32 = {}, {}, None, None
         self.layout, self.rec_len = tester.record_layout()
         # staging copies (pageable user array -> pinned buffer) run on a small private pool of plain memcpy workers
         # (NumPy releases the GIL): torch's intra-op pool would wake one spinning thread per core for every chunk,
@@ -60,6 +65,7 @@ class HostStreamer(object):
         # ... and are started one chunk AHEAD by a stager thread (it waits for the staging pair to be free, then fans the
         # memcpy out), so the Python thread keeps enqueueing kernels instead of waiting for 154 MB of memcpy per chunk
         self._stager = ThreadPoolExecutor(max_workers=1)
+        self._downloader = ThreadPoolExecutor(max_workers=1)        # queues a chunk's downloads when its records are ready
 
     def _stage(self, dst_pinned, src):
         """src (ndarray [n,...]) -> the first n rows of the pinned staging tensor."""
@@ -82,11 +88,15 @@ class HostStreamer(object):
             self._dev_in[dtype] = [torch.empty(shape, dtype=dtype, device=self.dev) for _ in range(2)]
         return self._pin[dtype], self._dev_in[dtype]
 
-    def _to_float(self, u8, n):
-        """uint8 crops on the device -> float32 in [-1, 1] (identity geometry of hmmr_crop_frames)."""
+    def _to_float(self, u8, n, slot):
+        """uint8 crops on the device -> float32 in [-1, 1] (identity geometry of hmmr_crop_frames), on the CURRENT
+        stream (the conversion stream: part of the upload, the compute stream only ever sees floats), into this
+        slot's float buffer, whose previous reader -- the ResNet of chunk k-2 -- has finished (in_free)."""
         if self._geom is None:
             self._geom = torch.tensor([[224, 224, 0, 0]] * self.chunk, dtype=torch.int32, device=self.dev)
-        out = torch.empty((n, 224, 224, 3), dtype=torch.float32, device=self.dev)
+        if self._dev_f32 is None:
+            self._dev_f32 = [torch.empty((self.chunk, 224, 224, 3), dtype=torch.float32, device=self.dev) for _ in range(2)]
+        out = self._dev_f32[slot][:n]
         L.check(self.eng.lib.hmmr_crop_frames(u8.data_ptr(), self._geom.data_ptr(), n, 224, 224, out.data_ptr(),
                                               torch.cuda.current_stream(self.dev).cuda_stream), "hmmr_crop_frames")
         return out
@@ -124,45 +134,70 @@ class HostStreamer(object):
         import os as _os, time as _time
         trace = [] if _os.environ.get("HMMR_STREAM_TRACE") else None
         tr = (lambda tag: trace.append((tag, _time.perf_counter()))) if trace is not None else (lambda tag: None)
+        gpu_marks = [] if trace is not None else None          # (tag, event): device-side timeline of the same call
+
+        def mark(tag, stream):
+            if gpu_marks is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(stream)
+                gpu_marks.append((tag, e))
+        self._mark = mark
+        mark("start", cur)
         is_staged = lambda k_: (k_ > 0) if self.staged == "auto" else bool(self.staged)
-        ahead = None                                                 # the stager's future for the chunk about to be consumed
 
         def stage_ahead(k_):
             if k_ >= n_chunks or not is_staged(k_):
                 return None
             lo_, hi_ = k_ * C, min(N, (k_ + 1) * C)
             return self._stager.submit(self._stage_when_free, pin[k_ % 2], src[lo_:hi_], in_free[k_ % 2])
-        if is_staged(0):
-            ahead = stage_ahead(0)
+
+        def upload(k_, ahead_):
+            """Chunk k_ -> HBM on the copy-in stream (+ conversion); returns (frames, event).  Blocks the host until the
+            buffer pair of the slot is free, i.e. until chunk k_-2 is encoded."""
+            lo_, hi_ = k_ * C, min(N, (k_ + 1) * C)
+            n_, slot_ = hi_ - lo_, k_ % 2
+            staged = is_staged(k_)
+            if staged:
+                ahead_.result()                                      # pageable -> pinned, done one chunk ahead
+                tr(" staged %d" % k_)
+            elif in_free[slot_] is not None:
+                in_free[slot_].synchronize()                         # the device-side pair is free again (chunk k_-2 is encoded)
+            with torch.cuda.stream(self.s_in):
+                if staged:
+                    dev_in[slot_][:n_].copy_(pin[slot_][:n_], non_blocking=True)
+                else:
+                    # straight from the caller's array; the call returns when the bytes have left it
+                    dev_in[slot_][:n_].copy_(torch.from_numpy(src[lo_:hi_]), non_blocking=True)
+                landed = torch.cuda.Event()
+                landed.record(self.s_in)
+            frames = dev_in[slot_][:n_]
+            if tdt == torch.uint8:
+                with torch.cuda.stream(self.s_conv):
+                    self.s_conv.wait_event(landed)
+                    frames = self._to_float(frames, n_, slot_)
+                    landed = torch.cuda.Event()
+                    landed.record(self.s_conv)
+            mark("upload %d landed" % k_, self.s_conv if tdt == torch.uint8 else self.s_in)
+            tr(" h2d %d queued" % k_)
+            return frames, landed
+
+        pending = upload(0, stage_ahead(0))
         for k in range(n_chunks + 1):
             tr("chunk %d" % k)
             if k < n_chunks:
                 lo, hi = k * C, min(N, (k + 1) * C)
-                n, slot = hi - lo, k % 2
-                staged = is_staged(k)
-                if staged:
-                    ahead.result()                                   # pageable -> pinned, done one chunk ahead
-                    tr(" staged")
-                elif in_free[slot] is not None:
-                    in_free[slot].synchronize()                      # the device-side pair is free again (chunk k-2 is encoded)
-                with torch.cuda.stream(self.s_in):
-                    if staged:
-                        dev_in[slot][:n].copy_(pin[slot][:n], non_blocking=True)
-                    else:
-                        # straight from the caller's array; the call returns when the bytes have left it
-                        dev_in[slot][:n].copy_(torch.from_numpy(src[lo:hi]), non_blocking=True)
-                    landed = torch.cuda.Event()
-                    landed.record(self.s_in)
+                slot = k % 2
+                frames, landed = pending
                 cur.wait_event(landed)
-                frames = dev_in[slot][:n]
-                if tdt == torch.uint8:
-                    frames = self._to_float(frames, n)
-                tr(" h2d queued")
                 eng.resnet(frames, out=phi[lo:hi])
                 tr(" resnet queued")
+                mark("resnet %d done" % k, cur)
                 in_free[slot] = torch.cuda.Event()
                 in_free[slot].record(cur)
-                ahead = stage_ahead(k + 1)                           # runs while this chunk's kernels are enqueued and executed
+                if k + 1 < n_chunks:
+                    # the NEXT upload goes into its queue before the tail (and the downloads) of chunk k-1 do: queued behind
+                    # them, the copy of chunk k+1 was seen to wait for those downloads, and the ResNet with it
+                    pending = upload(k + 1, stage_ahead(k + 1))
             if k >= 1:
                 # tail of output frames [o0, o1): their windows reach margin frames into chunk k, encoded just above
                 encoded = torch.cuda.Event()
@@ -172,12 +207,16 @@ class HostStreamer(object):
                     self._tail(k - 1, N, phi, recs, out_free, host, fields, keys, ar_T)
                 tr(" tail queued")
         self.s_tail.synchronize()
+        for f in out_free:
+            if f is not None:
+                f.result()                                           # the last downloads are queued (re-raises a failure)
         self.s_out.synchronize()
         cur.synchronize()
         tr("done")
         if trace is not None:
             t0 = trace[0][1]
             print("\n".join("%8.2f ms %s" % ((t - t0) * 1e3, tag) for tag, t in trace))
+            print("\n".join("%8.2f ms (device) %s" % (gpu_marks[0][1].elapsed_time(e), tag) for tag, e in gpu_marks[1:]))
         return {k: host[k].numpy() for k in keys}
 
     def _tail(self, j, N, phi, recs, out_free, host, fields, keys, ar_T):
@@ -190,15 +229,23 @@ class HostStreamer(object):
         idx = torch.where((f >= 0) & (f < N), f, torch.full_like(f, N))
         slot = j % 2
         if out_free[slot] is not None:
-            cur.wait_event(out_free[slot])                          # the previous copy-out of this buffer is done
+            cur.wait_event(out_free[slot].result())                 # the previous copy-out of this buffer is done
         rec = recs[slot]
         t.predict_strips_records(phi[idx], o1 - o0, out=rec)
-        ready = torch.cuda.Event()
+        ready = torch.cuda.Event(blocking=True)
         ready.record(cur)
-        with torch.cuda.stream(self.s_out):
-            self.s_out.wait_event(ready)
-            for k in keys:
-                shp, off, size = fields[k]
-                host[k][o0:o1].copy_(rec[:o1 - o0, off:off + size].reshape((o1 - o0,) + shp), non_blocking=True)
-            out_free[slot] = torch.cuda.Event()
-            out_free[slot].record(self.s_out)
+        self._mark("tail %d done" % j, cur)
+
+        def download():
+            # issued by the downloader thread once the records EXIST: copies queued while their producer is still running
+            # were seen to hold back the uploads queued after them (the copy queues serve in submission order)
+            ready.synchronize()
+            with torch.cuda.stream(self.s_out):
+                for k in keys:
+                    shp, off, size = fields[k]
+                    host[k][o0:o1].copy_(rec[:o1 - o0, off:off + size].reshape((o1 - o0,) + shp), non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(self.s_out)
+                self._mark("download %d done" % j, self.s_out)
+            return done
+        out_free[slot] = self._downloader.submit(download)

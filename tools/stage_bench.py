@@ -22,7 +22,7 @@ out = {"resnet257_ms": timed(lambda: eng.resnet(x, n_zero=1), 10), "temporal32x2
        "ief256_ms": timed(lambda: eng.ief(st)), "smpl256_ms(x1 of 3)": timed(lambda: eng.smpl(th, be, cm))}
 print(json.dumps(out))
 if len(sys.argv) > 2:       # temporal tiles
-    for t in (0, 5, 6, 1, 7):
+    for t in (5, 6, 7, 8):
         for i in range(3):
             eng.tw.block[i].conv1.tile = eng.tw.block[i].conv2.tile = t
         print("temporal tile", t, timed(lambda: eng.temporal(phi)))
