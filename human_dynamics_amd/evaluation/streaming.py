@@ -6,11 +6,17 @@ path is bound by PCIe and host copies unless they overlap the kernels, so the vi
 chunks of `chunk` frames and three HIP streams run side by side:
 
     copy-in stream   chunk k+1: the caller's array -> HBM (double-buffered device side; straight from the pageable
-                                array, which moves at the pinned rate on this platform, or via pinned staging buffers)
-    compute stream   chunk k  : [uint8 -> float crop] -> ResNet -> phi
+                                array, which moves at the pinned rate on this platform, or via pinned staging buffers);
+                                uint8 input is converted to float by one kernel on the ResNet's first stream
+    compute streams  chunk k  : ResNet -> phi
     tail stream      chunk k-1: the per-window tail (f_movie, IEF, 3 x SMPL), whose halo is encoded by now,
                                 underneath the ResNet of chunk k+1
     copy-out stream  chunk k-2: record fields -> one pinned host array per output key
+
+Copies are served in the order they were submitted, whatever stream they are on: a download that waits for its
+tail blocks every upload queued behind it, and the ResNet of the next chunk with it.  So the upload of chunk k+1
+is queued BEFORE the tail of chunk k-1, and a chunk's downloads are queued by a downloader thread at the moment
+its records exist (tools/stream_trace.py shows both timelines).
 
 Only the copy-in call occupies the Python thread (2.8 ms per 256 float32 frames), while the GPU works on the
 previous chunk.  Every kernel sees exactly the operands it sees in the
