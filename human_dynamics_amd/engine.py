@@ -227,6 +227,15 @@ class HmmrEngine(object):
                 "hmmr_resnet50_fwd")
         return np.frombuffer(pm, dtype=np.float32).astype(np.float64) if prof else None
 
+    def resnet_cuts(self, n, parts=None):
+        """Frame boundaries of the contiguous parts `resnet()` runs n frames as ([0, n]: one part).  A caller that
+        feeds the parts itself (evaluation/streaming.py: part i starts when ITS upload has landed) runs part i as
+        `resnet(images[a:b], parts=1, ws_key="resnet%d" % i)` on `side_stream(i)`."""
+        parts = self.resnet_streams if parts is None else int(parts)
+        if parts < 2 or n < self._SPLIT_MIN_FRAMES or self.resnet_chunk > 0:
+            return [0, n]
+        return [(i * n) // parts for i in range(parts + 1)]
+
     def resnet(self, images, prof=False, n_zero=0, out=None, ws_key="resnet", parts=None):
         """images [n,224,224,3] fp32 (device) -> phi [n + n_zero,2048] fp32; the last
         n_zero rows are the features of all-zero images (the padding frames of

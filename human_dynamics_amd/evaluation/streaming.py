@@ -8,7 +8,8 @@ chunks of `chunk` frames and three HIP streams run side by side:
     copy-in stream   chunk k+1: the caller's array -> HBM (double-buffered device side; straight from the pageable
                                 array, which moves at the pinned rate on this platform, or via pinned staging buffers);
                                 uint8 input is converted to float by one kernel on the ResNet's first stream
-    compute streams  chunk k  : ResNet -> phi
+    compute streams  chunk k  : ResNet -> phi, as the engine's two contiguous parts on its two streams; each part
+                                starts when ITS half of the upload has landed
     tail stream      chunk k-1: the per-window tail (f_movie, IEF, 3 x SMPL), whose halo is encoded by now,
                                 underneath the ResNet of chunk k+1
     copy-out stream  chunk k-2: record fields -> one pinned host array per output key
@@ -55,11 +56,6 @@ class HostStreamer(object):
         self.s_in = torch.cuda.Stream(device=self.dev)
         self.s_out = torch.cuda.Stream(device=self.dev)
         self.s_tail = torch.cuda.Stream(device=self.dev)       # the ~150 small launches of a chunk's tail run under the next ResNet
-        # uint8 -> float conversion of an uploaded chunk: a KERNEL, so it needs a hardware queue of its own -- ROCm multiplexes
-        # the streams of one priority onto 4 hardware queues, and on a queue shared with the tail stream the conversion of
-        # chunk k+2 sat behind the whole tail of chunk k (the ResNet starved for 8 ms per chunk).  High-priority streams
-        # (this one and the engine's two ResNet streams) have their own pool.
-        self.s_conv = self.eng.side_stream(0)
         self._pin, self._dev_in, self._geom, self._dev_f32 = {}, {}, None, None
         self.layout, self.rec_len = tester.record_layout()
         # staging copies (pageable user array -> pinned buffer) run on a small private pool of plain memcpy workers
@@ -94,15 +90,17 @@ class HostStreamer(object):
             self._dev_in[dtype] = [torch.empty(shape, dtype=dtype, device=self.dev) for _ in range(2)]
         return self._pin[dtype], self._dev_in[dtype]
 
-    def _to_float(self, u8, n, slot):
-        """uint8 crops on the device -> float32 in [-1, 1] (identity geometry of hmmr_crop_frames), on the CURRENT
-        stream (the conversion stream: part of the upload, the compute stream only ever sees floats), into this
-        slot's float buffer, whose previous reader -- the ResNet of chunk k-2 -- has finished (in_free)."""
-        if self._geom is None:
-            self._geom = torch.tensor([[224, 224, 0, 0]] * self.chunk, dtype=torch.int32, device=self.dev)
+    def _float_buf(self, slot):
         if self._dev_f32 is None:
             self._dev_f32 = [torch.empty((self.chunk, 224, 224, 3), dtype=torch.float32, device=self.dev) for _ in range(2)]
-        out = self._dev_f32[slot][:n]
+        return self._dev_f32[slot]
+
+    def _to_float(self, u8, n, out):
+        """uint8 crops on the device -> float32 in [-1, 1] (identity geometry of hmmr_crop_frames), on the CURRENT
+        stream, into `out` (rows of the slot's float buffer, whose previous reader -- the ResNet of chunk k-2 -- has
+        finished: in_free)."""
+        if self._geom is None:
+            self._geom = torch.tensor([[224, 224, 0, 0]] * self.chunk, dtype=torch.int32, device=self.dev)
         L.check(self.eng.lib.hmmr_crop_frames(u8.data_ptr(), self._geom.data_ptr(), n, 224, 224, out.data_ptr(),
                                               torch.cuda.current_stream(self.dev).cuda_stream), "hmmr_crop_frames")
         return out
@@ -157,9 +155,12 @@ class HostStreamer(object):
             lo_, hi_ = k_ * C, min(N, (k_ + 1) * C)
             return self._stager.submit(self._stage_when_free, pin[k_ % 2], src[lo_:hi_], in_free[k_ % 2])
 
-        def upload(k_, ahead_):
-            """Chunk k_ -> HBM on the copy-in stream (+ conversion); returns (frames, event).  Blocks the host until the
-            buffer pair of the slot is free, i.e. until chunk k_-2 is encoded."""
+        enc = [None] * n_chunks          # enc[k]: chunk k is encoded (recorded on the caller's stream)
+
+        def encode(k_, ahead_):
+            """Chunk k_: upload (+ conversion) and ResNet, part by part -- the engine's split of a chunk into contiguous
+            parts on concurrent streams, fed here so that part i starts when ITS frames have landed, under the upload of
+            part i+1.  Blocks the host until the buffer pair of the slot is free, i.e. until chunk k_-2 is encoded."""
             lo_, hi_ = k_ * C, min(N, (k_ + 1) * C)
             n_, slot_ = hi_ - lo_, k_ % 2
             staged = is_staged(k_)
@@ -168,48 +169,49 @@ class HostStreamer(object):
                 tr(" staged %d" % k_)
             elif in_free[slot_] is not None:
                 in_free[slot_].synchronize()                         # the device-side pair is free again (chunk k_-2 is encoded)
-            with torch.cuda.stream(self.s_in):
-                if staged:
-                    dev_in[slot_][:n_].copy_(pin[slot_][:n_], non_blocking=True)
-                else:
-                    # straight from the caller's array; the call returns when the bytes have left it
-                    dev_in[slot_][:n_].copy_(torch.from_numpy(src[lo_:hi_]), non_blocking=True)
-                landed = torch.cuda.Event()
-                landed.record(self.s_in)
+            cuts = eng.resnet_cuts(n_)
+            one = len(cuts) == 2
             frames = dev_in[slot_][:n_]
-            if tdt == torch.uint8:
-                with torch.cuda.stream(self.s_conv):
-                    self.s_conv.wait_event(landed)
-                    frames = self._to_float(frames, n_, slot_)
+            fl = self._float_buf(slot_)[:n_] if tdt == torch.uint8 else frames
+            streams = []
+            for i_, (a_, b_) in enumerate(zip(cuts[:-1], cuts[1:])):
+                with torch.cuda.stream(self.s_in):
+                    if staged:
+                        frames[a_:b_].copy_(pin[slot_][a_:b_], non_blocking=True)
+                    else:
+                        # straight from the caller's array; the call returns when the bytes have left it
+                        frames[a_:b_].copy_(torch.from_numpy(src[lo_ + a_:lo_ + b_]), non_blocking=True)
                     landed = torch.cuda.Event()
-                    landed.record(self.s_conv)
-            mark("upload %d landed" % k_, self.s_conv if tdt == torch.uint8 else self.s_in)
-            tr(" h2d %d queued" % k_)
-            return frames, landed
+                    landed.record(self.s_in)
+                sc = cur if one else eng.side_stream(i_)
+                with torch.cuda.stream(sc):
+                    if not one:
+                        sc.wait_stream(cur)
+                    sc.wait_event(landed)
+                    if tdt == torch.uint8:                           # a kernel: on the stream of its consumer
+                        self._to_float(frames[a_:b_], b_ - a_, fl[a_:b_])
+                    mark("upload %d.%d landed" % (k_, i_), sc)
+                    eng.resnet(fl[a_:b_], out=phi[lo_ + a_:lo_ + b_], parts=1, ws_key="resnet" if one else "resnet%d" % i_)
+                streams.append(sc)
+            for sc in streams:
+                if sc is not cur:
+                    cur.wait_stream(sc)
+            tr(" chunk %d queued" % k_)
+            mark("resnet %d done" % k_, cur)
+            enc[k_] = in_free[slot_] = torch.cuda.Event()
+            enc[k_].record(cur)
 
-        pending = upload(0, stage_ahead(0))
+        encode(0, stage_ahead(0))
         for k in range(n_chunks + 1):
             tr("chunk %d" % k)
-            if k < n_chunks:
-                lo, hi = k * C, min(N, (k + 1) * C)
-                slot = k % 2
-                frames, landed = pending
-                cur.wait_event(landed)
-                eng.resnet(frames, out=phi[lo:hi])
-                tr(" resnet queued")
-                mark("resnet %d done" % k, cur)
-                in_free[slot] = torch.cuda.Event()
-                in_free[slot].record(cur)
-                if k + 1 < n_chunks:
-                    # the NEXT upload goes into its queue before the tail (and the downloads) of chunk k-1 do: queued behind
-                    # them, the copy of chunk k+1 was seen to wait for those downloads, and the ResNet with it
-                    pending = upload(k + 1, stage_ahead(k + 1))
+            if k + 1 < n_chunks:
+                # chunk k+1 goes into the queues before the tail (and the downloads) of chunk k-1 do: queued behind them,
+                # the copy of chunk k+1 was seen to wait for those downloads, and its ResNet with it
+                encode(k + 1, stage_ahead(k + 1))
             if k >= 1:
                 # tail of output frames [o0, o1): their windows reach margin frames into chunk k, encoded just above
-                encoded = torch.cuda.Event()
-                encoded.record(cur)
                 with torch.cuda.stream(self.s_tail):
-                    self.s_tail.wait_event(encoded)
+                    self.s_tail.wait_event(enc[min(k, n_chunks - 1)])
                     self._tail(k - 1, N, phi, recs, out_free, host, fields, keys, ar_T)
                 tr(" tail queued")
         self.s_tail.synchronize()

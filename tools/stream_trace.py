@@ -34,7 +34,7 @@ if u8:
     import torch
     st = t._streamer
     d = torch.from_numpy(fr[:256]).cuda()
-    for i in range(3): st._to_float(d, 256, 0)
+    for i in range(3): st._to_float(d, 256, st._float_buf(0))
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for i in range(10): st._to_float(d, 256, 0)
+    for i in range(10): st._to_float(d, 256, st._float_buf(0))
     torch.cuda.synchronize(); print("crop 256 frames: %.3f ms" % ((time.perf_counter() - t0) * 100))
