@@ -128,3 +128,16 @@ def test_engine_refuses_to_run_without_a_gpu():
     from human_dynamics_amd.engine import HmmrEngine
     with pytest.raises(_lib.HmmrError):
         HmmrEngine(None, None)
+
+
+def test_integration_doc_stub_matches_the_struct():
+    """INTEGRATION.md shows a ctypes stub of hmmr_smpl_consts_t for a maintainer to paste: its fields are the
+    library's, in order (the doc had drifted once, when `vpad` was added)."""
+    import ctypes as C
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    txt = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = txt[txt.index("class SmplConsts(C.Structure)"):]
+    block = block[:block.index("def smpl_forward")]
+    doc_fields = re.findall(r"\('(\w+)',\s*C\.(\w+)\)", block)
+    lib_fields = [(n, "c_int" if t is C.c_int else "c_void_p") for n, t in _lib.SmplConsts._fields_]
+    assert doc_fields == lib_fields
