@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HMMR_ABI_VERSION 9
+#define HMMR_ABI_VERSION 10      /* 10: hmmr_resnet_unit_t lost w2_frag (the tails stage conv2's filters through LDS) */
 
 /* HMMR_BF16X3: "split" tensors -- every group of 8 consecutive channels is 32 bytes, [hi x8][lo x8] with
  * hi = bf16(x), lo = bf16(x - hi) (4 bytes per element, ~16 mantissa bits); GEMMs on them issue three bf16
