@@ -146,3 +146,16 @@ def test_packer_marks_the_fused_launches(weights):
     assert [i for i in range(16) if rw32.unit[i].sc_c1.w] == [7, 13]
     off = packing.pack_resnet(weights, _lib.HMMR_BF16, packing.DeviceStore("cpu"), fuse_tail=False, fuse_sc=False)
     assert sum(off.unit[i].fuse_tail for i in range(16)) == 0 and not any(off.unit[i].sc_c1.w for i in range(16))
+
+
+def test_resnet_part_boundaries():
+    """engine.resnet_cuts: the contiguous parts a ResNet call runs as (what the host streamer cuts its uploads by);
+    host arithmetic only -- the object is built without a device."""
+    from human_dynamics_amd.engine import HmmrEngine
+    e = HmmrEngine.__new__(HmmrEngine)
+    e.resnet_streams, e.resnet_chunk = 2, 0
+    assert e.resnet_cuts(256) == [0, 128, 256] and e.resnet_cuts(257) == [0, 128, 257]
+    assert e.resnet_cuts(127) == [0, 127] and e.resnet_cuts(128) == [0, 64, 128] and e.resnet_cuts(0) == [0, 0]
+    assert e.resnet_cuts(300, parts=3) == [0, 100, 200, 300] and e.resnet_cuts(300, parts=1) == [0, 300]
+    e.resnet_chunk = 64                     # dev switch: sequential chunks, one stream
+    assert e.resnet_cuts(256) == [0, 256]
