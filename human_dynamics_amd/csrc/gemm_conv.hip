@@ -160,14 +160,13 @@ template <int N> __device__ __forceinline__ void wait_vm_lgkm0() {
     __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (0 << 8) | ((N >> 4) << 14));
 }
 
-// KCM = true : K runs chunk-major, k' = (channel chunk of one K step, tap) instead of (tap, channel): the taps of a
-//              3x3 filter re-read a pixel's 128-byte line in CONSECUTIVE K steps (L2 hits) instead of one whole tap
-//              = cin/32 K steps apart (hmmr_conv_desc_t.k_order = 1; the filters are packed to match).
-template <typename TA, typename TO, int BM, int BN, int WGM, int WGN, bool PRO, bool UTAP, int NSTAGE, bool KCM = false>
+// (A chunk-major K order for the 3x3 layers -- k' = (channel chunk, tap), so that the nine re-reads of a pixel's line fall
+//  into consecutive K steps -- was written in round 2 and measured in round 3: equal to rounding, 0 ... 3 % SLOWER on
+//  every shape and tile, profiles/r03a_chunk_major_k.log; removed.)
+template <typename TA, typename TO, int BM, int BN, int WGM, int WGN, bool PRO, bool UTAP, int NSTAGE>
 __global__ __launch_bounds__(WGM * WGN * 64, NSTAGE >= 3 ? (WGM * WGN) / 4 : ((WGM * WGN == 8) ? 4 : 1))
 void conv_gemm_kernel(const ConvArgs a) {
     static_assert(NSTAGE >= 2 && NSTAGE <= 4, "2 stages (two workgroups per CU) or a 3/4-stage ring (one workgroup per CU)");
-    static_assert(!KCM || (UTAP && !PRO), "chunk-major K: one tap per K step, LDS-DMA route");
     static_assert(NSTAGE == 2 || WGM * WGN == 8, "the deep ring is written for 8-wave workgroups");
     static_assert(!PRO || UTAP, "the fused pre-activation needs one tap per K step");
     constexpr int NT = WGM * WGN * 64;            // threads per workgroup (4 or 8 waves)
@@ -234,23 +233,10 @@ void conv_gemm_kernel(const ConvArgs a) {
     constexpr int PCH = EPS;                                  // channels whose preact constants this lane needs (split: 4 of the group's 8)
     u32x4 ra[PRO ? PA : 1];
     f32x4 psc[PRO ? PCH / 4 : 1], psh[PRO ? PCH / 4 : 1];     // scale/shift of this lane's channels
-    // chunk-major K (KCM): K step kt = (channel chunk kt / taps, tap kt % taps)
-    [[maybe_unused]] auto kcm_of = [&](int kt, int& tap) -> int {
-        const int ntaps = a.KH * a.KW;
-        const int chunk = ntaps == 9 ? (int)(((unsigned)kt * 7282u) >> 16) : kt / ntaps;      // (kt < 2^14, host-checked)
-        tap = kt - chunk * ntaps;
-        int ky, kx;
-        if (a.KW == 1) { ky = tap; kx = 0; }
-        else if (a.KW == 3) { ky = (int)(((unsigned)tap * 43691u) >> 17); kx = tap - 3 * ky; }
-        else { ky = tap / a.KW; kx = tap - ky * a.KW; }
-        return ky * a.in_row_stride + kx * a.in_px_stride + chunk * BKE;
-    };
     // A operand of K step kt, LDS-DMA route (non-PRO)
     auto glds_a = [&](int kt, int buf) {
         int tap;
-        int koff;
-        if constexpr (KCM) koff = kcm_of(kt, tap);
-        else koff = UTAP ? tap_of(kt * BKE, tap) : tap_of(kt * BKE + lslot * EPS, tap) - lslot * EPS;
+        const int koff = UTAP ? tap_of(kt * BKE, tap) : tap_of(kt * BKE + lslot * EPS, tap) - lslot * EPS;
         char* sa = smem + buf * STAGE + wave * 1024;
         if (a.in2 && kt >= a.kt_split) {
             // second source (dense rows of cin2 elements): the address is rebuilt per instruction, nothing stays live
@@ -618,7 +604,7 @@ void conv_gemm_kernel(const ConvArgs a) {
 // ------------------------------------------------------------------------- //
 // Host side
 // ------------------------------------------------------------------------- //
-template <typename TA, typename TO, int BM, int BN, int WGM, int WGN, bool PRO, bool UTAP, int NSTAGE, bool KCM = false>
+template <typename TA, typename TO, int BM, int BN, int WGM, int WGN, bool PRO, bool UTAP, int NSTAGE>
 static int launch_cfg(const ConvArgs& base, int slices, hipStream_t stream) {
     ConvArgs a = base;
     const int tiles_m = (a.M + BM - 1) / BM;
@@ -628,7 +614,7 @@ static int launch_cfg(const ConvArgs& base, int slices, hipStream_t stream) {
     const int kloop = kring + ((PRO && NSTAGE >= 3) ? 8 * a.K : 0);      // deep PRO: [2][K] fp32 constants behind the ring
     const int lds = kloop > epi ? kloop : epi;
     if (lds > 160 * 1024) { hmmr_set_error("hmmr_conv_gemm: tile needs %d B of LDS (K = %d)", lds, a.K); return -1; }
-    auto kern = conv_gemm_kernel<TA, TO, BM, BN, WGM, WGN, PRO, UTAP, NSTAGE, KCM>;
+    auto kern = conv_gemm_kernel<TA, TO, BM, BN, WGM, WGN, PRO, UTAP, NSTAGE>;
     static DeviceOnce once;              // per kernel instantiation, per device
     if (const unsigned long long bit = once.due()) {
         HMMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -644,25 +630,7 @@ static int launch_cfg(const ConvArgs& base, int slices, hipStream_t stream) {
 }
 
 template <typename TA, typename TO, bool PRO, bool UTAP>
-static int launch_tiled(const ConvArgs& a, int tile, int slices, hipStream_t stream, bool kcm) {
-    if (kcm) {
-        // chunk-major K: split operands, plain LDS-DMA route (host-checked), every tile shape
-        if constexpr (!PRO && UTAP && std::is_same<TA, bsplit_t>::value && std::is_same<TO, bsplit_t>::value) {
-            switch (tile) {
-                case 1: return launch_cfg<TA, TO, 128, 128, 2, 2, false, true, 2, true>(a, slices, stream);
-                case 2: return launch_cfg<TA, TO, 128, 64, 2, 2, false, true, 2, true>(a, slices, stream);
-                case 3: return launch_cfg<TA, TO, 64, 64, 2, 2, false, true, 2, true>(a, slices, stream);
-                case 5: return launch_cfg<TA, TO, 128, 128, 4, 2, false, true, 2, true>(a, slices, stream);
-                case 6: return launch_cfg<TA, TO, 128, 64, 4, 2, false, true, 2, true>(a, slices, stream);
-                case 7: return launch_cfg<TA, TO, 256, 128, 4, 2, false, true, 3, true>(a, slices, stream);
-                case 8: return launch_cfg<TA, TO, 128, 256, 2, 4, false, true, 3, true>(a, slices, stream);
-                default: hmmr_set_error("hmmr_conv_gemm: bad tile %d", tile); return -1;
-            }
-        } else {
-            hmmr_set_error("hmmr_conv_gemm: k_order 1 is implemented for bf16x3 -> bf16x3 launches without pro_scale");
-            return -1;
-        }
-    }
+static int launch_tiled(const ConvArgs& a, int tile, int slices, hipStream_t stream) {
     switch (tile) {   // BM, BN, waves along M, waves along N
         case 1: return launch_cfg<TA, TO, 128, 128, 2, 2, PRO, UTAP, 2>(a, slices, stream);   // 4 waves, 64x64 each
         case 2: return launch_cfg<TA, TO, 128, 64, 2, 2, PRO, UTAP, 2>(a, slices, stream);    // 4 waves, 64x32 each
@@ -678,7 +646,7 @@ static int launch_tiled(const ConvArgs& a, int tile, int slices, hipStream_t str
 }
 
 template <typename TA, typename TO>
-static int launch_typed(const ConvArgs& a, int tile, int slices, hipStream_t stream, bool kcm) {
+static int launch_typed(const ConvArgs& a, int tile, int slices, hipStream_t stream) {
     if (tile == 0) {
         // Measured on the ResNet-50 shapes at batch 256 (tools/conv_bench.py): 8-wave workgroups
         // (4 waves per SIMD at 2 workgroups per CU) beat 4-wave ones by 5-20 %, and a tile count of
@@ -692,10 +660,10 @@ static int launch_typed(const ConvArgs& a, int tile, int slices, hipStream_t str
     const bool utap = ((size_t)1 << a.cin_log2) * sizeof(TA) >= 128;
     if (a.pro_scale) {
         if (!utap) { hmmr_set_error("hmmr_conv_gemm: fused pre-activation needs cin*sizeof >= 128"); return -1; }
-        return launch_tiled<TA, TO, true, true>(a, tile, slices, stream, kcm);
+        return launch_tiled<TA, TO, true, true>(a, tile, slices, stream);
     }
-    return utap ? launch_tiled<TA, TO, false, true>(a, tile, slices, stream, kcm)
-                : launch_tiled<TA, TO, false, false>(a, tile, slices, stream, kcm);
+    return utap ? launch_tiled<TA, TO, false, true>(a, tile, slices, stream)
+                : launch_tiled<TA, TO, false, false>(a, tile, slices, stream);
 }
 
 // Split-K second pass: sum the S fp32 partial planes in slice order, then the same epilogue as
@@ -817,10 +785,6 @@ extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
                              d->in_img_stride == (int64_t)d->hin * d->win * d->cin && d->ho == d->hin && d->wo == d->win),
                  "hmmr_conv_gemm: a second operand source (in2) needs a dense 1x1 stride-1 un-padded GEMM, cin and cin2 "
                  "multiples of the 128-byte K step, no pro_scale, no split_k");
-    HMMR_REQUIRE(d->k_order == 0 || d->k_order == 1, "hmmr_conv_gemm: k_order is 0 (tap-major) or 1 (chunk-major)");
-    HMMR_REQUIRE(!d->k_order || (d->in_dtype == HMMR_BF16X3 && d->out_dtype == HMMR_BF16X3 && d->cin % bke == 0 && !d->pro_scale &&
-                                 !d->in2 && d->split_k <= 1 && K / bke < (1 << 14)),
-                 "hmmr_conv_gemm: k_order 1 needs bf16x3 in and out, cin a multiple of the 128-byte K step, no pro_scale / in2 / split_k");
     ConvArgs a;
     a.in = d->in; a.w = d->w; a.scale = d->scale; a.shift = d->shift; a.res = d->res;
     a.out = d->out; a.out2 = d->out2; a.scale2 = d->scale2; a.shift2 = d->shift2;
@@ -857,9 +821,9 @@ extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
         p.scale = p.shift = nullptr; p.res = nullptr; p.out2 = nullptr; p.scale2 = p.shift2 = nullptr;
         // (a fused pre-activation, if any, stays: it acts on the A operand)
         p.relu = 0; p.out = d->ws; p.ldo = ldw; p.out_slice_stride = plane;
-        const int rc = in16 ? launch_typed<bf16_t, float>(p, d->tile, slices, s, false)
-                     : inx3 ? launch_typed<bsplit_t, float>(p, d->tile, slices, s, false)
-                            : launch_typed<float, float>(p, d->tile, slices, s, false);
+        const int rc = in16 ? launch_typed<bf16_t, float>(p, d->tile, slices, s)
+                     : inx3 ? launch_typed<bsplit_t, float>(p, d->tile, slices, s)
+                            : launch_typed<float, float>(p, d->tile, slices, s);
         if (rc) return rc;
         const long long nvec = (long long)a.M * ((a.cout + 7) / 8);
         const unsigned grid = (unsigned)((nvec + 255) / 256);
@@ -869,13 +833,13 @@ extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
         HMMR_CHECK_HIP(hipGetLastError());
         return 0;
     }
-    if (in16 && out16) return launch_typed<bf16_t, bf16_t>(a, d->tile, 1, s, d->k_order == 1);
-    if (in16 && out32) return launch_typed<bf16_t, float>(a, d->tile, 1, s, d->k_order == 1);
-    if (in32 && out32) return launch_typed<float, float>(a, d->tile, 1, s, d->k_order == 1);
-    if (in32 && out16) return launch_typed<float, bf16_t>(a, d->tile, 1, s, d->k_order == 1);
-    if (inx3 && outx3) return launch_typed<bsplit_t, bsplit_t>(a, d->tile, 1, s, d->k_order == 1);
-    if (inx3 && out32) return launch_typed<bsplit_t, float>(a, d->tile, 1, s, d->k_order == 1);
-    if (in32 && outx3) return launch_typed<float, bsplit_t>(a, d->tile, 1, s, d->k_order == 1);
+    if (in16 && out16) return launch_typed<bf16_t, bf16_t>(a, d->tile, 1, s);
+    if (in16 && out32) return launch_typed<bf16_t, float>(a, d->tile, 1, s);
+    if (in32 && out32) return launch_typed<float, float>(a, d->tile, 1, s);
+    if (in32 && out16) return launch_typed<float, bf16_t>(a, d->tile, 1, s);
+    if (inx3 && outx3) return launch_typed<bsplit_t, bsplit_t>(a, d->tile, 1, s);
+    if (inx3 && out32) return launch_typed<bsplit_t, float>(a, d->tile, 1, s);
+    if (in32 && outx3) return launch_typed<float, bsplit_t>(a, d->tile, 1, s);
     hmmr_set_error("hmmr_conv_gemm: unsupported dtypes %d -> %d", d->in_dtype, d->out_dtype);
     return -1;
 }

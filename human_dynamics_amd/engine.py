@@ -70,7 +70,7 @@ class HmmrEngine(object):
 
     def __init__(self, weights, smpl, dtype=DEFAULT_DTYPE, device="cuda:0", num_conv_layers=3,
                  delta_t_values=(-5, 5), joint_type="cocoplus", resnet_chunk=0,
-                 temporal_dtype=None, ief_dtype=None, autotune=True, fold_sc=None, fuse_tail=None, chunk_major_3x3=None):
+                 temporal_dtype=None, ief_dtype=None, autotune=True, fold_sc=None, fuse_tail=None):
         self.lib = L.load()
         _debug_from_env()
         if not torch.cuda.is_available():
@@ -91,12 +91,11 @@ class HmmrEngine(object):
         fsc = {"0": False, "1": True}.get(os.environ.get("HMMR_FUSE_SC", "1"), "all")               # dev A/B switch: 0, 1, all
         pfirst = os.environ.get("HMMR_PREACT_FIRST", "0") != "0"                                    # dev A/B switch
         fold = {"0": False, "1": True}.get(os.environ.get("HMMR_FOLD_SC", ""), None) if fold_sc is None else fold_sc   # dev A/B switch
-        kcm = (os.environ.get("HMMR_CHUNK_MAJOR", "0") != "0") if chunk_major_3x3 is None else bool(chunk_major_3x3)   # dev A/B switch (packing.pack_resnet: off until measured)
         # every stage is packed only when its variables exist: a ResNet-only checkpoint (hmr_noS5.ckpt-642561, what
         # FeatureExtractor is given: src/datasets/resnet_extractor.py:31-40) has no AZ_FC_* / single_view_ief* names
         w = weights if weights is not None else {}
         self.rw = (packing.pack_resnet(w, self.dtype, self.store, fuse_preact_blocks=fuse, fuse_tail=tail, fuse_sc=fsc,
-                                       fuse_preact_first=pfirst, fold_sc=fold, chunk_major_3x3=kcm)
+                                       fuse_preact_first=pfirst, fold_sc=fold)
                    if "resnet_v2_50/conv1/weights" in w else None)
         self.tw = (packing.pack_temporal(w, self.temporal_dtype, self.store, num_conv_layers)
                    if assets.temporal_scopes(0)[1] + "/weights" in w else None)
@@ -394,7 +393,7 @@ class HmmrEngine(object):
 
 def conv_gemm(x, w_hwio, stride=1, pad=0, scale=None, shift=None, res=None, relu=False,
               scale2=None, shift2=None, in_dtype=L.HMMR_F32, out_dtype=L.HMMR_F32, tile=0,
-              device="cuda:0", res_stride=1, split_k=0, pro=None, raw=False, second=None, k_order=0):
+              device="cuda:0", res_stride=1, split_k=0, pro=None, raw=False, second=None):
     """Test/utility entry: run one NHWC convolution through hmmr_conv_gemm.
     x [n,h,w,cin] (numpy/torch), w_hwio [kh,kw,cin,cout].  Returns (out, out2) as float32 arrays, or with
     raw=True the device tensors in their storage type; x may itself be such a device tensor."""
@@ -414,12 +413,11 @@ def conv_gemm(x, w_hwio, stride=1, pad=0, scale=None, shift=None, res=None, relu
     if second is not None:          # (x2 [n,h,w,cin2], w2 [1,1,cin2,cout]): a second 1x1 source appended along K (hmmr_conv_desc_t.in2)
         x2 = store.put(np.asarray(second[0], np.float32), packing.TORCH_DT[in_dtype])
         w_hwio = np.concatenate([np.asarray(w_hwio, np.float32), np.asarray(second[1], np.float32)], axis=2)
-    wt = store.put(packing.pack_conv_weight(np.asarray(w_hwio, np.float32), k_order), packing.TORCH_DT[in_dtype])
+    wt = store.put(packing.pack_conv_weight(np.asarray(w_hwio, np.float32)), packing.TORCH_DT[in_dtype])
     ldo = (cout + 7) // 8 * 8
     out = packing.empty_act((n, ho, wo, ldo), out_dtype, dev, zero=True)
     d = L.ConvDesc()
     d.in_, d.w, d.out = xt.data_ptr(), wt.data_ptr(), out.data_ptr()
-    d.k_order = k_order
     if x2 is not None:
         d.in2, d.cin2 = x2.data_ptr(), x2.shape[-1]
     d.scale = store.vec(scale).data_ptr() if scale is not None else None

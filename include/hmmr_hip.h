@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HMMR_ABI_VERSION 10      /* 10: hmmr_resnet_unit_t lost w2_frag (the tails stage conv2's filters through LDS) */
+#define HMMR_ABI_VERSION 11      /* 11: hmmr_conv_desc_t / hmmr_layer_t lost k_order (chunk-major K: measured, no gain, removed) */
 
 /* HMMR_BF16X3: "split" tensors -- every group of 8 consecutive channels is 32 bytes, [hi x8][lo x8] with
  * hi = bf16(x), lo = bf16(x - hi) (4 bytes per element, ~16 mantissa bits); GEMMs on them issue three bf16
@@ -118,13 +118,6 @@ typedef struct {
      * the 128-byte K step, no pro_scale, no split_k.  in2 == NULL: off. */
     const void* in2;
     int cin2;
-    /* order of K inside a filter row and along the gather.  0: (tap, channel) -- k = (ky*kw + kx)*cin + ci.
-     * 1: chunk-major -- k = ((ci / 32)*kh*kw + ky*kw + kx)*32 + ci % 32 (32 = the elements of one 128-byte K step of a
-     * bf16x3 tensor): the kh*kw taps of one channel chunk are consecutive K steps, so the re-reads of a pixel's
-     * 128-byte line by neighbouring taps are a K step apart instead of a whole tap (L2 hits for 3x3 layers whose
-     * input exceeds the L2).  bf16x3 in and out, cin % 32 == 0, not with pro_scale / in2 / split_k.  The sum over k is
-     * the same set of products in another order: results differ from k_order 0 by fp32 rounding only. */
-    int k_order;
 } hmmr_conv_desc_t;
 
 int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream);
@@ -143,7 +136,6 @@ typedef struct {
     int tile;              /* hmmr_conv_desc_t.tile for this layer's launch; 0 = library heuristic.
                               Results do not depend on it (same K order per output element);
                               the host may tune it per layer and batch size. */
-    int k_order;           /* hmmr_conv_desc_t.k_order the filter rows of `w` were packed in (read for the 3x3 conv2 layers) */
 } hmmr_layer_t;
 
 typedef struct {

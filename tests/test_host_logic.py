@@ -161,21 +161,11 @@ def test_resnet_part_boundaries():
     assert e.resnet_cuts(256) == [0, 256]
 
 
-def test_chunk_major_filter_pack():
-    """pack_conv_weight(k_order=1): k' = ((ci // 32)*kh*kw + tap)*32 + ci % 32 -- the order hmmr_conv_gemm gathers
-    the A operand in with hmmr_conv_desc_t.k_order = 1 (K step kt = chunk kt // taps, tap kt % taps); the packer keeps
-    it OFF (not yet run on the hardware) and never uses it for block 1, whose fused tails sum tap-major."""
+def test_filter_pack_order():
+    """pack_conv_weight: row co of the filter bank is K-contiguous with k = (ky*kw + kx)*cin + ci -- the order
+    hmmr_conv_gemm gathers the A operand in (csrc/gemm_conv.hip tap_of); rows padded to 128."""
     w = np.random.default_rng(0).normal(size=(3, 3, 128, 40)).astype(np.float32)
-    p0, p1 = packing.pack_conv_weight(w), packing.pack_conv_weight(w, 1)
-    assert p0.shape == p1.shape == (128, 1152) and np.array_equal(np.sort(p0, axis=1), np.sort(p1, axis=1))
+    p0 = packing.pack_conv_weight(w)
+    assert p0.shape == (128, 1152) and not p0[40:].any()
     for ky, kx, ci, co in ((0, 0, 0, 0), (1, 2, 37, 5), (2, 2, 127, 39), (0, 1, 64, 3)):
-        tap = ky * 3 + kx
-        assert p0[co, tap * 128 + ci] == w[ky, kx, ci, co]
-        assert p1[co, ((ci // 32) * 9 + tap) * 32 + ci % 32] == w[ky, kx, ci, co]
-    ws = assets.make_synthetic_weights(0)
-    rw = packing.pack_resnet(ws, _lib.HMMR_BF16X3, packing.DeviceStore("cpu"))
-    assert not any(rw.unit[i].conv2.k_order for i in range(16))
-    on = packing.pack_resnet(ws, _lib.HMMR_BF16X3, packing.DeviceStore("cpu"), chunk_major_3x3=True)
-    assert [on.unit[i].conv2.k_order for i in range(16)] == [0, 0, 0] + [1] * 13
-    assert not any(packing.pack_resnet(ws, _lib.HMMR_BF16, packing.DeviceStore("cpu"), chunk_major_3x3=True).unit[i].conv2.k_order
-                   for i in range(16))
+        assert p0[co, (ky * 3 + kx) * 128 + ci] == w[ky, kx, ci, co]

@@ -40,8 +40,6 @@ def run(lib, name, n, h, cin, cout, k, stride, kind, dt, tile, iters=20):
     d.in_img_stride, d.in_row_stride, d.in_px_stride = h * h * cin, h * cin, cin
     d.kh = d.kw = k; d.sy = d.sx = stride; d.py = d.px = pad
     d.ho = d.wo = ho; d.cout = cout; d.ldo = cout; d.tile = tile
-    if k == 3 and dt == "bf16x3" and cin % 32 == 0 and os.environ.get("KORD", "0") != "0":
-        d.k_order = 1        # chunk-major K (timing only: the random filter needs no re-packing)
     keep = [x, w, sc, sh, out]
     nbytes = x.numel() * x.element_size() / (stride * stride if k == 1 else 1) + out.numel() * out.element_size()
     if kind in ("bnrelu", "pro"):
