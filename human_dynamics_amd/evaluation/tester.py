@@ -33,11 +33,33 @@ from ..tf_smpl.batch_smpl import SMPL, load_smpl_constants
 OUTPUT_KEYS = ("cams", "joints", "kps", "poses", "shapes", "verts", "omegas")
 
 
-def load_weights(load_path, resnet_path=""):
+def mean_theta_from_file(path):
+    """The role of `neutral_smpl_meanwjoints.h5` (tester.py:118-135) from an .npy / .npz: either the assembled
+    [85] / [1,85] mean theta, or the h5's own fields `pose` [72] and `shape` [10], to which the reference's assembly is
+    applied: cam = [0.9, 0, 0], pose[:3] = [pi, 0, 0].  (The h5 itself is written by deepdish through PyTables' blosc
+    filter and cannot be decoded without that library; `python -c "import deepdish as dd, numpy as np;
+    np.savez('neutral_smpl_meanwjoints.npz', **dd.io.load('neutral_smpl_meanwjoints.h5'))"` converts it once.)"""
+    if not os.path.exists(path):
+        raise FileNotFoundError("{} doesnt exist..".format(path))
+    v = np.load(path)
+    if isinstance(v, np.ndarray):
+        if v.size != 85:
+            raise ValueError("%s holds %d values, the mean theta has 85" % (path, v.size))
+        return np.asarray(v, np.float32).reshape(1, 85)
+    pose = np.array(v["pose"], np.float64).reshape(72)
+    pose[:3] = 0.0
+    pose[0] = np.pi
+    shape = np.asarray(v["shape"], np.float64).reshape(10)
+    return np.hstack(([0.9, 0.0, 0.0], pose, shape))[None].astype(np.float32)
+
+
+def load_weights(load_path, resnet_path="", mean_param_path=""):
     """Checkpoint variables by name: a TensorFlow checkpoint-V2 prefix such as
     'models/hmmr_model.ckpt-1119816' (read natively, human_dynamics_amd/tf_checkpoint.py), an
     .npz with the same names, or 'synthetic[:seed]'.  ResNet variables come from `resnet_path`
-    when given (tester.py:99-112)."""
+    when given (tester.py:99-112).  mean_param_path: .npy / .npz initialiser of `mean_param` (mean_theta_from_file),
+    used only when the checkpoint does not carry the variable -- Saver.restore overwrites it otherwise
+    (tester.py:114-116)."""
     from .. import tf_checkpoint
 
     def one(path):
@@ -54,6 +76,9 @@ def load_weights(load_path, resnet_path=""):
         for k, v in one(resnet_path).items():
             if "resnet" in k:
                 w[k] = v
+    if mean_param_path:
+        mean = mean_theta_from_file(mean_param_path)
+        w.setdefault("mean_param", mean)
     return w
 
 
@@ -92,7 +117,8 @@ class Tester(object):
             raise Exception("Pred mode {} not recognized".format(self.pred_mode))
 
         if weights is None:
-            weights = load_weights(config.load_path, pretrained_resnet_path)
+            weights = load_weights(config.load_path, pretrained_resnet_path,
+                                   getattr(config, "mean_param_path", "") or self._default_mean_path(config))
         if smpl is None:
             smpl = load_smpl_constants(self.smpl_model_path, checkpoint_vars=weights)
         # operand type of the GEMM stages: the reference graph is fp32 throughout (tester.py:64-66); the default is
@@ -114,9 +140,21 @@ class Tester(object):
             # the reference initialises this variable from neutral_smpl_meanwjoints.h5 (tester.py:118-141) and then restores
             # it from the checkpoint (tester.py:114-116); the h5 (deepdish / blosc) is not read here -- see DESIGN.md section 7
             raise KeyError("the loaded weights have no 'mean_param' variable (the 1 x 85 mean theta both published "
-                           "checkpoints carry); add it to the .npz, or load a checkpoint that was saved by the reference")
+                           "checkpoints carry); add it to the .npz, load a checkpoint that was saved by the reference, or "
+                           "set config.mean_param_path to an .npy / .npz conversion of neutral_smpl_meanwjoints.h5")
         self.theta_mean = np.asarray(weights["mean_param"], np.float32).reshape(1, 85)
         self._streamer = None
+
+    @staticmethod
+    def _default_mean_path(config):
+        """neutral_smpl_meanwjoints.{npz,npy} next to the SMPL model, where the reference looks for the .h5
+        (tester.py:120-121); '' when there is none."""
+        d = os.path.dirname(str(getattr(config, "smpl_model_path", "") or ""))
+        for ext in (".npz", ".npy"):
+            p = os.path.join(d, "neutral_smpl_meanwjoints" + ext)
+            if d and os.path.exists(p):
+                return p
+        return ""
 
     # ------------------------------------------------------------------------
     def make_omega_pred(self, registry, use_optcam=False, batch_size=None):

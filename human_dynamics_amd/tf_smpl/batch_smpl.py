@@ -38,6 +38,9 @@ class _SmplUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
         if module.split(".")[0] == "chumpy":
             return _ChStub
+        if module.startswith("scipy.sparse."):      # py2-era pickles name scipy.sparse.csc.csc_matrix: a deprecated module path
+            import scipy.sparse
+            return getattr(scipy.sparse, name)
         return super().find_class(module, name)
 
 
