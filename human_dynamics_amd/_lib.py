@@ -9,9 +9,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+from . import devflags
+
 HERE = os.path.dirname(os.path.abspath(__file__))
-# HMMR_LIB_PATH lets a development run A/B two builds of the library; the default is the in-tree build
-LIB_PATH = os.environ.get("HMMR_LIB_PATH") or os.path.join(HERE, "libhmmr_hip.so")
+# devflags LIB_PATH (HMMR_LIB_PATH) lets a development run A/B two builds of the library; the default is the in-tree build
+LIB_PATH = devflags.get("LIB_PATH") or os.path.join(HERE, "libhmmr_hip.so")
 
 HMMR_F32, HMMR_BF16, HMMR_BF16X3 = 0, 1, 2
 ABI_VERSION = 11
@@ -59,7 +61,7 @@ class TailDesc(C.Structure):
 
 class Debug(C.Structure):
     """hmmr_debug_t: development switches, all zero = product defaults."""
-    _fields_ = [("stem_route", C.c_int), ("stem_no_conv1", C.c_int), ("reserved", C.c_int * 6)]
+    _fields_ = [("stem_route", C.c_int), ("stem_no_conv1", C.c_int), ("gemm_probe", C.c_int), ("reserved", C.c_int * 5)]
 
 
 class Layer(C.Structure):
@@ -97,7 +99,8 @@ class IefRegressor(C.Structure):
 
 class IefWeights(C.Structure):
     _fields_ = [("dtype", C.c_int), ("num_regressors", C.c_int), ("num_stages", C.c_int),
-                ("reg", IefRegressor * MAX_REGRESSORS), ("mean_theta", _fp)]
+                ("reg", IefRegressor * MAX_REGRESSORS), ("mean_theta", _fp),
+                ("no_optcam", C.c_int), ("delta_from_start", C.c_int)]
 
 
 class SmplConsts(C.Structure):
@@ -124,6 +127,7 @@ SIGNATURES = {
     "hmmr_groupnorm_relu": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp]),
     "hmmr_ief_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "hmmr_ief_fwd": (C.c_int, [C.POINTER(IefWeights), _fp, C.c_int, _fp, _vp, C.c_size_t, _vp]),
+    "hmmr_ief_fwd_from": (C.c_int, [C.POINTER(IefWeights), _fp, _fp, C.c_int, _fp, _vp, C.c_size_t, _vp]),
     "hmmr_smpl_workspace_bytes": (C.c_size_t, [C.c_int]),
     "hmmr_smpl_fwd": (C.c_int, [C.POINTER(SmplConsts), _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int,
                                 _fp, _fp, _fp, _fp, _vp, C.c_size_t, _vp]),
@@ -133,7 +137,7 @@ SIGNATURES = {
                                       _fp, _fp, _fp, _vp]),
     "hmmr_eval_joints": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _vp]),
     "hmmr_eval_verts": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int, C.c_int, _fp, _vp]),
-    "hmmr_global_rigid_transformation": (C.c_int, [_fp, _fp, _ip, C.c_int, _fp, _fp, _vp]),
+    "hmmr_global_rigid_transformation": (C.c_int, [_fp, _fp, _ip, C.c_int, _fp, _fp, C.c_int, _vp]),
     "hmmr_smpl_fwd_strided": (C.c_int, [C.POINTER(SmplConsts), _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int,
                                         _fp, _fp, _fp, _fp, C.c_int64, _vp, C.c_size_t, _vp]),
 }

@@ -149,6 +149,24 @@ def make_synthetic_weights(seed=0, num_conv_layers=3, delta_t_values=(-5, 5),
     return {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in w.items()}
 
 
+def make_synthetic_ief_weights(seed=0, delta_t_values=(-5, 5), delta_nd=72):
+    """Only the IEF variables + mean_param, with `delta_nd`-wide delta regressors: 72 = use_optcam=True (what
+    make_synthetic_weights builds), 75 = use_optcam=False (camera + pose, src/models.py:333-336)."""
+    rng = np.random.Generator(np.random.PCG64([seed, delta_nd]))
+    w = {}
+    for key, (scope, nd) in sorted(ief_scopes(delta_t_values).items()):
+        nd = nd if key == 0 else delta_nd
+        p = scope + "/3D_module"
+        w[p + "/fc1/weights"] = rng.standard_normal((FEAT_DIM + nd, 1024), dtype=np.float32) * np.sqrt(2.0 / (FEAT_DIM + nd))
+        w[p + "/fc1/biases"] = (rng.standard_normal(1024) * 0.1).astype(np.float32)
+        w[p + "/fc2/weights"] = rng.standard_normal((1024, 1024), dtype=np.float32) * np.sqrt(2.0 / 1024)
+        w[p + "/fc2/biases"] = (rng.standard_normal(1024) * 0.1).astype(np.float32)
+        w[p + "/fc3/weights"] = rng.standard_normal((1024, nd), dtype=np.float32) * (0.08 / np.sqrt(1024))
+        w[p + "/fc3/biases"] = (rng.standard_normal(nd) * 0.01).astype(np.float32)
+    w["mean_param"] = make_mean_theta(seed + 1000)[None, :]
+    return {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in w.items()}
+
+
 def make_mean_theta(seed=1000):
     """[cam(0.9,0,0), pose (root = pi,0,0), shape] as load_mean_params builds it."""
     rng = np.random.Generator(np.random.PCG64(seed))

@@ -388,7 +388,7 @@ int hmmr_bottleneck_tail_split(const hmmr_tail_desc_t* d, hipStream_t stream) {
     const bool conv2 = d->h1 != nullptr;
     HMMR_REQUIRE(!conv2 || (d->w2 && d->scale2 && d->shift2 && d->conv2_stride <= 1 && d->hin > 0 && d->win > 0 && d->hin % 8 == 0 &&
                             d->win % 8 == 0 && d->m % (d->hin * d->win) == 0 && d->c_mid == 64 && d->depth == 256 && d->n2 == 64),
-                 "hmmr_bottleneck_tail (bf16x3): conv2 in front needs the 64 -> 256 -> 64 shape, stride 1, w2 (fragment-major), "
+                 "hmmr_bottleneck_tail (bf16x3): conv2 in front needs the 64 -> 256 -> 64 shape, stride 1, w2 (packed [cout][9 * c_mid] like every filter bank), "
                  "scale2, shift2 and an image grid that is a multiple of 8 x 8");
     const bool folded = d->xp != nullptr;             // {h2, xp} x [W3 | Wsc]: the conv shortcut inside conv3's K
     HMMR_REQUIRE(folded != (d->res != nullptr), "hmmr_bottleneck_tail (bf16x3): either a shortcut tensor (res) or a folded one (xp)");

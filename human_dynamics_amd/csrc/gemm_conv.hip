@@ -800,7 +800,7 @@ extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
     a.kt_per_slice = 0; a.out_slice_stride = 0; a.probe = 0;
     a.in2 = d->in2; a.cin2 = d->in2 ? d->cin2 : 0; a.kt_split = d->cin / bke;
 #ifdef HMMR_GEMM_PROBE
-    if (const char* e = getenv("HMMR_GEMM_PROBE")) a.probe = atoi(e);
+    a.probe = hmmr_debug_state()->gemm_probe;
 #endif
     if (a.M <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;

@@ -1,6 +1,7 @@
 // IEF regressors for gfx950: batch_pred_omega / call_hmr_ief / hmr_ief /
 // encoder_fc3_dropout (src/models.py:80-116, 233-267, 299-415), inference mode
-// (dropout = identity), use_optcam=True, use_delta_from_pred=True.
+// (dropout = identity).  Default: use_optcam=True, use_delta_from_pred=True (tester.py:196-207); the other three
+// combinations through hmmr_ief_weights_t.no_optcam / delta_from_start.
 //
 //   theta <- theta + fc3(relu(fc2(relu(fc1([phi, theta])))))      x num_stages
 //
@@ -35,19 +36,22 @@ __global__ void ief_init_theta_kernel(const float* __restrict__ src, int ld_src,
     theta[i] = col < nd ? src[(long long)row * ld_src + off + col] : 0.f;
 }
 
-// omega_out[m, 85]: present regressor -> theta[:, :85];
-// delta regressor -> [1, 0, 0, theta[:, :72], omega0[:, 75:85]]  (models.py:367-371)
-__global__ void ief_finalize_kernel(const float* __restrict__ theta, const float* __restrict__ omega0,
-                                    int is_delta, float* __restrict__ out, int m) {
+// omega_out[m, 85]: mode 0 (present regressor) -> theta[:, :85];
+// mode 1 (delta, use_optcam)   -> [1, 0, 0, theta[:, :72], beta]     (models.py:367-371)
+// mode 2 (delta, no optcam)    -> [theta[:, :75], beta]              (models.py:372-373)
+// beta = columns 75..84 of the delta's starting omega: row `row` of `bsrc` (ld_b = 85) or one broadcast row (ld_b = 0)
+__global__ void ief_finalize_kernel(const float* __restrict__ theta, const float* __restrict__ bsrc, int ld_b,
+                                    int mode, float* __restrict__ out, int m) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)m * 85) return;
     const int row = (int)(i / 85), col = (int)(i % 85);
     float v;
-    if (!is_delta) v = theta[(long long)row * LDT + col];
+    if (mode == 0) v = theta[(long long)row * LDT + col];
+    else if (col >= 75) v = bsrc[(long long)row * ld_b + col];
+    else if (mode == 2) v = theta[(long long)row * LDT + col];
     else if (col == 0) v = 1.f;
     else if (col < 3) v = 0.f;
-    else if (col < 75) v = theta[(long long)row * LDT + (col - 3)];
-    else v = omega0[(long long)row * 85 + col];
+    else v = theta[(long long)row * LDT + (col - 3)];
     out[i] = v;
 }
 
@@ -90,6 +94,11 @@ static hmmr_conv_desc_t fc_desc(const void* in, int in_dtype, int m, int k, cons
 
 extern "C" int hmmr_ief_fwd(const hmmr_ief_weights_t* w, const float* strips, int m, float* omegas,
                             void* ws, size_t ws_bytes, void* stream) {
+    return hmmr_ief_fwd_from(w, strips, nullptr, m, omegas, ws, ws_bytes, stream);
+}
+
+extern "C" int hmmr_ief_fwd_from(const hmmr_ief_weights_t* w, const float* strips, const float* omega_start, int m,
+                                 float* omegas, void* ws, size_t ws_bytes, void* stream) {
     HMMR_REQUIRE(w && strips && omegas && ws, "hmmr_ief_fwd: null argument");
     HMMR_REQUIRE(m > 0, "hmmr_ief_fwd: m must be positive");
     HMMR_REQUIRE(w->num_regressors >= 1 && w->num_regressors <= HMMR_MAX_REGRESSORS, "hmmr_ief_fwd: bad num_regressors");
@@ -116,13 +125,21 @@ extern "C" int hmmr_ief_fwd(const hmmr_ief_weights_t* w, const float* strips, in
     const unsigned gfin = (unsigned)(((long long)m * 85 + 255) / 256);
     for (int r = 0; r < w->num_regressors; ++r) {
         const hmmr_ief_regressor_t& R = w->reg[r];
-        HMMR_REQUIRE(R.nd == 85 || R.nd == 72, "hmmr_ief_fwd: regressor %d has nd=%d", r, R.nd);
+        const int nd_delta = w->no_optcam ? 75 : 72;           // models.py:333-336
+        HMMR_REQUIRE(R.nd == (r == 0 ? 85 : nd_delta), "hmmr_ief_fwd: regressor %d has nd=%d (expected %d)", r, R.nd,
+                     r == 0 ? 85 : nd_delta);
         float* out_r = omegas + (size_t)r * m * 85;
-        // starting point: mean theta (tester.py:181) or omega0[:, 3:75] (models.py:349-356)
+        // the IEF's own starting point: omega_start rows, or the mean theta in every row (tester.py:181)
+        const float* start = omega_start ? omega_start : w->mean_theta;
+        const int ld_start = omega_start ? 85 : 0;
+        // a delta regressor starts from the present prediction omega0 (use_delta_from_pred) or from `start`
+        // (models.py:349), trimmed to [3:75] (use_optcam) or [:75] (models.py:353-357); beta = its last 10 columns
+        const float* dsrc = w->delta_from_start ? start : (const float*)omegas;
+        const int ld_d = w->delta_from_start ? ld_start : 85;
         if (r == 0)
-            hipLaunchKernelGGL(ief_init_theta_kernel, dim3(gth), dim3(256), 0, s, w->mean_theta, 0, 0, 85, th[0], m);
+            hipLaunchKernelGGL(ief_init_theta_kernel, dim3(gth), dim3(256), 0, s, start, ld_start, 0, 85, th[0], m);
         else
-            hipLaunchKernelGGL(ief_init_theta_kernel, dim3(gth), dim3(256), 0, s, (const float*)omegas, 85, 3, 72, th[0], m);
+            hipLaunchKernelGGL(ief_init_theta_kernel, dim3(gth), dim3(256), 0, s, dsrc, ld_d, w->no_optcam ? 0 : 3, nd_delta, th[0], m);
         HMMR_CHECK_HIP(hipGetLastError());
         HMMR_CHECK_HIP(hipMemsetAsync(th[1], 0, (size_t)m * LDT * 4, s));
         // pre = phi . W1[:2048] + b1
@@ -145,7 +162,7 @@ extern "C" int hmmr_ief_fwd(const hmmr_ief_weights_t* w, const float* strips, in
             cur ^= 1;
         }
         hipLaunchKernelGGL(ief_finalize_kernel, dim3(gfin), dim3(256), 0, s, (const float*)th[cur],
-                           (const float*)omegas, r != 0, out_r, m);
+                           dsrc, ld_d, r == 0 ? 0 : (w->no_optcam ? 2 : 1), out_r, m);
         HMMR_CHECK_HIP(hipGetLastError());
     }
     return 0;

@@ -269,13 +269,14 @@ __global__ __launch_bounds__(256) void smpl_joints_kernel(
     }
 }
 
-// ---- batch_global_rigid_transformation on its own (src/tf_smpl/batch_lbs.py:133-194, rotate_base=False) ---- //
+// ---- batch_global_rigid_transformation on its own (src/tf_smpl/batch_lbs.py:133-194) ---- //
+// rotate_base (batch_lbs.py:151-158): root rotation = R_0 . diag(1, -1, -1), i.e. columns 1 and 2 of R_0 negated (exact).
 // One thread per instance walks the kinematic chain in index order (parents[i] < i), with the same expression
 // order as smpl_pose_kernel: results[i] = results[parent] . [[R_i, J_i - J_parent], [0, 1]]; new_J = its
 // translation; A = results - [0 | results . [J; 0]].
 __global__ __launch_bounds__(64) void smpl_fk_kernel(const float* __restrict__ Rs, const float* __restrict__ Js,
                                                      const int* __restrict__ parents, int m, float* __restrict__ new_j,
-                                                     float* __restrict__ A44) {
+                                                     float* __restrict__ A44, int rotate_base) {
     const int inst = blockIdx.x * 64 + threadIdx.x;
     if (inst >= m) return;
     const float* R = Rs + (long long)inst * NJ * 9;
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(64) void smpl_fk_kernel(const float* __restrict__ R
         for (int c = 0; c < 3; ++c) t[c] = J[i * 3 + c] - (p >= 0 ? J[p * 3 + c] : 0.0f);
         if (p < 0) {
 #pragma unroll
-            for (int e = 0; e < 9; ++e) G[i][e] = Lc[e];
+            for (int e = 0; e < 9; ++e) G[i][e] = (rotate_base && e % 3 != 0) ? -Lc[e] : Lc[e];
 #pragma unroll
             for (int c = 0; c < 3; ++c) G[i][9 + c] = t[c];
         } else {
@@ -317,9 +318,9 @@ __global__ __launch_bounds__(64) void smpl_fk_kernel(const float* __restrict__ R
 }
 
 extern "C" int hmmr_global_rigid_transformation(const float* Rs, const float* Js, const int32_t* parents, int m,
-                                                float* new_j, float* A, void* stream) {
+                                                float* new_j, float* A, int rotate_base, void* stream) {
     HMMR_REQUIRE(Rs && Js && parents && new_j && A && m > 0, "hmmr_global_rigid_transformation: bad arguments");
-    hipLaunchKernelGGL(smpl_fk_kernel, dim3((m + 63) / 64), dim3(64), 0, (hipStream_t)stream, Rs, Js, (const int*)parents, m, new_j, A);
+    hipLaunchKernelGGL(smpl_fk_kernel, dim3((m + 63) / 64), dim3(64), 0, (hipStream_t)stream, Rs, Js, (const int*)parents, m, new_j, A, rotate_base);
     HMMR_CHECK_HIP(hipGetLastError());
     return 0;
 }

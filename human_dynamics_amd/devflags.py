@@ -1,0 +1,45 @@
+"""Development switches of the Python package -- the ONE place it reads the environment.
+
+`libhmmr_hip.so` never reads the environment (include/hmmr_hip.h); its development switches are the fields of
+`hmmr_debug_t`, set through `hmmr_set_debug`.  The package above it has A/B switches of its own (launch schedules,
+fusions, tuner candidates) that tools/ and a few tests flip per process; every one of them is declared in `FLAGS`
+below with its default and meaning, is read through `get()` and nowhere else, and leaves every result bit-identical
+unless its line says otherwise.  Product code paths take the same choices as constructor arguments (HmmrEngine,
+ShardedPredictor); a flag only overrides the default of the argument it names.
+"""
+from __future__ import annotations
+
+import os
+
+FLAGS = {
+    # name: (default, meaning)
+    "LIB_PATH": ("", "load this shared object instead of human_dynamics_amd/libhmmr_hip.so (tools/probe_build.sh)"),
+    "STEM": ("", "u[nfused] | f[used]: hmmr_debug_t.stem_route"),
+    "STEM_C1": ("1", "0: hmmr_debug_t.stem_no_conv1"),
+    "GEMM_PROBE": ("0", "hmmr_debug_t.gemm_probe (only the -DHMMR_GEMM_PROBE development build reads the field; results are garbage there)"),
+    "RESNET_CHUNK": ("", "encode the batch in sequential chunks of this many frames (heuristic tiles)"),
+    "FUSE_PREACT": ("block1,block2,block3,block4", "blocks whose units pre-activate inside the operand staging of conv1 / shortcut"),
+    "FUSE_TAIL": ("1", "0 | 1 | block1 | noconv2 | conv2b1 | nosc | nostride2: which fused bottleneck tails the packer marks"),
+    "FUSE_SC": ("1", "0 | 1 | all: shortcut + conv1 as one column-split GEMM (1: blocks 3-4)"),
+    "PREACT_FIRST": ("0", "1: a block's first unit fuses its pre-activation too"),
+    "FOLD_SC": ("", "0 | 1: conv shortcut folded into conv3's K (default: bf16x3 only)"),
+    "AUTOTUNE": ("1", "0: no per-layer tile tuning pass (shipped table / library heuristic only)"),
+    "TILE_TABLE": ("1", "0: ignore the shipped tile tables (tile_tables.json), tune or fall back to the heuristic"),
+    "TILE_CACHE": ("", "json file the tuned tile tables are read from / written to (profiling runs)"),
+    "TUNE_TILES": ("5,6,3,1,2,7,8", "hmmr_conv_desc_t.tile candidates of the tuner"),
+    "RESNET_STREAMS": ("2", "contiguous parts a large batch is encoded as, on concurrent streams"),
+    "RESNET_PRIORITY": ("-1", "HIP priority of the ResNet side streams"),
+    "TAIL_PRIORITY": ("0", "HIP priority of the tail stream (dist.ShardedPredictor)"),
+    "STEP_STREAMS": ("1", "0: keep consecutive steps' ResNet passes on one stream (dist.ShardedPredictor)"),
+    "STREAM_TRACE": ("", "1: evaluation/streaming.py prints the host and device timeline of a call"),
+}
+
+
+def get(name):
+    """Value of development switch HMMR_<name> (a string), or its declared default."""
+    default = FLAGS[name][0]
+    return os.environ.get("HMMR_" + name, default)
+
+
+def is_set(name):
+    return ("HMMR_" + name) in os.environ and name in FLAGS

@@ -12,11 +12,11 @@ tensors), which is how the N>1 plumbing is tested without GPUs.
 """
 from __future__ import annotations
 
-import os
-
 import numpy as np
 import torch
 import torch.distributed as dist
+
+from . import devflags
 
 # per-frame output record of one container, in make_fetch_dict order (tester.py:217-227)
 FIELDS = (("cams", (3,)), ("joints", (25, 3)), ("kps", (25, 2)), ("poses", (24, 3, 3)),
@@ -148,15 +148,15 @@ class ShardedPredictor(object):
         else:
             self.idx = None
         nbuf = 2 if (self.overlap or self.pipeline) else 1
-        self.s_tail = (torch.cuda.Stream(device=eng.device, priority=int(os.environ.get("HMMR_TAIL_PRIORITY", "0")))
-                       if self.pipeline else None)     # env: dev A/B switch
+        self.s_tail = (torch.cuda.Stream(device=eng.device, priority=int(devflags.get("TAIL_PRIORITY")))
+                       if self.pipeline else None)
         # pipeline + step_streams: consecutive calls encode on ALTERNATING high-priority streams, each as ONE whole-batch
         # launch sequence with its own workspace, so two ResNet passes (of steps k and k+1) are in flight instead of the two
         # half-batch sequences of one step: twice the tiles per launch against the same gap filling (measured 8.28 -> 7.87 ms
         # per 256-frame step).  Same kernels on the same per-frame operands => the same bits.  The caller must not overwrite
         # a `frames` tensor before `ready()` of that call's result (the encode stream reads it after run() has returned).
         self.step_streams = ([torch.cuda.Stream(device=eng.device, priority=-1) for _ in range(nbuf)]
-                             if (self.pipeline and step_streams and os.environ.get("HMMR_STEP_STREAMS", "1") != "0") else None)
+                             if (self.pipeline and step_streams and devflags.get("STEP_STREAMS") != "0") else None)
         self.done = [None] * nbuf
         self.n_reg = 1 + len(tester.delta_t_values)
         self.locals = [torch.zeros((p.out_per_rank, self.n_reg * 85 if self.theta else self.rec_len),

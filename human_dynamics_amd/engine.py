@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from . import assets, packing
+from . import assets, devflags, packing
 
 DTYPES = {"f32": L.HMMR_F32, "fp32": L.HMMR_F32, "float32": L.HMMR_F32,
           "bf16": L.HMMR_BF16, "bfloat16": L.HMMR_BF16,
@@ -23,23 +23,25 @@ DTYPE_NAMES = {L.HMMR_F32: "f32", L.HMMR_BF16: "bf16", L.HMMR_BF16X3: "bf16x3"}
 # the fastest mode whose end-to-end vertices / joints stay within the reference tolerance of 1e-4.
 # 'bf16' is the opt-in throughput mode (vertex error ~7e-3), 'f32' the exact-fp32 MFMA mode.
 DEFAULT_DTYPE = "bf16x3"
+TILE_TABLES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tile_tables.json")
 
 
-def set_debug(stem_route=0, stem_no_conv1=0):
+def set_debug(stem_route=0, stem_no_conv1=0, gemm_probe=0):
     """Development switches of libhmmr_hip.so (hmmr_debug_t; process-wide, zeros = product defaults)."""
     d = L.Debug()
-    d.stem_route, d.stem_no_conv1 = int(stem_route), int(stem_no_conv1)
+    d.stem_route, d.stem_no_conv1, d.gemm_probe = int(stem_route), int(stem_no_conv1), int(gemm_probe)
     L.load().hmmr_set_debug(C.byref(d))
 
 
 def _debug_from_env():
-    """HMMR_STEM=unfused|fused and HMMR_STEM_C1=0 (tools/ A/B scripts) -> hmmr_set_debug; the library itself
-    never reads the environment."""
-    e = os.environ.get("HMMR_STEM", "")
-    c1 = os.environ.get("HMMR_STEM_C1", "1")
-    if e or c1 == "0" or _debug_from_env.was_set:
-        set_debug(stem_route={"u": 1, "f": 2}.get(e[:1], 0), stem_no_conv1=int(c1 == "0"))
-        _debug_from_env.was_set = bool(e or c1 == "0")
+    """devflags STEM / STEM_C1 / GEMM_PROBE (tools/ A/B scripts) -> hmmr_set_debug; the library itself never reads the
+    environment."""
+    e = devflags.get("STEM")
+    c1 = devflags.get("STEM_C1")
+    probe = int(devflags.get("GEMM_PROBE") or 0)
+    if e or c1 == "0" or probe or _debug_from_env.was_set:
+        set_debug(stem_route={"u": 1, "f": 2}.get(e[:1], 0), stem_no_conv1=int(c1 == "0"), gemm_probe=probe)
+        _debug_from_env.was_set = bool(e or c1 == "0" or probe)
 
 
 _debug_from_env.was_set = False
@@ -65,8 +67,9 @@ class _Workspace(object):
 
 class HmmrEngine(object):
     """weights: dict of checkpoint-named arrays (assets.py); smpl: dict in the
-    src/tf_smpl layout.  dtype: GEMM operand type of ResNet / temporal / IEF
-    ('bf16' or 'f32'); SMPL is always fp32."""
+    src/tf_smpl layout.  dtype: GEMM operand mode of ResNet / temporal / IEF: 'bf16x3' (default: split-bf16 hi/lo
+    operands, three bf16 MFMAs per product -- the mode inside the reference tolerance), 'bf16' or 'f32'; SMPL is
+    always fp32."""
 
     def __init__(self, weights, smpl, dtype=DEFAULT_DTYPE, device="cuda:0", num_conv_layers=3,
                  delta_t_values=(-5, 5), joint_type="cocoplus", resnet_chunk=0,
@@ -80,17 +83,18 @@ class HmmrEngine(object):
         self.dtype = _dt(dtype)
         self.temporal_dtype = self.dtype if temporal_dtype is None else _dt(temporal_dtype)
         self.ief_dtype = self.dtype if ief_dtype is None else _dt(ief_dtype)
-        self.resnet_chunk = int(os.environ.get("HMMR_RESNET_CHUNK", resnet_chunk))   # env: dev A/B switch
+        self.resnet_chunk = int(devflags.get("RESNET_CHUNK") or resnet_chunk)
         self.store = packing.DeviceStore(self.device)
         self.num_conv_layers = num_conv_layers
         self.delta_keys = sorted(int(d) for d in delta_t_values)
-        fuse = tuple(b for b in os.environ.get("HMMR_FUSE_PREACT", "block1,block2,block3,block4").split(",") if b)   # dev A/B switch
-        tail = {"0": False, "1": True}.get(os.environ.get("HMMR_FUSE_TAIL", "1"), os.environ.get("HMMR_FUSE_TAIL"))   # dev A/B switch: 0, 1, "block1", "noconv2", "conv2b1", "nosc", "nostride2"
+        # packer choices: constructor arguments, defaults overridable by the development switches of devflags.py
+        fuse = tuple(b for b in devflags.get("FUSE_PREACT").split(",") if b)
+        tail = {"0": False, "1": True}.get(devflags.get("FUSE_TAIL"), devflags.get("FUSE_TAIL"))
         if fuse_tail is not None:
             tail = fuse_tail
-        fsc = {"0": False, "1": True}.get(os.environ.get("HMMR_FUSE_SC", "1"), "all")               # dev A/B switch: 0, 1, all
-        pfirst = os.environ.get("HMMR_PREACT_FIRST", "0") != "0"                                    # dev A/B switch
-        fold = {"0": False, "1": True}.get(os.environ.get("HMMR_FOLD_SC", ""), None) if fold_sc is None else fold_sc   # dev A/B switch
+        fsc = {"0": False, "1": True}.get(devflags.get("FUSE_SC"), "all")
+        pfirst = devflags.get("PREACT_FIRST") != "0"
+        fold = {"0": False, "1": True}.get(devflags.get("FOLD_SC"), None) if fold_sc is None else fold_sc
         # every stage is packed only when its variables exist: a ResNet-only checkpoint (hmr_noS5.ckpt-642561, what
         # FeatureExtractor is given: src/datasets/resnet_extractor.py:31-40) has no AZ_FC_* / single_view_ief* names
         w = weights if weights is not None else {}
@@ -108,21 +112,34 @@ class HmmrEngine(object):
         self.num_kps = self.sc.num_kps if self.sc is not None else assets.NUM_KPS
         self.num_verts = self.sc.num_verts if self.sc is not None else assets.NUM_VERTS
         self._ws = {k: _Workspace(self.device) for k in ("resnet", "temporal", "ief", "smpl", "hal")}   # + "resnet<i>" per side stream
-        # per-layer conv tiles of the ResNet, tuned per batch size on first use (see _tune_resnet)
-        self.autotune = bool(autotune) and os.environ.get("HMMR_AUTOTUNE", "1") != "0"
-        self._tiles = {}
-        self.tune_log = []       # [(frames, ms)] of every tuning pass run by this engine (HMMR_AUTOTUNE=0 / autotune=False: none)
-        # optional on-disk copy of the tuned tables (HMMR_TILE_CACHE=file.json): profiling runs load it so
-        # that no tuning pass ends up inside the rocprofv3 trace
-        self._tile_cache = os.environ.get("HMMR_TILE_CACHE", "")
+        # per-layer conv tiles of the ResNet.  Shipped tables (tile_tables.json: measured on an MI355X for the batch sizes
+        # the BASELINE configurations produce, per operand mode) make the first call cost nothing; a batch size with no
+        # shipped table within 30 % is tuned on first use (_tune_resnet), autotune="force" tunes every size and ignores
+        # the shipped tables, autotune=False never tunes.  The tile never changes a result bit.
+        at = devflags.get("AUTOTUNE")
+        self.autotune = False if (not autotune or at == "0") else ("force" if (autotune == "force" or at == "force") else True)
+        self._tiles, self._shipped = {}, set()
+        self.tune_log = []       # [(frames, ms)] of every tuning pass run by this engine: never silent
+        # optional on-disk copy of the tuned tables (devflags TILE_CACHE): profiling runs load it so that no tuning
+        # pass ends up inside the rocprofv3 trace; tools/make_tile_tables.py writes the shipped file through it
+        self._tile_cache = devflags.get("TILE_CACHE")
+        sources = []
+        if self.autotune != "force" and devflags.get("TILE_TABLE") != "0" and os.path.exists(TILE_TABLES):
+            sources.append((TILE_TABLES, True))
         if self._tile_cache and os.path.exists(self._tile_cache):
+            sources.append((self._tile_cache, False))
+        for path, shipped in sources:
             import json
-            for key, tab in json.load(open(self._tile_cache)).items():
+            for key, tab in json.load(open(path)).items():
+                if key.startswith("_"):
+                    continue
                 dt, nt = key.split(":")
                 if int(dt) == self.dtype:
                     self._tiles[int(nt)] = {(int(k.split(":")[0]), k.split(":")[1]): int(v) for k, v in tab.items()}
+                    if shipped:
+                        self._shipped.add(int(nt))
         # concurrent half-batches (see resnet()); env: dev A/B switch
-        self.resnet_streams = int(os.environ.get("HMMR_RESNET_STREAMS", "2"))
+        self.resnet_streams = int(devflags.get("RESNET_STREAMS"))
         self._side_streams = []
 
     # -- helpers ---------------------------------------------------------------
@@ -140,7 +157,7 @@ class HmmrEngine(object):
         return torch.from_numpy(np.ascontiguousarray(a)).to(self.device).to(dtype).contiguous()
 
     # -- ResNet launch tuning ----------------------------------------------------
-    _TUNE_TILES = tuple(int(t) for t in os.environ.get("HMMR_TUNE_TILES", "5,6,3,1,2,7,8").split(","))   # hmmr_conv_desc_t.tile candidates (8-wave 128x128 / 128x64, 4-wave 64x64 / 128x128 / 128x64, 8-wave ping-pong 256x128 / 128x256)
+    _TUNE_TILES = tuple(int(t) for t in devflags.get("TUNE_TILES").split(","))   # hmmr_conv_desc_t.tile candidates (8-wave 128x128 / 128x64, 4-wave 64x64 / 128x128 / 128x64, 8-wave ping-pong 256x128 / 128x256)
     _TUNE_MIN_FRAMES = 32
     _SPLIT_MIN_FRAMES = 128
 
@@ -165,7 +182,18 @@ class HmmrEngine(object):
         for (u, nm), t in table.items():
             self._layer_of(u, nm).tile = int(t)
 
-    def _tune_resnet(self, images, n, n_zero):
+    def _needs_tuning(self, nt):
+        """A tuning pass is due for batch size nt: tuning is on, the size is worth it, it has no table of its own and (unless
+        forced) no shipped or tuned table within 30 % of it; at most 8 passes per engine."""
+        if not self.autotune or nt < self._TUNE_MIN_FRAMES or nt in self._tiles or torch.cuda.is_current_stream_capturing():
+            return False
+        if len(self.tune_log) >= 8:
+            return False
+        if self.autotune == "force":
+            return True
+        return not any(max(k, nt) <= 1.3 * min(k, nt) for k in self._tiles)
+
+    def _tune_resnet(self, images, n, n_zero, ws_key="resnet"):
         """Pick hmmr_layer_t.tile for every ResNet conv at this batch size: one instrumented pass per
         candidate tile (every layer timed in place, behind its real producer), fastest wins per layer.
         The tile never changes a result bit (each output element is one fixed-order K reduction), it
@@ -175,14 +203,17 @@ class HmmrEngine(object):
         t_start = time.perf_counter()
         nt = n + n_zero
         nbytes = self.lib.hmmr_resnet50_workspace_bytes(nt, self.dtype)
-        ws = self._ws["resnet"].get(nbytes)
+        ws = self._ws.setdefault(ws_key, _Workspace(self.device)).get(nbytes)     # the workspace of the pass being tuned
         phi = torch.empty((nt, 2048), dtype=torch.float32, device=self.device)
         src = images.data_ptr() if n else None
         best = {}
         for cand in (0,) + self._TUNE_TILES:
             for slot, u, nm in layers:
                 lay = self._layer_of(u, nm)
-                cout = self.rw.unit[u].base if nm in ("conv1", "conv2") else self.rw.unit[u].depth
+                U = self.rw.unit[u]
+                cout = U.base if nm in ("conv1", "conv2") else U.depth
+                if nm == "shortcut" and U.sc_c1.w:          # shortcut + conv1 as one column-split GEMM: depth + base columns
+                    cout = U.depth + U.base
                 lay.tile = cand if ((cand not in (1, 5, 7) or cout % 128 == 0) and (cand != 8 or cout % 256 == 0)) else 0
             t = None
             for rep in range(3):
@@ -210,9 +241,9 @@ class HmmrEngine(object):
         images) -> phi[:n + n_zero]."""
         nt = n + n_zero
         table = None
-        if tune and self.autotune and nt >= self._TUNE_MIN_FRAMES:
-            if nt not in self._tiles and len(self._tiles) < 8 and not torch.cuda.is_current_stream_capturing():
-                self._tiles[nt] = self._tune_resnet(images, n, n_zero)
+        if tune and nt >= self._TUNE_MIN_FRAMES:
+            if self._needs_tuning(nt):
+                self._tiles[nt] = self._tune_resnet(images, n, n_zero, ws_key)
             if self._tiles:                                  # an untuned size borrows the nearest tuned one
                 table = self._tiles[min(self._tiles, key=lambda k: abs(k - nt))]
         if table is not None:
@@ -277,8 +308,8 @@ class HmmrEngine(object):
         if self.autotune:                                    # tune every part size before anything overlaps
             for i in range(parts):
                 ni, nz = cuts[i + 1] - cuts[i], (n_zero if i == parts - 1 else 0)
-                if ni + nz >= self._TUNE_MIN_FRAMES and ni + nz not in self._tiles and len(self._tiles) < 8:
-                    self._tiles[ni + nz] = self._tune_resnet(images[cuts[i]:cuts[i + 1]], ni, nz)
+                if self._needs_tuning(ni + nz):
+                    self._tiles[ni + nz] = self._tune_resnet(images[cuts[i]:cuts[i + 1]], ni, nz, "resnet%d" % i)
         for i in range(parts):
             side = self._side_streams[i]
             side.wait_stream(cur)                            # the frames are ready on the caller's stream
@@ -293,7 +324,7 @@ class HmmrEngine(object):
     def side_stream(self, i):
         """The i-th of the high-priority streams the ResNet parts run on (created on first use)."""
         while len(self._side_streams) <= i:
-            self._side_streams.append(torch.cuda.Stream(device=self.device, priority=int(os.environ.get("HMMR_RESNET_PRIORITY", "-1"))))
+            self._side_streams.append(torch.cuda.Stream(device=self.device, priority=int(devflags.get("RESNET_PRIORITY"))))
         return self._side_streams[i]
 
     def temporal(self, phi):
@@ -323,9 +354,11 @@ class HmmrEngine(object):
                                                ws.data_ptr(), nbytes, self._stream()), "hmmr_hallucinator_fwd")
         return out.reshape(phi.shape)
 
-    def ief(self, strips):
+    def ief(self, strips, omega_start=None, use_delta_from_pred=True):
         """strips [m,2048] -> omegas [R,m,85]; R = 1 + len(delta_t_values), deltas in sorted order.
-        batch_pred_omega, src/models.py:233-267."""
+        batch_pred_omega / call_hmr_ief, src/models.py:233-267, 299-377.  omega_start: [m,85] starting point of the IEF
+        (`omega_mean`; None = the checkpoint's mean theta in every row, tester.py:181).  use_optcam is a property of the
+        packed delta regressors (72- or 75-wide, `self.use_optcam`)."""
         self._need(self.iw, "single_view_ief*/3D_module/* and mean_param")
         strips = self.to_device(strips)
         m = strips.shape[0]
@@ -333,9 +366,22 @@ class HmmrEngine(object):
         out = torch.empty((R, m, 85), dtype=torch.float32, device=self.device)
         nbytes = self.lib.hmmr_ief_workspace_bytes(m, R, self.ief_dtype)
         ws = self._ws["ief"].get(nbytes)
-        L.check(self.lib.hmmr_ief_fwd(C.byref(self.iw), strips.data_ptr(), m, out.data_ptr(),
-                                      ws.data_ptr(), nbytes, self._stream()), "hmmr_ief_fwd")
+        start = None
+        if omega_start is not None:
+            start = self.to_device(omega_start).reshape(-1, 85)
+            if start.shape[0] == 1:
+                start = start.expand(m, 85).contiguous()
+            assert start.shape == (m, 85), start.shape
+        self.iw.delta_from_start = int(not use_delta_from_pred)
+        L.check(self.lib.hmmr_ief_fwd_from(C.byref(self.iw), strips.data_ptr(), L.ptr(start), m, out.data_ptr(),
+                                           ws.data_ptr(), nbytes, self._stream()), "hmmr_ief_fwd")
+        self.iw.delta_from_start = 0
         return out
+
+    @property
+    def use_optcam(self):
+        """True when the packed delta regressors predict 72 values and get the fixed camera [1, 0, 0] (models.py:333-371)."""
+        return self.iw is None or not self.iw.no_optcam
 
     def smpl(self, theta, beta, cams=None, want_rs=True):
         """theta [m,72], beta [m,10], cams [m,3] or None (row-major views with a

@@ -108,7 +108,7 @@ class HostStreamer(object):
     def run(self, all_images, want=None):
         t, eng, dev = self.t, self.eng, self.dev
         N = len(all_images)
-        keys = [k + s for s in ("", "_delta") for k in OUTPUT_KEYS]
+        keys = [k for k, _, _, _ in self.layout]        # a Tester without delta_t_values has no *_delta fields
         if want is not None:
             unknown = [k for k in want if k not in keys]
             if unknown:
@@ -135,8 +135,9 @@ class HostStreamer(object):
         out_free = [None, None]         # copy-out finished reading recs[slot]
         ar_T = torch.arange(T, device=dev)
         eng.resnet(torch.empty((0, 224, 224, 3), dtype=torch.float32, device=dev), n_zero=1, out=phi[N:N + 1])                                 # the zero padding image, once, up front
-        import os as _os, time as _time
-        trace = [] if _os.environ.get("HMMR_STREAM_TRACE") else None
+        import time as _time
+        from .. import devflags
+        trace = [] if devflags.get("STREAM_TRACE") else None
         tr = (lambda tag: trace.append((tag, _time.perf_counter()))) if trace is not None else (lambda tag: None)
         gpu_marks = [] if trace is not None else None          # (tag, event): device-side timeline of the same call
 
@@ -201,13 +202,19 @@ class HostStreamer(object):
             enc[k_] = in_free[slot_] = torch.cuda.Event()
             enc[k_].record(cur)
 
-        encode(0, stage_ahead(0))
+        # staging runs ONE CHUNK AHEAD of its use: chunk k+2's memcpy is handed to the stager thread as soon as chunk k+1 is
+        # queued (it first waits, on its own thread, for the slot's previous user -- chunk k -- to be encoded), so the Python
+        # thread finds chunk k+1 already staged when it comes to encode it
+        ahead = {0: stage_ahead(0)}
+        encode(0, ahead.pop(0))
+        ahead[1] = stage_ahead(1)
         for k in range(n_chunks + 1):
             tr("chunk %d" % k)
             if k + 1 < n_chunks:
                 # chunk k+1 goes into the queues before the tail (and the downloads) of chunk k-1 do: queued behind them,
                 # the copy of chunk k+1 was seen to wait for those downloads, and its ResNet with it
-                encode(k + 1, stage_ahead(k + 1))
+                encode(k + 1, ahead.pop(k + 1))
+                ahead[k + 2] = stage_ahead(k + 2)
             if k >= 1:
                 # tail of output frames [o0, o1): their windows reach margin frames into chunk k, encoded just above
                 with torch.cuda.stream(self.s_tail):

@@ -60,17 +60,25 @@ def fc2_res(phi, engine, name="fc2_res"):
 def batch_pred_omega(input_features, batch_size, is_training, num_output, omega_mean,
                      sequence_length, scope, engine, predict_delta_keys=(),
                      use_delta_from_pred=False, use_optcam=False):
-    """[B,T,2048] -> (omega [B,T,85], {delta_t: [B,T,85]})  (src/models.py:233-267).
+    """[B,T,2048] -> (omega [B,T,85], {delta_t: [B,T,85]})  (src/models.py:233-267, call_hmr_ief :299-377).
 
-    The engine's IEF weights carry the mean theta and the regressor set, so
-    `omega_mean`/`scope` are only validated."""
+    omega_mean: [B*T,85] starting point of the IEF (None = the checkpoint's mean theta in every row, what
+    tester.py:79-83,181 passes).  use_delta_from_pred: the delta regressors start from the present prediction (True) or
+    from omega_mean (False, models.py:349).  use_optcam: they regress 72 values and get the camera [1,0,0] (True) or
+    regress camera + pose, 75 values (False, models.py:333-373) -- a property of the checkpoint's fc1 / fc3 shapes, so
+    the argument is validated against the packed regressors.  `scope` is validated too."""
     _inference_only(is_training)
-    if num_output != 85 or not use_delta_from_pred or not use_optcam or scope != "single_view_ief":
-        raise NotImplementedError("only the Tester configuration of batch_pred_omega is implemented "
-                                  "(tester.py:196-207)")
+    if num_output != 85:
+        raise ValueError("batch_pred_omega: num_output is 85 (3 camera + 72 pose + 10 shape), got %r" % (num_output,))
+    if scope != "single_view_ief":
+        raise ValueError("the engine's regressors were packed from scope 'single_view_ief', got %r" % (scope,))
     keys = [k for k in sorted(predict_delta_keys) if k != 0]
     if keys != [k for k in engine.reg_keys if k != 0]:
         raise ValueError("engine was packed for delta keys %s" % engine.reg_keys)
-    om = engine.ief(input_features.reshape(batch_size * sequence_length, -1))
+    if keys and bool(use_optcam) != engine.use_optcam:
+        raise ValueError("use_optcam=%s, but the checkpoint's delta regressors are %d-wide" %
+                         (use_optcam, 72 if engine.use_optcam else 75))
+    om = engine.ief(input_features.reshape(batch_size * sequence_length, -1), omega_start=omega_mean,
+                    use_delta_from_pred=use_delta_from_pred)
     om = om.reshape(om.shape[0], batch_size, sequence_length, 85)
     return om[0], {k: om[i] for i, k in enumerate(engine.reg_keys) if k != 0}

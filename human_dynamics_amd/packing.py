@@ -266,7 +266,11 @@ def pack_ief(w, dtype, store, delta_t_values=(-5, 5), num_stages=3):
         scope, nd = scopes[key]
         p = scope + "/3D_module"
         W1 = w[p + "/fc1/weights"]
-        assert W1.shape == (assets.FEAT_DIM + nd, 1024)
+        if key != 0:
+            nd = W1.shape[0] - assets.FEAT_DIM          # 72 (use_optcam) or 75 (models.py:333-336): the checkpoint decides
+            if nd not in (72, 75):
+                raise ValueError("%s/fc1/weights has %d rows: a delta regressor takes 2048 + 72 or 2048 + 75" % (p, W1.shape[0]))
+        assert W1.shape == (assets.FEAT_DIM + nd, 1024) and w[p + "/fc3/weights"].shape == (1024, nd)
         reg = iw.reg[r]
         reg.nd = nd
         reg.fc1_phi = _layer(store, _pad_rows(np.ascontiguousarray(W1[:assets.FEAT_DIM].T)), dtype,
@@ -279,6 +283,10 @@ def pack_ief(w, dtype, store, delta_t_values=(-5, 5), num_stages=3):
         reg.fc3 = _layer(store, _pad_rows(np.ascontiguousarray(w[p + "/fc3/weights"].T)), dtype,
                          shift=w[p + "/fc3/biases"])
     iw.mean_theta = store.put(np.asarray(w["mean_param"], np.float32).reshape(85)).data_ptr()
+    nds = {iw.reg[r].nd for r in range(1, len(keys))}
+    if len(nds) > 1:
+        raise ValueError("the delta regressors disagree on use_optcam (theta widths %s)" % sorted(nds))
+    iw.no_optcam = int(nds == {75})
     return iw, keys
 
 

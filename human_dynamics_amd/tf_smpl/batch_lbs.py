@@ -22,11 +22,10 @@ def batch_rodrigues(theta, engine):
 def batch_global_rigid_transformation(Rs, Js, parent, rotate_base=False, engine=None):
     """Rs [N,24,3,3], Js [N,24,3], parent [24] -> (new_J [N,24,3], A [N,24,4,4]): absolute joint
     locations and the relative joint transforms for LBS (src/tf_smpl/batch_lbs.py:133-194).
-    rotate_base must be False (it is False on every call of the reference's hot path, batch_smpl.py:136)."""
+    rotate_base: the root rotation is multiplied by diag(1, -1, -1) (batch_lbs.py:151-158; False on the hot path,
+    batch_smpl.py:136)."""
     import ctypes as C  # noqa: F401
     from .. import _lib as L
-    if rotate_base:
-        raise NotImplementedError("rotate_base=True is not used by the reference's inference path")
     lib = L.load()
     dev = engine.device if engine is not None else torch.device("cuda:0")
     to = (engine.to_device if engine is not None else
@@ -37,6 +36,6 @@ def batch_global_rigid_transformation(Rs, Js, parent, rotate_base=False, engine=
     new_j = torch.empty((n, 24, 3), dtype=torch.float32, device=dev)
     A = torch.empty((n, 24, 4, 4), dtype=torch.float32, device=dev)
     L.check(lib.hmmr_global_rigid_transformation(Rs.data_ptr(), Js.data_ptr(), par.data_ptr(), n, new_j.data_ptr(),
-                                                 A.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+                                                 A.data_ptr(), int(bool(rotate_base)), torch.cuda.current_stream(dev).cuda_stream),
             "hmmr_global_rigid_transformation")
     return new_j, A

@@ -47,7 +47,10 @@ typedef struct hmmr_debug_s {
     int stem_route;        /* 0: default (fused stem kernel for bf16 / bf16x3, re-pack + GEMM + pool for f32);
                               1: always the three-kernel route; 2: always the fused kernel */
     int stem_no_conv1;     /* 1: the fused bf16 stem leaves block1/unit_1's conv1 to its own launch */
-    int reserved[6];
+    int gemm_probe;        /* read only by the -DHMMR_GEMM_PROBE development build (tools/probe_build.sh): the GEMM K loop
+                              drops its MFMAs (1), its operand loads after the first stage (2) or its barriers (4), to see
+                              which of the three bounds a shape; results are garbage then.  The product build ignores it. */
+    int reserved[5];
 } hmmr_debug_t;
 void hmmr_set_debug(const hmmr_debug_t* d);     /* NULL = defaults */
 void hmmr_get_debug(hmmr_debug_t* d);
@@ -264,14 +267,19 @@ int hmmr_groupnorm_relu(const float* x, const float* gamma, const float* beta, i
 
 /* ------------------------------------------------------------------------- *
  * IEF regressors: batch_pred_omega / call_hmr_ief / hmr_ief /
- * encoder_fc3_dropout (src/models.py:80-116, 233-267, 299-415) with
- * use_optcam=True, use_delta_from_pred=True (tester.py:196-207).
+ * encoder_fc3_dropout (src/models.py:80-116, 233-267, 299-415).
  * strips [m,2048] fp32 -> omega[r] [m,85] fp32 for r = 0 (present) and each
- * delta regressor, already in the final layout ([1,0,0 | pose | beta of omega0]
- * for deltas, models.py:367-371).
+ * delta regressor, already in the final layout.  Default (all flags 0) = the
+ * Tester configuration use_optcam=True, use_delta_from_pred=True
+ * (tester.py:196-207): a delta regressor starts from omega0[:, 3:75], predicts
+ * 72 values and returns [1,0,0 | pose | beta of omega0] (models.py:349-371).
+ * no_optcam (use_optcam=False): it starts from [:, :75], predicts 75 values
+ * and returns [cam, pose | beta] (models.py:357-373).  delta_from_start
+ * (use_delta_from_pred=False): start and beta come from the IEF's own
+ * starting point (omega_start / the mean theta) instead of omega0 (:349-351).
  * ------------------------------------------------------------------------- */
 typedef struct {
-    int nd;                            /* 85 (present) or 72 (delta) */
+    int nd;                            /* 85 (present); 72 (delta) or 75 (delta with no_optcam) */
     hmmr_layer_t fc1_phi;              /* w [1024][2048], shift = fc1 bias */
     hmmr_layer_t fc1_theta;            /* w [1024][128]: rows of fc1 for theta, zero padded */
     hmmr_layer_t fc2;                  /* w [1024][1024], shift = bias */
@@ -286,12 +294,18 @@ typedef struct {
     int num_stages;                    /* 3 */
     hmmr_ief_regressor_t reg[HMMR_MAX_REGRESSORS];
     const float* mean_theta;           /* [85] */
+    int no_optcam;                     /* 1: use_optcam=False (every delta regressor has nd == 75) */
+    int delta_from_start;              /* 1: use_delta_from_pred=False */
 } hmmr_ief_weights_t;
 
 size_t hmmr_ief_workspace_bytes(int m, int num_regressors, int dtype);
-/* omegas: [num_regressors][m][85] fp32 */
+/* omegas: [num_regressors][m][85] fp32.  The IEF starts from w->mean_theta in every row (tester.py:79-83, 181). */
 int hmmr_ief_fwd(const hmmr_ief_weights_t* w, const float* strips, int m, float* omegas,
                  void* ws, size_t ws_bytes, void* stream);
+/* ... or from a caller-given starting point per row: omega_start [m][85] fp32 (`omega_mean` of batch_pred_omega,
+ * src/models.py:231-249); NULL = w->mean_theta. */
+int hmmr_ief_fwd_from(const hmmr_ief_weights_t* w, const float* strips, const float* omega_start, int m, float* omegas,
+                      void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * SMPL forward + keypoint projection: SMPL.__call__ (src/tf_smpl/batch_smpl.py:
@@ -334,10 +348,11 @@ int hmmr_smpl_fwd_strided(const hmmr_smpl_consts_t* c, const float* theta, int l
                           const float* beta, int ld_beta, const float* cams, int ld_cam, int m,
                           float* verts, float* joints, float* kps, float* rs, int64_t ld_out,
                           void* ws, size_t ws_bytes, void* stream);
-/* batch_global_rigid_transformation on its own (src/tf_smpl/batch_lbs.py:133-194, rotate_base=False):
- * Rs [m,24,3,3], Js [m,24,3], parents [24] -> new_J [m,24,3], A [m,24,4,4] (relative transforms for LBS). */
+/* batch_global_rigid_transformation on its own (src/tf_smpl/batch_lbs.py:133-194):
+ * Rs [m,24,3,3], Js [m,24,3], parents [24] -> new_J [m,24,3], A [m,24,4,4] (relative transforms for LBS).
+ * rotate_base != 0: the root rotation is R_0 . diag(1, -1, -1) (batch_lbs.py:151-158; the hot path passes 0). */
 int hmmr_global_rigid_transformation(const float* Rs, const float* Js, const int32_t* parents, int m,
-                                     float* new_j, float* A, void* stream);
+                                     float* new_j, float* A, int rotate_base, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Crop before the path (process_image, src/evaluation/run_video.py:56-107; resize_img,

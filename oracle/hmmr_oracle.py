@@ -267,18 +267,24 @@ def hmr_ief(phi, omega_start, w, scope, num_stage=3, dtype=torch.float64, emulat
     return theta
 
 
-def call_hmr_ief(phi, omega_start, w, delta_t_values=(-5, 5), dtype=torch.float64, emulate=None):
-    """use_optcam=True, use_delta_from_pred=True as tester.py:196-207 calls it."""
+def call_hmr_ief(phi, omega_start, w, delta_t_values=(-5, 5), dtype=torch.float64, emulate=None,
+                 use_optcam=True, use_delta_from_pred=True):
+    """models.py:299-377.  Defaults = use_optcam=True, use_delta_from_pred=True as tester.py:196-207 calls it."""
     theta_here = hmr_ief(phi, omega_start, w, "single_view_ief", dtype=dtype, emulate=emulate)
+    nd = 72 if use_optcam else 3 + 72                   # models.py:333-336
     deltas = {}
     for dt in delta_t_values:
         scope = "single_view_ief" + ("_future%d" % dt if dt > 0 else "_past%d" % abs(dt))
-        beta = theta_here[:, -10:]
-        start = theta_here[:, 3:3 + 72]                 # models.py:349-356
+        start_full = theta_here if use_delta_from_pred else omega_start      # models.py:349
+        beta = start_full[:, -10:]
+        start = start_full[:, 3:3 + nd] if use_optcam else start_full[:, :nd]   # models.py:353-357
         d = hmr_ief(phi, start, w, scope, dtype=dtype, emulate=emulate)
         n = d.shape[0]
-        deltas[dt] = torch.cat([torch.ones(n, 1, dtype=dtype), torch.zeros(n, 2, dtype=dtype),
-                                d, beta], dim=1)        # models.py:367-371
+        if use_optcam:
+            deltas[dt] = torch.cat([torch.ones(n, 1, dtype=dtype), torch.zeros(n, 2, dtype=dtype),
+                                    d, beta], dim=1)    # models.py:367-371
+        else:
+            deltas[dt] = torch.cat([d[:, :75], beta], dim=1)                  # models.py:372-373
     return theta_here, deltas
 
 
@@ -305,10 +311,13 @@ def batch_rodrigues(theta):
     return cos * eye + (1 - cos) * outer + sin * batch_skew(r)
 
 
-def batch_global_rigid_transformation(Rs, Js, parents):
-    """batch_lbs.py:133-194 (rotate_base=False)."""
+def batch_global_rigid_transformation(Rs, Js, parents, rotate_base=False):
+    """batch_lbs.py:133-194."""
     N = Rs.shape[0]
     dtype = Rs.dtype
+    if rotate_base:                                     # batch_lbs.py:151-158
+        rot_x = torch.tensor([[1, 0, 0], [0, -1, 0], [0, 0, -1]], dtype=dtype)
+        Rs = torch.cat([(Rs[:, 0] @ rot_x).unsqueeze(1), Rs[:, 1:]], dim=1)
 
     def make_A(R, t):
         top = torch.cat([R, t.reshape(N, 3, 1)], dim=2)

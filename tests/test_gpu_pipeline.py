@@ -349,6 +349,21 @@ def test_streamed_host_path_is_byte_identical_to_one_shot(weights, smpl_consts, 
     assert np.array_equal(sub["joints"], ref["joints"]) and np.array_equal(sub["omegas_delta"], ref["omegas_delta"])
 
 
+def test_streamed_host_path_without_delta_regressors(weights, smpl_consts, gpu_device):
+    """config.delta_t_values = []: the record has no *_delta fields (tester.py:245-255 adds them per delta); the
+    streamed path derives its keys from the record layout and equals the one-shot path, 640 frames = 3 chunks."""
+    from human_dynamics_amd.evaluation.tester import Tester
+    t = Tester(Config(batch_size=8, delta_t_values=[]), weights=weights, smpl=smpl_consts, dtype="bf16", device=gpu_device)
+    frames = assets.make_synthetic_frames(70, seed=9)
+    ref = t.predict_all_images(frames, stream=False)
+    got = t.predict_all_images(frames)
+    assert sorted(got) == sorted(ref) == sorted(["cams", "joints", "kps", "poses", "shapes", "verts", "omegas"])
+    for k in ref:
+        assert np.array_equal(got[k], ref[k]), k
+    with pytest.raises(KeyError):
+        t.predict_all_images(frames, want=("verts_delta",))
+
+
 def test_streamed_uint8_input_matches_reference_normalisation(weights, smpl_consts, gpu_device):
     """uint8 crops are uploaded as bytes and normalised on the device with the reference's arithmetic
     ((x / 255.0 - 0.5) * 2 in float64, run_video.py:73): identical to feeding the float32 array."""
