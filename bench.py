@@ -18,8 +18,11 @@ before the timed region and outputs stay in HBM; the PCIe-inclusive rate
 separately as `pcie_inclusive_fps`.
 
 `value` is the mode that meets the reference tolerance (vertices / joints within
-1e-4 of the fp32 TF graph): `--dtype bf16x3`, split-bf16 operands (hi/lo pairs,
-three bf16 MFMAs per product, fp32 accumulate).  On one GPU the same line also
+1e-4 of the fp32 TF graph): `--dtype auto` (the drop-in default), which probes the
+weights on the device (human_dynamics_amd/precision.py) and for the synthetic
+seed-0 weights settles on bf16x3 -- split-bf16 operands (hi/lo pairs, three bf16
+MFMAs per product, fp32 accumulate).  `stress` in the same line repeats the
+end-to-end error for more weight seeds and two hard-conditioned sets.  On one GPU the same line also
 carries `modes`: fps and the END-TO-END vertex / joint error against the float64
 oracle for every operand mode timed (bf16x3, bf16, f32), so the throughput of the
 cheaper, out-of-tolerance bf16 mode is visible next to it but never the headline.
@@ -139,7 +142,7 @@ def run_mode(dtype, args, world, rank, device, weights, smpl, span, n_total, ste
     tester / predictor (for the roofline leg) and the last output tensor."""
     from human_dynamics_amd import dist as hd
     from human_dynamics_amd.evaluation.tester import Tester
-    tester = Tester(Cfg(), weights=weights, smpl=smpl, dtype=dtype, device=str(device))
+    tester = Tester(Cfg(), weights=weights, smpl=smpl, dtype=dtype, device=str(device))      # "auto": precision.choose_engine
     eng = tester.engine
     pipeline = not (args.no_pipeline or args.graph or args.serial)
     if args.serial or args.graph:
@@ -197,6 +200,51 @@ def e2e_errors(out, tester, ref, sliced=False):
     return {"e2e_%s_max_abs_err" % k: float(np.abs(rec[k].cpu().numpy() - ref[k]).max()) for k in ("verts", "joints", "omegas")}
 
 
+def stress_leg(span, span_host, plan, n_total, smpl, device):
+    """The end-to-end error of the DEFAULT operand selection (dtype="auto") for more weight sets than the headline's:
+    two more seeds of the ordinary generator and the two hard-conditioned sets of oracle/hard_weights.py.  Per set: the
+    mode the probe settled on, the error against the float64 oracle on the window that keeps output frames
+    [ERR_WINDOW_START, +8), and the distance from the exact-fp32 operand mode over ALL output frames of the step."""
+    from human_dynamics_amd import assets, dist as hd
+    from human_dynamics_amd.evaluation.tester import Tester
+    from oracle import hard_weights as H
+    out = []
+    plain3 = assets.make_synthetic_weights(3)
+    hard = H.make_hard_weights(3)
+    sets = [("seed 1", assets.make_synthetic_weights(1)), ("seed 2", assets.make_synthetic_weights(2))]
+    hb = dict(hard)
+    fx = dict(plain3)
+    for k in plain3:
+        if k.endswith("fc3/weights"):
+            hb[k], fx[k] = plain3[k], hard[k]
+    sets += [("hard BN / GN conditioning (oracle/hard_weights.py), seed 3", hb), ("fc3 at 10 x small_xavier, seed 3", fx)]
+    del plain3, hard
+    for name, w in sets:
+        ref = oracle_window(span_host, plan.f0, n_total, w, smpl)
+        recs = {}
+        for dt in ("f32", None):
+            t = Tester(Cfg(), weights=w, smpl=smpl, dtype=dt, device=str(device))
+            p = hd.ShardedPredictor(t, n_total, 0, 1)
+            recs[dt] = p.run(span).clone()
+            torch.cuda.synchronize(device)
+            if dt is None:
+                e = e2e_errors(recs[dt], t, ref)
+                layout, _ = hd.record_layout(len(t.delta_t_values))
+                a, b = hd.unpack_outputs(recs[None], layout), hd.unpack_outputs(recs["f32"], layout)
+                d = {k: float((a[k] - b[k]).abs().max()) for k in ("verts", "joints", "verts_delta", "joints_delta")}
+                e32 = e2e_errors(recs["f32"], t, ref)
+                out.append({"weights": name, "operands": t.precision["operands"],
+                            "probe": [{k: (round(v, 8) if isinstance(v, float) else v) for k, v in r.items()} for r in t.precision["rungs"]],
+                            "e2e_verts_max_abs_err": e["e2e_verts_max_abs_err"], "e2e_joints_max_abs_err": e["e2e_joints_max_abs_err"],
+                            "max_abs_diff_from_f32_operands_all_%d_frames" % n_total: d,
+                            "f32_operands_e2e_verts_max_abs_err": e32["e2e_verts_max_abs_err"],
+                            "within_tolerance": bool(max(e["e2e_verts_max_abs_err"], e["e2e_joints_max_abs_err"]) <= 1e-4 and
+                                                     max(d.values()) + e32["e2e_verts_max_abs_err"] <= 1e-4)})
+            del t, p
+            torch.cuda.empty_cache()
+    return out
+
+
 def roofline_leg(tester, plan, span, dtype, frames):
     """Per-launch timing of the ResNet's MFMA launches, one stream, HIP events inside the library."""
     eng = tester.engine
@@ -237,9 +285,10 @@ def roofline_leg(tester, plan, span, dtype, frames):
     avg_launch_s = conv_ms * 1e-3 / n_conv
     achieved = flops_per_launch / avg_launch_s
     peak = PEAKS[dtype]
+    mfma_per_product = 3 if dtype == "bf16x3" else 1
     # HBM traffic per launch comes from separate rocprofv3 --pmc passes of this same command
     # (FETCH_SIZE x2, WRITE_SIZE x1, KiB; tools/pmc_summary.py) committed under profiles/
-    traffic, traffic_src, mfma_util = None, None, None
+    traffic, traffic_src, mfma_util, traffic_commit, families = None, None, None, None, None
     here = os.path.dirname(os.path.abspath(__file__))
     for pm in sorted(glob.glob(os.path.join(here, "profiles", "r*_pmc_summary.json")), reverse=True):
         js = json.load(open(pm))
@@ -247,16 +296,23 @@ def roofline_leg(tester, plan, span, dtype, frames):
             rc = js.get("resnet_conv_gemm", {})
             traffic, mfma_util = rc.get("hbm_bytes_per_launch"), rc.get("mfma_util")
             traffic_src = "profiles/" + os.path.basename(pm)
+            traffic_commit = js.get("commit")            # stamped by tools/collect_profiles.py: the kernels the counters saw
+            families = {k: v.get("mfma_util") for k, v in js.get("families", {}).items()} or None
             break
     return {"bound": "mfma",
             "kernel": "conv_gemm_kernel%s (ResNet-v2-50, %s operands: %d MFMA launches/pass, %d of them fused bottleneck units)"
                       % ({"bf16": " / bottleneck_tail_kernel / stem_fused_kernel", "bf16x3": " / tail_split_kernel / stem_fused_split_kernel"}.get(dtype, ""), dtype, n_conv, n_tails),
             "achieved": round(achieved / 1e12, 2), "peak": round(peak / 1e12, 1), "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4),
+            # the other reading of the same measurement: algorithmic FLOP/s against the RAW dense bf16 MFMA peak (2.5 PF),
+            # i.e. what fraction of the machine's headline rate the arithmetic of the reference graph proceeds at
+            "frac_of_bf16_dense_peak": round(achieved / PEAK_BF16, 4),
+            "mfma_instruction_flops": round(achieved * mfma_per_product / 1e12, 2),
             "peak_note": {"bf16": "dense bf16 MFMA", "f32": "fp32 MFMA",
                           "bf16x3": "dense bf16 MFMA / 3 (three bf16 MFMAs per algorithmic multiply-add)"}[dtype],
             "traffic": traffic, "traffic_unit": "B/launch",
-            "traffic_source": traffic_src, "mfma_util_pmc": mfma_util,
+            "traffic_source": traffic_src, "traffic_commit": traffic_commit, "mfma_util_pmc": mfma_util,
+            "mfma_util_pmc_by_family": families,
             "avg_launch_us": round(avg_launch_s * 1e6, 2),
             "flops_per_launch": flops_per_launch,
             "measured": "one stream, no co-running kernels (the timed steps overlap streams)",
@@ -271,8 +327,10 @@ def main():
     ap.add_argument("--frames", type=int, default=256, help="output frames per GPU per step (weak scaling)")
     ap.add_argument("--video-frames", type=int, default=0,
                     help="strong scaling: ONE video of this many frames sharded over the ranks (BASELINE configs[4]: 4096)")
-    ap.add_argument("--dtype", default="bf16x3", choices=["bf16x3", "bf16", "f32"],
-                    help="operand mode of the headline `value`; bf16x3 is the one inside the reference tolerance")
+    ap.add_argument("--dtype", default="auto", choices=["auto", "bf16x3", "bf16", "f32"],
+                    help="operand mode of the headline `value`; auto = the drop-in default (probed on the device against the "
+                         "exact-fp32 mode, precision.py): bf16x3 for well-conditioned weights")
+    ap.add_argument("--no-stress", action="store_true", help="skip the tolerance stress leg (more weight seeds, hard conditioning)")
     ap.add_argument("--only-main", action="store_true", help="skip the other operand modes (`modes`)")
     ap.add_argument("--gather", default="records", choices=["records", "theta"],
                     help="N > 1: all-gather the packed per-frame records (253 KB/frame) or only the 3 x 85 omegas "
@@ -326,6 +384,11 @@ def main():
     timing, tester, predictor, out = run_mode(args.dtype, args, world, rank, device, weights, smpl, span, n_total,
                                               args.steps, args.warmup)
     value, ms_per_step = timing["fps"], timing["ms_per_step"]
+    from human_dynamics_amd import precision
+    from human_dynamics_amd.engine import DTYPE_NAMES
+    requested = args.dtype
+    args.dtype = DTYPE_NAMES[tester.engine.dtype]         # the ResNet's operand mode (what "auto" resolved to)
+    operands_desc = precision.describe(tester.engine)
 
     # isolated cost of the one collective of a step (outside the timed region)
     all_gather_ms, gather_bytes = None, None
@@ -354,12 +417,20 @@ def main():
         # work of this script (oracle, PCIe legs): under the container's CPU quota the oracle's thread pool slows the launch
         # thread down afterwards, and the 190-launch bf16 step is the first thing to become host-bound.
         others, modes = {}, {}
+        all_frames_diff = None
         if single and not args.only_main:
             for other in [m for m in ("bf16x3", "bf16", "f32") if m != args.dtype]:
                 tm, t_o, pred_o, out_o = run_mode(other, args, world, rank, device, weights, smpl, span, n_total,
                                                   args.steps, args.warmup)
                 modes[other] = dict(fps=round(tm["fps"], 1), ms_per_step=round(tm["ms_per_step"], 3))
                 others[other] = (t_o, out_o[ERR_WINDOW_START:ERR_WINDOW_START + 8].clone())
+                if other == "f32" or args.dtype == "f32":
+                    # every output frame of the step, headline mode against exact-fp32 operands: with the f32 mode's own
+                    # distance from the float64 oracle (in `modes`) this bounds the error of ALL frames, not of 8
+                    layout_, _ = hd.record_layout(len(tester.delta_t_values))
+                    a_, b_ = hd.unpack_outputs(out, layout_), hd.unpack_outputs(out_o, layout_)
+                    all_frames_diff = {k: float((a_[k] - b_[k]).abs().max()) for k in ("verts", "joints", "verts_delta", "joints_delta")}
+                    del a_, b_
                 del pred_o, out_o
                 torch.cuda.empty_cache()
         span_host = span.cpu().numpy() if single else None
@@ -405,7 +476,9 @@ def main():
             "metric": "frames/sec/GPU (ResNet+temporal+SMPL, 224x224); SMPL verts max-abs-err",
             "value": round(value, 1), "unit": "frames/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "dtype": args.dtype if operands_desc == args.dtype else operands_desc, "dtype_requested": requested,
+            "precision_probe": tester.precision, "data": "synthetic",
             "config": {"workload": ("BASELINE configs[4]: one %d-frame video sharded over %d GPU(s), full pipeline incl. "
                                     "SMPL LBS (6890 verts), predict_all_images contract B=8 T=20" % (n_total, world))
                        if strong else
@@ -451,8 +524,12 @@ def main():
                 result["e2e_verts_max_abs_err"] = modes[args.dtype]["e2e_verts_max_abs_err"]
                 result["e2e_joints_max_abs_err"] = modes[args.dtype]["e2e_joints_max_abs_err"]
                 result["value_meets_tolerance"] = bool(max(result["e2e_verts_max_abs_err"], result["e2e_joints_max_abs_err"]) <= tol)
+            if all_frames_diff is not None:
+                result["max_abs_diff_from_f32_operands_all_%d_frames" % n_total] = all_frames_diff
         if pcie_other:
             result["pcie_inclusive_fps_bf16"] = pcie_other.get("bf16")
+        if single and ref is not None and not args.no_stress and not args.only_main:
+            result["stress"] = stress_leg(span, span_host, plan, n_total, smpl, device)
         if not args.no_cpu_baseline and single:
             result["cpu_baseline"] = cpu_baseline()
             # second half of the metric: SMPL-stage vertex error vs the float64 oracle on device-regressed theta

@@ -121,14 +121,20 @@ class Tester(object):
                                    getattr(config, "mean_param_path", "") or self._default_mean_path(config))
         if smpl is None:
             smpl = load_smpl_constants(self.smpl_model_path, checkpoint_vars=weights)
-        # operand type of the GEMM stages: the reference graph is fp32 throughout (tester.py:64-66); the default is
-        # the fastest mode that stays inside its 1e-4 tolerance ('bf16x3'); 'bf16' / 'f32' are explicit choices
-        dtype = dtype or getattr(config, "dtype", DEFAULT_DTYPE)
+        # operand type of the GEMM stages: the reference graph is fp32 throughout (tester.py:64-66).  Default "auto": the
+        # fastest rung of precision.LADDER (bf16x3 -> f32 ResNet -> all f32) whose vertices / joints stay within 0.3 x
+        # the 1e-4 tolerance of the exact-fp32 mode on a probe batch run here, on the device, with THESE weights
+        # (precision.py; the report is self.precision).  'bf16x3' / 'bf16' / 'f32' are explicit choices, not probed.
+        dtype = dtype or getattr(config, "dtype", None) or "auto"
         device = device or getattr(config, "device", "cuda:0")
-        self.engine = HmmrEngine(weights, smpl, dtype=dtype, device=device,
-                                 num_conv_layers=self.num_conv_layers,
-                                 delta_t_values=self.delta_t_values,
-                                 resnet_chunk=getattr(config, "resnet_chunk", 0))
+        kw = dict(num_conv_layers=self.num_conv_layers, delta_t_values=self.delta_t_values,
+                  resnet_chunk=getattr(config, "resnet_chunk", 0))
+        self.precision = None
+        if dtype == "auto":
+            from .. import precision
+            self.engine, self.precision = precision.choose_engine(weights, smpl, device, pred_mode=self.pred_mode, **kw)
+        else:
+            self.engine = HmmrEngine(weights, smpl, dtype=dtype, device=device, **kw)
         self.smpl = SMPL(smpl, engine=self.engine)
         if self.engine.num_kps != config.num_kps:
             raise ValueError("config.num_kps=%d but the SMPL regressor has %d keypoints"

@@ -180,3 +180,44 @@ def test_fused_stem_equals_three_kernel_route(weights, gpu_device, dt):
         assert torch.equal(o, ref), "%s stem route differs from the three-kernel route: max |d| %.3e" % (
             name, float((o - ref).abs().max()))
     assert torch.equal(ref[-1], ref[-2]) and torch.equal(ref[-1], ref[3])    # zero images: tail == explicit
+
+
+# --------------------------------------------------------------------------- config 5 on one GPU
+def test_config5_4096_frame_video_on_one_gpu(weights, smpl_consts, gpu_device):
+    """BASELINE config 5's code path (`bench.py --gpus N --video-frames 4096`: ShardPlan of ONE 4096-frame video,
+    ShardedPredictor with the pipelined tail, 1024-frame ResNet passes) executed on hardware with N = 1: the packed
+    records of one step equal Tester.predict_all_images on the same 4096 device-resident frames bit for bit, and the
+    command line itself runs and reports the strong-scaling line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from human_dynamics_amd import dist as hd
+    from human_dynamics_amd.evaluation.tester import Tester
+    n = 4096
+    t = Tester(Config(batch_size=8), weights=weights, smpl=smpl_consts, dtype="bf16x3", device=gpu_device)
+    plan = hd.ShardPlan(n, 8, 20, 13, 1, 0)
+    assert (plan.f0, plan.f1, plan.o0, plan.o1, plan.w1 - plan.w0) == (0, n, 0, n, 512)
+    gen = torch.Generator(device=gpu_device)
+    gen.manual_seed(1234)                                      # bench.py's rank-0 span
+    span = torch.rand((n, 224, 224, 3), generator=gen, device=gpu_device) * 2 - 1
+    pred = hd.ShardedPredictor(t, n, 0, 1, pipeline=True, overlap_gather=True, step_streams=True)
+    rec = pred.run(span)
+    pred.finish()
+    torch.cuda.synchronize()
+    layout, _ = t.record_layout()
+    got = hd.unpack_outputs(rec, layout)
+    ref = t.predict_all_images(span)
+    for k, v in ref.items():
+        assert v.shape[0] == n and np.array_equal(got[k].cpu().numpy(), v), k
+    del pred, rec, got, ref, span
+    torch.cuda.empty_cache()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--video-frames", str(n), "--steps", "1", "--warmup", "0",
+                        "--only-main", "--no-cpu-baseline", "--no-pcie", "--dtype", "bf16x3"], cwd=root, capture_output=True,
+                       text=True, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and lines, r.stderr[-800:]
+    js = json.loads(lines[-1])
+    assert js["scaling"] == "strong" and js["frames_total"] == n and js["n_gpus"] == 1 and js["steps"] == 1
+    assert js["config"]["resnet_frames_encoded_per_gpu"] == n + 1 and js["value"] > 2000

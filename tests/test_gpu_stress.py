@@ -1,0 +1,94 @@
+"""Stress of the 1e-4 tolerance: the whole path on a 256-frame video (BASELINE config 4) for
+several weight seeds and two hard-conditioned sets (oracle/hard_weights.py), every one of the 256 output frames checked:
+
+  * against the float64 CPU oracle on sampled windows (first, last, inside), every element;
+  * against the exact-fp32 operand mode of the same kernels on ALL 256 frames (which is itself checked against the oracle
+    on the sampled windows, so the two bounds add up to a bound for every frame).
+
+Plain seeds must hold 1e-4 in bf16x3.  The hard sets are the ones bf16x3 does NOT survive; there the default operand
+selection (dtype="auto", human_dynamics_amd/precision.py) has to notice on its own and fall back to f32 operands where
+needed -- the test asserts both that bf16x3 alone breaks the probe bound and that the chosen mode holds 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import Config
+from human_dynamics_amd import assets
+
+pytestmark = pytest.mark.gpu
+F64 = torch.float64
+KEYS = ("verts", "joints", "verts_delta", "joints_delta")
+
+
+def _windows_of(frames, starts, T=20, margin=6):
+    out = np.zeros((len(starts), T) + frames.shape[1:], np.float32)
+    for k, s in enumerate(starts):
+        for j in range(T):
+            f = s - margin + j
+            if 0 <= f < len(frames):
+                out[k, j] = frames[f]
+    return out
+
+
+def _weights(kind):
+    if kind.startswith("seed"):
+        return assets.make_synthetic_weights(int(kind[4:]))
+    from oracle import hard_weights as H
+    w = H.make_hard_weights(3)
+    if kind == "hard_bn_gn":                 # hard BN / GN conditioning, the generator's ordinary fc3
+        plain = assets.make_synthetic_weights(3)
+        for k in plain:
+            if k.endswith("fc3/weights"):
+                w[k] = plain[k]
+        return w
+    if kind == "fc3_x10":                    # ordinary conditioning, fc3 at 10 x small_xavier (models.py:106-113)
+        plain = assets.make_synthetic_weights(3)
+        for k in plain:
+            if k.endswith("fc3/weights"):
+                plain[k] = w[k]
+        return plain
+    raise ValueError(kind)
+
+
+def _errors(got, ref, starts):
+    return {k: float(np.abs(np.stack([got[k][s:s + 8] for s in starts]) - ref[k][:, 6:14]).max()) for k in KEYS}
+
+
+@pytest.mark.parametrize("kind,starts", [("seed1", (0, 168)), ("seed2", (96, 248)), ("seed3", (0, 248)),
+                                         ("hard_bn_gn", (0, 96, 168, 248)), ("fc3_x10", (0, 96, 168, 248))])
+def test_tolerance_over_weight_sets(smpl_consts, gpu_device, kind, starts):
+    from human_dynamics_amd.evaluation.tester import Tester
+    from human_dynamics_amd import precision
+    from oracle import hmmr_oracle as O
+    w = _weights(kind)
+    frames = assets.make_synthetic_frames(256, seed=60 + len(kind))
+    ref = O.OracleTester(w, smpl_consts, batch_size=len(starts), dtype=F64).predict(_windows_of(frames, starts))
+    dev = torch.from_numpy(frames).to(gpu_device)
+    t32 = Tester(Config(batch_size=8), weights=w, smpl=smpl_consts, dtype="f32", device=gpu_device)
+    r32 = t32.predict_all_images(dev)
+    e32 = _errors(r32, ref, starts)
+    del t32
+    tx3 = Tester(Config(batch_size=8), weights=w, smpl=smpl_consts, dtype="bf16x3", device=gpu_device)
+    rx3 = tx3.predict_all_images(dev)
+    ex3 = _errors(rx3, ref, starts)
+    dx3 = {k: float(np.abs(rx3[k] - r32[k]).max()) for k in KEYS}            # all 256 frames
+    del tx3
+    ta = Tester(Config(batch_size=8), weights=w, smpl=smpl_consts, device=gpu_device)      # dtype="auto"
+    ra = ta.predict_all_images(dev)
+    ea = _errors(ra, ref, starts)
+    da = {k: float(np.abs(ra[k] - r32[k]).max()) for k in KEYS}
+    rep = ta.precision
+    print("\n[%s] f32 vs oracle %s\n[%s] bf16x3 vs oracle %s; vs f32 on all 256 frames %s\n[%s] auto -> %s: vs oracle %s; vs f32 on all "
+          "256 frames %s; probe %s" % (kind, e32, kind, ex3, dx3, kind, rep["operands"], ea, da, rep["rungs"]))
+    assert max(e32.values()) < 1e-4, (kind, "f32", e32)
+    # what the default ships: inside the tolerance on the sampled windows, and on every frame via the f32 mode
+    assert max(ea.values()) < precision.TOLERANCE, (kind, rep["operands"], ea)
+    assert max(da.values()) + max(e32.values()) < precision.TOLERANCE, (kind, rep["operands"], da, e32)
+    if kind.startswith("seed"):
+        assert rep["operands"] == "bf16x3" and max(ex3.values()) < precision.TOLERANCE
+        for k in KEYS:
+            assert np.array_equal(ra[k], rx3[k])                             # auto chose the same engine configuration
+    else:
+        # the hard sets break bf16x3 (if they ever stop doing so, make them harder): the selection must have moved on
+        assert max(dx3.values()) > rep["probe_tolerance"], (kind, dx3)
+        assert rep["operands"] != "bf16x3" and not rep["rungs"][0]["accepted"]

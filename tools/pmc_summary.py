@@ -72,7 +72,18 @@ def main():
     w = sum(1024 * wr[k][1] for k in rn if k in wr)
     busy = sum(mf[k][1] for k in rn if k in mf)
     g = sum(gui[k][1] for k in rn if k in gui)
+    fam = {}
+    for name, pred in (("conv_gemm_kernel", lambda k: "conv_gemm_kernel" in k and resnet_kernel(k, dtype)),
+                       ("fused_unit_tails", lambda k: "tail_split_kernel" in k or "bottleneck_tail_kernel" in k),
+                       ("fused_stem", lambda k: "stem_fused" in k)):
+        ks = [k for k in rn if pred(k)]
+        gg = sum(gui[k][1] for k in ks if k in gui)
+        if ks and gg:
+            fam[name] = {"launches_per_pass": round(sum(fe[k][0] for k in ks) / max(passes, 1), 2),
+                         "mfma_util": round(sum(mf[k][1] for k in ks if k in mf) / (gg / 8.0 * 1024.0), 4),
+                         "hbm_bytes_per_pass": round(sum(2 * 1024 * fe[k][1] + (1024 * wr[k][1] if k in wr else 0) for k in ks) / max(passes, 1))}
     if n and passes:
+        res["families"] = fam
         res["resnet_conv_gemm"] = {
             "launches": n, "resnet_passes": passes, "launches_per_pass": round(n / passes, 2),
             "hbm_bytes_per_pass": round((rd + w) / passes), "hbm_bytes_per_launch": round((rd + w) / n),
