@@ -324,9 +324,12 @@ def test_resnet_tile_choice_never_changes_a_bit(dt, weights, gpu_device):
             table[(u, nm)] = tile if ((tile not in (1, 5, 7) or cout % 128 == 0) and (tile != 8 or cout % 256 == 0)) else 6
         eng._set_tiles(table)
         assert torch.equal(eng.resnet(x, n_zero=1), ref), tile
-    tuned = HmmrEngine(weights, None, dtype=dt, device=gpu_device, autotune=True)
+    tuned = HmmrEngine(weights, None, dtype=dt, device=gpu_device, autotune="force")     # ignore the shipped tables: tune this size
     assert torch.equal(tuned.resnet(x, n_zero=1), ref)
-    assert 41 in tuned._tiles and len(tuned._tiles[41]) == len(layers)
+    assert 41 in tuned._tiles and len(tuned._tiles[41]) == len(layers) and [n for n, _ in tuned.tune_log] == [41]
+    shipped = HmmrEngine(weights, None, dtype=dt, device=gpu_device)                       # default: the shipped table of the nearest size
+    if shipped._shipped:
+        assert torch.equal(shipped.resnet(x, n_zero=1), ref) and shipped.tune_log == []
     assert torch.equal(tuned.resnet(x[:33], n_zero=0), eng.resnet(x[:33], n_zero=0))
 
 

@@ -106,6 +106,8 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     dt = sys.argv[2] if len(sys.argv) > 2 else "bf16"
     lib = L.load()
+    from human_dynamics_amd import engine as E
+    E._debug_from_env()              # HMMR_GEMM_PROBE (probe build only): K loop without MFMAs (1) / loads (2) / barriers (4)
     rows = []
     for name, h, cin, cout, k, stride, kind in SHAPES:
         if only and not any(o in name for o in only):
