@@ -61,7 +61,7 @@ class TailDesc(C.Structure):
 
 class Debug(C.Structure):
     """hmmr_debug_t: development switches, all zero = product defaults."""
-    _fields_ = [("stem_route", C.c_int), ("stem_no_conv1", C.c_int), ("gemm_probe", C.c_int), ("reserved", C.c_int * 5)]
+    _fields_ = [("stem_route", C.c_int), ("stem_no_conv1", C.c_int), ("gemm_probe", C.c_int), ("smpl_blend_valu", C.c_int), ("reserved", C.c_int * 4)]
 
 
 class Layer(C.Structure):
@@ -138,6 +138,8 @@ SIGNATURES = {
     "hmmr_eval_joints": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _vp]),
     "hmmr_eval_verts": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int, C.c_int, _fp, _vp]),
     "hmmr_global_rigid_transformation": (C.c_int, [_fp, _fp, _ip, C.c_int, _fp, _fp, C.c_int, _vp]),
+    "hmmr_smpl_fwd_records": (C.c_int, [C.POINTER(SmplConsts), _fp, C.c_int, C.c_int, _fp, C.c_int64, C.POINTER(C.c_int32),
+                                        _vp, C.c_size_t, _vp]),
     "hmmr_smpl_fwd_strided": (C.c_int, [C.POINTER(SmplConsts), _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int,
                                         _fp, _fp, _fp, _fp, C.c_int64, _vp, C.c_size_t, _vp]),
 }

@@ -27,13 +27,15 @@ __global__ void cast_rows_kernel(const float* __restrict__ in, TO* __restrict__ 
     store8(out + i * 8, v);
 }
 
-// theta0[m, :] = [src(row m or broadcast)[off : off+nd], 0...]
+// theta0[m, :] = [src(row m or broadcast)[off : off+nd], 0...]; the second state buffer starts as zeros (its padding
+// columns are operands of the K = 128 theta GEMM and are never written by fc3)
 __global__ void ief_init_theta_kernel(const float* __restrict__ src, int ld_src, int off, int nd,
-                                      float* __restrict__ theta, int m) {
+                                      float* __restrict__ theta, float* __restrict__ theta_other, int m) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)m * LDT) return;
     const int row = (int)(i / LDT), col = (int)(i % LDT);
     theta[i] = col < nd ? src[(long long)row * ld_src + off + col] : 0.f;
+    theta_other[i] = 0.f;
 }
 
 // omega_out[m, 85]: mode 0 (present regressor) -> theta[:, :85];
@@ -137,11 +139,10 @@ extern "C" int hmmr_ief_fwd_from(const hmmr_ief_weights_t* w, const float* strip
         const float* dsrc = w->delta_from_start ? start : (const float*)omegas;
         const int ld_d = w->delta_from_start ? ld_start : 85;
         if (r == 0)
-            hipLaunchKernelGGL(ief_init_theta_kernel, dim3(gth), dim3(256), 0, s, start, ld_start, 0, 85, th[0], m);
+            hipLaunchKernelGGL(ief_init_theta_kernel, dim3(gth), dim3(256), 0, s, start, ld_start, 0, 85, th[0], th[1], m);
         else
-            hipLaunchKernelGGL(ief_init_theta_kernel, dim3(gth), dim3(256), 0, s, dsrc, ld_d, w->no_optcam ? 0 : 3, nd_delta, th[0], m);
+            hipLaunchKernelGGL(ief_init_theta_kernel, dim3(gth), dim3(256), 0, s, dsrc, ld_d, w->no_optcam ? 0 : 3, nd_delta, th[0], th[1], m);
         HMMR_CHECK_HIP(hipGetLastError());
-        HMMR_CHECK_HIP(hipMemsetAsync(th[1], 0, (size_t)m * LDT * 4, s));
         // pre = phi . W1[:2048] + b1
         hmmr_conv_desc_t d = fc_desc(xin, w->dtype, m, 2048, R.fc1_phi, pre, w->dtype, 1024, 1024, base + L.sk, L.skbytes);
         if (hmmr_conv_gemm(&d, s)) return -2;

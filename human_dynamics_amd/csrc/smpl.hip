@@ -31,12 +31,22 @@ static constexpr int NFEAT_PAD = 220;    // blend loop length (multiple of 4; ro
 static constexpr int VT = 128;           // vertices per workgroup
 static constexpr int IB = 16;            // instances per workgroup
 
+// Record mode (hmmr_smpl_fwd_records): the m = R x n instances are R containers of n frames; instance r*n + i writes
+// field f of frame i's packed record at rec + i*ld + off[r][f].  n_per == 0: plain mode, instance i writes base + i*ld.
+enum { F_CAMS = 0, F_JOINTS, F_KPS, F_POSES, F_SHAPES, F_VERTS, F_OMEGAS, F_COUNT };
+struct RecMap { int n_per; int off[HMMR_MAX_REGRESSORS][F_COUNT]; };
+__device__ __forceinline__ float* rec_ptr(float* base, int inst, long long ld, const RecMap& rm, int field) {
+    if (rm.n_per == 0) return base + (long long)inst * ld;
+    const int r = inst / rm.n_per, i = inst - r * rm.n_per;
+    return base + (long long)i * ld + rm.off[r][field];
+}
+
 // ---- kernel 1 ------------------------------------------------------------ //
 __global__ __launch_bounds__(256) void smpl_pose_kernel(
     const float* __restrict__ theta, int ld_theta, const float* __restrict__ beta, int ld_beta,
     const float* __restrict__ j_template, const float* __restrict__ j_shapedirs,
     const int* __restrict__ parents, int m, float* __restrict__ feat, float* __restrict__ Aout,
-    float* __restrict__ rs, long long ld_rs) {
+    float* __restrict__ rs, long long ld_rs, const RecMap rm) {
     // per instance slot: local transform (R 9, t 3) and global (R 9, t 3) per joint
     __shared__ float sLoc[8][NJ][12];
     __shared__ float sGlb[8][NJ][12];
@@ -58,7 +68,7 @@ __global__ __launch_bounds__(256) void smpl_pose_kernel(
         R[3] = oc * ry * rx + s * rz; R[4] = c + oc * ry * ry;      R[5] = oc * ry * rz - s * rx;
         R[6] = oc * rz * rx - s * ry; R[7] = oc * rz * ry + s * rx; R[8] = c + oc * rz * rz;
         if (rs) {
-            float* o = rs + (long long)inst * ld_rs + j * 9;
+            float* o = rec_ptr(rs, inst, ld_rs, rm, F_POSES) + j * 9;
 #pragma unroll
             for (int e = 0; e < 9; ++e) o[e] = R[e];
         }
@@ -138,7 +148,7 @@ __global__ __launch_bounds__(256) void smpl_pose_kernel(
 __global__ __launch_bounds__(VT) void smpl_verts_kernel(
     const float* __restrict__ dirs, int vpad, const float* __restrict__ feat, const float* __restrict__ A,
     const int* __restrict__ lbs_idx, const float* __restrict__ lbs_w, int nnz, int nv, int m,
-    float* __restrict__ verts, long long ld_verts) {
+    float* __restrict__ verts, long long ld_verts, const RecMap rm) {
     __shared__ __attribute__((aligned(16))) float smem[IB * LDA + NFEAT_PAD * IB];
     float (*sA)[LDA] = (float (*)[LDA])smem;
     float (*sF)[IB] = (float (*)[IB])(smem + IB * LDA);          // [k][instance]: 4 instances per ds_read_b128
@@ -226,7 +236,111 @@ __global__ __launch_bounds__(VT) void smpl_verts_kernel(
         for (int q = 0; q < 4; ++q) {
             if (i0 + g + q < m) {
                 const float x = acc[(g + q) >> 1][0][(g + q) & 1], y = acc[(g + q) >> 1][1][(g + q) & 1], z = acc[(g + q) >> 1][2][(g + q) & 1];
-                float* o = verts + (long long)(i0 + g + q) * ld_verts + v * 3;
+                float* o = rec_ptr(verts, i0 + g + q, ld_verts, rm, F_VERTS) + v * 3;
+                o[0] = T[q][0] * x + T[q][1] * y + T[q][2] * z + T[q][3];
+                o[1] = T[q][4] * x + T[q][5] * y + T[q][6] * z + T[q][7];
+                o[2] = T[q][8] * x + T[q][9] * y + T[q][10] * z + T[q][11];
+            }
+        }
+    }
+}
+
+// ---- kernel 2, matrix-core form ------------------------------------------- //
+// The blend-shape product v_posed = [1, beta, pose_feature] . [v_template; shapedirs; posedirs] (batch_smpl.py:110-112,
+// 131-133) is the dense contraction of the stage: [m, 218] x [218, 3 x 6890].  Here it runs on the matrix cores in EXACT
+// fp32 (v_mfma_f32_32x32x2_f32: per output element an fmaf chain over k in ascending order -- the very sums
+// smpl_verts_kernel forms on the vector units), D[instance][vertex] per coordinate: a wave owns 32 vertices x 32
+// instances, the A operand (instance rows of the feature matrix) comes from LDS, the B operand (one basis row of the
+// planar `dirs` layout) is a coalesced 128-byte read per half wave, requested four k-pairs ahead.  A lane ends up with
+// its vertex's blended position for 16 instances, which is exactly what the skinning loop (unchanged: ELL weights, A in
+// LDS) consumes.  The skinning sum itself stays on the vector units: with SMPL's weights it is 4-sparse per vertex.
+static constexpr int IBM = 32;           // instances per workgroup (= MFMA rows)
+__global__ __launch_bounds__(256, 2) void smpl_verts_mfma_kernel(
+    const float* __restrict__ dirs, int vpad, const float* __restrict__ feat, const float* __restrict__ A,
+    const int* __restrict__ lbs_idx, const float* __restrict__ lbs_w, int nnz, int nv, int m,
+    float* __restrict__ verts, long long ld_verts, const RecMap rm) {
+    __shared__ __attribute__((aligned(16))) float smem[IBM * LDA + NFEAT_PAD * IBM];
+    float (*sA)[LDA] = (float (*)[LDA])smem;
+    float (*sF)[IBM] = (float (*)[IBM])(smem + IBM * LDA);       // [k][instance]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lc = lane & 31, lh = lane >> 5;
+    const int v = blockIdx.x * VT + wave * 32 + lc;              // this lane's vertex = its column of D (v < vpad always)
+    const int i0 = blockIdx.y * IBM;
+    for (int e = threadIdx.x; e < IBM * LDA; e += 256) {
+        const int ii = e / LDA;
+        sA[ii][e % LDA] = (i0 + ii < m) ? A[(long long)(i0 + ii) * LDA + (e % LDA)] : 0.f;
+    }
+    for (int e = threadIdx.x; e < IBM * NFEAT_PAD; e += 256) {   // (the scratch rows are sized for m rounded up to IBM)
+        const int ii = e / NFEAT_PAD, k = e % NFEAT_PAD;
+        sF[k][ii] = feat[(long long)(i0 + ii) * LDF + k];
+    }
+    f32x16 acc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+    // K step kk covers k = 2 kk (lanes 0-31) and 2 kk + 1 (lanes 32-63)
+    constexpr int NKK = NFEAT_PAD / 2, PF = 4;
+    static_assert(NKK % PF == 2, "the two-set loop below peels two steps");
+    float dv[2][PF][3];
+    auto fetch = [&](int kk, int set) {
+#pragma unroll
+        for (int q = 0; q < PF; ++q)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                dv[set][q][c] = (kk + q < NKK) ? (dirs + (long long)((2 * (kk + q) + lh) * 3 + c) * vpad)[v] : 0.f;
+    };
+    auto blend = [&](int kk, int set) {
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            if (kk + q < NKK) {
+                const float a = sF[2 * (kk + q) + lh][lc];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, dv[set][q][c], acc[c], 0, 0, 0);
+            }
+        }
+    };
+    fetch(0, 0);
+    __syncthreads();
+    for (int kk = 0; kk < NKK; kk += 2 * PF) {
+        fetch(kk + PF, 1);
+        blend(kk, 0);
+        fetch(kk + 2 * PF, 0);
+        blend(kk + PF, 1);
+    }
+    if (v >= nv) return;
+    // skinning, as in smpl_verts_kernel: the lane holds instances i0 + 8 g + 4 lh + {0..3} in accumulator rows 4 g .. 4 g + 3
+    const int* vidx = lbs_idx + (long long)v * nnz;
+    const float* vw = lbs_w + (long long)v * nnz;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int ib = 8 * g + 4 * lh;
+        if (i0 + ib >= m) continue;
+        float T[4][12];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 12; ++e) T[q][e] = 0.f;
+        for (int z = 0; z < nnz; ++z) {
+            const int jj = vidx[z] * 12;
+            const float wv = vw[z];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4* a4 = (const f32x4*)&sA[ib + q][jj];
+                const f32x4 r0 = a4[0], r1 = a4[1], r2 = a4[2];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    T[q][e] = fmaf(wv, r0[e], T[q][e]);
+                    T[q][4 + e] = fmaf(wv, r1[e], T[q][4 + e]);
+                    T[q][8 + e] = fmaf(wv, r2[e], T[q][8 + e]);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (i0 + ib + q < m) {
+                const float x = acc[0][4 * g + q], y = acc[1][4 * g + q], z = acc[2][4 * g + q];
+                float* o = rec_ptr(verts, i0 + ib + q, ld_verts, rm, F_VERTS) + v * 3;
                 o[0] = T[q][0] * x + T[q][1] * y + T[q][2] * z + T[q][3];
                 o[1] = T[q][4] * x + T[q][5] * y + T[q][6] * z + T[q][7];
                 o[2] = T[q][8] * x + T[q][9] * y + T[q][10] * z + T[q][11];
@@ -241,10 +355,21 @@ __global__ __launch_bounds__(256) void smpl_joints_kernel(
     const float* __restrict__ verts, const int* __restrict__ kptr, const int* __restrict__ kidx,
     const float* __restrict__ kval, const float* __restrict__ cams, int ld_cam, int nv, int nk,
     float* __restrict__ joints, float* __restrict__ kps, long long ld_verts, long long ld_joints,
-    long long ld_kps) {
+    long long ld_kps, const RecMap rm, const float* __restrict__ omegas) {
     const int inst = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const float* vb = verts + (long long)inst * ld_verts;
+    const float* vb = rec_ptr(const_cast<float*>(verts), inst, ld_verts, rm, F_VERTS);
+    const int cam_inst = rm.n_per ? inst % rm.n_per : inst;     // record mode: every container projects with omega_0's camera (tester.py:211-213)
+    if (rm.n_per) {
+        // the container's raw omega, its shape and the camera it was projected with: the record's remaining fields
+        // (make_fetch_dict, tester.py:217-227), written here instead of by three copies per container
+        const float* om = omegas + (long long)inst * 85;
+        const float* cm = cams + (long long)cam_inst * ld_cam;
+        const int t = threadIdx.x;
+        if (t < 85) rec_ptr(joints, inst, ld_joints, rm, F_OMEGAS)[t] = om[t];
+        else if (t < 95) rec_ptr(joints, inst, ld_joints, rm, F_SHAPES)[t - 85] = om[75 + (t - 85)];
+        else if (t < 98) rec_ptr(joints, inst, ld_joints, rm, F_CAMS)[t - 95] = cm[t - 95];
+    }
     for (int k = wave; k < nk; k += 4) {
         float sx = 0.f, sy = 0.f, sz = 0.f;
         for (int e = kptr[k] + lane; e < kptr[k + 1]; e += 64) {
@@ -257,11 +382,11 @@ __global__ __launch_bounds__(256) void smpl_joints_kernel(
             sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o); sz += __shfl_xor(sz, o);
         }
         if (lane == 0) {
-            float* jo = joints + (long long)inst * ld_joints + k * 3;
+            float* jo = rec_ptr(joints, inst, ld_joints, rm, F_JOINTS) + k * 3;
             jo[0] = sx; jo[1] = sy; jo[2] = sz;
             if (kps && cams) {
-                const float* cm = cams + (long long)inst * ld_cam;
-                float* ko = kps + (long long)inst * ld_kps + k * 2;
+                const float* cm = cams + (long long)cam_inst * ld_cam;
+                float* ko = rec_ptr(kps, inst, ld_kps, rm, F_KPS) + k * 2;
                 ko[0] = cm[0] * (sx + cm[1]);
                 ko[1] = cm[0] * (sy + cm[2]);
             }
@@ -330,14 +455,15 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 extern "C" size_t hmmr_smpl_workspace_bytes(int m) {
     if (m <= 0) return 0;
-    const size_t mp = ((size_t)m + IB - 1) / IB * IB;          // the verts kernel reads whole instance groups
+    const size_t mp = ((size_t)m + IBM - 1) / IBM * IBM;       // the verts kernels read whole instance groups
     return align_up(mp * LDF * 4, 256) + align_up(mp * LDA * 4, 256);
 }
 
 static int smpl_launch(const hmmr_smpl_consts_t* c, const float* theta, int ld_theta, const float* beta,
                        int ld_beta, const float* cams, int ld_cam, int m, float* verts, float* joints,
                        float* kps, float* rs, long long ld_verts, long long ld_joints, long long ld_kps,
-                       long long ld_rs, void* ws, size_t ws_bytes, void* stream) {
+                       long long ld_rs, void* ws, size_t ws_bytes, void* stream, const RecMap& rm = RecMap{},
+                       const float* omegas = nullptr) {
     HMMR_REQUIRE(c && theta && beta && verts && joints && ws, "hmmr_smpl_fwd: null argument");
     HMMR_REQUIRE(m > 0, "hmmr_smpl_fwd: m must be positive");
     HMMR_REQUIRE(c->lbs_nnz >= 1 && c->lbs_nnz <= NJ, "hmmr_smpl_fwd: lbs_nnz=%d out of range", c->lbs_nnz);
@@ -347,18 +473,23 @@ static int smpl_launch(const hmmr_smpl_consts_t* c, const float* theta, int ld_t
                  "hmmr_smpl_fwd: dirs row stride vpad=%d must be a multiple of %d covering num_verts=%d", c->vpad, VT, c->num_verts);
     hipStream_t s = (hipStream_t)stream;
     float* feat = (float*)ws;
-    float* A = (float*)((char*)ws + align_up(((size_t)m + IB - 1) / IB * IB * LDF * 4, 256));
+    float* A = (float*)((char*)ws + align_up(((size_t)m + IBM - 1) / IBM * IBM * LDF * 4, 256));
     const int vtiles = (c->num_verts + VT - 1) / VT;
     hipLaunchKernelGGL(smpl_pose_kernel, dim3((m + 7) / 8), dim3(256), 0, s, theta, ld_theta, beta, ld_beta,
-                       c->j_template, c->j_shapedirs, c->parents, m, feat, A, rs, ld_rs);
+                       c->j_template, c->j_shapedirs, c->parents, m, feat, A, rs, ld_rs, rm);
     HMMR_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(smpl_verts_kernel, dim3(vtiles, (m + IB - 1) / IB), dim3(VT), 0, s, c->dirs,
-                       c->vpad, (const float*)feat, (const float*)A, c->lbs_idx, c->lbs_w, c->lbs_nnz,
-                       c->num_verts, m, verts, ld_verts);
+    if (hmmr_debug_state()->smpl_blend_valu)     // development switch: the vector-unit form of the blend product
+        hipLaunchKernelGGL(smpl_verts_kernel, dim3(vtiles, (m + IB - 1) / IB), dim3(VT), 0, s, c->dirs,
+                           c->vpad, (const float*)feat, (const float*)A, c->lbs_idx, c->lbs_w, c->lbs_nnz,
+                           c->num_verts, m, verts, ld_verts, rm);
+    else
+        hipLaunchKernelGGL(smpl_verts_mfma_kernel, dim3(vtiles, (m + IBM - 1) / IBM), dim3(256), 0, s, c->dirs,
+                           c->vpad, (const float*)feat, (const float*)A, c->lbs_idx, c->lbs_w, c->lbs_nnz,
+                           c->num_verts, m, verts, ld_verts, rm);
     HMMR_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(smpl_joints_kernel, dim3(m), dim3(256), 0, s, (const float*)verts, c->kreg_ptr,
                        c->kreg_idx, c->kreg_val, cams, ld_cam, c->num_verts, c->num_kps, joints, kps,
-                       ld_verts, ld_joints, ld_kps);
+                       ld_verts, ld_joints, ld_kps, rm, omegas);
     HMMR_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -379,4 +510,22 @@ extern "C" int hmmr_smpl_fwd_strided(const hmmr_smpl_consts_t* c, const float* t
                                      void* ws, size_t ws_bytes, void* stream) {
     return smpl_launch(c, theta, ld_theta, beta, ld_beta, cams, ld_cam, m, verts, joints, kps, rs,
                        ld_out, ld_out, ld_out, ld_out, ws, ws_bytes, stream);
+}
+
+// R containers of n frames in ONE launch set, every field of the packed per-frame record written in place.
+extern "C" int hmmr_smpl_fwd_records(const hmmr_smpl_consts_t* c, const float* omegas, int num_containers, int n,
+                                     float* rec, int64_t ld_rec, const int32_t* field_offsets, void* ws, size_t ws_bytes,
+                                     void* stream) {
+    HMMR_REQUIRE(c && omegas && rec && field_offsets, "hmmr_smpl_fwd_records: null argument");
+    HMMR_REQUIRE(num_containers >= 1 && num_containers <= HMMR_MAX_REGRESSORS && n > 0, "hmmr_smpl_fwd_records: bad container count / frames");
+    RecMap rm;
+    rm.n_per = n;
+    for (int r = 0; r < HMMR_MAX_REGRESSORS; ++r)
+        for (int f = 0; f < F_COUNT; ++f) {
+            rm.off[r][f] = r < num_containers ? field_offsets[r * F_COUNT + f] : 0;
+            HMMR_REQUIRE(rm.off[r][f] >= 0 && rm.off[r][f] < ld_rec, "hmmr_smpl_fwd_records: field offset outside the record");
+        }
+    // instance r*n + i: theta / beta = columns 3..74 / 75..84 of omegas row r*n + i; camera = omegas row i (container 0)
+    return smpl_launch(c, omegas + 3, 85, omegas + 75, 85, omegas, 85, num_containers * n, rec, rec, rec, rec,
+                       ld_rec, ld_rec, ld_rec, ld_rec, ws, ws_bytes, stream, rm, omegas);
 }

@@ -26,10 +26,11 @@ DEFAULT_DTYPE = "bf16x3"
 TILE_TABLES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tile_tables.json")
 
 
-def set_debug(stem_route=0, stem_no_conv1=0, gemm_probe=0):
+def set_debug(stem_route=0, stem_no_conv1=0, gemm_probe=0, smpl_blend_valu=0):
     """Development switches of libhmmr_hip.so (hmmr_debug_t; process-wide, zeros = product defaults)."""
     d = L.Debug()
     d.stem_route, d.stem_no_conv1, d.gemm_probe = int(stem_route), int(stem_no_conv1), int(gemm_probe)
+    d.smpl_blend_valu = int(smpl_blend_valu)
     L.load().hmmr_set_debug(C.byref(d))
 
 
@@ -426,6 +427,19 @@ class HmmrEngine(object):
             cams.data_ptr(), cams.stride(0), m, base + 4 * off_verts, base + 4 * off_joints,
             base + 4 * off_kps, base + 4 * off_rs, rec.stride(0), ws.data_ptr(), nbytes, self._stream()),
             "hmmr_smpl_fwd_strided")
+
+    def smpl_records(self, om, rec, field_offsets):
+        """All containers in one launch set (hmmr_smpl_fwd_records): om [R,n,85] contiguous fp32 (present first), rec
+        [>= n, rec_len] fp32 with unit inner stride, field_offsets [R][7] = float offsets of (cams, joints, kps, poses,
+        shapes, verts, omegas) of each container inside a record."""
+        R, n = om.shape[0], om.shape[1]
+        assert om.is_cuda and om.dtype == torch.float32 and om.is_contiguous() and om.shape[2] == 85
+        assert rec.dtype == torch.float32 and rec.stride(1) == 1 and rec.shape[0] >= n
+        offs = (C.c_int32 * (R * 7))(*[int(o) for row in field_offsets for o in row])
+        nbytes = self.lib.hmmr_smpl_workspace_bytes(R * n)
+        ws = self._ws["smpl"].get(nbytes)
+        L.check(self.lib.hmmr_smpl_fwd_records(C.byref(self.sc), om.data_ptr(), R, n, rec.data_ptr(), rec.stride(0), offs,
+                                               ws.data_ptr(), nbytes, self._stream()), "hmmr_smpl_fwd_records")
 
     def groupnorm_relu(self, x, gamma, beta, groups=32, out_dtype=L.HMMR_F32):
         x = self.to_device(x)

@@ -241,20 +241,17 @@ class Tester(object):
         off = {k: (o, sz) for k, shp, o, sz in layout}
         if out is None:
             out = torch.empty((n, rec_len), dtype=torch.float32, device=eng.device)
-        rec = out[:n]
-        cams0 = om[0][:, :3]
+        if n == 0:
+            return out
+        rows = []
         for r, key in enumerate(eng.reg_keys):
             if key == 0:
-                base = {k: off[k][0] for k in OUTPUT_KEYS}
+                rows.append([off[k][0] for k in OUTPUT_KEYS])
             else:
                 d = r - 1
-                base = {k: off[k + "_delta"][0] + d * (off[k + "_delta"][1] // len(self.delta_t_values))
-                        for k in OUTPUT_KEYS}
-            eng.smpl_into(om[r][:, 3:75], om[r][:, 75:85], cams0, rec,
-                          base["verts"], base["joints"], base["kps"], base["poses"])
-            rec[:, base["cams"]:base["cams"] + 3] = cams0
-            rec[:, base["shapes"]:base["shapes"] + 10] = om[r][:, 75:85]
-            rec[:, base["omegas"]:base["omegas"] + 85] = om[r]
+                rows.append([off[k + "_delta"][0] + d * (off[k + "_delta"][1] // len(self.delta_t_values)) for k in OUTPUT_KEYS])
+        # one launch set for every container; cams / shapes / omegas are written by the keypoint kernel (no copies)
+        eng.smpl_records(om.contiguous(), out, rows)
         return out
 
     def _movie_strips(self, img_feat_full):

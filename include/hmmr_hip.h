@@ -50,7 +50,9 @@ typedef struct hmmr_debug_s {
     int gemm_probe;        /* read only by the -DHMMR_GEMM_PROBE development build (tools/probe_build.sh): the GEMM K loop
                               drops its MFMAs (1), its operand loads after the first stage (2) or its barriers (4), to see
                               which of the three bounds a shape; results are garbage then.  The product build ignores it. */
-    int reserved[5];
+    int smpl_blend_valu;   /* 1: the SMPL blend-shape product on the vector units (smpl_verts_kernel) instead of the exact-fp32
+                              matrix-core form (smpl_verts_mfma_kernel); the two form the same fmaf chains */
+    int reserved[4];
 } hmmr_debug_t;
 void hmmr_set_debug(const hmmr_debug_t* d);     /* NULL = defaults */
 void hmmr_get_debug(hmmr_debug_t* d);
@@ -348,6 +350,16 @@ int hmmr_smpl_fwd_strided(const hmmr_smpl_consts_t* c, const float* theta, int l
                           const float* beta, int ld_beta, const float* cams, int ld_cam, int m,
                           float* verts, float* joints, float* kps, float* rs, int64_t ld_out,
                           void* ws, size_t ws_bytes, void* stream);
+/* The tail of build_test_model for ALL containers at once (tester.py:196-227: OmegasPred.compute_all_smpl over the present
+ * container and the delta containers + make_fetch_dict): omegas [num_containers][n][85] fp32 (container 0 = present, as
+ * hmmr_ief_fwd writes them) -> every field of frame i's packed record rec[i * ld_rec ...]: container r's cams [3], joints
+ * [K,3], kps [K,2], poses [24,3,3], shapes [10], verts [V,3] and raw omega [85] at float offset
+ * field_offsets[r * 7 + {0..6}] (HOST array, that field order).  Every container is projected with container 0's camera
+ * (tester.py:211-213), and `cams` holds that camera.  One launch set (three kernels) whatever num_containers is;
+ * workspace = hmmr_smpl_workspace_bytes(num_containers * n). */
+int hmmr_smpl_fwd_records(const hmmr_smpl_consts_t* c, const float* omegas, int num_containers, int n,
+                          float* rec, int64_t ld_rec, const int32_t* field_offsets, void* ws, size_t ws_bytes,
+                          void* stream);
 /* batch_global_rigid_transformation on its own (src/tf_smpl/batch_lbs.py:133-194):
  * Rs [m,24,3,3], Js [m,24,3], parents [24] -> new_J [m,24,3], A [m,24,4,4] (relative transforms for LBS).
  * rotate_base != 0: the root rotation is R_0 . diag(1, -1, -1) (batch_lbs.py:151-158; the hot path passes 0). */

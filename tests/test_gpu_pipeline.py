@@ -407,3 +407,53 @@ def test_batch_global_rigid_transformation_mirror(smpl_consts, gpu_device):
     assert new_j.shape == (7, 24, 3) and A.shape == (7, 24, 4, 4)
     assert np.abs(new_j.cpu().numpy() - ref_j.numpy()).max() < 2e-6
     assert np.abs(A.cpu().numpy() - ref_A.numpy()).max() < 2e-6
+
+
+def test_one_smpl_launch_set_for_all_containers_equals_per_container_calls(weights, smpl_consts, gpu_device):
+    """hmmr_smpl_fwd_records (all containers in three launches, cams / shapes / omegas written by the keypoint kernel)
+    against one hmmr_smpl_fwd_strided per container + the three field copies it replaces: the same bytes in every
+    record, including a ragged instance count (the verts kernel works on groups of 16 instances)."""
+    import torch
+    from human_dynamics_amd.evaluation.tester import Tester, OUTPUT_KEYS
+    t = Tester(Config(batch_size=8), weights=weights, smpl=smpl_consts, dtype="f32", device=gpu_device)
+    eng = t.engine
+    layout, rec_len = t.record_layout()
+    off = {k: (o, sz) for k, shp, o, sz in layout}
+    for n in (1, 21, 64):
+        strips = torch.randn((n, 2048), generator=torch.Generator(device=gpu_device).manual_seed(n), device=gpu_device)
+        om = eng.ief(strips)
+        got = t.records_from_omegas(om, torch.full((n, rec_len), float("nan"), device=gpu_device))
+        ref = torch.full((n, rec_len), float("nan"), device=gpu_device)
+        cams0 = om[0][:, :3]
+        for r, key in enumerate(eng.reg_keys):
+            base = ({k: off[k][0] for k in OUTPUT_KEYS} if key == 0 else
+                    {k: off[k + "_delta"][0] + (r - 1) * (off[k + "_delta"][1] // 2) for k in OUTPUT_KEYS})
+            eng.smpl_into(om[r][:, 3:75], om[r][:, 75:85], cams0, ref, base["verts"], base["joints"], base["kps"], base["poses"])
+            ref[:, base["cams"]:base["cams"] + 3] = cams0
+            ref[:, base["shapes"]:base["shapes"] + 10] = om[r][:, 75:85]
+            ref[:, base["omegas"]:base["omegas"] + 85] = om[r]
+        assert not torch.isnan(ref).any() and not torch.isnan(got).any()          # every float of the record is written
+        assert torch.equal(got, ref), n
+
+
+def test_smpl_blend_on_matrix_cores_equals_the_vector_form(smpl_consts, gpu_device):
+    """smpl_verts_mfma_kernel (the dense blend-shape product [m,218] x [218,3 x 6890] as exact-fp32 MFMAs,
+    v_mfma_f32_32x32x2_f32) against smpl_verts_kernel (the same fmaf chains on the vector units): the vertices, and
+    everything computed from them, bit for bit -- ragged instance counts included (32-instance MFMA blocks, the last
+    vertex tile reaches past vertex 6889)."""
+    import torch
+    from human_dynamics_amd.engine import HmmrEngine, set_debug
+    eng = HmmrEngine(None, smpl_consts, device=gpu_device)
+    rng = np.random.default_rng(8)
+    for m in (1, 33, 70):
+        theta = (rng.normal(size=(m, 72)) * 0.6).astype(np.float32)
+        beta = rng.normal(size=(m, 10)).astype(np.float32)
+        cams = rng.normal(size=(m, 3)).astype(np.float32)
+        try:
+            set_debug(smpl_blend_valu=1)
+            ref = [t.clone() for t in eng.smpl(theta, beta, cams)]
+        finally:
+            set_debug()
+        got = eng.smpl(theta, beta, cams)
+        for a, b, name in zip(got, ref, ("verts", "joints", "kps", "Rs")):
+            assert torch.equal(a, b), (name, m, float((a - b).abs().max()))
