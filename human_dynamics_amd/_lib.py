@@ -61,7 +61,7 @@ class TailDesc(C.Structure):
 
 class Debug(C.Structure):
     """hmmr_debug_t: development switches, all zero = product defaults."""
-    _fields_ = [("stem_route", C.c_int), ("stem_no_conv1", C.c_int), ("gemm_probe", C.c_int), ("smpl_blend_valu", C.c_int), ("reserved", C.c_int * 4)]
+    _fields_ = [("stem_route", C.c_int), ("stem_no_conv1", C.c_int), ("gemm_probe", C.c_int), ("smpl_blend_mfma", C.c_int), ("reserved", C.c_int * 4)]
 
 
 class Layer(C.Structure):

@@ -248,8 +248,8 @@ __global__ __launch_bounds__(VT) void smpl_verts_kernel(
 // ---- kernel 2, matrix-core form ------------------------------------------- //
 // The blend-shape product v_posed = [1, beta, pose_feature] . [v_template; shapedirs; posedirs] (batch_smpl.py:110-112,
 // 131-133) is the dense contraction of the stage: [m, 218] x [218, 3 x 6890].  Here it runs on the matrix cores in EXACT
-// fp32 (v_mfma_f32_32x32x2_f32: per output element an fmaf chain over k in ascending order -- the very sums
-// smpl_verts_kernel forms on the vector units), D[instance][vertex] per coordinate: a wave owns 32 vertices x 32
+// fp32 (v_mfma_f32_32x32x2_f32: exact fp32 products and fp32 accumulation; measured within one ulp of the fmaf chains
+// smpl_verts_kernel forms on the vector units, not bit-identical to them), D[instance][vertex] per coordinate: a wave owns 32 vertices x 32
 // instances, the A operand (instance rows of the feature matrix) comes from LDS, the B operand (one basis row of the
 // planar `dirs` layout) is a coalesced 128-byte read per half wave, requested four k-pairs ahead.  A lane ends up with
 // its vertex's blended position for 16 instances, which is exactly what the skinning loop (unchanged: ELL weights, A in
@@ -478,7 +478,11 @@ static int smpl_launch(const hmmr_smpl_consts_t* c, const float* theta, int ld_t
     hipLaunchKernelGGL(smpl_pose_kernel, dim3((m + 7) / 8), dim3(256), 0, s, theta, ld_theta, beta, ld_beta,
                        c->j_template, c->j_shapedirs, c->parents, m, feat, A, rs, ld_rs, rm);
     HMMR_CHECK_HIP(hipGetLastError());
-    if (hmmr_debug_state()->smpl_blend_valu)     // development switch: the vector-unit form of the blend product
+    // Default: the vector-unit form.  Measured on MI355X (tools/smpl_bench.py, profiles/r03b): 86.9 us per 256 instances
+    // against 106.7 us for the matrix-core form below -- v_mfma_f32_32x32x2_f32 runs at the vector units' own fp32 rate,
+    // so the MFMA form can only win on operand delivery, and the packed-FMA kernel (two instances per v_pk_fma_f32, the
+    // coefficients as LDS broadcasts) already has the cheaper one.  hmmr_debug_t.smpl_blend_mfma selects the MFMA form.
+    if (!hmmr_debug_state()->smpl_blend_mfma)
         hipLaunchKernelGGL(smpl_verts_kernel, dim3(vtiles, (m + IB - 1) / IB), dim3(VT), 0, s, c->dirs,
                            c->vpad, (const float*)feat, (const float*)A, c->lbs_idx, c->lbs_w, c->lbs_nnz,
                            c->num_verts, m, verts, ld_verts, rm);

@@ -436,10 +436,11 @@ def test_one_smpl_launch_set_for_all_containers_equals_per_container_calls(weigh
         assert torch.equal(got, ref), n
 
 
-def test_smpl_blend_on_matrix_cores_equals_the_vector_form(smpl_consts, gpu_device):
+def test_smpl_blend_on_matrix_cores_agrees_with_the_vector_form(smpl_consts, gpu_device):
     """smpl_verts_mfma_kernel (the dense blend-shape product [m,218] x [218,3 x 6890] as exact-fp32 MFMAs,
-    v_mfma_f32_32x32x2_f32) against smpl_verts_kernel (the same fmaf chains on the vector units): the vertices, and
-    everything computed from them, bit for bit -- ragged instance counts included (32-instance MFMA blocks, the last
+    v_mfma_f32_32x32x2_f32; selectable through hmmr_debug_t.smpl_blend_mfma) against the default smpl_verts_kernel
+    (fmaf chains on the vector units): both are fp32 sums of the same exact products, they agree to rounding (measured
+    6e-8 = one ulp at the vertices' magnitude) -- ragged instance counts included (32-instance MFMA blocks, the last
     vertex tile reaches past vertex 6889)."""
     import torch
     from human_dynamics_amd.engine import HmmrEngine, set_debug
@@ -449,11 +450,12 @@ def test_smpl_blend_on_matrix_cores_equals_the_vector_form(smpl_consts, gpu_devi
         theta = (rng.normal(size=(m, 72)) * 0.6).astype(np.float32)
         beta = rng.normal(size=(m, 10)).astype(np.float32)
         cams = rng.normal(size=(m, 3)).astype(np.float32)
+        ref = [t.clone() for t in eng.smpl(theta, beta, cams)]
         try:
-            set_debug(smpl_blend_valu=1)
-            ref = [t.clone() for t in eng.smpl(theta, beta, cams)]
+            set_debug(smpl_blend_mfma=1)
+            got = [t.clone() for t in eng.smpl(theta, beta, cams)]
         finally:
             set_debug()
-        got = eng.smpl(theta, beta, cams)
         for a, b, name in zip(got, ref, ("verts", "joints", "kps", "Rs")):
-            assert torch.equal(a, b), (name, m, float((a - b).abs().max()))
+            assert float((a - b).abs().max()) < 5e-7, (name, m, float((a - b).abs().max()))
+        assert torch.equal(got[3], ref[3])                # the rotations do not depend on the blend kernel
