@@ -9,7 +9,7 @@ R=$(pwd); O=$R/gpurun_out/$TAG; mkdir -p $O
 export HMMR_TILE_CACHE=/tmp/tiles_$TAG.json
 cd /tmp && export TMPDIR=/tmp
 SER="python $R/bench.py --dtype $DT --serial --only-main --no-cpu-baseline --no-pcie --steps 6 --warmup 2"
-python $R/bench.py --dtype $DT --steps 20 > $O/bench.json 2> $O/bench.err
+python $R/bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err      # the driver's command (dtype auto)
 $SER > $O/bench_serial.json 2>> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- $SER > $O/bench_serial_under_rocprof.json 2>> $O/rocprof.err
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES"; do
