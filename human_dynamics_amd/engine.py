@@ -194,9 +194,9 @@ class HmmrEngine(object):
             return True
         return not any(max(k, nt) <= 1.3 * min(k, nt) for k in self._tiles)
 
-    def _tune_resnet(self, images, n, n_zero, ws_key="resnet"):
-        """Pick hmmr_layer_t.tile for every ResNet conv at this batch size: one instrumented pass per
-        candidate tile (every layer timed in place, behind its real producer), fastest wins per layer.
+    def _tune_resnet(self, images, n, n_zero, ws_key="resnet", reps=3):
+        """Pick hmmr_layer_t.tile for every ResNet conv at this batch size: `reps` instrumented passes per
+        candidate tile (the first is a warm-up; every layer timed in place, behind its real producer), fastest wins per layer.
         The tile never changes a result bit (each output element is one fixed-order K reduction), it
         only moves the balance between tile-count quantisation, occupancy and operand reuse, which
         flips between layers as the batch grows.  ~90 ms once per batch size."""
@@ -217,7 +217,7 @@ class HmmrEngine(object):
                     cout = U.depth + U.base
                 lay.tile = cand if ((cand not in (1, 5, 7) or cout % 128 == 0) and (cand != 8 or cout % 256 == 0)) else 0
             t = None
-            for rep in range(3):
+            for rep in range(reps):
                 pm = (C.c_float * L.RESNET_PROF_SLOTS)()
                 L.check(self.lib.hmmr_resnet50_fwd(C.byref(self.rw), src, n, n_zero, phi.data_ptr(), ws.data_ptr(),
                                                    nbytes, self._stream(), pm), "hmmr_resnet50_fwd")

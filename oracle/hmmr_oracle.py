@@ -83,7 +83,10 @@ def quantize(x, emulate):
         return hi.to(x.dtype)
     if emulate == "bf16x3":
         return (hi.to(torch.float64) + (x32 - hi).to(torch.bfloat16).to(torch.float64)).to(x.dtype)
-    raise ValueError("emulate must be None, 'bf16' or 'bf16x3'")
+    if emulate == "f16x3":      # the same split with fp16 halves (11 + 11 bits; fp16 subnormals kept, as the f16 MFMA keeps them)
+        h16 = x32.to(torch.float16).to(torch.float32)
+        return (h16.to(torch.float64) + (x32 - h16).to(torch.float16).to(torch.float64)).to(x.dtype)
+    raise ValueError("emulate must be None, 'bf16', 'bf16x3' or 'f16x3'")
 
 
 def _fold_bn32(w, prefix):
@@ -105,8 +108,8 @@ def resnet_v2_50_emulated(images_nhwc, w, emulate, fold_shortcut=None):
     such a difference tips over a rounding boundary)."""
     dt = torch.float64
     q = lambda t: quantize(t, emulate)
-    if fold_shortcut is None:      # bf16x3: the conv shortcut of a stride-1 unit is accumulated inside conv3's GEMM, never stored
-        fold_shortcut = emulate == "bf16x3"
+    if fold_shortcut is None:      # split modes: the conv shortcut of a stride-1 unit is accumulated inside conv3's GEMM, never stored
+        fold_shortcut = emulate in ("bf16x3", "f16x3")
 
     def conv(x, name, stride=1, pad=0):
         wt = q(_t(w[name], dt)).permute(3, 2, 0, 1).contiguous()

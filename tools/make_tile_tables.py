@@ -6,7 +6,7 @@ write them in the format `human_dynamics_amd/tile_tables.json` ships (dev aid, r
 Keys "<hmmr_dtype_t>:<frames>" -> {"<unit>:<layer>": tile}.  Sizes: 20-frame windows are below the tuner's floor; 40 (the operand-mode probe, precision.py); 64 / 65
 (config 2, FeatureExtractor batches), 128 / 129 (the two concurrent parts of a 256-frame shard + its zero image), 256 / 257
 (a 256-frame shard as one pass: the bench's step streams), 512 / 513 and 1024 (config 3 / long device-resident videos).
-The engine uses the nearest size within 30 %, so these cover 32 ... 1330 frames.  Best of two tuning passes per size."""
+The engine uses the nearest size within 30 %, so these cover 32 ... 1330 frames.  Per candidate tile the minimum over five timed passes (the on-line tuner takes two)."""
 import json
 import os
 import sys
@@ -32,7 +32,7 @@ for dt in dtypes:
     for nt in SIZES:
         n_zero = nt % 2                       # the odd sizes are "shard + the zero padding image"
         n = nt - n_zero
-        tab = eng._tune_resnet(frames[:n], n, n_zero)
+        tab = eng._tune_resnet(frames[:n], n, n_zero, reps=6)       # min over five timed passes per candidate tile
         eng._set_tiles(tab)
         result["%d:%d" % (DTYPES[dt], nt)] = {"%d:%s" % k: int(v) for k, v in sorted(tab.items())}
         print(dt, nt, "tuned in %.0f ms" % eng.tune_log[-1][1], flush=True)
