@@ -1,6 +1,6 @@
 """Headline benchmark: frames/sec/GPU of HMMR's inference hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames 256] [--dtype bf16x3] [--video-frames V]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames 256] [--dtype f16x3] [--video-frames V]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -20,11 +20,11 @@ separately as `pcie_inclusive_fps`.
 `value` is the mode that meets the reference tolerance (vertices / joints within
 1e-4 of the fp32 TF graph): `--dtype auto` (the drop-in default), which probes the
 weights on the device (human_dynamics_amd/precision.py) and for the synthetic
-seed-0 weights settles on bf16x3 -- split-bf16 operands (hi/lo pairs, three bf16
-MFMAs per product, fp32 accumulate).  `stress` in the same line repeats the
+seed-0 weights settles on f16x3 -- split-fp16 operands (hi/lo pairs, three fp16
+MFMAs per product, fp32 accumulate; filters scaled per output channel).  `stress` in the same line repeats the
 end-to-end error for more weight seeds and two hard-conditioned sets.  On one GPU the same line also
 carries `modes`: fps and the END-TO-END vertex / joint error against the float64
-oracle for every operand mode timed (bf16x3, bf16, f32), so the throughput of the
+oracle for every operand mode timed (f16x3, bf16, f32), so the throughput of the
 cheaper, out-of-tolerance bf16 mode is visible next to it but never the headline.
 
 With N > 1 ranks: default = weak scaling (every rank its own 256-frame shard; one
@@ -57,8 +57,8 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 RESNET_FLOPS_PER_FRAME = 6.9604e9        # 3.4802 GMAC, 53 convs
 PEAK_BF16 = 2.5e15                       # dense MFMA peak, MI355X_MICROARCH.md
 PEAK_F32 = 157.3e12
-# bf16x3 issues three bf16 MFMAs per algorithmic multiply-add: its MFMA ceiling in algorithmic FLOP/s
-PEAKS = {"bf16": PEAK_BF16, "bf16x3": PEAK_BF16 / 3.0, "f32": PEAK_F32}
+# f16x3 issues three fp16 MFMAs (same rate as bf16: 2.5 PF dense) per algorithmic multiply-add: its MFMA ceiling in algorithmic FLOP/s
+PEAKS = {"bf16": PEAK_BF16, "f16x3": PEAK_BF16 / 3.0, "f32": PEAK_F32}
 ERR_WINDOW_START = 96                    # output frames [96, 104) are checked end to end against the oracle
 
 
@@ -270,7 +270,7 @@ def roofline_leg(tester, plan, span, dtype, frames):
     _, prof = eng.resnet(span, prof=True, n_zero=1)
     eng.resnet_streams = streams_used
     mask = conv_slot_mask()
-    fused_stem = dtype in ("bf16", "bf16x3")      # slot 0 = the fused stem kernel (an MFMA launch); else slot 1 = the stem GEMM
+    fused_stem = dtype in ("bf16", "f16x3")      # slot 0 = the fused stem kernel (an MFMA launch); else slot 1 = the stem GEMM
     if fused_stem:
         mask[0], mask[1] = True, False
     conv_share = float(prof[:len(mask)][mask].sum()) / float(prof[:len(mask)].sum())
@@ -285,7 +285,7 @@ def roofline_leg(tester, plan, span, dtype, frames):
     avg_launch_s = conv_ms * 1e-3 / n_conv
     achieved = flops_per_launch / avg_launch_s
     peak = PEAKS[dtype]
-    mfma_per_product = 3 if dtype == "bf16x3" else 1
+    mfma_per_product = 3 if dtype == "f16x3" else 1
     # HBM traffic per launch comes from separate rocprofv3 --pmc passes of this same command
     # (FETCH_SIZE x2, WRITE_SIZE x1, KiB; tools/pmc_summary.py) committed under profiles/
     traffic, traffic_src, mfma_util, traffic_commit, families = None, None, None, None, None
@@ -301,15 +301,15 @@ def roofline_leg(tester, plan, span, dtype, frames):
             break
     return {"bound": "mfma",
             "kernel": "conv_gemm_kernel%s (ResNet-v2-50, %s operands: %d MFMA launches/pass, %d of them fused bottleneck units)"
-                      % ({"bf16": " / bottleneck_tail_kernel / stem_fused_kernel", "bf16x3": " / tail_split_kernel / stem_fused_split_kernel"}.get(dtype, ""), dtype, n_conv, n_tails),
+                      % ({"bf16": " / bottleneck_tail_kernel / stem_fused_kernel", "f16x3": " / tail_split_kernel / stem_fused_split_kernel"}.get(dtype, ""), dtype, n_conv, n_tails),
             "achieved": round(achieved / 1e12, 2), "peak": round(peak / 1e12, 1), "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4),
-            # the other reading of the same measurement: algorithmic FLOP/s against the RAW dense bf16 MFMA peak (2.5 PF),
+            # the other reading of the same measurement: algorithmic FLOP/s against the RAW dense bf16 / fp16 MFMA peak (2.5 PF),
             # i.e. what fraction of the machine's headline rate the arithmetic of the reference graph proceeds at
-            "frac_of_bf16_dense_peak": round(achieved / PEAK_BF16, 4),
+            "frac_of_16bit_dense_peak": round(achieved / PEAK_BF16, 4),
             "mfma_instruction_flops": round(achieved * mfma_per_product / 1e12, 2),
             "peak_note": {"bf16": "dense bf16 MFMA", "f32": "fp32 MFMA",
-                          "bf16x3": "dense bf16 MFMA / 3 (three bf16 MFMAs per algorithmic multiply-add)"}[dtype],
+                          "f16x3": "dense fp16 MFMA (2.5 PF, = bf16) / 3 (three fp16 MFMAs per algorithmic multiply-add)"}[dtype],
             "traffic": traffic, "traffic_unit": "B/launch",
             "traffic_source": traffic_src, "traffic_commit": traffic_commit, "mfma_util_pmc": mfma_util,
             "mfma_util_pmc_by_family": families,
@@ -327,9 +327,9 @@ def main():
     ap.add_argument("--frames", type=int, default=256, help="output frames per GPU per step (weak scaling)")
     ap.add_argument("--video-frames", type=int, default=0,
                     help="strong scaling: ONE video of this many frames sharded over the ranks (BASELINE configs[4]: 4096)")
-    ap.add_argument("--dtype", default="auto", choices=["auto", "bf16x3", "bf16", "f32"],
+    ap.add_argument("--dtype", default="auto", choices=["auto", "f16x3", "bf16", "f32"],
                     help="operand mode of the headline `value`; auto = the drop-in default (probed on the device against the "
-                         "exact-fp32 mode, precision.py): bf16x3 for well-conditioned weights")
+                         "exact-fp32 mode, precision.py): f16x3 for well-conditioned weights")
     ap.add_argument("--no-stress", action="store_true", help="skip the tolerance stress leg (more weight seeds, hard conditioning)")
     ap.add_argument("--only-main", action="store_true", help="skip the other operand modes (`modes`)")
     ap.add_argument("--gather", default="records", choices=["records", "theta"],
@@ -419,7 +419,7 @@ def main():
         others, modes = {}, {}
         all_frames_diff = None
         if single and not args.only_main:
-            for other in [m for m in ("bf16x3", "bf16", "f32") if m != args.dtype]:
+            for other in [m for m in ("f16x3", "bf16", "f32") if m != args.dtype]:
                 tm, t_o, pred_o, out_o = run_mode(other, args, world, rank, device, weights, smpl, span, n_total,
                                                   args.steps, args.warmup)
                 modes[other] = dict(fps=round(tm["fps"], 1), ms_per_step=round(tm["ms_per_step"], 3))
@@ -487,7 +487,7 @@ def main():
                        "frames_per_gpu_per_step": plan.o1 - plan.o0, "windows_per_gpu": plan.w1 - plan.w0,
                        "resnet_frames_encoded_per_gpu": plan.f1 - plan.f0 + 1,
                        "resnet_schedule": "de-duplicated (1x per frame + halo; reference-literal is 2.5x)",
-                       "operands": {"bf16x3": "split bf16 (hi/lo pairs, 3 bf16 MFMAs per product, fp32 accumulate; "
+                       "operands": {"f16x3": "split fp16 (hi/lo pairs, 3 fp16 MFMAs per product, fp32 accumulate, filters scaled by a power of two per output channel; "
                                               "tensors 4 B/element): inside the 1e-4 tolerance",
                                     "bf16": "bf16 operands and activations, fp32 accumulate: OUTSIDE the 1e-4 tolerance",
                                     "f32": "exact fp32 MFMA"}[args.dtype],
@@ -519,7 +519,7 @@ def main():
             result["modes"] = modes
             result["tolerance"] = tol
             for m, d in modes.items():
-                result[{"bf16x3": "bf16x3_fps", "bf16": "bf16_fps", "f32": "fp32_fps"}[m]] = d["fps"]
+                result[{"f16x3": "f16x3_fps", "bf16": "bf16_fps", "f32": "fp32_fps"}[m]] = d["fps"]
             if "e2e_verts_max_abs_err" in modes.get(args.dtype, {}):
                 result["e2e_verts_max_abs_err"] = modes[args.dtype]["e2e_verts_max_abs_err"]
                 result["e2e_joints_max_abs_err"] = modes[args.dtype]["e2e_joints_max_abs_err"]

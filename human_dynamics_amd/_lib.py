@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # devflags LIB_PATH (HMMR_LIB_PATH) lets a development run A/B two builds of the library; the default is the in-tree build
 LIB_PATH = devflags.get("LIB_PATH") or os.path.join(HERE, "libhmmr_hip.so")
 
-HMMR_F32, HMMR_BF16, HMMR_BF16X3 = 0, 1, 2
+HMMR_F32, HMMR_BF16, HMMR_F16X3 = 0, 1, 2
 ABI_VERSION = 11
 RESNET_UNITS = 16
 RESNET_PROF_SLOTS = 64

@@ -1,4 +1,4 @@
-// Fused tail of a ResNet-v2 bottleneck unit for gfx950, bf16x3 ("split") operands:
+// Fused tail of a ResNet-v2 bottleneck unit for gfx950, f16x3 ("split") operands:
 //
 //     trunk' = conv3({h2 [, xp]}) + bias [+ shortcut]               (1x1; bottleneck_v2 `conv3` + add; with xp the unit's
 //                                                                     conv shortcut is folded into the same GEMM)
@@ -40,25 +40,25 @@ struct SplitTailArgs {
     const float* scale2; const float* shift2;
 };
 
-struct wfrag { bf16x8 hi, lo; };
+struct wfrag { shalf8 hi, lo; };
 
-__device__ __forceinline__ f32x16 mma3(const wfrag& w, const bf16x8& xh, const bf16x8& xl, f32x16 c) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, xl, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.lo, xh, c, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, xh, c, 0, 0, 0);
+__device__ __forceinline__ f32x16 mma3(const wfrag& w, const shalf8& xh, const shalf8& xl, f32x16 c) {
+    c = mfma_split(w.hi, xl, c);
+    c = mfma_split(w.lo, xh, c);
+    return mfma_split(w.hi, xh, c);
 }
-__device__ __forceinline__ float bf_lo(unsigned v) { return __uint_as_float(v << 16); }
-__device__ __forceinline__ float bf_hi(unsigned v) { return __uint_as_float(v & 0xffff0000u); }
+__device__ __forceinline__ float bf_lo(unsigned v) { return shalf_lo(v); }
+__device__ __forceinline__ float bf_hi(unsigned v) { return shalf_hi(v); }
 
-// four fp32 values -> their split halves, 4 bf16 (8 bytes) each
+// four fp32 values -> their split halves, 4 halves (8 bytes) each; clamped to the fp16 range like store8<bsplit_t>
 __device__ __forceinline__ void split4(const float (&v)[4], unsigned long long& hi, unsigned long long& lo) {
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
     unsigned h[2], l[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const bf16_t a = (bf16_t)v[2 * i], b = (bf16_t)v[2 * i + 1];
-        h[i] = __builtin_bit_cast(unsigned, bf16x2{a, b});
-        l[i] = __builtin_bit_cast(unsigned, bf16x2{(bf16_t)(v[2 * i] - (float)a), (bf16_t)(v[2 * i + 1] - (float)b)});
+        const float c0 = split_clamp(v[2 * i]), c1 = split_clamp(v[2 * i + 1]);
+        const shalf_t a = (shalf_t)c0, b = (shalf_t)c1;
+        h[i] = shalf_pack(a, b);
+        l[i] = shalf_pack((shalf_t)(c0 - (float)a), (shalf_t)(c1 - (float)b));
     }
     hi = (unsigned long long)h[0] | ((unsigned long long)h[1] << 32);
     lo = (unsigned long long)l[0] | ((unsigned long long)l[1] << 32);
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256, NCH > 4 ? 2 : 3) void tail_split_kernel(const 
     const int fsw = (lr >> 1) & 7;
     const int prow = (wm * 32 + lr) * 128;
     auto xfrag = [&](int plane_off, int kc) {
-        return *(const bf16x8*)(smem + plane_off + prow + (((2 * kc + lh) ^ fsw) << 4));
+        return *(const shalf8*)(smem + plane_off + prow + (((2 * kc + lh) ^ fsw) << 4));
     };
     // Filter fragments straight from L2, requested a whole chunk before their use.  ALLW (block 2: 256-VGPR budget of two
     // workgroups per CU): every fragment of a chunk (KS x 4 of conv3, J2 x 4 of conv1') is held at once; otherwise four of
@@ -145,14 +145,14 @@ __global__ __launch_bounds__(256, NCH > 4 ? 2 : 3) void tail_split_kernel(const 
     auto load_w3 = [&](int nc, int ks) {             // row block 2 nc + wn, K chunks 4 ks .. 4 ks + 3
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
-            const bf16x8* p = (const bf16x8*)(a.w3f + ((long long)((2 * nc + wn) * (KS * 4) + ks * 4 + kc) * 64 + lane) * 32);
+            const shalf8* p = (const shalf8*)(a.w3f + ((long long)((2 * nc + wn) * (KS * 4) + ks * 4 + kc) * 64 + lane) * 32);
             w3[(ALLW ? ks * 4 : 0) + kc].hi = p[0]; w3[(ALLW ? ks * 4 : 0) + kc].lo = p[1];
         }
     };
     auto load_w1 = [&](int nc, int j) {              // row block wn * J2 + j, K chunks 4 nc .. 4 nc + 3
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
-            const bf16x8* p = (const bf16x8*)(a.w1f + ((long long)((wn * J2 + j) * (depth / 16) + 4 * nc + kc) * 64 + lane) * 32);
+            const shalf8* p = (const shalf8*)(a.w1f + ((long long)((wn * J2 + j) * (depth / 16) + 4 * nc + kc) * 64 + lane) * 32);
             w1[(ALLW ? j * 4 : 0) + kc].hi = p[0]; w1[(ALLW ? j * 4 : 0) + kc].lo = p[1];
         }
     };
@@ -221,10 +221,10 @@ __global__ __launch_bounds__(256, NCH > 4 ? 2 : 3) void tail_split_kernel(const 
 #pragma unroll
             for (int kc = 0; kc < 4; ++kc) {
                 wfrag w;
-                w.hi = *(const bf16x8*)(smem + OFF_H2 + wrow + (((2 * kc + lh) ^ fsw) << 4));
-                w.lo = *(const bf16x8*)(smem + OFF_H2 + PLANE + wrow + (((2 * kc + lh) ^ fsw) << 4));
-                const bf16x8 xh = *(const bf16x8*)(ph + (((2 * kc + lh) ^ sw) << 4));
-                const bf16x8 xl = *(const bf16x8*)(ph + PPLANE + (((2 * kc + lh) ^ sw) << 4));
+                w.hi = *(const shalf8*)(smem + OFF_H2 + wrow + (((2 * kc + lh) ^ fsw) << 4));
+                w.lo = *(const shalf8*)(smem + OFF_H2 + PLANE + wrow + (((2 * kc + lh) ^ fsw) << 4));
+                const shalf8 xh = *(const shalf8*)(ph + (((2 * kc + lh) ^ sw) << 4));
+                const shalf8 xl = *(const shalf8*)(ph + PPLANE + (((2 * kc + lh) ^ sw) << 4));
                 acc0 = mma3(w, xh, xl, acc0);
             }
             __syncthreads();                                          // every wave is done with this tap's filters
@@ -380,18 +380,18 @@ int launch_split_tail(const SplitTailArgs& a, hipStream_t stream) {
 
 }  // namespace
 
-// hmmr_bottleneck_tail for HMMR_BF16X3 (called from bottleneck.hip).  w3 / w1 are FRAGMENT-MAJOR here (hmmr_hip.h).
+// hmmr_bottleneck_tail for HMMR_F16X3 (called from bottleneck.hip).  w3 / w1 are FRAGMENT-MAJOR here (hmmr_hip.h).
 int hmmr_bottleneck_tail_split(const hmmr_tail_desc_t* d, hipStream_t stream) {
     HMMR_REQUIRE((d->h2 != nullptr) != (d->h1 != nullptr) && d->w1 && d->out && d->out_h1 && d->pre_scale && d->pre_shift && d->scale1 &&
                  d->shift1 && !d->out_pre && !d->res_strided,
-                 "hmmr_bottleneck_tail (bf16x3): needs h2 or h1 (conv2 in front), the next conv1, out, out_h1 and a dense shortcut");
+                 "hmmr_bottleneck_tail (f16x3): needs h2 or h1 (conv2 in front), the next conv1, out, out_h1 and a dense shortcut");
     const bool conv2 = d->h1 != nullptr;
     HMMR_REQUIRE(!conv2 || (d->w2 && d->scale2 && d->shift2 && d->conv2_stride <= 1 && d->hin > 0 && d->win > 0 && d->hin % 8 == 0 &&
                             d->win % 8 == 0 && d->m % (d->hin * d->win) == 0 && d->c_mid == 64 && d->depth == 256 && d->n2 == 64),
-                 "hmmr_bottleneck_tail (bf16x3): conv2 in front needs the 64 -> 256 -> 64 shape, stride 1, w2 (packed [cout][9 * c_mid] like every filter bank), "
+                 "hmmr_bottleneck_tail (f16x3): conv2 in front needs the 64 -> 256 -> 64 shape, stride 1, w2 (packed [cout][9 * c_mid] like every filter bank), "
                  "scale2, shift2 and an image grid that is a multiple of 8 x 8");
     const bool folded = d->xp != nullptr;             // {h2, xp} x [W3 | Wsc]: the conv shortcut inside conv3's K
-    HMMR_REQUIRE(folded != (d->res != nullptr), "hmmr_bottleneck_tail (bf16x3): either a shortcut tensor (res) or a folded one (xp)");
+    HMMR_REQUIRE(folded != (d->res != nullptr), "hmmr_bottleneck_tail (f16x3): either a shortcut tensor (res) or a folded one (xp)");
     SplitTailArgs a = {};
     a.w3f = (const char*)d->w3; a.scale3 = d->scale3; a.shift3 = d->shift3;
     a.res = (const bsplit_t*)d->res; a.ldr = d->ldr; a.out = (bsplit_t*)d->out;
@@ -414,7 +414,7 @@ int hmmr_bottleneck_tail_split(const hmmr_tail_desc_t* d, hipStream_t stream) {
         a.src[1] = (const bsplit_t*)d->h2 + 64; a.src_ld[1] = 128;
         return launch_split_tail<2, 8, 128, true>(a, stream);
     }
-    hmmr_set_error("hmmr_bottleneck_tail (bf16x3): supported shapes are 64 -> 256 -> 64 (optionally with a folded 64-channel "
+    hmmr_set_error("hmmr_bottleneck_tail (f16x3): supported shapes are 64 -> 256 -> 64 (optionally with a folded 64-channel "
                    "shortcut) and 128 -> 512 -> 128 (got %d, %d, %d)", d->c_mid, d->depth, d->n2);
     return -1;
 }

@@ -7,6 +7,9 @@
 
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -75,25 +78,45 @@ template <> struct elem_traits<bf16_t> {
     __device__ static __forceinline__ bf16_t from_f32(float v) { return (bf16_t)v; }
 };
 
-// HMMR_BF16X3 storage ("split" tensors): every group of 8 consecutive channels is 32 bytes,
-// [hi0..hi7][lo0..lo7] with hi = bf16(x), lo = bf16(x - hi): x ~ hi + lo carries 16 mantissa bits
-// (relative error <= 2^-17).  The element is 4 bytes wide for all address arithmetic (offsets are
-// multiples of 8 elements); a 16-byte slot holds the hi OR the lo half of one group.  The GEMM
-// kernels multiply two split operands with three bf16 MFMAs (hi*hi + hi*lo + lo*hi, fp32
-// accumulate): ~16-bit operands at a third of the bf16 MFMA rate, 5x the fp32-MFMA rate.
+// HMMR_F16X3 storage ("split" tensors): every group of 8 consecutive channels is 32 bytes,
+// [hi0..hi7][lo0..lo7] with hi = fp16(x), lo = fp16(x - hi): x ~ hi + lo carries 22 mantissa bits for values whose lo
+// half stays a normal fp16 (|x| > ~0.12; below that lo is an fp16 subnormal with an ABSOLUTE resolution of 6e-8 -- the
+// matrix pipe keeps subnormals, tools/probes/mfma_f16_denorm.hip).  Filter banks are scaled per output channel by a
+// power of two to a maximum of 2^14 at pack time so that their lo halves are normal numbers too (undone exactly by
+// the epilogue's scale, packing.py).  Values are clamped to the fp16 range (+-65504) where they are split.  The element
+// is 4 bytes wide for all address arithmetic (offsets are multiples of 8 elements); a 16-byte slot holds the hi OR the
+// lo half of one group.  The GEMM kernels multiply two split operands with three fp16 MFMAs (lo*hi + hi*lo + hi*hi,
+// fp32 accumulate; the dropped lo*lo term is <= 2^-22 of the product): fp32-class operands at a third of the 16-bit
+// MFMA rate, 5x the fp32-MFMA rate.  (Rounds 1-2 used bf16 halves: 16-17 bits, "f16x3".)
 struct bsplit_t { unsigned int raw; };
 static_assert(sizeof(bsplit_t) == 4, "bsplit_t is addressed as a 4-byte element");
 template <> struct elem_traits<bsplit_t> {
     static constexpr int EPS = 4;      // "elements" of address arithmetic per 16-byte slot
 };
+typedef f16_t shalf_t;                  // the half type of a split tensor
+typedef f16x8 shalf8;
+typedef f16x2 shalf2;
+#define HMMR_SPLIT_MAX 65504.0f
+__device__ __forceinline__ float split_clamp(float v) { return __builtin_amdgcn_fmed3f(v, -HMMR_SPLIT_MAX, HMMR_SPLIT_MAX); }
+// relu + clamp in one instruction
+__device__ __forceinline__ float split_relu(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, HMMR_SPLIT_MAX); }
+// one 32x32x16 MFMA on split halves
+__device__ __forceinline__ f32x16 mfma_split(const shalf8& a, const shalf8& b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+// the two halves packed in one dword <-> floats
+__device__ __forceinline__ float shalf_lo(unsigned v) { return (float)__builtin_bit_cast(shalf2, v)[0]; }
+__device__ __forceinline__ float shalf_hi(unsigned v) { return (float)__builtin_bit_cast(shalf2, v)[1]; }
+__device__ __forceinline__ unsigned shalf_pack(shalf_t a, shalf_t b) { return __builtin_bit_cast(unsigned, shalf2{a, b}); }
 
 // the value an output element has after being stored in type T and read back
 template <typename T> __device__ __forceinline__ float stored_value(float v);
 template <> __device__ __forceinline__ float stored_value<float>(float v) { return v; }
 template <> __device__ __forceinline__ float stored_value<bf16_t>(float v) { return (float)(bf16_t)v; }
 template <> __device__ __forceinline__ float stored_value<bsplit_t>(float v) {
-    const float hi = (float)(bf16_t)v;
-    return hi + (float)(bf16_t)(v - hi);
+    v = split_clamp(v);
+    const float hi = (float)(shalf_t)v;
+    return hi + (float)(shalf_t)(v - hi);
 }
 
 // 8 consecutive elements <-> 8 floats
@@ -108,7 +131,7 @@ __device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
     for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
 }
 __device__ __forceinline__ void load8(const bsplit_t* p, float (&v)[8]) {      // p: start of an 8-channel group
-    const bf16x8 hi = *(const bf16x8*)p, lo = *((const bf16x8*)p + 1);
+    const shalf8 hi = *(const shalf8*)p, lo = *((const shalf8*)p + 1);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (float)hi[i] + (float)lo[i];
 }
@@ -125,14 +148,15 @@ __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
 }
 
 __device__ __forceinline__ void store8(bsplit_t* p, const float (&v)[8]) {
-    bf16x8 hi, lo;
+    shalf8 hi, lo;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        hi[i] = (bf16_t)v[i];
-        lo[i] = (bf16_t)(v[i] - (float)hi[i]);
+        const float c = split_clamp(v[i]);
+        hi[i] = (shalf_t)c;
+        lo[i] = (shalf_t)(c - (float)hi[i]);
     }
-    *(bf16x8*)p = hi;
-    *((bf16x8*)p + 1) = lo;
+    *(shalf8*)p = hi;
+    *((shalf8*)p + 1) = lo;
 }
 
 // 8 consecutive elements held as raw 16-byte pieces -> 8 floats
@@ -151,8 +175,8 @@ template <> __device__ __forceinline__ void unpack8<bf16_t>(const u32x4 (&r)[1],
 template <> __device__ __forceinline__ void unpack8<bsplit_t>(const u32x4 (&r)[2], float (&v)[8]) {   // r[0] = hi, r[1] = lo
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        v[2 * i] = __uint_as_float(r[0][i] << 16) + __uint_as_float(r[1][i] << 16);
-        v[2 * i + 1] = __uint_as_float(r[0][i] & 0xffff0000u) + __uint_as_float(r[1][i] & 0xffff0000u);
+        v[2 * i] = shalf_lo(r[0][i]) + shalf_lo(r[1][i]);
+        v[2 * i + 1] = shalf_hi(r[0][i]) + shalf_hi(r[1][i]);
     }
 }
 
@@ -170,18 +194,17 @@ __device__ __forceinline__ u32x4 preact_slot_split(const u32x4& v, const f32x4& 
     const unsigned r0 = dpp_swap(is_lo ? v[0] : v[2]), r1 = dpp_swap(is_lo ? v[1] : v[3]);
     const unsigned h0 = is_lo ? r0 : v[0], h1 = is_lo ? r1 : v[1];       // hi halves of this lane's four channels
     const unsigned l0 = is_lo ? v[2] : r0, l1 = is_lo ? v[3] : r1;       // lo halves
-    float y[4];
-    y[0] = fmaxf(fmaf(__uint_as_float(h0 << 16) + __uint_as_float(l0 << 16), sc[0], sh[0]), 0.f);
-    y[1] = fmaxf(fmaf(__uint_as_float(h0 & 0xffff0000u) + __uint_as_float(l0 & 0xffff0000u), sc[1], sh[1]), 0.f);
-    y[2] = fmaxf(fmaf(__uint_as_float(h1 << 16) + __uint_as_float(l1 << 16), sc[2], sh[2]), 0.f);
-    y[3] = fmaxf(fmaf(__uint_as_float(h1 & 0xffff0000u) + __uint_as_float(l1 & 0xffff0000u), sc[3], sh[3]), 0.f);
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    float y[4];       // relu and the clamp to the fp16 range are one v_med3_f32 (= store8's split_clamp of a ReLU'd value)
+    y[0] = split_relu(fmaf(shalf_lo(h0) + shalf_lo(l0), sc[0], sh[0]));
+    y[1] = split_relu(fmaf(shalf_hi(h0) + shalf_hi(l0), sc[1], sh[1]));
+    y[2] = split_relu(fmaf(shalf_lo(h1) + shalf_lo(l1), sc[2], sh[2]));
+    y[3] = split_relu(fmaf(shalf_hi(h1) + shalf_hi(l1), sc[3], sh[3]));
     unsigned ph[2], pl[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const bf16_t a = (bf16_t)y[2 * i], b = (bf16_t)y[2 * i + 1];
-        ph[i] = __builtin_bit_cast(unsigned, bf16x2{a, b});
-        pl[i] = __builtin_bit_cast(unsigned, bf16x2{(bf16_t)(y[2 * i] - (float)a), (bf16_t)(y[2 * i + 1] - (float)b)});
+        const shalf_t a = (shalf_t)y[2 * i], b = (shalf_t)y[2 * i + 1];
+        ph[i] = shalf_pack(a, b);
+        pl[i] = shalf_pack((shalf_t)(y[2 * i] - (float)a), (shalf_t)(y[2 * i + 1] - (float)b));
     }
     // the partner's slot needs this lane's OTHER half: hi lane sends its lo[0..3], lo lane sends its hi[4..7]
     const unsigned s0 = dpp_swap(is_lo ? ph[0] : pl[0]), s1 = dpp_swap(is_lo ? ph[1] : pl[1]);

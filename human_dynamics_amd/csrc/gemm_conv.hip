@@ -68,7 +68,7 @@ struct ConvArgs {
 template <typename TA> struct Frag;
 template <> struct Frag<float>  { typedef f32x4 type; };
 template <> struct Frag<bf16_t> { typedef bf16x8 type; };
-struct split_frag { bf16x8 hi, lo; };
+struct split_frag { shalf8 hi, lo; };
 template <> struct Frag<bsplit_t> { typedef split_frag type; };
 
 __device__ __forceinline__ f32x16 mma(const f32x4& a, const f32x4& b, f32x16 c) {
@@ -79,12 +79,12 @@ __device__ __forceinline__ f32x16 mma(const f32x4& a, const f32x4& b, f32x16 c) 
 __device__ __forceinline__ f32x16 mma(const bf16x8& a, const bf16x8& b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
-// split operands: (ah + al)(bh + bl) ~ ah*bh + ah*bl + al*bh; every bf16 product is exact in fp32, the
-// dropped al*bl term is <= 2^-18 of |a*b|.  The two small terms go first.
+// split operands: (ah + al)(bh + bl) ~ ah*bh + ah*bl + al*bh; every fp16 product is exact in fp32, the
+// dropped al*bl term is <= 2^-22 of |a*b|.  The two small terms go first.
 __device__ __forceinline__ f32x16 mma(const split_frag& a, const split_frag& b, f32x16 c) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, c, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, c, 0, 0, 0);
+    c = mfma_split(a.lo, b.hi, c);
+    c = mfma_split(a.hi, b.lo, c);
+    return mfma_split(a.hi, b.hi, c);
 }
 // fragment of MFMA chunk c out of a 128-byte LDS row (fsw = the row's slot swizzle, lh = lane half).
 // bf16 / fp32: 4 chunks of two 16-byte slots (one per lane half).  split: 2 chunks of two 8-channel
@@ -100,8 +100,8 @@ template <> struct FragIO<bsplit_t> {
     __device__ static __forceinline__ split_frag read(const char* row, int c, int lh, int fsw) {
         const int g = 2 * (2 * c + lh);
         split_frag f;
-        f.hi = *(const bf16x8*)(row + ((g ^ fsw) << 4));
-        f.lo = *(const bf16x8*)(row + (((g + 1) ^ fsw) << 4));
+        f.hi = *(const shalf8*)(row + ((g ^ fsw) << 4));
+        f.lo = *(const shalf8*)(row + (((g + 1) ^ fsw) << 4));
         return f;
     }
 };
@@ -751,15 +751,15 @@ extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
     HMMR_REQUIRE(d && d->in && d->w && (d->out || d->out2), "hmmr_conv_gemm: null operand");
     const int esz = d->in_dtype == HMMR_BF16 ? 2 : 4;
     // alignment unit of the gather in elements: one 16-byte slot, or one 32-byte hi/lo group of a split tensor
-    const int eps = d->in_dtype == HMMR_BF16X3 ? 8 : 16 / esz;
+    const int eps = d->in_dtype == HMMR_F16X3 ? 8 : 16 / esz;
     const int cl2 = ilog2_exact(d->cin);
     HMMR_REQUIRE(cl2 >= 0 && d->cin % eps == 0, "hmmr_conv_gemm: cin=%d must be a power of two >= %d", d->cin, eps);
     const int K = d->kh * d->kw * d->cin + (d->in2 ? d->cin2 : 0);      // (in2: a second 1x1 source appended along K)
     HMMR_REQUIRE(d->kh * d->kw <= 32, "hmmr_conv_gemm: at most 32 filter taps");
     const int bke = 128 / esz;             // elements per 128-byte K step
     HMMR_REQUIRE(K % bke == 0, "hmmr_conv_gemm: K=%d must be a multiple of %d", K, bke);
-    HMMR_REQUIRE(d->out_dtype != HMMR_BF16X3 || d->cout % 8 == 0,
-                 "hmmr_conv_gemm: a split (bf16x3) output needs cout %% 8 == 0 (rows are whole hi/lo groups)");
+    HMMR_REQUIRE(d->out_dtype != HMMR_F16X3 || d->cout % 8 == 0,
+                 "hmmr_conv_gemm: a split (f16x3) output needs cout %% 8 == 0 (rows are whole hi/lo groups)");
     HMMR_REQUIRE(d->ldo % 8 == 0, "hmmr_conv_gemm: ldo=%d must be a multiple of 8", d->ldo);
     // every gathered 16-byte slot must stay aligned: ix = ox*sx + kx - px
     const bool px_ok = d->in_px_stride % eps == 0 ||
@@ -804,8 +804,8 @@ extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
 #endif
     if (a.M <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    const bool in16 = d->in_dtype == HMMR_BF16, in32 = d->in_dtype == HMMR_F32, inx3 = d->in_dtype == HMMR_BF16X3;
-    const bool out16 = d->out_dtype == HMMR_BF16, out32 = d->out_dtype == HMMR_F32, outx3 = d->out_dtype == HMMR_BF16X3;
+    const bool in16 = d->in_dtype == HMMR_BF16, in32 = d->in_dtype == HMMR_F32, inx3 = d->in_dtype == HMMR_F16X3;
+    const bool out16 = d->out_dtype == HMMR_BF16, out32 = d->out_dtype == HMMR_F32, outx3 = d->out_dtype == HMMR_F16X3;
     HMMR_REQUIRE((in16 || in32 || inx3) && (out16 || out32 || outx3), "hmmr_conv_gemm: unsupported dtypes %d -> %d", d->in_dtype, d->out_dtype);
     const int nk = K / bke;
     int slices = d->split_k > 1 ? d->split_k : 1;

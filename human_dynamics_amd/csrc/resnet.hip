@@ -24,13 +24,13 @@
 #include "hmmr_hip.h"
 
 // csrc/stem.hip
-int hmmr_stem_fused(const float* images, int n_real, int n, const void* wts, const float* bias,
+int hmmr_stem_fused(const float* images, int n_real, int n, const void* wts, const float* wscale, const float* bias,
                     const float* pscale, const float* pshift, void* out, int dtype, hipStream_t s,
                     const void* w1, const float* s1, const float* b1, void* out_h1);
 
 static constexpr int IMG = 224, PADH = 230, PADW = 232;
 
-// split (bf16x3) image: one 8-"channel" group = two RGBX pixels; PADW is even, so a pair never straddles a row
+// split (f16x3) image: one 8-"channel" group = two RGBX pixels; PADW is even, so a pair never straddles a row
 __global__ void stem_repack_split_kernel(const float* __restrict__ img, bsplit_t* __restrict__ out, long long npairs,
                                          long long n_real) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npairs;
@@ -215,7 +215,7 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
     // Default: ONE fused kernel (csrc/stem.hip).  HMMR_STEM=unfused keeps the three-kernel route
     // (re-pack, implicit GEMM, pool) for A/B measurements.
     // In fp32-operand mode the fused kernel needs 104 KB of LDS (one workgroup per CU) and measures
-    // ~1 % slower than the three-kernel route, which therefore stays the fp32 default.  bf16x3 has its own
+    // ~1 % slower than the three-kernel route, which therefore stays the fp32 default.  f16x3 has its own
     // fused kernel (stem_fused_split_kernel: hi/lo planes, 32 output channels per workgroup).
     const hmmr_debug_t* dbg = hmmr_debug_state();
     const bool unfused = dbg->stem_route == 1 || (dbg->stem_route == 0 && w->dtype == HMMR_F32);
@@ -225,7 +225,7 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
         const hmmr_resnet_unit_t& U0 = w->unit[0];
         stem_c1 = !dbg->stem_no_conv1 && w->dtype == HMMR_BF16 && !U0.sc_c1.w && U0.c_in == 64 && U0.base == 64 &&
                   U0.conv1.scale && U0.conv1.shift;
-        if (hmmr_stem_fused(images, n_real, n, w->stem.w, w->stem.shift, U0.pre_scale, U0.pre_shift, P[0], w->dtype, s,
+        if (hmmr_stem_fused(images, n_real, n, w->stem.w, w->stem.scale, w->stem.shift, U0.pre_scale, U0.pre_shift, P[0], w->dtype, s,
                             stem_c1 ? U0.conv1.w : nullptr, U0.conv1.scale, U0.conv1.shift, stem_c1 ? T1 : nullptr))
             return -2;
         if (prof_mark(pf)) return -2;
@@ -376,7 +376,7 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
             t.out = d.out; t.out_pre = d.out2; t.pre_scale = d.scale2; t.pre_shift = d.shift2;
             if (hmmr_bottleneck_tail(&t, s)) return -2;
         } else if (U.fuse_tail) {     // conv3 + add + the next unit's preact + conv1 in one launch (csrc/bottleneck.hip)
-            HMMR_REQUIRE(!last && (w->dtype == HMMR_BF16 || (w->dtype == HMMR_BF16X3 && U.w3_frag && U.w1n_frag && U.fuse_tail <= 2)) &&
+            HMMR_REQUIRE(!last && (w->dtype == HMMR_BF16 || (w->dtype == HMMR_F16X3 && U.w3_frag && U.w1n_frag && U.fuse_tail <= 2)) &&
                          U.stride == 1 && write_raw && !write_pre && next_fused &&
                          next_identity && w->unit[u + 1].base == U.base && w->unit[u + 1].c_in == U.depth &&
                          ((U.base == 64 && U.depth == 256) || (U.base == 128 && U.depth == 512)),
@@ -392,7 +392,7 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
                 t.h2 = T2;
             }
             t.w3 = U.conv3.w; t.scale3 = U.conv3.scale; t.shift3 = U.conv3.shift;
-            if (w->dtype == HMMR_BF16X3) {            // fragment-major filters; a folded shortcut rides in conv3's K
+            if (w->dtype == HMMR_F16X3) {            // fragment-major filters; a folded shortcut rides in conv3's K
                 t.w3 = U.w3_frag;
                 if (sc_in_c3) { t.scale3 = U.c3sc.scale; t.shift3 = U.c3sc.shift; t.xp = xin; }
             }
@@ -405,7 +405,7 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
             }
             t.ho = Ho; t.wo = Ho;
             t.out = xn; t.pre_scale = N.pre_scale; t.pre_shift = N.pre_shift;
-            t.w1 = w->dtype == HMMR_BF16X3 ? U.w1n_frag : N.conv1.w;
+            t.w1 = w->dtype == HMMR_F16X3 ? U.w1n_frag : N.conv1.w;
             t.scale1 = N.conv1.scale; t.shift1 = N.conv1.shift; t.relu1 = 1; t.n2 = N.base;
             t.out_h1 = conv2_in_tail ? T2 : T1;
             if (hmmr_bottleneck_tail(&t, s)) return -2;
@@ -439,7 +439,7 @@ extern "C" int hmmr_resnet50_fwd(const hmmr_resnet_weights_t* w, const float* im
     HMMR_REQUIRE(w->unit[0].c_in == 64 && w->unit[15].depth == 2048, "hmmr_resnet50_fwd: bad unit table");
     if (w->dtype == HMMR_BF16) return resnet_fwd_t<bf16_t>(w, images, n, nt, phi, (char*)ws, (hipStream_t)stream, prof_ms);
     if (w->dtype == HMMR_F32) return resnet_fwd_t<float>(w, images, n, nt, phi, (char*)ws, (hipStream_t)stream, prof_ms);
-    if (w->dtype == HMMR_BF16X3) return resnet_fwd_t<bsplit_t>(w, images, n, nt, phi, (char*)ws, (hipStream_t)stream, prof_ms);
+    if (w->dtype == HMMR_F16X3) return resnet_fwd_t<bsplit_t>(w, images, n, nt, phi, (char*)ws, (hipStream_t)stream, prof_ms);
     hmmr_set_error("hmmr_resnet50_fwd: bad dtype %d", w->dtype);
     return -1;
 }

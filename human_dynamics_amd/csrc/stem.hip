@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const float* __restrict
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// bf16x3 (split) operands: the same tile geometry with hi and lo PLANES of the patch and of the filters in LDS and
+// f16x3 (split) operands: the same tile geometry with hi and lo PLANES of the patch and of the filters in LDS and
 // three MFMAs per product (act.lo*w.hi, act.hi*w.lo, act.hi*w.hi -- the order of gemm_conv.hip's mma(split, split)).
 // A workgroup (5 waves, two MFMA row tiles each) computes 32 of the 64 output channels (blockIdx.z), which keeps
 // patch planes + filter planes / fp32 pooling stage at 66 KB: two workgroups per CU.  Rounding points are those of
@@ -251,13 +251,14 @@ __global__ __launch_bounds__(256) void stem_fused_kernel(const float* __restrict
 // by tap, 16 elements at a time, so the result is that route's, bit for bit (tests/test_gpu_sizes.py).
 namespace {
 constexpr int X3_NT = 320, X3_CO = 32;
-constexpr int X3_PLANE = IP * IPW * 8;                       // one bf16 RGBX plane of the patch
+constexpr int X3_PLANE = IP * IPW * 8;                       // one 16-bit RGBX plane of the patch
 constexpr int X3_WROW = 7 * TAPK * 2 + 16;                   // padded filter row of one plane (464 B: conflict-free b128 reads)
 constexpr int X3_WPLANE = X3_CO * X3_WROW;
 constexpr int X3_STAGE = MT * 32 * X3_CO * 4;                // conv + bias as fp32 [pixel][32] (overlaps the filters)
 constexpr int X3_LDS = 2 * X3_PLANE + (2 * X3_WPLANE > X3_STAGE ? 2 * X3_WPLANE : X3_STAGE);
 
 __global__ __launch_bounds__(X3_NT) void stem_fused_split_kernel(const float* __restrict__ img, const bsplit_t* __restrict__ wts,
+                                                                 const float* __restrict__ wscale,
                                                                  const float* __restrict__ bias, const float* __restrict__ pscale,
                                                                  const float* __restrict__ pshift, bsplit_t* __restrict__ out,
                                                                  int n_real) {
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(X3_NT) void stem_fused_split_kernel(const float* __
     const int cy0 = 2 * PT * ty, cx0 = 2 * PT * tx;
     const int iy0 = 2 * cy0 - 3, ix0 = 2 * cx0 - 3;
 
-    // ---- 1. input patch -> two bf16 RGBX planes (hi = bf16(x), lo = bf16(x - hi): stem_repack_split_kernel's values)
+    // ---- 1. input patch -> two fp16 RGBX planes (hi = fp16(x), lo = fp16(x - hi): stem_repack_split_kernel's values)
     const float* im = img + (long long)n * IMG * IMG * 3;
     for (int i = tid; i < IP * 11; i += X3_NT) {
         const int py = i / 11, q = i - py * 11;
@@ -293,16 +294,17 @@ __global__ __launch_bounds__(X3_NT) void stem_fused_split_kernel(const float* __
         for (int e = 0; e < 4; ++e) {
             const int px = 4 * q - 1 + e;
             if ((unsigned)px < (unsigned)IPW) {
-                typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-                bf16x4 h, l;
+                typedef __attribute__((ext_vector_type(4))) shalf_t shalf4;
+                shalf4 h, l;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    h[c] = (bf16_t)f[3 * e + c];
-                    l[c] = (bf16_t)(f[3 * e + c] - (float)h[c]);
+                    const float cv = split_clamp(f[3 * e + c]);
+                    h[c] = (shalf_t)cv;
+                    l[c] = (shalf_t)(cv - (float)h[c]);
                 }
-                h[3] = (bf16_t)0.f; l[3] = (bf16_t)0.f;
-                *(bf16x4*)(s_ph + (py * IPW + px) * 8) = h;
-                *(bf16x4*)(s_pl + (py * IPW + px) * 8) = l;
+                h[3] = (shalf_t)0.f; l[3] = (shalf_t)0.f;
+                *(shalf4*)(s_ph + (py * IPW + px) * 8) = h;
+                *(shalf4*)(s_pl + (py * IPW + px) * 8) = l;
             }
         }
     }
@@ -337,15 +339,15 @@ __global__ __launch_bounds__(X3_NT) void stem_fused_split_kernel(const float* __
     for (int ky = 0; ky < 7; ++ky) {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const bf16x8 bh = *(const bf16x8*)(s_wh + bbase + ky * 64 + c * 32);
-            const bf16x8 bl = *(const bf16x8*)(s_wl + bbase + ky * 64 + c * 32);
+            const shalf8 bh = *(const shalf8*)(s_wh + bbase + ky * 64 + c * 32);
+            const shalf8 bl = *(const shalf8*)(s_wl + bbase + ky * 64 + c * 32);
 #pragma unroll
             for (int i = 0; i < MPW; ++i) {
-                const bf16x8 ah = *(const bf16x8*)(s_ph + abase[i] + ky * IPW * 8 + c * 32);
-                const bf16x8 al = *(const bf16x8*)(s_pl + abase[i] + ky * IPW * 8 + c * 32);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i], 0, 0, 0);
+                const shalf8 ah = *(const shalf8*)(s_ph + abase[i] + ky * IPW * 8 + c * 32);
+                const shalf8 al = *(const shalf8*)(s_pl + abase[i] + ky * IPW * 8 + c * 32);
+                acc[i] = mfma_split(al, bh, acc[i]);
+                acc[i] = mfma_split(ah, bl, acc[i]);
+                acc[i] = mfma_split(ah, bh, acc[i]);
             }
         }
     }
@@ -354,12 +356,14 @@ __global__ __launch_bounds__(X3_NT) void stem_fused_split_kernel(const float* __
     // ---- 4a. conv + bias, rounded to what split storage holds, -> LDS fp32 [pixel][32]
     {
         const float bch = bias[ch0 + lr];
+        const float sch = wscale ? wscale[ch0 + lr] : 1.0f;   // undoes the pack-time power-of-two scale of the filter row
 #pragma unroll
         for (int i = 0; i < MPW; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int p = (wave + 5 * i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                s_c[p * X3_CO + lr] = stored_value<bsplit_t>(acc[i][r] + bch);
+                // (one explicit fma, like conv_gemm's epilogue: fma(v, 1, b) == v + b when there is no scale)
+                s_c[p * X3_CO + lr] = stored_value<bsplit_t>(fmaf(acc[i][r], sch, bch));
             }
     }
     __syncthreads();
@@ -395,10 +399,10 @@ __global__ __launch_bounds__(X3_NT) void stem_fused_split_kernel(const float* __
 // images [n_real,224,224,3] fp32 (+ n - n_real implicit zero images) -> out [n,56,56,64] (dtype)
 // w1 / s1 / b1 / out_h1 (bf16 only, may be NULL): block1/unit_1's conv1 [64][64] + folded BN, computed on the
 // pooled tile in the same launch -> out_h1 [n,56,56,64]
-int hmmr_stem_fused(const float* images, int n_real, int n, const void* wts, const float* bias,
+int hmmr_stem_fused(const float* images, int n_real, int n, const void* wts, const float* wscale, const float* bias,
                     const float* pscale, const float* pshift, void* out, int dtype, hipStream_t s,
                     const void* w1, const float* s1, const float* b1, void* out_h1) {
-    if (dtype == HMMR_BF16X3) {
+    if (dtype == HMMR_F16X3) {
         auto kern = stem_fused_split_kernel;
         static DeviceOnce oncex3;
         if (const unsigned long long bit = oncex3.due()) {
@@ -406,7 +410,7 @@ int hmmr_stem_fused(const float* images, int n_real, int n, const void* wts, con
             oncex3.mark(bit);
         }
         hipLaunchKernelGGL(kern, dim3((POOL / PT) * (POOL / PT), n, CO / X3_CO), dim3(X3_NT), X3_LDS, s, images,
-                           (const bsplit_t*)wts, bias, pscale, pshift, (bsplit_t*)out, n_real);
+                           (const bsplit_t*)wts, wscale, bias, pscale, pshift, (bsplit_t*)out, n_real);
     } else if (dtype == HMMR_BF16) {
         auto kern = stem_fused_kernel<bf16_t>;
         static DeviceOnce once16;

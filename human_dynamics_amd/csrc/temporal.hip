@@ -78,7 +78,7 @@ extern "C" int hmmr_groupnorm_relu(const float* x, const float* gamma, const flo
     else if (out_dtype == HMMR_F32)
         hipLaunchKernelGGL(groupnorm_relu_kernel<float>, dim3(b * groups), dim3(256), 0, s, x, gamma, beta,
                            (float*)out, t, c, groups);
-    else if (out_dtype == HMMR_BF16X3)
+    else if (out_dtype == HMMR_F16X3)
         hipLaunchKernelGGL(groupnorm_relu_kernel<bsplit_t>, dim3(b * groups), dim3(256), 0, s, x, gamma, beta,
                            (bsplit_t*)out, t, c, groups);
     else { hmmr_set_error("hmmr_groupnorm_relu: bad dtype %d", out_dtype); return -1; }

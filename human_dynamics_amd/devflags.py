@@ -22,7 +22,7 @@ FLAGS = {
     "FUSE_TAIL": ("1", "0 | 1 | block1 | noconv2 | conv2b1 | nosc | nostride2: which fused bottleneck tails the packer marks"),
     "FUSE_SC": ("1", "0 | 1 | all: shortcut + conv1 as one column-split GEMM (1: blocks 3-4)"),
     "PREACT_FIRST": ("0", "1: a block's first unit fuses its pre-activation too"),
-    "FOLD_SC": ("", "0 | 1: conv shortcut folded into conv3's K (default: bf16x3 only)"),
+    "FOLD_SC": ("", "0 | 1: conv shortcut folded into conv3's K (default: f16x3 only)"),
     "AUTOTUNE": ("1", "0: no per-layer tile tuning pass (shipped table / library heuristic only)"),
     "TILE_TABLE": ("1", "0: ignore the shipped tile tables (tile_tables.json), tune or fall back to the heuristic"),
     "TILE_CACHE": ("", "json file the tuned tile tables are read from / written to (profiling runs)"),

@@ -17,12 +17,12 @@ from . import assets, devflags, packing
 
 DTYPES = {"f32": L.HMMR_F32, "fp32": L.HMMR_F32, "float32": L.HMMR_F32,
           "bf16": L.HMMR_BF16, "bfloat16": L.HMMR_BF16,
-          "bf16x3": L.HMMR_BF16X3, "split": L.HMMR_BF16X3}
-DTYPE_NAMES = {L.HMMR_F32: "f32", L.HMMR_BF16: "bf16", L.HMMR_BF16X3: "bf16x3"}
-# The drop-in default: split-bf16 operands (hi/lo pairs, three bf16 MFMAs per product, fp32 accumulate) --
+          "f16x3": L.HMMR_F16X3, "split": L.HMMR_F16X3}
+DTYPE_NAMES = {L.HMMR_F32: "f32", L.HMMR_BF16: "bf16", L.HMMR_F16X3: "f16x3"}
+# The explicit fast mode: split-fp16 operands (hi/lo pairs, three fp16 MFMAs per product, fp32 accumulate) --
 # the fastest mode whose end-to-end vertices / joints stay within the reference tolerance of 1e-4.
 # 'bf16' is the opt-in throughput mode (vertex error ~7e-3), 'f32' the exact-fp32 MFMA mode.
-DEFAULT_DTYPE = "bf16x3"
+DEFAULT_DTYPE = "f16x3"
 TILE_TABLES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tile_tables.json")
 
 
@@ -68,7 +68,7 @@ class _Workspace(object):
 
 class HmmrEngine(object):
     """weights: dict of checkpoint-named arrays (assets.py); smpl: dict in the
-    src/tf_smpl layout.  dtype: GEMM operand mode of ResNet / temporal / IEF: 'bf16x3' (default: split-bf16 hi/lo
+    src/tf_smpl layout.  dtype: GEMM operand mode of ResNet / temporal / IEF: 'f16x3' (default: split-fp16 hi/lo
     operands, three bf16 MFMAs per product -- the mode inside the reference tolerance), 'bf16' or 'f32'; SMPL is
     always fp32."""
 
@@ -473,7 +473,15 @@ def conv_gemm(x, w_hwio, stride=1, pad=0, scale=None, shift=None, res=None, relu
     if second is not None:          # (x2 [n,h,w,cin2], w2 [1,1,cin2,cout]): a second 1x1 source appended along K (hmmr_conv_desc_t.in2)
         x2 = store.put(np.asarray(second[0], np.float32), packing.TORCH_DT[in_dtype])
         w_hwio = np.concatenate([np.asarray(w_hwio, np.float32), np.asarray(second[1], np.float32)], axis=2)
-    wt = store.put(packing.pack_conv_weight(np.asarray(w_hwio, np.float32)), packing.TORCH_DT[in_dtype])
+    wp = packing.pack_conv_weight(np.asarray(w_hwio, np.float32))
+    if packing.TORCH_DT[in_dtype] is packing.SPLIT:     # as packing._layer: rows scaled by a power of two, undone by `scale`
+        k = packing.row_pow2(wp)
+        wp = packing.scale_rows(wp, k)
+        sc = np.ones(wp.shape[0], np.float64)
+        if scale is not None:
+            sc[:len(scale)] = np.asarray(scale, np.float64)
+        scale = (sc * np.exp2(-k.astype(np.float64))).astype(np.float32)
+    wt = store.put(wp, packing.TORCH_DT[in_dtype])
     ldo = (cout + 7) // 8 * 8
     out = packing.empty_act((n, ho, wo, ldo), out_dtype, dev, zero=True)
     d = L.ConvDesc()

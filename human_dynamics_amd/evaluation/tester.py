@@ -122,9 +122,9 @@ class Tester(object):
         if smpl is None:
             smpl = load_smpl_constants(self.smpl_model_path, checkpoint_vars=weights)
         # operand type of the GEMM stages: the reference graph is fp32 throughout (tester.py:64-66).  Default "auto": the
-        # fastest rung of precision.LADDER (bf16x3 -> f32 ResNet -> all f32) whose vertices / joints stay within 0.3 x
+        # fastest rung of precision.LADDER (f16x3 -> f32 ResNet -> all f32) whose vertices / joints stay within 0.3 x
         # the 1e-4 tolerance of the exact-fp32 mode on a probe batch run here, on the device, with THESE weights
-        # (precision.py; the report is self.precision).  'bf16x3' / 'bf16' / 'f32' are explicit choices, not probed.
+        # (precision.py; the report is self.precision).  'f16x3' / 'bf16' / 'f32' are explicit choices, not probed.
         dtype = dtype or getattr(config, "dtype", None) or "auto"
         device = device or getattr(config, "device", "cuda:0")
         kw = dict(num_conv_layers=self.num_conv_layers, delta_t_values=self.delta_t_values,

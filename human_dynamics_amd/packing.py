@@ -19,18 +19,21 @@ import torch
 from . import _lib as L
 from . import assets
 
-SPLIT = "split"      # storage marker of HMMR_BF16X3 tensors (int32 words holding bf16 hi/lo halves)
-TORCH_DT = {L.HMMR_F32: torch.float32, L.HMMR_BF16: torch.bfloat16, L.HMMR_BF16X3: SPLIT}
+SPLIT = "split"      # storage marker of HMMR_F16X3 (f16x3) tensors (int32 words holding fp16 hi/lo halves)
+SPLIT_HALF = torch.float16
+SPLIT_MAX = 65504.0  # values are clamped to the fp16 range where they are split (csrc/common.h split_clamp)
+W_TARGET_LOG2 = 14   # filter rows are scaled by a power of two to a maximum in [2^13, 2^14)
+TORCH_DT = {L.HMMR_F32: torch.float32, L.HMMR_BF16: torch.bfloat16, L.HMMR_F16X3: SPLIT}
 
 
 def to_split(t):
-    """fp32 tensor [..., C] (C % 8 == 0) -> int32 tensor [..., C] in the HMMR_BF16X3 layout: every group of 8
-    channels is 32 bytes, [hi x8][lo x8] with hi = bf16(x), lo = bf16(x - hi) (include/hmmr_hip.h)."""
-    t = t.to(torch.float32)
+    """fp32 tensor [..., C] (C % 8 == 0) -> int32 tensor [..., C] in the split (f16x3) layout: every group of 8
+    channels is 32 bytes, [hi x8][lo x8] with hi = fp16(x), lo = fp16(x - hi), x clamped to +-65504 (include/hmmr_hip.h)."""
+    t = t.to(torch.float32).clamp(-SPLIT_MAX, SPLIT_MAX)
     C = t.shape[-1]
     assert C % 8 == 0, "split tensors need a channel count that is a multiple of 8"
-    hi = t.to(torch.bfloat16)
-    lo = (t - hi.to(torch.float32)).to(torch.bfloat16)
+    hi = t.to(SPLIT_HALF)
+    lo = (t - hi.to(torch.float32)).to(SPLIT_HALF)
     g = torch.stack([hi.reshape(t.shape[:-1] + (C // 8, 8)), lo.reshape(t.shape[:-1] + (C // 8, 8))], dim=-2)
     return g.reshape(t.shape[:-1] + (2 * C,)).contiguous().view(torch.int32)
 
@@ -38,7 +41,7 @@ def to_split(t):
 def from_split(t):
     """inverse of to_split: int32 [..., C] -> fp32 [..., C] (hi + lo)."""
     C = t.shape[-1]
-    g = t.contiguous().view(torch.bfloat16).reshape(t.shape[:-1] + (C // 8, 2, 8)).to(torch.float32)
+    g = t.contiguous().view(SPLIT_HALF).reshape(t.shape[:-1] + (C // 8, 2, 8)).to(torch.float32)
     return (g[..., 0, :] + g[..., 1, :]).reshape(t.shape[:-1] + (C,))
 
 
@@ -75,15 +78,35 @@ def pack_conv_weight(w_hwio):
     return _pad_rows(np.ascontiguousarray(w_hwio.reshape(kh * kw * cin, cout).T))
 
 
+def row_pow2(w_rows):
+    """Per-row exponents k of the power-of-two scaling of a split filter bank [n_out][K]: row r is stored as
+    w[r] * 2^k[r] with max |w[r]| * 2^k[r] in [2^13, 2^14), so that the lo half of every filter value (2^-11 of it) is a
+    NORMAL fp16 number down to values 2^-14 x the row's largest (an unscaled fp16 split keeps 2-3 bits of a 0.003-sized
+    filter's lo half: fp16 subnormals).  The epilogue's per-channel `scale` is multiplied by 2^-k[r]: exact, so the
+    arithmetic is that of the unscaled filters with 22-bit operands.  All-zero rows (padding): k = 0.  A pure function
+    of the row's values, so every packing of the same rows (K-contiguous, fragment-major) scales them alike."""
+    w_rows = np.asarray(w_rows, np.float64)
+    m = np.abs(w_rows).max(axis=1)
+    k = np.zeros(len(m), np.int64)
+    nz = m > 0
+    k[nz] = W_TARGET_LOG2 - 1 - np.floor(np.log2(m[nz])).astype(np.int64)
+    return k
+
+
+def scale_rows(w_rows, k):
+    return (np.asarray(w_rows, np.float64) * np.exp2(k.astype(np.float64))[:, None]).astype(np.float32)
+
+
 def pack_frag_major(w_nk):
-    """[n_out][K] fp32 -> bf16 [n_out / 32][K / 16][64 lanes][2 (hi, lo)][8]: the MFMA A-operand fragments of a split
+    """[n_out][K] fp32 -> fp16 [n_out / 32][K / 16][64 lanes][2 (hi, lo)][8]: the MFMA A-operand fragments of a split
     filter bank, one coalesced 2 KB read per (32-row block, 16-wide K chunk); lane = 32 * (k half) + row
-    (hmmr_tail_desc_t, csrc/bottleneck_split.hip)."""
-    t = torch.from_numpy(np.ascontiguousarray(w_nk, dtype=np.float32))
+    (hmmr_tail_desc_t, csrc/bottleneck_split.hip).  Rows carry the power-of-two scale of row_pow2()."""
+    w_nk = np.ascontiguousarray(w_nk, dtype=np.float32)
+    t = torch.from_numpy(scale_rows(w_nk, row_pow2(w_nk)))
     n, K = t.shape
     assert n % 32 == 0 and K % 16 == 0, (n, K)
-    hi = t.to(torch.bfloat16)
-    lo = (t - hi.to(torch.float32)).to(torch.bfloat16)
+    hi = t.to(SPLIT_HALF)
+    lo = (t - hi.to(torch.float32)).to(SPLIT_HALF)
 
     def frag(x):
         x = x.reshape(n // 32, 32, K // 16, 2, 8)                # rb, row, kc, half, e
@@ -125,7 +148,18 @@ class DeviceStore(object):
 
 
 def _layer(store, w_packed, dtype, scale=None, shift=None):
+    """One hmmr_layer_t.  Split (f16x3) filter banks are scaled row by row (row_pow2) and the epilogue scale takes the
+    inverse factor -- a bias-only layer gets a scale vector of pure powers of two for it."""
     lay = L.Layer()
+    if TORCH_DT[dtype] is SPLIT:
+        w_packed = np.asarray(w_packed, np.float32)
+        k = row_pow2(w_packed)
+        w_packed = scale_rows(w_packed, k)
+        inv = np.exp2(-k.astype(np.float64))
+        sc = np.ones(len(k), np.float64)
+        if scale is not None:
+            sc[:len(scale)] = np.asarray(scale, np.float64)
+        scale = (sc * inv).astype(np.float32)          # exact: a power of two times a float32
     lay.w = store.put(w_packed, TORCH_DT[dtype]).data_ptr()
     lay.scale = store.vec(scale).data_ptr() if scale is not None else None
     lay.shift = store.vec(shift).data_ptr() if shift is not None else None
@@ -141,9 +175,9 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
     hmmr_bottleneck_tail launch (bf16; the stride-1 units of block1 and block2)."""
     if fold_sc is None:
         # fold every conv shortcut into its unit's conv3 (one GEMM over {h2, preact}: hmmr_resnet_unit_t.c3sc).  Default in
-        # the bf16x3 mode, where it removes the widest tensor of the unit (4 B/element) from HBM; the bf16 mode has its own
+        # the f16x3 mode, where it removes the widest tensor of the unit (4 B/element) from HBM; the bf16 mode has its own
         # fused units, and in f32 mode it would move the accumulation order away from the layer-per-launch schedule.
-        fold_sc = dtype == L.HMMR_BF16X3
+        fold_sc = dtype == L.HMMR_F16X3
     bke = 64 if dtype == L.HMMR_BF16 else 32
     rw = L.ResnetWeights()
     rw.dtype = dtype
@@ -185,8 +219,8 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
                                  np.concatenate([np.asarray(w[scope + "/shortcut/biases"], np.float32), b1]))
         s, b = fold_bn(w, scope + "/preact")
         u.pre_scale, u.pre_shift = store.vec(s).data_ptr(), store.vec(b).data_ptr()
-    if dtype == L.HMMR_BF16X3 and fuse_tail:
-        # bf16x3: conv3 + add + the next unit's preact + conv1 as one launch (csrc/bottleneck_split.hip) for the stride-1
+    if dtype == L.HMMR_F16X3 and fuse_tail:
+        # f16x3: conv3 + add + the next unit's preact + conv1 as one launch (csrc/bottleneck_split.hip) for the stride-1
         # units of blocks 1-2 whose successor has an identity shortcut; filters fragment-major, a folded shortcut
         # (c3sc) only with a 64-channel unit input (block1/unit_1)
         for i, (scope, c_in, base, depth, stride, has_sc) in enumerate(units[:-1]):
@@ -210,7 +244,7 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
     for i in range(L.RESNET_UNITS - 1):
         u, nx = rw.unit[i], rw.unit[i + 1]
         shapes = ((64, 256),) if fuse_tail == "block1" else ((64, 256), (128, 512))
-        if dtype == L.HMMR_BF16X3:
+        if dtype == L.HMMR_F16X3:
             break
         u.fuse_tail = int(bool(fuse_tail) and dtype == L.HMMR_BF16 and u.stride == 1 and
                           (u.base, u.depth) in shapes and nx.c_in == u.depth and nx.base == u.base and
@@ -239,7 +273,7 @@ def pack_temporal(w, dtype, store, num_conv_layers=3):
         b.gn2_gamma, b.gn2_beta = store.put(w[gn2 + "/gamma"]).data_ptr(), store.put(w[gn2 + "/beta"]).data_ptr()
         b.conv1 = _layer(store, pack_conv_weight(w[c1 + "/weights"]), dtype, shift=w[c1 + "/biases"])
         b.conv2 = _layer(store, pack_conv_weight(w[c2 + "/weights"]), dtype, shift=w[c2 + "/biases"])
-        if dtype == L.HMMR_BF16X3:      # measured (tools/stage_bench.py, 32 windows): the ping-pong tile, 0.51 -> 0.44 ms per f_movie pass
+        if dtype == L.HMMR_F16X3:      # measured (tools/stage_bench.py, 32 windows): the ping-pong tile, 0.51 -> 0.44 ms per f_movie pass
             b.conv1.tile = b.conv2.tile = 7
     return tw
 

@@ -33,10 +33,14 @@ extern "C" {
 
 #define HMMR_ABI_VERSION 11      /* 11: hmmr_conv_desc_t / hmmr_layer_t lost k_order (chunk-major K: measured, no gain, removed) */
 
-/* HMMR_BF16X3: "split" tensors -- every group of 8 consecutive channels is 32 bytes, [hi x8][lo x8] with
- * hi = bf16(x), lo = bf16(x - hi) (4 bytes per element, ~16 mantissa bits); GEMMs on them issue three bf16
- * MFMAs per operand pair (hi*hi + hi*lo + lo*hi, fp32 accumulate).  The parity-grade throughput mode. */
-enum { HMMR_F32 = 0, HMMR_BF16 = 1, HMMR_BF16X3 = 2 };
+/* HMMR_F16X3: "split" tensors -- every group of 8 consecutive channels is 32 bytes, [hi x8][lo x8] with
+ * hi = fp16(x), lo = fp16(x - hi), x clamped to +-65504 (4 bytes per element, 22 mantissa bits while lo is a normal
+ * fp16, an absolute 6e-8 below that); GEMMs on them issue three fp16 MFMAs per operand pair (lo*hi + hi*lo + hi*hi,
+ * fp32 accumulate; v_mfma_f32_32x32x16_f16 keeps fp16 subnormals).  Filter banks of this dtype are expected with every
+ * output-channel row scaled by a power of two to a maximum in [2^13, 2^14) and the inverse factor in the layer's `scale`
+ * (packing.row_pow2) -- unscaled filters work too, with fewer bits for small values.  The parity-grade throughput mode:
+ * fp32-class operands at the 16-bit MFMA rate / 3.  (Rounds 1-2 used bf16 halves: 16-17 bits.) */
+enum { HMMR_F32 = 0, HMMR_BF16 = 1, HMMR_F16X3 = 2 };
 
 int hmmr_abi_version(void);
 const char* hmmr_last_error(void);
@@ -44,7 +48,7 @@ const char* hmmr_last_error(void);
 /* Development switches for A/B measurements and tests.  Process-wide; all zero = the product defaults.  No
  * switch changes a result beyond what its comment says; the library never reads the environment. */
 typedef struct hmmr_debug_s {
-    int stem_route;        /* 0: default (fused stem kernel for bf16 / bf16x3, re-pack + GEMM + pool for f32);
+    int stem_route;        /* 0: default (fused stem kernel for bf16 / f16x3, re-pack + GEMM + pool for f32);
                               1: always the three-kernel route; 2: always the fused kernel */
     int stem_no_conv1;     /* 1: the fused bf16 stem leaves block1/unit_1's conv1 to its own launch */
     int gemm_probe;        /* read only by the -DHMMR_GEMM_PROBE development build (tools/probe_build.sh): the GEMM K loop
@@ -79,7 +83,7 @@ typedef struct {
                               dtype (= what a consumer applying pro_scale/pro_shift to `out` computes), or NULL */
     const float* scale2;
     const float* shift2;
-    int in_dtype;          /* HMMR_F32 / HMMR_BF16 / HMMR_BF16X3 */
+    int in_dtype;          /* HMMR_F32 / HMMR_BF16 / HMMR_F16X3 */
     int out_dtype;
     /* input geometry (element strides) */
     int n_img, hin, win, cin;          /* cin: channels per tap, power of two, >= 32B/elt */
@@ -152,7 +156,7 @@ typedef struct {
     hmmr_layer_t sc_c1;        /* optional: rows [shortcut (depth); conv1 (base)] of one [depth+base][c_in] filter
                                   bank with scale = [1..1; BN scale], shift = [bias; BN shift]: both convs as
                                   one column-split GEMM.  w == NULL: two launches. */
-    const void* w3_frag;       /* bf16x3 fused tail (fuse_tail == 1): this unit's conv3 filters ([W3 | Wsc] when c3sc is set) */
+    const void* w3_frag;       /* f16x3 fused tail (fuse_tail == 1): this unit's conv3 filters ([W3 | Wsc] when c3sc is set) */
     const void* w1n_frag;      /* ... and the NEXT unit's conv1 filters, both FRAGMENT-MAJOR (hmmr_tail_desc_t); else NULL */
     const float* pre_scale;    /* this unit's folded `preact` BN, [c_in] */
     const float* pre_shift;
@@ -187,7 +191,7 @@ typedef struct {
  * [block1] or (128, 512, 128) [block2].
  * The shortcut is read as rows of `ldr` elements, or (res_strided) as x[:, ::s, ::s] of an NHWC
  * tensor like hmmr_conv_desc_t's strided residual (ho, wo = output grid).
- * dtype HMMR_BF16X3 (csrc/bottleneck_split.hip): the next conv1 always; conv2 in front (h1; w2 packed like every filter bank; stride 1, 8 x 8
+ * dtype HMMR_F16X3 (csrc/bottleneck_split.hip): the next conv1 always; conv2 in front (h1; w2 packed like every filter bank; stride 1, 8 x 8
  * pixel tiles: hin, win multiples of 8) for the 64 -> 256 -> 64 shape only; w3 and w1 are
  * FRAGMENT-MAJOR: [rows / 32][K / 16][64 lanes][hi 16 B | lo 16 B], lane = 32 * (k half) + row, the 16 bytes = the 8
  * bf16 of W[32 rb + row][16 kc + 8 half .. + 7] (one coalesced 2 KB read per MFMA A operand, straight from L2).  With xp
@@ -195,7 +199,7 @@ typedef struct {
  * into conv3 exactly as hmmr_conv_desc_t.in2 does.  Bit-identical to the launches it replaces in either form.
  * ------------------------------------------------------------------------- */
 typedef struct {
-    int dtype;                      /* HMMR_BF16 or HMMR_BF16X3 */
+    int dtype;                      /* HMMR_BF16 or HMMR_F16X3 */
     const void* h2; int m; int c_mid; int depth;
     const void* w3; const float* scale3; const float* shift3;      /* [depth][c_mid]; scale3 may be NULL */
     const void* res; int ldr; int res_strided; int64_t res_img_stride; int res_row_stride, res_px_stride; int ho, wo;

@@ -72,9 +72,10 @@ def _conv(x, w_hwio, dtype, stride=1, pad=0, bias=None):
 # exactly those points (and nowhere else, accumulating in float64) turns "bf16-sized error" into a
 # tight comparison.  emulate = None | 'bf16' | 'bf16x3'.
 # --------------------------------------------------------------------------- #
-def quantize(x, emulate):
-    """x as the HIP path stores it: bf16 (round to nearest even), or the bf16x3 hi/lo pair
-    (hi = bf16(x), lo = bf16(x - hi); x ~ hi + lo)."""
+def quantize(x, emulate, weight=False):
+    """x as the HIP path stores it: bf16 (round to nearest even), or the f16x3 hi/lo pair
+    (hi = fp16(x), lo = fp16(x - hi); x ~ hi + lo; filters scaled, see below).  'bf16x3' = the bf16 hi/lo pair of
+    rounds 1-2, kept for comparison."""
     if emulate is None:
         return x
     x32 = x.to(torch.float32)
@@ -83,10 +84,24 @@ def quantize(x, emulate):
         return hi.to(x.dtype)
     if emulate == "bf16x3":
         return (hi.to(torch.float64) + (x32 - hi).to(torch.bfloat16).to(torch.float64)).to(x.dtype)
-    if emulate == "f16x3":      # the same split with fp16 halves (11 + 11 bits; fp16 subnormals kept, as the f16 MFMA keeps them)
+    if emulate == "f16x3":
+        # the split format of csrc/common.h: fp16 halves (11 + 11 bits; fp16 subnormals kept, as the f16 MFMA keeps them),
+        # values clamped to +-65504.  Filter banks (weight=True; output channel = last axis, HWIO / [in, out]) are scaled
+        # per output channel by a power of two to a maximum in [2^13, 2^14) before the split, exactly undone afterwards --
+        # packing.row_pow2: it keeps their lo halves out of the fp16 subnormal range.
+        x32 = x32.clamp(-65504.0, 65504.0)
+        scale = None
+        if weight:
+            m = x32.abs().reshape(-1, x32.shape[-1]).max(dim=0).values.to(torch.float64)
+            k = torch.where(m > 0, 13.0 - torch.floor(torch.log2(torch.where(m > 0, m, torch.ones_like(m)))), torch.zeros_like(m))
+            scale = torch.pow(torch.tensor(2.0, dtype=torch.float64), k).to(torch.float32)
+            x32 = x32 * scale
         h16 = x32.to(torch.float16).to(torch.float32)
-        return (h16.to(torch.float64) + (x32 - h16).to(torch.float16).to(torch.float64)).to(x.dtype)
-    raise ValueError("emulate must be None, 'bf16', 'bf16x3' or 'f16x3'")
+        out = h16.to(torch.float64) + (x32 - h16).to(torch.float16).to(torch.float64)
+        if scale is not None:
+            out = out / scale.to(torch.float64)
+        return out.to(x.dtype)
+    raise ValueError("emulate must be None, 'bf16', 'f16x3' or 'bf16x3' (the split format of rounds 1-2)")
 
 
 def _fold_bn32(w, prefix):
@@ -112,7 +127,7 @@ def resnet_v2_50_emulated(images_nhwc, w, emulate, fold_shortcut=None):
         fold_shortcut = emulate in ("bf16x3", "f16x3")
 
     def conv(x, name, stride=1, pad=0):
-        wt = q(_t(w[name], dt)).permute(3, 2, 0, 1).contiguous()
+        wt = quantize(_t(w[name], dt), emulate, weight=True).permute(3, 2, 0, 1).contiguous()
         return F.conv2d(x, wt, None, stride=stride, padding=pad)
 
     def affine(x, scale, shift):
@@ -226,9 +241,9 @@ def az_fc2_groupnorm(phi_btc, w, num_conv_layers=3, dtype=torch.float64, emulate
         gn1, c1 = "AZ_FC_block_preact_gn1" + n, "AZ_FC_block2_conv1" + n
         gn2, c2 = "AZ_FC_block_preact_gn2" + n, "AZ_FC_block2_conv2" + n
         h = q(torch.relu(group_norm_time(net, _t(w[gn1 + "/gamma"], dtype), _t(w[gn1 + "/beta"], dtype))))
-        h = temporal_conv3(h, q(_t(w[c1 + "/weights"], dtype)), _t(w[c1 + "/biases"], dtype))
+        h = temporal_conv3(h, quantize(_t(w[c1 + "/weights"], dtype), emulate, weight=True), _t(w[c1 + "/biases"], dtype))
         h = q(torch.relu(group_norm_time(h, _t(w[gn2 + "/gamma"], dtype), _t(w[gn2 + "/beta"], dtype))))
-        h = temporal_conv3(h, q(_t(w[c2 + "/weights"], dtype)), _t(w[c2 + "/biases"], dtype))
+        h = temporal_conv3(h, quantize(_t(w[c2 + "/weights"], dtype), emulate, weight=True), _t(w[c2 + "/biases"], dtype))
         net = h + net                                   # src/models.py:226
     return net
 
@@ -256,11 +271,12 @@ def hmr_ief(phi, omega_start, w, scope, num_stage=3, dtype=torch.float64, emulat
     theta = omega_start
     if emulate is not None:
         nphi = phi.shape[1]
-        pre = q(q(phi) @ q(W1[:nphi]) + b1)
+        qw = lambda t: quantize(t, emulate, weight=True)
+        pre = q(q(phi) @ qw(W1[:nphi]) + b1)
         for _ in range(num_stage):
             h = q(torch.relu(pre + theta @ W1[nphi:]))
-            h = q(torch.relu(h @ q(W2) + b2))
-            theta = theta + (h @ q(W3) + b3)
+            h = q(torch.relu(h @ qw(W2) + b2))
+            theta = theta + (h @ qw(W3) + b3)
         return theta
     for _ in range(num_stage):
         state = torch.cat([phi, theta], dim=1)          # models.py:402

@@ -36,8 +36,8 @@ def test_workspace_queries_need_no_gpu():
     assert lib.hmmr_smpl_workspace_bytes(256) >= 256 * (224 + 288) * 4
     assert lib.hmmr_temporal_workspace_bytes(8, 20, _lib.HMMR_F32) >= 4 * 160 * 2048 * 4
     assert lib.hmmr_ief_workspace_bytes(160, 3, _lib.HMMR_F32) > 0
-    # split (bf16x3) tensors are 4 bytes per element, like fp32
-    assert lib.hmmr_resnet50_workspace_bytes(64, _lib.HMMR_BF16X3) == f32
+    # split (f16x3) tensors are 4 bytes per element, like fp32
+    assert lib.hmmr_resnet50_workspace_bytes(64, _lib.HMMR_F16X3) == f32
 
 
 def test_debug_switches_round_trip():
@@ -65,7 +65,7 @@ def test_argument_validation_reports_errors():
         _lib.check(rc, "hmmr_conv_gemm")
 
 
-def _dense_1x1(m=256, cin=64, cout=256, dtype=_lib.HMMR_BF16X3):
+def _dense_1x1(m=256, cin=64, cout=256, dtype=_lib.HMMR_F16X3):
     """a syntactically valid 1x1 descriptor with dummy (never dereferenced) pointers: validation runs before any launch"""
     d = _lib.ConvDesc()
     d.in_, d.w, d.out = 0x1000, 0x2000, 0x3000
@@ -95,7 +95,7 @@ def test_conv_desc_validation_of_the_round_2_fields():
     d.tile = 8
     assert lib.hmmr_conv_gemm(d, None) != 0 and b"tile 8" in lib.hmmr_last_error()
     t = _lib.TailDesc()
-    t.dtype, t.h2, t.w3, t.res, t.m, t.c_mid, t.depth, t.n2 = _lib.HMMR_BF16X3, 0x1000, 0x2000, 0x3000, 64, 256, 1024, 256
+    t.dtype, t.h2, t.w3, t.res, t.m, t.c_mid, t.depth, t.n2 = _lib.HMMR_F16X3, 0x1000, 0x2000, 0x3000, 64, 256, 1024, 256
     t.w1 = t.out = t.out_h1 = t.pre_scale = t.pre_shift = t.scale1 = t.shift1 = 0x4000
     t.ldr = 1024
     assert lib.hmmr_bottleneck_tail(t, None) != 0 and b"supported shapes" in lib.hmmr_last_error()
@@ -103,22 +103,27 @@ def test_conv_desc_validation_of_the_round_2_fields():
 
 def test_fragment_major_packing_layout():
     """packing.pack_frag_major: [n][K] -> [n / 32][K / 16][64 lanes][hi, lo][8]; lane = 32 * (k half) + row, i.e. the 16 bytes a
-    lane feeds v_mfma_f32_32x32x16_bf16 as its A operand (csrc/bottleneck_split.hip reads them straight from L2)."""
+    lane feeds v_mfma_f32_32x32x16_f16 as its A operand (csrc/bottleneck_split.hip reads them straight from L2); fp16 halves
+    of the rows scaled by packing.row_pow2."""
     import numpy as np
     import torch
     from human_dynamics_amd import packing
     rng = np.random.default_rng(0)
     w = rng.normal(size=(64, 48)).astype(np.float32)
     f = packing.pack_frag_major(w)
-    assert tuple(f.shape) == (2, 3, 64, 2, 8) and f.dtype == torch.bfloat16
-    hi = torch.from_numpy(w).to(torch.bfloat16)
-    lo = (torch.from_numpy(w) - hi.float()).to(torch.bfloat16)
+    assert tuple(f.shape) == (2, 3, 64, 2, 8) and f.dtype == torch.float16
+    k = packing.row_pow2(w)
+    ws = torch.from_numpy(packing.scale_rows(w, k))
+    assert float(ws.abs().max()) < 2.0 ** 14 and float(ws.abs().max(dim=1).values.min()) >= 2.0 ** 13
+    hi = ws.to(torch.float16)
+    lo = (ws - hi.float()).to(torch.float16)
     for rb, kc, lane in ((0, 0, 0), (1, 2, 63), (0, 1, 37), (1, 0, 31)):
         row, half = rb * 32 + lane % 32, lane // 32
         k0 = kc * 16 + 8 * half
         assert torch.equal(f[rb, kc, lane, 0], hi[row, k0:k0 + 8]) and torch.equal(f[rb, kc, lane, 1], lo[row, k0:k0 + 8])
     back = (f[:, :, :, 0].float() + f[:, :, :, 1].float()).reshape(2, 3, 2, 32, 8).permute(0, 3, 1, 2, 4).reshape(64, 48)
-    assert float((back - torch.from_numpy(w)).abs().max()) < 2.0 ** -15
+    unscaled = back.double() / torch.from_numpy(np.exp2(k.astype(np.float64)))[:, None]
+    assert float(((unscaled - torch.from_numpy(w).double()).abs() / torch.from_numpy(w).double().abs()).max()) < 2.0 ** -20
 
 
 def test_engine_refuses_to_run_without_a_gpu():

@@ -1,8 +1,8 @@
-"""GPU parity of the split-bf16 ("bf16x3", HMMR_BF16X3) mode: the throughput mode that has to stay
+"""GPU parity of the split-fp16 ("f16x3", HMMR_F16X3) mode: the throughput mode that has to stay
 inside the reference tolerance (vertices / joints within 1e-4 of the fp32 TF graph,
 BASELINE.json north_star; the reference computes in fp32 throughout, tester.py:64-66).
 
-Operands are bf16 hi/lo pairs (x ~ hi + lo, 16 mantissa bits), every product is three bf16 MFMAs
+Operands are fp16 hi/lo pairs (x ~ hi + lo, 22 mantissa bits; filters scaled per output channel), every product is three fp16 MFMAs
 (hi*hi + hi*lo + lo*hi) accumulated in fp32, activations between layers stay hi/lo pairs.
 """
 import numpy as np
@@ -16,26 +16,39 @@ from test_gpu_kernels import _ref_conv
 
 pytestmark = pytest.mark.gpu
 F64 = torch.float64
-X3 = L.HMMR_BF16X3
+X3 = L.HMMR_F16X3
 
 
 def _split_round(a):
-    """The value a split tensor holds for fp32 input a (hi + lo)."""
-    t = torch.tensor(np.asarray(a, np.float32))
-    hi = t.to(torch.bfloat16).to(torch.float32)
-    return (hi.to(F64) + (t - hi).to(torch.bfloat16).to(F64)).numpy()
+    """The value a split tensor holds for fp32 input a (hi + lo, fp16 halves, clamped to the fp16 range)."""
+    t = torch.tensor(np.asarray(a, np.float32)).clamp(-65504.0, 65504.0)
+    hi = t.to(torch.float16).to(torch.float32)
+    return (hi.to(F64) + (t - hi).to(torch.float16).to(F64)).numpy()
+
+
+def _split_round_w(w_hwio):
+    """... and a filter bank [kh,kw,cin,cout]: every output channel scaled by its power of two before the split
+    (packing.row_pow2) and unscaled after it."""
+    from human_dynamics_amd import packing
+    w = np.asarray(w_hwio, np.float32)
+    rows = w.reshape(-1, w.shape[-1]).T                       # [cout][K]
+    f = np.exp2(packing.row_pow2(rows).astype(np.float64))
+    return (_split_round((rows * f[:, None]).astype(np.float32)) / f[:, None]).T.reshape(w.shape)
 
 
 def test_split_layout_round_trip():
-    """to_split / from_split: 16 mantissa bits, 32-byte groups [hi x8][lo x8]."""
+    """to_split / from_split: 22 mantissa bits (values whose lo half is a normal fp16; an absolute 6e-8 below that),
+    32-byte groups [hi x8][lo x8], values beyond the fp16 range clamped."""
     from human_dynamics_amd.packing import from_split, to_split
     x = torch.randn(5, 7, 64, generator=torch.Generator().manual_seed(0)) * 3
+    x[0, 0, :4] = torch.tensor([1e5, -3e6, 65504.0, 1e-7])
     s = to_split(x)
     assert s.dtype == torch.int32 and s.shape == x.shape
     y = from_split(s)
-    assert float(((x - y).abs() / x.abs().clamp_min(1e-30)).max()) < 2.0 ** -16
-    raw = s.view(torch.bfloat16).reshape(5, 7, 8, 2, 8)
-    assert torch.equal(raw[..., 0, :].reshape(5, 7, 64), x.to(torch.bfloat16))
+    xc = x.clamp(-65504.0, 65504.0)
+    assert bool(((xc - y).abs() <= torch.maximum(xc.abs() * 2.0 ** -21, torch.tensor(6.0e-8))).all())
+    raw = s.view(torch.float16).reshape(5, 7, 8, 2, 8)
+    assert torch.equal(raw[..., 0, :].reshape(5, 7, 64), xc.to(torch.float16))
 
 
 CASES = [
@@ -85,7 +98,7 @@ def test_conv_gemm_split(case, tile, out_dt, gpu_device):
     out, out2 = conv_gemm(x, w, stride, pad, scale, shift, res, "r" in flags, s2, b2, in_dtype=X3, out_dtype=odt,
                           tile=tile, device=gpu_device, res_stride=res_stride)
     res_r = res if (res is None or out_dt == "f32") else _split_round(res)     # the residual is read in the output type
-    ref, ref2 = _ref_conv(_split_round(x), _split_round(w), stride, pad, scale, shift, res_r, "r" in flags, s2, b2,
+    ref, ref2 = _ref_conv(_split_round(x), _split_round_w(w), stride, pad, scale, shift, res_r, "r" in flags, s2, b2,
                           res_stride)
     mag = max(1.0, np.abs(ref).max())
     err = np.abs(out - ref).max()
@@ -110,7 +123,7 @@ def test_conv_gemm_split_fused_preactivation(tile, gpu_device):
     b = rng.normal(size=128).astype(np.float32)
     out, _ = conv_gemm(x, w, 1, 0, s, b, None, True, in_dtype=X3, tile=tile, device=gpu_device, pro=(ps, pb))
     xa = _split_round(np.maximum(_split_round(x) * ps.astype(np.float64) + pb, 0).astype(np.float32))
-    ref, _ = _ref_conv(xa, _split_round(w), 1, 0, s, b, None, True, None, None)
+    ref, _ = _ref_conv(xa, _split_round_w(w), 1, 0, s, b, None, True, None, None)
     assert np.abs(out - ref).max() < 3e-5 * max(1.0, np.abs(ref).max())
     # producer-side route: an identity 1x1 conv writes relu(x*ps+pb) as its second output, the GEMM reads that
     eye = np.eye(256, dtype=np.float32).reshape(1, 1, 256, 256)
@@ -129,7 +142,7 @@ def test_conv_gemm_split_with_split_k(split_k, gpu_device):
     b = rng.normal(size=200).astype(np.float32)
     res = rng.normal(size=(3, 20, 1, 200)).astype(np.float32)
     out, _ = conv_gemm(x, w, 1, (1, 0), None, b, res, True, in_dtype=X3, device=gpu_device, split_k=split_k)
-    ref, _ = _ref_conv(_split_round(x), _split_round(w), 1, (1, 0), None, b, res, True, None, None)
+    ref, _ = _ref_conv(_split_round(x), _split_round_w(w), 1, (1, 0), None, b, res, True, None, None)
     assert np.abs(out - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
     x2 = np.concatenate([x, rng.normal(size=(5, 20, 1, 256)).astype(np.float32)])
     res2 = np.concatenate([res, rng.normal(size=(5, 20, 1, 200)).astype(np.float32)])
@@ -152,7 +165,7 @@ def test_conv_gemm_f32_in_split_out(gpu_device):
 @pytest.fixture(scope="module")
 def eng_x3(weights, smpl_consts, gpu_device):
     from human_dynamics_amd.engine import HmmrEngine
-    return HmmrEngine(weights, smpl_consts, dtype="bf16x3", device=gpu_device)
+    return HmmrEngine(weights, smpl_consts, dtype="f16x3", device=gpu_device)
 
 
 def test_groupnorm_relu_split_output(eng_x3):
@@ -175,7 +188,7 @@ def test_resnet_split_matches_oracle(eng_x3, golden_window):
     ref = golden_window["phi"][:3]
     err = np.abs(phi - ref).max()
     rel = np.linalg.norm(phi - ref) / np.linalg.norm(ref)
-    print("ResNet bf16x3: phi max-abs-err %.3e rel-L2 %.3e (|phi|max %.2f)" % (err, rel, np.abs(ref).max()))
+    print("ResNet f16x3: phi max-abs-err %.3e rel-L2 %.3e (|phi|max %.2f)" % (err, rel, np.abs(ref).max()))
     assert rel < 1e-4 and err < 1e-3
 
 
@@ -194,7 +207,7 @@ def test_temporal_and_ief_split_match_oracle(eng_x3, golden_window):
     e1 = np.abs(out[0] - golden_window["strips"]).max()
     om = eng_x3.ief(golden_window["strips"]).cpu().numpy()
     e2 = np.abs(om - golden_window["omegas_all"]).max()
-    print("bf16x3: strips max-abs-err %.3e, omegas max-abs-err %.3e" % (e1, e2))
+    print("f16x3: strips max-abs-err %.3e, omegas max-abs-err %.3e" % (e1, e2))
     assert e1 < 2e-4 and e2 < 5e-5
 
 
@@ -208,17 +221,17 @@ def test_predict_split_meets_reference_tolerance(weights, smpl_consts, gpu_devic
     assert t.engine.dtype == X3
     res = t.predict(frames[None])
     errs = _check(res, golden_window, 1e-4)
-    print("bf16x3 end to end: verts %.3e joints %.3e omegas %.3e" % (errs["verts"], errs["joints"], errs["omegas"]))
+    print("f16x3 end to end: verts %.3e joints %.3e omegas %.3e" % (errs["verts"], errs["joints"], errs["omegas"]))
 
 
 def test_predict_all_images_split_matches_golden_video(weights, smpl_consts, gpu_device, golden_video):
     from human_dynamics_amd.evaluation.tester import Tester
     from test_gpu_pipeline import _check
     frames = assets.make_synthetic_frames(24, seed=7)
-    t = Tester(Config(batch_size=2), weights=weights, smpl=smpl_consts, dtype="bf16x3", device=gpu_device)
+    t = Tester(Config(batch_size=2), weights=weights, smpl=smpl_consts, dtype="f16x3", device=gpu_device)
     res = t.predict_all_images(frames)
     _check(res, dict(golden_video), 1e-4)
-    lit = Tester(Config(batch_size=2), weights=weights, smpl=smpl_consts, dtype="bf16x3", device=gpu_device,
+    lit = Tester(Config(batch_size=2), weights=weights, smpl=smpl_consts, dtype="f16x3", device=gpu_device,
                  dedup=False).predict_all_images(frames)
     for k in res:
         assert np.array_equal(res[k], lit[k]), k
@@ -252,15 +265,15 @@ def test_conv_gemm_second_operand_source(tile, dt, gpu_device):
 
 
 def test_resnet_folded_shortcut_is_the_separate_shortcut_up_to_its_rounding(weights, gpu_device):
-    """bf16x3 default: the conv shortcut of every block's first unit is accumulated inside conv3's GEMM instead of being
+    """f16x3 default: the conv shortcut of every block's first unit is accumulated inside conv3's GEMM instead of being
     stored (rounded to 16 bits) and added back.  Against the launch-per-layer schedule the features move by that one
     rounding; against the float64 oracle both stay inside the mode's bound."""
     from human_dynamics_amd.engine import HmmrEngine
     from oracle import hmmr_oracle as O
     frames = assets.make_synthetic_frames(5, seed=9)
-    folded = HmmrEngine(weights, None, dtype="bf16x3", device=gpu_device, autotune=False)
+    folded = HmmrEngine(weights, None, dtype="f16x3", device=gpu_device, autotune=False)
     assert [i for i in range(16) if folded.rw.unit[i].c3sc.w] == [0, 3, 7, 13]
-    plain = HmmrEngine(weights, None, dtype="bf16x3", device=gpu_device, autotune=False, fold_sc=False)
+    plain = HmmrEngine(weights, None, dtype="f16x3", device=gpu_device, autotune=False, fold_sc=False)
     assert not any(plain.rw.unit[i].c3sc.w for i in range(16))
     a, b = folded.resnet(frames, n_zero=1).cpu().numpy(), plain.resnet(frames, n_zero=1).cpu().numpy()
     ref = O.resnet_v2_50(np.concatenate([frames, np.zeros_like(frames[:1])]), weights, torch.float64).numpy()
@@ -268,8 +281,8 @@ def test_resnet_folded_shortcut_is_the_separate_shortcut_up_to_its_rounding(weig
     ea, eb, d = np.linalg.norm(a - ref) / n, np.linalg.norm(b - ref) / n, np.linalg.norm(a - b) / n
     print("folded shortcut: rel-L2 vs f64 %.2e (separate launches %.2e), folded vs separate %.2e" % (ea, eb, d))
     assert ea < 5e-5 and eb < 5e-5 and d < 2e-5
-    emu = O.resnet_v2_50_emulated(frames[:2], weights, "bf16x3").numpy()
-    emu_sep = O.resnet_v2_50_emulated(frames[:2], weights, "bf16x3", fold_shortcut=False).numpy()
+    emu = O.resnet_v2_50_emulated(frames[:2], weights, "f16x3").numpy()
+    emu_sep = O.resnet_v2_50_emulated(frames[:2], weights, "f16x3", fold_shortcut=False).numpy()
     assert np.linalg.norm(a[:2] - emu) / np.linalg.norm(emu) < 5e-6
     assert np.linalg.norm(b[:2] - emu_sep) / np.linalg.norm(emu_sep) < 5e-6
 
@@ -280,13 +293,13 @@ def test_resnet_split_fused_tails_equal_layer_per_launch(weights, gpu_device):
     features are bit-identical (6 images: block 2's 4704 pixels end in a half tile)."""
     from human_dynamics_amd.engine import HmmrEngine
     frames = assets.make_synthetic_frames(5, seed=17)
-    fused = HmmrEngine(weights, None, dtype="bf16x3", device=gpu_device, autotune=False)
+    fused = HmmrEngine(weights, None, dtype="f16x3", device=gpu_device, autotune=False)
     assert [int(fused.rw.unit[i].fuse_tail) for i in range(16)] == [2, 2, 0, 0, 1, 1, 0] + [0] * 9
-    plain = HmmrEngine(weights, None, dtype="bf16x3", device=gpu_device, autotune=False, fuse_tail=False)
+    plain = HmmrEngine(weights, None, dtype="f16x3", device=gpu_device, autotune=False, fuse_tail=False)
     assert not any(plain.rw.unit[i].fuse_tail for i in range(16))
     a, b = fused.resnet(frames, n_zero=1), plain.resnet(frames, n_zero=1)
     assert float(b.abs().max()) > 0.1
     assert torch.equal(a, b), float((a - b).abs().max())
     for variant in ("block1", "noconv2"):
-        eng = HmmrEngine(weights, None, dtype="bf16x3", device=gpu_device, autotune=False, fuse_tail=variant)
+        eng = HmmrEngine(weights, None, dtype="f16x3", device=gpu_device, autotune=False, fuse_tail=variant)
         assert torch.equal(eng.resnet(frames, n_zero=1), b), variant

@@ -24,11 +24,11 @@ def _oracle():
 @pytest.fixture(scope="module")
 def engines(weights, smpl_consts, gpu_device):
     from human_dynamics_amd.engine import HmmrEngine
-    return {dt: HmmrEngine(weights, smpl_consts, dtype=dt, device=gpu_device) for dt in ("bf16x3", "bf16", "f32")}
+    return {dt: HmmrEngine(weights, smpl_consts, dtype=dt, device=gpu_device) for dt in ("f16x3", "bf16", "f32")}
 
 
 # --------------------------------------------------------------------------- config 2
-@pytest.mark.parametrize("dt,emulate,tol_rel", [("bf16x3", None, 5e-5), ("bf16x3", "bf16x3", 5e-6), ("f32", None, 5e-6)])
+@pytest.mark.parametrize("dt,emulate,tol_rel", [("f16x3", None, 5e-5), ("f16x3", "f16x3", 5e-6), ("f32", None, 5e-6)])
 def test_config2_resnet_batch64(engines, weights, dt, emulate, tol_rel):
     """BASELINE config 2: batch = 64 frames through the ResNet; phi against the float64 oracle on every
     8th frame.  emulate = the oracle rounds operands and stored tensors exactly where that mode does."""
@@ -69,7 +69,7 @@ def test_config2_resnet_batch64_bf16_error_is_the_predicted_size(engines, weight
 # --------------------------------------------------------------------------- config 3
 def test_config3_64_windows(weights, smpl_consts, gpu_device):
     """BASELINE config 3: 64 windows x T=20 (1280 frames): ResNet + f_movie + IEF in the default
-    (bf16x3) mode; omega_0 and both delta omegas of three sampled windows against the float64 oracle."""
+    (f16x3) mode; omega_0 and both delta omegas of three sampled windows against the float64 oracle."""
     from human_dynamics_amd.evaluation.tester import Tester
     O = _oracle()
     frames = assets.make_synthetic_frames(1280, seed=31).reshape(64, 20, 224, 224, 3)
@@ -84,7 +84,7 @@ def test_config3_64_windows(weights, smpl_consts, gpu_device):
     e0 = np.abs(om[sel] - ref["omegas"]).max()
     e1 = np.abs(omd[sel] - ref["omegas_delta"]).max()
     ev = np.abs(out["verts"].cpu().numpy()[sel] - ref["verts"]).max()
-    print("config 3 [bf16x3]: omegas %.3e omegas_delta %.3e verts %.3e" % (e0, e1, ev))
+    print("config 3 [f16x3]: omegas %.3e omegas_delta %.3e verts %.3e" % (e0, e1, ev))
     assert e0 < 1e-4 and e1 < 1e-4 and ev < 1e-4
 
 
@@ -112,7 +112,7 @@ def config4_ref(weights, smpl_consts):
     return frames, ot.predict(_windows_of(frames, C4_STARTS))
 
 
-@pytest.mark.parametrize("dt,tol", [("bf16x3", 1e-4), ("f32", 1e-4)])
+@pytest.mark.parametrize("dt,tol", [("f16x3", 1e-4), ("f32", 1e-4)])
 def test_config4_256_frame_video(weights, smpl_consts, gpu_device, config4_ref, dt, tol):
     """BASELINE config 4: a 256-frame video through predict_all_images (B=8, T=20 -> 32 windows, the
     autotuned tile table of a 257-frame ResNet pass): vertices / joints of four sampled windows (first,
@@ -154,7 +154,7 @@ def test_bf16_mode_against_its_emulation(weights, smpl_consts, gpu_device):
 
 
 # --------------------------------------------------------------------------- fused stem
-@pytest.mark.parametrize("dt", ["bf16", "bf16x3", "f32"])
+@pytest.mark.parametrize("dt", ["bf16", "f16x3", "f32"])
 def test_fused_stem_equals_three_kernel_route(weights, gpu_device, dt):
     """stem.hip (7x7/2 conv + bias + pool1 + unit_1 preact [+ unit_1 conv1] in one launch) against the
     re-pack + implicit-GEMM + pool route, through the whole ResNet: image-edge tiles, interior tiles
@@ -195,7 +195,7 @@ def test_config5_4096_frame_video_on_one_gpu(weights, smpl_consts, gpu_device):
     from human_dynamics_amd import dist as hd
     from human_dynamics_amd.evaluation.tester import Tester
     n = 4096
-    t = Tester(Config(batch_size=8), weights=weights, smpl=smpl_consts, dtype="bf16x3", device=gpu_device)
+    t = Tester(Config(batch_size=8), weights=weights, smpl=smpl_consts, dtype="f16x3", device=gpu_device)
     plan = hd.ShardPlan(n, 8, 20, 13, 1, 0)
     assert (plan.f0, plan.f1, plan.o0, plan.o1, plan.w1 - plan.w0) == (0, n, 0, n, 512)
     gen = torch.Generator(device=gpu_device)
@@ -214,7 +214,7 @@ def test_config5_4096_frame_video_on_one_gpu(weights, smpl_consts, gpu_device):
     torch.cuda.empty_cache()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--video-frames", str(n), "--steps", "1", "--warmup", "0",
-                        "--only-main", "--no-cpu-baseline", "--no-pcie", "--dtype", "bf16x3"], cwd=root, capture_output=True,
+                        "--only-main", "--no-cpu-baseline", "--no-pcie", "--dtype", "f16x3"], cwd=root, capture_output=True,
                        text=True, timeout=600)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and lines, r.stderr[-800:]

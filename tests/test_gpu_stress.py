@@ -5,9 +5,11 @@ several weight seeds and two hard-conditioned sets (oracle/hard_weights.py), eve
   * against the exact-fp32 operand mode of the same kernels on ALL 256 frames (which is itself checked against the oracle
     on the sampled windows, so the two bounds add up to a bound for every frame).
 
-Plain seeds must hold 1e-4 in bf16x3.  The hard sets are the ones bf16x3 does NOT survive; there the default operand
-selection (dtype="auto", human_dynamics_amd/precision.py) has to notice on its own and fall back to f32 operands where
-needed -- the test asserts both that bf16x3 alone breaks the probe bound and that the chosen mode holds 1e-4."""
+Every set must hold 1e-4 in what the default ships (dtype="auto", human_dynamics_amd/precision.py), on the sampled windows
+against the oracle and on every frame through the exact-fp32 mode.  The hard sets are the ones the split format of rounds
+1-2 (bf16 halves) did NOT survive (1.2e-4 ... 4.4e-4; tests/test_oracle.py keeps that comparison on the CPU); with fp16
+halves and scaled filters the split mode is expected to hold them too, and where the probe decides otherwise the test
+accepts the fallback as long as the shipped mode is inside the tolerance."""
 import numpy as np
 import pytest
 import torch
@@ -68,7 +70,7 @@ def test_tolerance_over_weight_sets(smpl_consts, gpu_device, kind, starts):
     r32 = t32.predict_all_images(dev)
     e32 = _errors(r32, ref, starts)
     del t32
-    tx3 = Tester(Config(batch_size=8), weights=w, smpl=smpl_consts, dtype="bf16x3", device=gpu_device)
+    tx3 = Tester(Config(batch_size=8), weights=w, smpl=smpl_consts, dtype="f16x3", device=gpu_device)
     rx3 = tx3.predict_all_images(dev)
     ex3 = _errors(rx3, ref, starts)
     dx3 = {k: float(np.abs(rx3[k] - r32[k]).max()) for k in KEYS}            # all 256 frames
@@ -78,17 +80,17 @@ def test_tolerance_over_weight_sets(smpl_consts, gpu_device, kind, starts):
     ea = _errors(ra, ref, starts)
     da = {k: float(np.abs(ra[k] - r32[k]).max()) for k in KEYS}
     rep = ta.precision
-    print("\n[%s] f32 vs oracle %s\n[%s] bf16x3 vs oracle %s; vs f32 on all 256 frames %s\n[%s] auto -> %s: vs oracle %s; vs f32 on all "
+    print("\n[%s] f32 vs oracle %s\n[%s] f16x3 vs oracle %s; vs f32 on all 256 frames %s\n[%s] auto -> %s: vs oracle %s; vs f32 on all "
           "256 frames %s; probe %s" % (kind, e32, kind, ex3, dx3, kind, rep["operands"], ea, da, rep["rungs"]))
     assert max(e32.values()) < 1e-4, (kind, "f32", e32)
     # what the default ships: inside the tolerance on the sampled windows, and on every frame via the f32 mode
     assert max(ea.values()) < precision.TOLERANCE, (kind, rep["operands"], ea)
     assert max(da.values()) + max(e32.values()) < precision.TOLERANCE, (kind, rep["operands"], da, e32)
     if kind.startswith("seed"):
-        assert rep["operands"] == "bf16x3" and max(ex3.values()) < precision.TOLERANCE
+        assert rep["operands"] == "f16x3" and max(ex3.values()) < precision.TOLERANCE
         for k in KEYS:
             assert np.array_equal(ra[k], rx3[k])                             # auto chose the same engine configuration
-    else:
-        # the hard sets break bf16x3 (if they ever stop doing so, make them harder): the selection must have moved on
-        assert max(dx3.values()) > rep["probe_tolerance"], (kind, dx3)
-        assert rep["operands"] != "bf16x3" and not rep["rungs"][0]["accepted"]
+    elif rep["operands"] == "f16x3":
+        assert max(ex3.values()) < precision.TOLERANCE, (kind, ex3)
+        for k in KEYS:
+            assert np.array_equal(ra[k], rx3[k])

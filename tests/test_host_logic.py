@@ -135,8 +135,8 @@ def test_packer_marks_the_fused_launches(weights):
     assert [i for i in range(16) if rw.unit[i].sc_c1.w] == [7, 13]
     assert [i for i in range(16) if not rw.unit[i].fuse_preact] == [0, 3, 7, 13]      # the blocks' first units
     assert not any(rw.unit[i].c3sc.w for i in range(16))
-    # bf16x3: every conv shortcut is folded into its unit's conv3 (one GEMM over {h2, preact}); no column-split GEMMs then
-    rwx = packing.pack_resnet(weights, _lib.HMMR_BF16X3, packing.DeviceStore("cpu"))
+    # f16x3: every conv shortcut is folded into its unit's conv3 (one GEMM over {h2, preact}); no column-split GEMMs then
+    rwx = packing.pack_resnet(weights, _lib.HMMR_F16X3, packing.DeviceStore("cpu"))
     assert [i for i in range(16) if rwx.unit[i].c3sc.w] == [0, 3, 7, 13] and not any(rwx.unit[i].sc_c1.w for i in range(16))
     # ... and conv3 + add + the next conv1 run as one launch for the stride-1 units of blocks 1-2 with an identity successor
     assert [rwx.unit[i].fuse_tail for i in range(16)] == [2, 2, 0, 0, 1, 1, 0] + [0] * 9      # block 1: conv2 inside as well

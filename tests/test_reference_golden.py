@@ -222,7 +222,7 @@ def test_oracle_fc2_res_equals_reference(weights):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dt,tol", [("f32", 2e-5), ("bf16x3", 2e-4)])
+@pytest.mark.parametrize("dt,tol", [("f32", 2e-5), ("f16x3", 2e-4)])
 def test_hip_resnet_equals_reference_encoder_resnet(ref_resnet, weights, gpu_device, dt, tol):
     from human_dynamics_amd.engine import HmmrEngine
     eng = HmmrEngine(weights, None, dtype=dt, device=gpu_device)
@@ -240,7 +240,7 @@ def test_hip_hallucinator_equals_reference_fc2_res(gpu_device):
     from human_dynamics_amd.engine import HmmrEngine
     g = dict(np.load(os.path.join(GOLDEN, "reference_fc2_res.npz")))
     wh = assets.make_synthetic_weights(0, with_hallucinator=True)
-    for dt, tol in (("f32", 2e-5), ("bf16x3", 1e-4)):
+    for dt, tol in (("f32", 2e-5), ("f16x3", 1e-4)):
         eng = HmmrEngine(wh, None, dtype=dt, device=gpu_device)
         out = eng.hallucinate(g["phi"].astype(np.float32)).cpu().numpy()
         err = np.abs(out - g["out"]).max()

@@ -59,7 +59,7 @@ def test_pack_ief_reads_use_optcam_from_the_checkpoint_shapes():
 
 # ------------------------------------------------------------------------------------------------ the HIP path
 @pytest.mark.gpu
-@pytest.mark.parametrize("dt,tol", [("f32", 2e-6), ("bf16x3", 5e-5)])
+@pytest.mark.parametrize("dt,tol", [("f32", 2e-6), ("f16x3", 5e-5)])
 @pytest.mark.parametrize("optcam,from_pred", COMBOS)
 def test_hip_batch_pred_omega_modes_equal_reference(ref, gpu_device, optcam, from_pred, dt, tol):
     from human_dynamics_amd.engine import HmmrEngine

@@ -14,7 +14,7 @@ sys.path.insert(0, ".")
 from human_dynamics_amd import _lib as L
 from human_dynamics_amd import packing
 
-DT = {"bf16": (L.HMMR_BF16, torch.bfloat16), "f32": (L.HMMR_F32, torch.float32), "bf16x3": (L.HMMR_BF16X3, packing.SPLIT)}
+DT = {"bf16": (L.HMMR_BF16, torch.bfloat16), "f32": (L.HMMR_F32, torch.float32), "f16x3": (L.HMMR_F16X3, packing.SPLIT)}
 
 
 def cast(t, tdt):

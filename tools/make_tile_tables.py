@@ -15,7 +15,7 @@ import torch
 
 sys.path.insert(0, ".")
 out_path = sys.argv[1]
-dtypes = sys.argv[2:] or ["bf16x3", "bf16", "f32"]
+dtypes = sys.argv[2:] or ["f16x3", "bf16", "f32"]
 os.environ["HMMR_TILE_TABLE"] = "0"
 os.environ["HMMR_AUTOTUNE"] = "force"
 from human_dynamics_amd import assets                     # noqa: E402

@@ -26,7 +26,7 @@ def t(fn, n=3):
 
 
 def main():
-    dt = sys.argv[1] if len(sys.argv) > 1 else "bf16x3"
+    dt = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
     dev = torch.device("cuda:0")
     x = np.random.default_rng(0).random((256, 224, 224, 3), dtype=np.float32) * 2 - 1
     pin = torch.empty((256, 224, 224, 3), dtype=torch.float32, pin_memory=True)

@@ -42,14 +42,14 @@ def resnet_kernel(k, dtype):
         return False
     if dtype == "bf16":
         return "conv_gemm_kernelIDF16bDF16b" in k or "conv_gemm_kernel<__bf16, __bf16" in k
-    if dtype == "bf16x3":
+    if dtype == "f16x3":
         return "8bsplit_tS0_" in k or "conv_gemm_kernel<bsplit_t, bsplit_t" in k
     return "conv_gemm_kernelIffL" in k or "conv_gemm_kernel<float, float" in k
 
 
 def main():
     root, out = sys.argv[1], sys.argv[2]
-    dtype = sys.argv[3] if len(sys.argv) > 3 else "bf16x3"
+    dtype = sys.argv[3] if len(sys.argv) > 3 else "f16x3"
     fe, wr = agg(root, "FETCH_SIZE", "FETCH_SIZE"), agg(root, "WRITE_SIZE", "WRITE_SIZE")
     mf = agg(root, "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES")
     gui = agg(root, "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE")

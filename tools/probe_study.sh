@@ -6,5 +6,5 @@ N=${1:-257}; T=${2:-5,6,8}
 export HMMR_LIB_PATH=$PWD/human_dynamics_amd/libhmmr_hip_probe.so
 for p in 0 1 2 3 7; do
   echo "== HMMR_GEMM_PROBE=$p"
-  HMMR_GEMM_PROBE=$p timeout 120 python tools/conv_bench.py $N bf16x3 $T "b1.conv3,b2.conv3,b3.conv1,b3.conv3,b4.conv1,b4.conv3,b3.conv2" 2>&1 | grep "^{"
+  HMMR_GEMM_PROBE=$p timeout 120 python tools/conv_bench.py $N f16x3 $T "b1.conv3,b2.conv3,b3.conv1,b3.conv3,b4.conv1,b4.conv3,b3.conv2" 2>&1 | grep "^{"
 done

@@ -4,7 +4,7 @@
 # 1. default bench line; 2. serial bench under rocprofv3 --kernel-trace --stats (tile table from a file so that no
 # tuning pass sits in the trace); 3. three separate --pmc passes (FETCH_SIZE / WRITE_SIZE / MFMA busy) of the same
 # serial command; 4. per-layer table.  Summaries are copied to profiles/ by tools/collect_profiles.py afterwards.
-TAG=${1:-x}; DT=${2:-bf16x3}
+TAG=${1:-x}; DT=${2:-f16x3}
 R=$(pwd); O=$R/gpurun_out/$TAG; mkdir -p $O
 export HMMR_TILE_CACHE=/tmp/tiles_$TAG.json
 cd /tmp && export TMPDIR=/tmp

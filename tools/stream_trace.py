@@ -11,7 +11,7 @@ class Config(object):
     load_path, batch_size, sequence_length, pred_mode, num_conv_layers = "synthetic:0", 8, 20, "pred", 3
     delta_t_values, smpl_model_path, num_kps = ["-5", "5"], "synthetic:2", 25
 
-dt = sys.argv[1] if len(sys.argv) > 1 else "bf16x3"
+dt = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 u8 = len(sys.argv) > 3 and sys.argv[3] == "u8"
 ramp = not (len(sys.argv) > 4 and sys.argv[4] == "noramp")
