@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = devflags.get("LIB_PATH") or os.path.join(HERE, "libhmmr_hip.so")
 
 HMMR_F32, HMMR_BF16, HMMR_F16X3 = 0, 1, 2
-ABI_VERSION = 11
+ABI_VERSION = 12
 RESNET_UNITS = 16
 RESNET_PROF_SLOTS = 64
 MAX_TEMPORAL_BLOCKS = 8
@@ -40,7 +40,7 @@ class ConvDesc(C.Structure):
         ("split_k", C.c_int), ("ws", _vp), ("ws_bytes", C.c_size_t),
         ("pro_scale", _fp), ("pro_shift", _fp),
         ("out_b", _vp), ("ldo_b", C.c_int), ("n_split", C.c_int), ("relu_b", C.c_int),
-        ("in2", _vp), ("cin2", C.c_int),
+        ("in2", _vp), ("cin2", C.c_int), ("k_order", C.c_int),
     ]
 
 
@@ -65,7 +65,7 @@ class Debug(C.Structure):
 
 
 class Layer(C.Structure):
-    _fields_ = [("w", _vp), ("scale", _fp), ("shift", _fp), ("tile", C.c_int)]
+    _fields_ = [("w", _vp), ("scale", _fp), ("shift", _fp), ("tile", C.c_int), ("k_order", C.c_int)]
 
 
 class ResnetUnit(C.Structure):

@@ -9,12 +9,12 @@
 // bottleneck.hip (bf16): a workgroup owns BM pixels and walks conv3's output channels in chunks of 64, which are the K
 // steps of conv1'; MFMA operands are swapped (weights = A, activations = B) so a lane owns 4 consecutive channels of
 // one pixel and every read-modify-write is lane-local.  What differs for split operands:
-//   * every LDS tile is a PAIR of bf16 planes (hi, lo), each in the [rows][64 bf16] / XOR-swizzled geometry of
+//   * every LDS tile is a PAIR of fp16 planes (hi, lo), each in the [rows][64 halves] / XOR-swizzled geometry of
 //     gemm_conv.hip; a product is three MFMAs (w.hi*x.lo, w.lo*x.hi, w.hi*x.hi: gemm_conv.hip's order with the
 //     operands swapped, so the sums are bit-identical to the separate launches);
 //   * the filters never enter LDS: the packer stores them FRAGMENT-MAJOR ([32-row block][16-wide K chunk][lane]
 //     [hi 16 B | lo 16 B]), a wave's A operand is one coalesced 2 KB read from L2 per (block, chunk) -- that keeps the
-//     workgroup at 36-52 KB of LDS (3-4 per CU) where the bf16 layout would need 132 KB;
+//     workgroup at 36-52 KB of LDS (3-4 per CU) where bottleneck.hip's layout would need 132 KB;
 //   * workgroups are 4 waves on 64 pixels (168-VGPR budget at three waves per SIMD).
 // Global tensors keep the interleaved split layout ([hi8][lo8] per 8 channels): a 64-channel chunk of a row is 256
 // contiguous bytes = 16 slots, staged by 16 lanes (even slots -> hi plane, odd -> lo plane).
@@ -74,7 +74,7 @@ __device__ __forceinline__ void split4(const float (&v)[4], unsigned long long& 
 template <int KS, int NCH, int N2, bool RES, bool CONV2>
 __global__ __launch_bounds__(256, NCH > 4 ? 2 : 3) void tail_split_kernel(const SplitTailArgs a) {
     constexpr int BM = 64, NT = 256, depth = NCH * 64;
-    constexpr int PLANE = BM * 128;                  // one bf16 plane of a [64 rows][64 channels] tile
+    constexpr int PLANE = BM * 128;                  // one fp16 plane of a [64 rows][64 channels] tile
     constexpr int PPLANE = 104 * 128;                // one plane of the 10 x 10 pixel patch (CONV2)
     constexpr int OFF_H2 = 0;                        // KS tiles x (hi, lo); later the conv1' output tiles
     // CONV2: only K tile 0 (h2, produced in the launch) sits in the H2 region -- which holds the conv2 filter tap while

@@ -87,7 +87,7 @@ template <> struct elem_traits<bf16_t> {
 // is 4 bytes wide for all address arithmetic (offsets are multiples of 8 elements); a 16-byte slot holds the hi OR the
 // lo half of one group.  The GEMM kernels multiply two split operands with three fp16 MFMAs (lo*hi + hi*lo + hi*hi,
 // fp32 accumulate; the dropped lo*lo term is <= 2^-22 of the product): fp32-class operands at a third of the 16-bit
-// MFMA rate, 5x the fp32-MFMA rate.  (Rounds 1-2 used bf16 halves: 16-17 bits, "f16x3".)
+// MFMA rate, 5x the fp32-MFMA rate.  (Rounds 1-2 used bf16 halves: 16-17 bits, "bf16x3".)
 struct bsplit_t { unsigned int raw; };
 static_assert(sizeof(bsplit_t) == 4, "bsplit_t is addressed as a 4-byte element");
 template <> struct elem_traits<bsplit_t> {

@@ -463,12 +463,22 @@ void conv_gemm_kernel(const ConvArgs a) {
             frag_t fa[NCHK][FM], fb[NCHK][FN];
 #pragma unroll
             for (int c = 0; c < NCHK; ++c) {
+                if (c > 0 && HMMR_PROBE(a, 16)) {                  // probe: half the fragment reads
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) fa[c][i] = fa[0][i];
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) fb[c][j] = fb[0][j];
+                    continue;
+                }
 #pragma unroll
                 for (int i = 0; i < FM; ++i) fa[c][i] = FragIO<TA>::read(sbuf + a_row_off + i * 32 * 128, c, lh, fsw);
 #pragma unroll
                 for (int j = 0; j < FN; ++j) fb[c][j] = FragIO<TA>::read(sbuf + b_row_off + j * 32 * 128, c, lh, fsw);
             }
-            if (fill) { glds_a(kt + NSTAGE - 1, nxt); glds_b(kt + NSTAGE - 1, nxt); }
+            if (fill) {
+                if (!HMMR_PROBE(a, 64)) glds_a(kt + NSTAGE - 1, nxt);
+                if (!HMMR_PROBE(a, 32)) glds_b(kt + NSTAGE - 1, nxt);
+            }
             if (grp == 1 && kt + 1 < kt1) {
                 wait_ahead(min(NSTAGE - 2, kt1 - 2 - kt));
                 transform(kt + 1, c1);
@@ -599,6 +609,258 @@ void conv_gemm_kernel(const ConvArgs a) {
             else store_tail(out2 + oo, u, a.cout - n);
         }
     }
+}
+
+// ------------------------------------------------------------------------- //
+// 3x3 / stride 1 / SAME convolutions out of an LDS-resident input PATCH (hmmr_conv_desc_t.k_order = 1; tiles 9, 10)
+// ------------------------------------------------------------------------- //
+// What the probe build measured on the ring tiles (profiles/r03j_ring_probe.log): the im2col gather of the A operand
+// -- one 128-byte line per output row per K step, the same input line nine times over a launch -- is the most
+// expensive single piece of a 3x3 launch (15-24 % of it), more than the B stream that moves twice the bytes; halving
+// the fragment reads out of LDS changes nothing.  So the A operand does not come through the ring here: with K in
+// chunk-major order (K step kt = chunk kt / 9, tap kt % 9) a workgroup loads the 128-byte chunk of every input pixel
+// its tile can touch ONCE per chunk into a PATCH and reads the nine taps as nine shifted fragment sets.
+//   * patch geometry: input pixels are numbered with a shared zero column per image row and a shared zero row per
+//     image, P(img, y, x) = (img*(H+1) + y+1)*(W+1) + x+1; tap (ky, kx) of output pixel (img, y, x) is patch row
+//     P(img, y, x) + (ky-1)*(W+1) + (kx-1) - P0, whatever the pixel's position: the SAME padding lives in the zero
+//     rows / columns (DMA'd from the zero page), no per-lane masks;
+//   * the patch of chunk c+1 (NPP x 64 rows) is DMA'd during tap 0 of chunk c into the other of two patch buffers;
+//     the B operand keeps the 3-stage ring and the ping-pong schedule of tiles 7 / 8 (see conv_gemm_kernel);
+//   * LDS rows keep the 128-byte / XOR-swizzled geometry, the swizzle of a fragment row now follows the patch row.
+template <typename TA, typename TO, int BM, int BN, int WGM, int WGN, int NPP>
+__global__ __launch_bounds__(512, 1) void conv3x3_patch_kernel(const ConvArgs a) {
+    static_assert(WGM * WGN == 8, "8-wave workgroups");
+    constexpr int NT = 512, RPP = 64, NSB = 3;
+    constexpr int EPS = elem_traits<TA>::EPS, BKE = 8 * EPS;
+    constexpr int TM = BM / WGM, TN = BN / WGN, FM = TM / 32, FN = TN / 32;
+    constexpr int PB = BN / RPP;
+    constexpr int B_BYTES = BN * 128, P_BYTES = NPP * RPP * 128, OFF_P = NSB * B_BYTES;
+    constexpr int NCHK = FragIO<TA>::CHUNKS;
+    typedef typename Frag<TA>::type frag_t;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int L = xcd_remap(blockIdx.x, a.n_tiles);
+    const int m0 = (L / a.tiles_n) * BM;
+    const int n0 = (L % a.tiles_n) * BN;
+    const int W1 = a.Win + 1, H1 = a.Hin + 1, n_img = a.M / a.HoWo, C = 1 << a.cin_log2;
+    auto padded = [&](int m) {
+        const int img = m / a.HoWo, rem = m - img * a.HoWo;
+        const int y = rem / a.Wo, x = rem - y * a.Wo;
+        return (img * H1 + y + 1) * W1 + x + 1;
+    };
+    const int P0 = padded(m0) - W1 - 1;                 // patch row 0 = tap (0, 0) of the tile's first output pixel
+
+    // ---- staging geometry (as conv_gemm_kernel): 8 lanes per 128-byte row, 64 rows per pass
+    const int pslot = tid & 7, r0 = tid >> 3;
+    const int lslot = pslot ^ ((r0 >> 1) & 7);
+    const TA* __restrict__ in = (const TA*)a.in;
+    const TA* pptr[NPP];                                // source line of this lane's slot of patch row 64 p + r0; NULL: zero
+#pragma unroll
+    for (int p = 0; p < NPP; ++p) {
+        const int P = P0 + RPP * p + r0;
+        const int gr = P / W1, col = P - gr * W1;
+        const int img = gr / H1, yy = gr - img * H1;
+        pptr[p] = (col >= 1 && yy >= 1 && img < n_img)
+                      ? in + ((long long)(img * a.Hin + yy - 1) * a.Win + (col - 1)) * C + lslot * EPS : nullptr;
+    }
+    const TA* wptr = (const TA*)a.w + (long long)(n0 + r0) * a.K + lslot * EPS;
+    auto glds_patch = [&](int c, int buf) {
+        char* sp = smem + OFF_P + buf * P_BYTES + wave * 1024;
+#pragma unroll
+        for (int p = 0; p < NPP; ++p) {
+            const void* src = pptr[p] ? (const void*)(pptr[p] + c * BKE) : (const void*)g_zero_page;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sp + p * (RPP * 128)), 16, 0, 0);
+        }
+    };
+    auto glds_b = [&](int kt, int buf) {
+        char* sb = smem + buf * B_BYTES + wave * 1024;
+#pragma unroll
+        for (int p = 0; p < PB; ++p)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wptr + (long long)(RPP * p) * a.K + kt * BKE),
+                                             (lptr_t)(sb + p * (RPP * 128)), 16, 0, 0);
+    };
+
+    // ---- fragment geometry
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int fswb = (lr >> 1) & 7;
+    const int b_row_off = (wn * TN + lr) * 128;
+    int prow[FM];                                       // patch row of tap (0, 0) of this lane's output pixels
+#pragma unroll
+    for (int i = 0; i < FM; ++i) prow[i] = padded(min(m0 + wm * TM + i * 32 + lr, a.M - 1)) - W1 - 1 - P0;
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nc = C / BKE, nk = 9 * nc;
+    // counted waits: `pend` = the patch of the next chunk was issued (AFTER the B stage of that step) during tap 0 of
+    // this chunk and may stay outstanding through taps 0 and 1; vmcnt retires in order, so the wait of tap 2 covers it
+    auto wait_stage = [&](int kt, int t, int c) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < nk) {
+            if (t <= 1 && c + 1 < nc) wait_vm_lgkm0<PB + NPP>();
+            else wait_vm_lgkm0<PB>();
+        } else wait_vm_lgkm0<0>();
+    };
+    glds_patch(0, 0);
+    glds_b(0, 0);
+    glds_b(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    wait_vm_lgkm0<PB>();
+    __builtin_amdgcn_s_barrier();
+    const int grp = wave >> 2;
+    int cur = 0, nxt = NSB - 1, t = 0, c = 0;
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* sb = smem + cur * B_BYTES;
+        const char* sp = smem + OFF_P + (c & 1) * P_BYTES;
+        const int c1 = (cur + 1 == NSB) ? 0 : cur + 1;
+        const int ky = (t * 11) >> 5;                   // t / 3 for t < 9
+        const int ts = ky * W1 + (t - 3 * ky);
+        // ---- LOAD segment
+        frag_t fa[NCHK][FM], fb[NCHK][FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int row = prow[i] + ts;
+            const char* rp = sp + row * 128;
+            const int fsw = (row >> 1) & 7;
+#pragma unroll
+            for (int ch = 0; ch < NCHK; ++ch) {
+                if (ch > 0 && HMMR_PROBE(a, 16)) { fa[ch][i] = fa[0][i]; continue; }
+                fa[ch][i] = FragIO<TA>::read(rp, ch, lh, fsw);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int ch = 0; ch < NCHK; ++ch) {
+                if (ch > 0 && HMMR_PROBE(a, 16)) { fb[ch][j] = fb[0][j]; continue; }
+                fb[ch][j] = FragIO<TA>::read(sb + b_row_off + j * 32 * 128, ch, lh, fswb);
+            }
+        if (kt + 2 < nk && !HMMR_PROBE(a, 32)) glds_b(kt + 2, nxt);
+        if (t == 0 && c + 1 < nc && !HMMR_PROBE(a, 64)) glds_patch(c + 1, (c + 1) & 1);
+        if (grp == 1 && kt + 1 < nk) wait_stage(kt, t, c);
+        wait_vm_lgkm0<63>();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- COMPUTE segment
+        if (!HMMR_PROBE(a, 1)) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ch = 0; ch < NCHK; ++ch)
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) acc[i][j] = mma(fa[ch][i], fb[ch][j], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        if (grp == 0 && kt + 1 < nk) wait_stage(kt, t, c);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        nxt = cur; cur = c1;
+        if (++t == 9) { t = 0; ++c; }
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+
+    // ---- epilogue: accumulators -> LDS as fp32 [BM][BN] -> folded BN, ReLU, 8 channels per lane
+    float* sc = (float*)smem;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int col = wn * TN + j * 32 + lr;
+                sc[row * BN + col] = acc[i][j][r];
+            }
+    __syncthreads();
+    constexpr int VPR = BN / 8, NIT = (BM * VPR) / NT;
+    TO* __restrict__ out = (TO*)a.out;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = it * NT + tid;
+        const int row = idx / VPR, col = (idx % VPR) * 8;
+        const int m = m0 + row, n = n0 + col;
+        if (m >= a.M || n >= a.cout) continue;
+        float v[8];
+        load8(sc + row * BN + col, v);
+        if (a.scale && a.shift) {
+            float s[8], b[8]; load8(a.scale + n, s); load8(a.shift + n, b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], s[j], b[j]);
+        } else if (a.scale) {
+            float s[8]; load8(a.scale + n, s);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= s[j];
+        } else if (a.shift) {
+            float b[8]; load8(a.shift + n, b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += b[j];
+        }
+        if (a.relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        store8(out + (long long)m * a.ldo + n, v);
+    }
+}
+
+// rows of the patch a BM-row tile can need: the padded distance between its first and last pixel + the halo
+static int patch_rows_bound(int bm, int h, int w) {
+    const int row_x = (bm - 1 + w - 1) / w;                 // image-row crossings inside the tile
+    const int img_x = (bm - 1 + h * w - 1) / (h * w);       // image crossings
+    return (bm - 1) + row_x + img_x * (w + 1) + 2 * (w + 1) + 3;
+}
+
+template <typename TA, typename TO, int BM, int BN, int WGM, int WGN, int NPP>
+static int launch_patch(const ConvArgs& base, hipStream_t stream) {
+    ConvArgs a = base;
+    const int tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_n = (a.cout + BN - 1) / BN;
+    a.n_tiles = tiles_m * a.tiles_n;
+    constexpr int kloop = 3 * BN * 128 + 2 * NPP * 64 * 128, epi = BM * BN * 4;
+    constexpr int lds = kloop > epi ? kloop : epi;
+    static_assert(lds <= 160 * 1024, "LDS");
+    auto kern = conv3x3_patch_kernel<TA, TO, BM, BN, WGM, WGN, NPP>;
+    static DeviceOnce once;
+    if (const unsigned long long bit = once.due()) {
+        HMMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        once.mark(bit);
+    }
+    hipLaunchKernelGGL(kern, dim3(a.n_tiles), dim3(512), lds, stream, a);
+    HMMR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+template <typename TA, typename TO>
+static int launch_patch_tiled(const ConvArgs& a, int tile, hipStream_t stream) {
+    if (tile == 0) tile = (a.cout % 256 == 0) ? 10 : 9;
+    const int bm = tile == 9 ? 256 : 128;
+    const int npp = (patch_rows_bound(bm, a.Hin, a.Win) + 63) / 64;
+    if (tile == 9) {
+        if (npp <= 6) return launch_patch<TA, TO, 256, 128, 4, 2, 6>(a, stream);
+        if (npp <= 7) return launch_patch<TA, TO, 256, 128, 4, 2, 7>(a, stream);
+    } else if (tile == 10) {
+        if (npp <= 3) return launch_patch<TA, TO, 128, 256, 2, 4, 3>(a, stream);
+        if (npp <= 4) return launch_patch<TA, TO, 128, 256, 2, 4, 4>(a, stream);
+    } else {
+        hmmr_set_error("hmmr_conv_gemm: k_order 1 runs tiles 9 (256x128) and 10 (128x256), not %d", tile);
+        return -1;
+    }
+    hmmr_set_error("hmmr_conv_gemm: k_order 1, tile %d: a %d x %d image needs a patch of %d x 64 rows, more than LDS holds",
+                   tile, a.Hin, a.Win, npp);
+    return -1;
 }
 
 // ------------------------------------------------------------------------- //
@@ -804,6 +1066,18 @@ extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
 #endif
     if (a.M <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
+    if (d->k_order) {
+        HMMR_REQUIRE(d->k_order == 1 && d->kh == 3 && d->kw == 3 && d->sy == 1 && d->sx == 1 && d->py == 1 && d->px == 1 &&
+                     d->ho == d->hin && d->wo == d->win && d->in_px_stride == d->cin && d->in_row_stride == d->win * d->cin &&
+                     d->in_img_stride == (int64_t)d->hin * d->win * d->cin && (d->cin * esz) % 128 == 0 &&
+                     !d->res && !d->out2 && !d->out_b && !d->pro_scale && !d->in2 && d->split_k <= 1 && d->out && d->cout % 8 == 0,
+                     "hmmr_conv_gemm: k_order 1 is for 3x3 / stride 1 / pad 1 convolutions over a dense NHWC tensor with "
+                     "cin a multiple of the 128-byte K step and a scale/shift/relu epilogue (no res, out2, out_b, pro_scale, in2, split_k)");
+        HMMR_REQUIRE(d->in_dtype == HMMR_F16X3 && d->out_dtype == HMMR_F16X3, "hmmr_conv_gemm: k_order 1 is built for split (f16x3) tensors");
+        const int ptile = d->tile ? d->tile : (d->cout % 256 == 0 ? 10 : 9);
+        HMMR_REQUIRE((ptile == 9 ? d->cout % 128 : d->cout % 256) == 0, "hmmr_conv_gemm: k_order 1: cout must fill the tile's columns (filter rows are padded to 128)");
+        return launch_patch_tiled<bsplit_t, bsplit_t>(a, ptile, s);
+    }
     const bool in16 = d->in_dtype == HMMR_BF16, in32 = d->in_dtype == HMMR_F32, inx3 = d->in_dtype == HMMR_F16X3;
     const bool out16 = d->out_dtype == HMMR_BF16, out32 = d->out_dtype == HMMR_F32, outx3 = d->out_dtype == HMMR_F16X3;
     HMMR_REQUIRE((in16 || in32 || inx3) && (out16 || out32 || outx3), "hmmr_conv_gemm: unsupported dtypes %d -> %d", d->in_dtype, d->out_dtype);

@@ -334,6 +334,7 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
         if (!conv2_in_tail) {
             d = hmmr_conv_desc_t{};
             d.in = T1; d.w = U.conv2.w; d.scale = U.conv2.scale; d.shift = U.conv2.shift; d.relu = 1; d.tile = U.conv2.tile;
+            d.k_order = U.conv2.k_order;
             d.out = T2; d.in_dtype = d.out_dtype = w->dtype;
             d.n_img = n; d.hin = H; d.win = H; d.cin = U.base;
             d.in_img_stride = (int64_t)H * H * U.base; d.in_row_stride = H * U.base; d.in_px_stride = U.base;

@@ -74,7 +74,7 @@ class HmmrEngine(object):
 
     def __init__(self, weights, smpl, dtype=DEFAULT_DTYPE, device="cuda:0", num_conv_layers=3,
                  delta_t_values=(-5, 5), joint_type="cocoplus", resnet_chunk=0,
-                 temporal_dtype=None, ief_dtype=None, autotune=True, fold_sc=None, fuse_tail=None):
+                 temporal_dtype=None, ief_dtype=None, autotune=True, fold_sc=None, fuse_tail=None, patch_3x3=None):
         self.lib = L.load()
         _debug_from_env()
         if not torch.cuda.is_available():
@@ -100,7 +100,8 @@ class HmmrEngine(object):
         # FeatureExtractor is given: src/datasets/resnet_extractor.py:31-40) has no AZ_FC_* / single_view_ief* names
         w = weights if weights is not None else {}
         self.rw = (packing.pack_resnet(w, self.dtype, self.store, fuse_preact_blocks=fuse, fuse_tail=tail, fuse_sc=fsc,
-                                       fuse_preact_first=pfirst, fold_sc=fold)
+                                       fuse_preact_first=pfirst, fold_sc=fold,
+                                       patch_3x3=(devflags.get("PATCH_3X3") != "0") if patch_3x3 is None else patch_3x3)
                    if "resnet_v2_50/conv1/weights" in w else None)
         self.tw = (packing.pack_temporal(w, self.temporal_dtype, self.store, num_conv_layers)
                    if assets.temporal_scopes(0)[1] + "/weights" in w else None)
@@ -179,9 +180,27 @@ class HmmrEngine(object):
             return U.c3sc
         return getattr(U, nm)
 
+    @staticmethod
+    def _tile_for(lay, cand, cout):
+        """hmmr_layer_t.tile for candidate `cand` on a layer with `cout` output columns: 0 (the library's choice) where
+        the tile does not fit; a layer packed chunk-major (k_order 1, the 3x3 patch kernel) runs tiles 9 / 10, the patch
+        forms of 7 / 8."""
+        if lay.k_order:
+            cand = {7: 9, 8: 10}.get(cand, cand)
+            return cand if (cand == 9 and cout % 128 == 0) or (cand == 10 and cout % 256 == 0) else 0
+        if cand in (9, 10) or (cand in (1, 5, 7) and cout % 128) or (cand == 8 and cout % 256):
+            return 0
+        return cand
+
+    def _layer_cout(self, u, nm):
+        U = self.rw.unit[u]
+        if nm == "shortcut" and U.sc_c1.w:          # shortcut + conv1 as one column-split GEMM: depth + base columns
+            return U.depth + U.base
+        return U.base if nm in ("conv1", "conv2") else U.depth
+
     def _set_tiles(self, table):
         for (u, nm), t in table.items():
-            self._layer_of(u, nm).tile = int(t)
+            self._layer_of(u, nm).tile = self._tile_for(self._layer_of(u, nm), int(t), self._layer_cout(u, nm))
 
     def _needs_tuning(self, nt):
         """A tuning pass is due for batch size nt: tuning is on, the size is worth it, it has no table of its own and (unless
@@ -211,11 +230,7 @@ class HmmrEngine(object):
         for cand in (0,) + self._TUNE_TILES:
             for slot, u, nm in layers:
                 lay = self._layer_of(u, nm)
-                U = self.rw.unit[u]
-                cout = U.base if nm in ("conv1", "conv2") else U.depth
-                if nm == "shortcut" and U.sc_c1.w:          # shortcut + conv1 as one column-split GEMM: depth + base columns
-                    cout = U.depth + U.base
-                lay.tile = cand if ((cand not in (1, 5, 7) or cout % 128 == 0) and (cand != 8 or cout % 256 == 0)) else 0
+                lay.tile = self._tile_for(lay, cand, self._layer_cout(u, nm))
             t = None
             for rep in range(reps):
                 pm = (C.c_float * L.RESNET_PROF_SLOTS)()
@@ -453,7 +468,7 @@ class HmmrEngine(object):
 
 def conv_gemm(x, w_hwio, stride=1, pad=0, scale=None, shift=None, res=None, relu=False,
               scale2=None, shift2=None, in_dtype=L.HMMR_F32, out_dtype=L.HMMR_F32, tile=0,
-              device="cuda:0", res_stride=1, split_k=0, pro=None, raw=False, second=None):
+              device="cuda:0", res_stride=1, split_k=0, pro=None, raw=False, second=None, k_order=0):
     """Test/utility entry: run one NHWC convolution through hmmr_conv_gemm.
     x [n,h,w,cin] (numpy/torch), w_hwio [kh,kw,cin,cout].  Returns (out, out2) as float32 arrays, or with
     raw=True the device tensors in their storage type; x may itself be such a device tensor."""
@@ -473,7 +488,7 @@ def conv_gemm(x, w_hwio, stride=1, pad=0, scale=None, shift=None, res=None, relu
     if second is not None:          # (x2 [n,h,w,cin2], w2 [1,1,cin2,cout]): a second 1x1 source appended along K (hmmr_conv_desc_t.in2)
         x2 = store.put(np.asarray(second[0], np.float32), packing.TORCH_DT[in_dtype])
         w_hwio = np.concatenate([np.asarray(w_hwio, np.float32), np.asarray(second[1], np.float32)], axis=2)
-    wp = packing.pack_conv_weight(np.asarray(w_hwio, np.float32))
+    wp = packing.pack_conv_weight(np.asarray(w_hwio, np.float32), k_order)
     if packing.TORCH_DT[in_dtype] is packing.SPLIT:     # as packing._layer: rows scaled by a power of two, undone by `scale`
         k = packing.row_pow2(wp)
         wp = packing.scale_rows(wp, k)
@@ -510,7 +525,7 @@ def conv_gemm(x, w_hwio, stride=1, pad=0, scale=None, shift=None, res=None, relu
     d.in_img_stride, d.in_row_stride, d.in_px_stride = h * w_ * cin, w_ * cin, cin
     d.kh, d.kw, d.sy, d.sx, d.py, d.px = kh, kw, stride, stride, py, px
     d.ho, d.wo, d.cout, d.ldo = ho, wo, cout, ldo
-    d.relu, d.tile = int(relu), tile
+    d.relu, d.tile, d.k_order = int(relu), tile, k_order
     if pro is not None:
         d.pro_scale, d.pro_shift = store.put(pro[0]).data_ptr(), store.put(pro[1]).data_ptr()
     if split_k > 1:

@@ -72,9 +72,15 @@ def fold_bn(w, prefix, eps=assets.BN_EPS):
     return scale.astype(np.float32), (b - m * scale).astype(np.float32)
 
 
-def pack_conv_weight(w_hwio):
-    """[kh,kw,cin,cout] -> [cout_pad][kh*kw*cin] float32, k = (ky*kw + kx)*cin + ci."""
+def pack_conv_weight(w_hwio, k_order=0, chunk=32):
+    """[kh,kw,cin,cout] -> [cout_pad][kh*kw*cin] float32.  k_order 0: k = (ky*kw + kx)*cin + ci.  k_order 1
+    (hmmr_conv_desc_t.k_order, chunk-major, the 3x3 patch kernel): k = ((ci // chunk)*kh*kw + ky*kw + kx)*chunk +
+    ci % chunk, chunk = the elements of one 128-byte K step of the tensor the filter meets (32 for a split tensor)."""
     kh, kw, cin, cout = w_hwio.shape
+    if k_order:
+        assert cin % chunk == 0, (cin, chunk)
+        wk = w_hwio.reshape(kh * kw, cin // chunk, chunk, cout).transpose(1, 0, 2, 3)     # [chunk idx][tap][e][cout]
+        return _pad_rows(np.ascontiguousarray(wk.reshape(kh * kw * cin, cout).T))
     return _pad_rows(np.ascontiguousarray(w_hwio.reshape(kh * kw * cin, cout).T))
 
 
@@ -167,12 +173,15 @@ def _layer(store, w_packed, dtype, scale=None, shift=None):
 
 
 def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3", "block4"), fuse_tail=True,
-                fuse_sc=True, fuse_preact_first=False, fold_sc=None):
+                fuse_sc=True, fuse_preact_first=False, fold_sc=None, patch_3x3=True):
     """fuse_preact_blocks: blocks whose units apply their `preact` BN+ReLU inside the operand
     staging of conv1/shortcut instead of reading a materialised preact tensor (csrc/resnet.hip;
     measured at batch 256: -4.5 % ResNet time with blocks 1-2 fused, neutral for blocks 3-4).
     fuse_tail: mark the units whose conv3 + add runs with the next unit's preact + conv1 as one
-    hmmr_bottleneck_tail launch (bf16; the stride-1 units of block1 and block2)."""
+    hmmr_bottleneck_tail launch (bf16; the stride-1 units of block1 and block2).
+    patch_3x3 (f16x3 only): the stride-1 3x3 conv2 of blocks 2-4 packed chunk-major (hmmr_conv_desc_t.k_order = 1) and run
+    by the patch kernel (csrc/gemm_conv.hip, tiles 9 / 10).  Block 1 keeps the tap-major order its fused tails reproduce bit
+    for bit; the stride-2 units keep the im2col gather."""
     if fold_sc is None:
         # fold every conv shortcut into its unit's conv3 (one GEMM over {h2, preact}: hmmr_resnet_unit_t.c3sc).  Default in
         # the f16x3 mode, where it removes the widest tensor of the unit (4 B/element) from HBM; the bf16 mode has its own
@@ -197,7 +206,9 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
         s, b = fold_bn(w, scope + "/conv1/BatchNorm")
         u.conv1 = _layer(store, pack_conv_weight(w[scope + "/conv1/weights"]), dtype, s, b)
         s, b = fold_bn(w, scope + "/conv2/BatchNorm")
-        u.conv2 = _layer(store, pack_conv_weight(w[scope + "/conv2/weights"]), dtype, s, b)
+        kord = int(bool(patch_3x3) and dtype == L.HMMR_F16X3 and stride == 1 and base >= 128)
+        u.conv2 = _layer(store, pack_conv_weight(w[scope + "/conv2/weights"], kord), dtype, s, b)
+        u.conv2.k_order = kord
         u.conv3 = _layer(store, pack_conv_weight(w[scope + "/conv3/weights"]), dtype,
                          shift=w[scope + "/conv3/biases"])
         if has_sc:

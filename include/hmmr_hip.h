@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HMMR_ABI_VERSION 11      /* 11: hmmr_conv_desc_t / hmmr_layer_t lost k_order (chunk-major K: measured, no gain, removed) */
+#define HMMR_ABI_VERSION 12      /* 12: hmmr_conv_desc_t / hmmr_layer_t k_order = 1: 3x3 SAME convolutions out of an LDS-resident input patch (tiles 9, 10) */
 
 /* HMMR_F16X3: "split" tensors -- every group of 8 consecutive channels is 32 bytes, [hi x8][lo x8] with
  * hi = fp16(x), lo = fp16(x - hi), x clamped to +-65504 (4 bytes per element, 22 mantissa bits while lo is a normal
@@ -102,7 +102,8 @@ typedef struct {
     int relu;              /* ReLU on `out` after the residual add */
     int tile;              /* 0 = auto; 4-wave tiles: 1 = 128x128, 2 = 128x64, 3 = 64x64;
                               8-wave tiles: 5 = 128x128, 6 = 128x64 (two workgroups per CU, 2 LDS stages);
-                              7 = 256x128, 8 = 128x256 (one workgroup per CU: 3-stage LDS ring, ping-pong wave groups) */
+                              7 = 256x128, 8 = 128x256 (one workgroup per CU: 3-stage LDS ring, ping-pong wave groups);
+                              k_order 1 only: 9 = 256x128, 10 = 128x256 (the same structure, A operand out of an input patch) */
     /* split-K (for GEMMs with few output tiles and a long K): split_k > 1 slices K into that many
      * contiguous ranges, each range leaves an fp32 partial plane in `ws`, and a second launch adds the
      * planes IN SLICE ORDER and applies the epilogue.  The caller fixes split_k per layer (never from
@@ -128,6 +129,15 @@ typedef struct {
      * the 128-byte K step, no pro_scale, no split_k.  in2 == NULL: off. */
     const void* in2;
     int cin2;
+    /* order of K inside a filter row.  0: (tap, channel) -- k = (ky*kw + kx)*cin + ci.
+     * 1: chunk-major -- k = ((ci / E)*9 + ky*3 + kx)*E + ci % E, E = the elements of one 128-byte K step (32 for a
+     * split tensor).  For 3x3 / stride 1 / pad 1 convolutions over a dense NHWC tensor only, and it selects another
+     * kernel: a workgroup keeps the 128-byte channel chunk of every input pixel its tile touches (a zero-bordered
+     * PATCH of the image rows) in LDS and reads the nine taps of that chunk as nine shifted fragment sets, so an input
+     * line leaves L2 once per chunk instead of once per tap (tiles 9 / 10; scale/shift/relu epilogue only: no res,
+     * out2, out_b, pro_scale, in2, split_k).  The sum over k is the same set of products in another order: results
+     * differ from k_order 0 by fp32 rounding of the accumulation only. */
+    int k_order;
 } hmmr_conv_desc_t;
 
 int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream);
@@ -146,6 +156,7 @@ typedef struct {
     int tile;              /* hmmr_conv_desc_t.tile for this layer's launch; 0 = library heuristic.
                               Results do not depend on it (same K order per output element);
                               the host may tune it per layer and batch size. */
+    int k_order;           /* hmmr_conv_desc_t.k_order the filter rows of `w` were packed in (read for the 3x3 conv2 layers) */
 } hmmr_layer_t;
 
 typedef struct {

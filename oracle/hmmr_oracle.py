@@ -70,7 +70,7 @@ def _conv(x, w_hwio, dtype, stride=1, pad=0, bias=None):
 # Storage-precision emulation (NOT part of the reference): the HIP path's reduced-precision modes
 # round the GEMM operands and every tensor they store between launches; an oracle that rounds at
 # exactly those points (and nowhere else, accumulating in float64) turns "bf16-sized error" into a
-# tight comparison.  emulate = None | 'bf16' | 'bf16x3'.
+# tight comparison.  emulate = None | 'bf16' | 'f16x3' | 'bf16x3'.
 # --------------------------------------------------------------------------- #
 def quantize(x, emulate, weight=False):
     """x as the HIP path stores it: bf16 (round to nearest even), or the f16x3 hi/lo pair
@@ -405,7 +405,7 @@ class OracleTester(object):
         self.delta_t_values = [int(d) for d in delta_t_values]
         self.pred_mode = pred_mode
         self.dtype = dtype
-        self.emulate = emulate          # None | 'bf16' | 'bf16x3': storage-precision emulation of the HIP modes
+        self.emulate = emulate          # None | 'bf16' | 'f16x3' | 'bf16x3': storage-precision emulation of the HIP modes
         if emulate is not None and (dtype != torch.float64 or pred_mode != "pred"):
             raise ValueError("storage-precision emulation runs in float64, pred_mode 'pred'")
         self.img_size = 224

@@ -109,6 +109,66 @@ def test_conv_gemm_split(case, tile, out_dt, gpu_device):
     assert np.abs(out - exact).max() < 6e-5 * mag          # vs the unrounded operands: 2^-17-sized inputs
 
 
+PATCH_CASES = [
+    # name, n, h, w, cin, cout: 3x3 / stride 1 / SAME through the patch kernel (hmmr_conv_desc_t.k_order = 1)
+    ("b3_14x14", 5, 14, 14, 256, 256),          # a 128-pixel tile straddles two images
+    ("b4_7x7", 9, 7, 7, 512, 512),              # ... four images
+    ("b2_28x28", 3, 28, 28, 128, 128),          # 128 output columns: tile 9 only
+    ("odd_5x9", 4, 5, 9, 64, 256),              # non-square image, two channel chunks
+    ("one_image", 1, 14, 14, 256, 256),         # M tail inside the second tile
+    ("tiny_3x3", 2, 3, 3, 32, 256),             # every pixel is a border pixel, one chunk
+    ("ragged_384", 7, 7, 7, 128, 384),          # three column tiles of 128
+    ("wide_28x28", 2, 28, 28, 128, 256),
+]
+
+
+@pytest.mark.parametrize("case", PATCH_CASES, ids=[c[0] for c in PATCH_CASES])
+def test_conv3x3_patch_kernel(case, gpu_device):
+    """The 3x3 patch kernel (tiles 9 / 10: the A operand out of an LDS-resident, zero-bordered input patch, K chunk-major)
+    against a float64 convolution of the same 16-bit operands and against the im2col ring tiles: the same products,
+    another accumulation order.  Tiles 9 and 10 agree bit for bit (one fixed-order K reduction per output element)."""
+    from human_dynamics_amd.engine import conv_gemm
+    name, n, h, w_, cin, cout = case
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(name.encode()) % 1000)
+    x = rng.normal(size=(n, h, w_, cin)).astype(np.float32)
+    w = (rng.normal(size=(3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.normal(size=cout).astype(np.float32)
+    kw = dict(stride=1, pad=1, scale=scale, shift=shift, relu=True, in_dtype=X3, out_dtype=X3, device=gpu_device)
+    outs = {}
+    for tile in (0, 9, 10):
+        if tile == 10 and cout % 256:
+            continue
+        if tile == 9 and name == "tiny_3x3":       # 256 pixels of 3 x 3 images: the zero-bordered patch outgrows LDS
+            with pytest.raises(L.HmmrError, match="more than LDS holds"):
+                conv_gemm(x, w, tile=tile, k_order=1, **kw)
+            continue
+        outs[tile], _ = conv_gemm(x, w, tile=tile, k_order=1, **kw)
+    ref, _ = _ref_conv(_split_round(x), _split_round_w(w), 1, 1, scale, shift, None, True, None, None, 1)
+    mag = max(1.0, np.abs(ref).max())
+    for tile, out in outs.items():
+        assert np.abs(out - ref).max() < 2e-5 * mag, "%s tile %d" % (name, tile)
+        assert np.array_equal(out, outs[0]), "%s: tile %d differs from the library's choice" % (name, tile)
+    ring, _ = conv_gemm(x, w, tile=0, **kw)
+    assert np.abs(outs[0] - ring).max() < 2e-5 * mag
+
+
+def test_conv3x3_patch_kernel_refuses_what_it_is_not_built_for(gpu_device):
+    from human_dynamics_amd.engine import conv_gemm
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(2, 14, 14, 64)).astype(np.float32)
+    w = rng.normal(size=(3, 3, 64, 256)).astype(np.float32)
+    for kw in (dict(stride=2, pad=1), dict(stride=1, pad=0), dict(stride=1, pad=1, tile=8),
+               dict(stride=1, pad=1, res=np.zeros((2, 14, 14, 256), np.float32))):
+        with pytest.raises(L.HmmrError):
+            conv_gemm(x, w, in_dtype=X3, out_dtype=X3, device=gpu_device, k_order=1, **kw)
+    with pytest.raises(L.HmmrError):           # a tile of the other K order
+        conv_gemm(x, w, stride=1, pad=1, in_dtype=X3, out_dtype=X3, device=gpu_device, tile=9)
+    with pytest.raises(L.HmmrError):           # built for split tensors
+        conv_gemm(x, w, stride=1, pad=1, in_dtype=L.HMMR_F32, out_dtype=L.HMMR_F32, device=gpu_device, k_order=1)
+
+
 @pytest.mark.parametrize("tile", [0, 3, 5, 6, 1, 7])
 def test_conv_gemm_split_fused_preactivation(tile, gpu_device):
     """A = relu(x*scale[ci] + shift[ci]) applied while staging a split operand (hi and lo halves sit in

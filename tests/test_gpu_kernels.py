@@ -307,7 +307,7 @@ def test_conv_gemm_fused_preactivation(tile, dt, gpu_device):
     assert np.abs(out - ref).max() < 3e-5 * max(1.0, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("dt", ["bf16", "f32", "f16x3"])
 def test_resnet_tile_choice_never_changes_a_bit(dt, weights, gpu_device):
     """hmmr_layer_t.tile (and therefore the per-batch-size autotuner) only moves work between
     workgroup shapes: every output element stays one fixed-order K reduction."""

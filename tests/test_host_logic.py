@@ -169,3 +169,23 @@ def test_filter_pack_order():
     assert p0.shape == (128, 1152) and not p0[40:].any()
     for ky, kx, ci, co in ((0, 0, 0, 0), (1, 2, 37, 5), (2, 2, 127, 39), (0, 1, 64, 3)):
         assert p0[co, (ky * 3 + kx) * 128 + ci] == w[ky, kx, ci, co]
+
+
+def test_chunk_major_filter_pack():
+    """pack_conv_weight(k_order=1): k' = ((ci // 32)*9 + tap)*32 + ci % 32 -- the K order of the 3x3 patch kernel
+    (hmmr_conv_desc_t.k_order = 1: K step kt = chunk kt // 9, tap kt % 9).  pack_resnet gives it to the stride-1 conv2 of
+    blocks 2-4 in the f16x3 mode only: block 1's fused tails sum tap-major, the stride-2 units keep the im2col gather."""
+    w = np.random.default_rng(0).normal(size=(3, 3, 128, 40)).astype(np.float32)
+    p0, p1 = packing.pack_conv_weight(w), packing.pack_conv_weight(w, 1)
+    assert p0.shape == p1.shape == (128, 1152) and np.array_equal(np.sort(p0, axis=1), np.sort(p1, axis=1))
+    for ky, kx, ci, co in ((0, 0, 0, 0), (1, 2, 37, 5), (2, 2, 127, 39), (0, 1, 64, 3)):
+        tap = ky * 3 + kx
+        assert p0[co, tap * 128 + ci] == w[ky, kx, ci, co]
+        assert p1[co, ((ci // 32) * 9 + tap) * 32 + ci % 32] == w[ky, kx, ci, co]
+    ws = assets.make_synthetic_weights(0)
+    on = packing.pack_resnet(ws, _lib.HMMR_F16X3, packing.DeviceStore("cpu"))
+    assert [on.unit[i].conv2.k_order for i in range(16)] == [0, 0, 0, 1, 1, 1, 0, 1, 1, 1, 1, 1, 0, 1, 1, 1]
+    off = packing.pack_resnet(ws, _lib.HMMR_F16X3, packing.DeviceStore("cpu"), patch_3x3=False)
+    assert not any(off.unit[i].conv2.k_order for i in range(16))
+    for dt in (_lib.HMMR_BF16, _lib.HMMR_F32):
+        assert not any(packing.pack_resnet(ws, dt, packing.DeviceStore("cpu")).unit[i].conv2.k_order for i in range(16))
