@@ -20,7 +20,14 @@ def agg(root, tag, counter):
     # gpurun merges into existing local directories: take the newest run (highest rocprofv3 pid prefix)
     files = glob.glob("%s/pmc_%s/*/*counter_collection.csv" % (root, tag))
     if not files:
-        return {}
+        # the raw per-dispatch files stay on the GPU box: re-summarise from the per-kernel sums a run there left behind
+        per = "%s/pmc_%s_per_kernel.csv" % (root, counter)
+        d = collections.defaultdict(lambda: [0, 0.0])
+        if os.path.exists(per):
+            for x in csv.reader(open(per)):
+                if x[0] != "kernel":
+                    d[x[0]] = [int(x[1]), float(x[2])]
+        return d
     f = max(files, key=lambda x: int(os.path.basename(x).split("_")[0]))
     d = collections.defaultdict(lambda: [0, 0.0])
     for x in csv.DictReader(open(f)):
@@ -38,6 +45,8 @@ def resnet_kernel(k, dtype):
     """The ResNet's MFMA launches of one operand mode (the IEF GEMMs of the same instantiation ride along: < 1 % of the bytes)."""
     if "stem_fused" in k or "bottleneck_tail_kernel" in k or "tail_split_kernel" in k:
         return True
+    if "conv3x3_patch_kernel" in k:
+        return dtype == "f16x3"
     if "conv_gemm_kernel" not in k:
         return False
     if dtype == "bf16":
@@ -74,6 +83,7 @@ def main():
     g = sum(gui[k][1] for k in rn if k in gui)
     fam = {}
     for name, pred in (("conv_gemm_kernel", lambda k: "conv_gemm_kernel" in k and resnet_kernel(k, dtype)),
+                       ("conv3x3_patch_kernel", lambda k: "conv3x3_patch_kernel" in k),
                        ("fused_unit_tails", lambda k: "tail_split_kernel" in k or "bottleneck_tail_kernel" in k),
                        ("fused_stem", lambda k: "stem_fused" in k)):
         ks = [k for k in rn if pred(k)]
