@@ -620,10 +620,14 @@ void conv_gemm_kernel(const ConvArgs a) {
 // the fragment reads out of LDS changes nothing.  So the A operand does not come through the ring here: with K in
 // chunk-major order (K step kt = chunk kt / 9, tap kt % 9) a workgroup loads the 128-byte chunk of every input pixel
 // its tile can touch ONCE per chunk into a PATCH and reads the nine taps as nine shifted fragment sets.
-//   * patch geometry: input pixels are numbered with a shared zero column per image row and a shared zero row per
-//     image, P(img, y, x) = (img*(H+1) + y+1)*(W+1) + x+1; tap (ky, kx) of output pixel (img, y, x) is patch row
-//     P(img, y, x) + (ky-1)*(W+1) + (kx-1) - P0, whatever the pixel's position: the SAME padding lives in the zero
-//     rows / columns (DMA'd from the zero page), no per-lane masks;
+//   * patch geometry: patch row r holds input pixel m0 - (W+1) + r of the flattened [img][y][x] order (zero page beyond
+//     the tensor), so tap (ky, kx) of tile row i is patch row i + ky*W + kx for EVERY pixel: the 32 lanes of a
+//     fragment read consecutive rows, exactly the conflict-free geometry of the ring tiles (a first version numbered
+//     the pixels with in-line zero columns / rows instead: no masks, but the skipped rows put two lanes of a
+//     ds_read_b128 group on one bank -- SQ_LDS_BANK_CONFLICT 33 % of the LDS cycles, profiles/r03l).  The SAME
+//     padding is an ADDRESS select: a lane whose tap falls outside its image (a 9-bit mask per fragment row,
+//     computed once) reads one of the patch's last two rows instead, which the DMA keeps zero -- the one of its
+//     own row's parity, at its own row's slot, so it stays on its own bank;
 //   * the patch of chunk c+1 (NPP x 64 rows) is DMA'd during tap 0 of chunk c into the other of two patch buffers;
 //     the B operand keeps the 3-stage ring and the ping-pong schedule of tiles 7 / 8 (see conv_gemm_kernel);
 //   * LDS rows keep the 128-byte / XOR-swizzled geometry, the swizzle of a fragment row now follows the patch row.
@@ -645,13 +649,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_patch_kernel(const ConvArgs a)
     const int L = xcd_remap(blockIdx.x, a.n_tiles);
     const int m0 = (L / a.tiles_n) * BM;
     const int n0 = (L % a.tiles_n) * BN;
-    const int W1 = a.Win + 1, H1 = a.Hin + 1, n_img = a.M / a.HoWo, C = 1 << a.cin_log2;
-    auto padded = [&](int m) {
-        const int img = m / a.HoWo, rem = m - img * a.HoWo;
-        const int y = rem / a.Wo, x = rem - y * a.Wo;
-        return (img * H1 + y + 1) * W1 + x + 1;
-    };
-    const int P0 = padded(m0) - W1 - 1;                 // patch row 0 = tap (0, 0) of the tile's first output pixel
+    const int W = a.Win, C = 1 << a.cin_log2;
+    const int need = BM + 2 * W + 2;                    // patch rows the tile reads; the rows behind them stay zero
+    constexpr int ZROW = NPP * RPP - 2;                 // ... and the last two (one per row parity) stand in for every out-of-image tap
+    const int base = m0 - W - 1;                        // input pixel of patch row 0
 
     // ---- staging geometry (as conv_gemm_kernel): 8 lanes per 128-byte row, 64 rows per pass
     const int pslot = tid & 7, r0 = tid >> 3;
@@ -660,11 +661,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_patch_kernel(const ConvArgs a)
     const TA* pptr[NPP];                                // source line of this lane's slot of patch row 64 p + r0; NULL: zero
 #pragma unroll
     for (int p = 0; p < NPP; ++p) {
-        const int P = P0 + RPP * p + r0;
-        const int gr = P / W1, col = P - gr * W1;
-        const int img = gr / H1, yy = gr - img * H1;
-        pptr[p] = (col >= 1 && yy >= 1 && img < n_img)
-                      ? in + ((long long)(img * a.Hin + yy - 1) * a.Win + (col - 1)) * C + lslot * EPS : nullptr;
+        const int r = RPP * p + r0, px = base + r;
+        pptr[p] = (r < need && px >= 0 && px < a.M) ? in + (long long)px * C + lslot * EPS : nullptr;
     }
     const TA* wptr = (const TA*)a.w + (long long)(n0 + r0) * a.K + lslot * EPS;
     auto glds_patch = [&](int c, int buf) {
@@ -689,8 +687,22 @@ __global__ __launch_bounds__(512, 1) void conv3x3_patch_kernel(const ConvArgs a)
     const int fswb = (lr >> 1) & 7;
     const int b_row_off = (wn * TN + lr) * 128;
     int prow[FM];                                       // patch row of tap (0, 0) of this lane's output pixels
+    unsigned pmask[FM];                                 // bit t: tap t of that pixel lies inside its image
 #pragma unroll
-    for (int i = 0; i < FM; ++i) prow[i] = padded(min(m0 + wm * TM + i * 32 + lr, a.M - 1)) - W1 - 1 - P0;
+    for (int i = 0; i < FM; ++i) {
+        prow[i] = wm * TM + i * 32 + lr;
+        const int m = m0 + prow[i];
+        unsigned mk = 0u;
+        if (m < a.M) {
+            const int rem = m % a.HoWo, y = rem / W, x = rem - y * W;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                if ((unsigned)yy < (unsigned)a.Hin && (unsigned)xx < (unsigned)W) mk |= 1u << t;
+            }
+        }
+        pmask[i] = mk;
+    }
 
     f32x16 acc[FM][FN];
 #pragma unroll
@@ -724,14 +736,20 @@ __global__ __launch_bounds__(512, 1) void conv3x3_patch_kernel(const ConvArgs a)
         const char* sp = smem + OFF_P + (c & 1) * P_BYTES;
         const int c1 = (cur + 1 == NSB) ? 0 : cur + 1;
         const int ky = (t * 11) >> 5;                   // t / 3 for t < 9
-        const int ts = ky * W1 + (t - 3 * ky);
+        int ts = ky * W + (t - 3 * ky);
+        if (HMMR_PROBE(a, 128)) ts = 0;                 // probes: which tap shifts make the fragment reads collide
+        if (HMMR_PROBE(a, 256)) ts &= ~1;
+        if (HMMR_PROBE(a, 512)) ts &= ~15;
         // ---- LOAD segment
         frag_t fa[NCHK][FM], fb[NCHK][FN];
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
-            const int row = prow[i] + ts;
+            const int tap_row = prow[i] + ts;
+            // an out-of-image tap reads the zero row of the same parity AT THE SLOT the tap's own row would use: the
+            // lane stays on the bank it would have had, so the 16 lanes of a ds_read_b128 group stay conflict-free
+            const int row = ((pmask[i] >> t) & 1u) ? tap_row : ZROW + (tap_row & 1);
             const char* rp = sp + row * 128;
-            const int fsw = (row >> 1) & 7;
+            const int fsw = (tap_row >> 1) & 7;
 #pragma unroll
             for (int ch = 0; ch < NCHK; ++ch) {
                 if (ch > 0 && HMMR_PROBE(a, 16)) { fa[ch][i] = fa[0][i]; continue; }
@@ -816,12 +834,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_patch_kernel(const ConvArgs a)
     }
 }
 
-// rows of the patch a BM-row tile can need: the padded distance between its first and last pixel + the halo
-static int patch_rows_bound(int bm, int h, int w) {
-    const int row_x = (bm - 1 + w - 1) / w;                 // image-row crossings inside the tile
-    const int img_x = (bm - 1 + h * w - 1) / (h * w);       // image crossings
-    return (bm - 1) + row_x + img_x * (w + 1) + 2 * (w + 1) + 3;
-}
+// rows of the patch of a BM-row tile: its pixels, a halo of W + 1 on either side, and the two zero rows
+static int patch_rows_bound(int bm, int h, int w) { (void)h; return bm + 2 * w + 2 + 2; }
 
 template <typename TA, typename TO, int BM, int BN, int WGM, int WGN, int NPP>
 static int launch_patch(const ConvArgs& base, hipStream_t stream) {
@@ -849,7 +863,7 @@ static int launch_patch_tiled(const ConvArgs& a, int tile, hipStream_t stream) {
     const int bm = tile == 9 ? 256 : 128;
     const int npp = (patch_rows_bound(bm, a.Hin, a.Win) + 63) / 64;
     if (tile == 9) {
-        if (npp <= 6) return launch_patch<TA, TO, 256, 128, 4, 2, 6>(a, stream);
+        if (npp <= 5) return launch_patch<TA, TO, 256, 128, 4, 2, 5>(a, stream);
         if (npp <= 7) return launch_patch<TA, TO, 256, 128, 4, 2, 7>(a, stream);
     } else if (tile == 10) {
         if (npp <= 3) return launch_patch<TA, TO, 128, 256, 2, 4, 3>(a, stream);

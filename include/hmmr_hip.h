@@ -132,8 +132,9 @@ typedef struct {
     /* order of K inside a filter row.  0: (tap, channel) -- k = (ky*kw + kx)*cin + ci.
      * 1: chunk-major -- k = ((ci / E)*9 + ky*3 + kx)*E + ci % E, E = the elements of one 128-byte K step (32 for a
      * split tensor).  For 3x3 / stride 1 / pad 1 convolutions over a dense NHWC tensor only, and it selects another
-     * kernel: a workgroup keeps the 128-byte channel chunk of every input pixel its tile touches (a zero-bordered
-     * PATCH of the image rows) in LDS and reads the nine taps of that chunk as nine shifted fragment sets, so an input
+     * kernel: a workgroup keeps the 128-byte channel chunk of every input pixel its tile touches (a PATCH: the tile's
+     * pixels and a halo of win + 1 pixels on either side) in LDS and reads the nine taps of that chunk as nine shifted
+     * fragment sets (out-of-image taps read a zero row), so an input
      * line leaves L2 once per chunk instead of once per tap (tiles 9 / 10; scale/shift/relu epilogue only: no res,
      * out2, out_b, pro_scale, in2, split_k).  The sum over k is the same set of products in another order: results
      * differ from k_order 0 by fp32 rounding of the accumulation only. */

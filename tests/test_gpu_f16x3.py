@@ -124,7 +124,7 @@ PATCH_CASES = [
 
 @pytest.mark.parametrize("case", PATCH_CASES, ids=[c[0] for c in PATCH_CASES])
 def test_conv3x3_patch_kernel(case, gpu_device):
-    """The 3x3 patch kernel (tiles 9 / 10: the A operand out of an LDS-resident, zero-bordered input patch, K chunk-major)
+    """The 3x3 patch kernel (tiles 9 / 10: the A operand out of an LDS-resident input patch, K chunk-major, out-of-image taps read a zero row)
     against a float64 convolution of the same 16-bit operands and against the im2col ring tiles: the same products,
     another accumulation order.  Tiles 9 and 10 agree bit for bit (one fixed-order K reduction per output element)."""
     from human_dynamics_amd.engine import conv_gemm
@@ -139,10 +139,6 @@ def test_conv3x3_patch_kernel(case, gpu_device):
     outs = {}
     for tile in (0, 9, 10):
         if tile == 10 and cout % 256:
-            continue
-        if tile == 9 and name == "tiny_3x3":       # 256 pixels of 3 x 3 images: the zero-bordered patch outgrows LDS
-            with pytest.raises(L.HmmrError, match="more than LDS holds"):
-                conv_gemm(x, w, tile=tile, k_order=1, **kw)
             continue
         outs[tile], _ = conv_gemm(x, w, tile=tile, k_order=1, **kw)
     ref, _ = _ref_conv(_split_round(x), _split_round_w(w), 1, 1, scale, shift, None, True, None, None, 1)
@@ -163,6 +159,9 @@ def test_conv3x3_patch_kernel_refuses_what_it_is_not_built_for(gpu_device):
                dict(stride=1, pad=1, res=np.zeros((2, 14, 14, 256), np.float32))):
         with pytest.raises(L.HmmrError):
             conv_gemm(x, w, in_dtype=X3, out_dtype=X3, device=gpu_device, k_order=1, **kw)
+    with pytest.raises(L.HmmrError, match="more than LDS holds"):     # the patch = the tile's pixels + a halo of W + 1 on either side
+        conv_gemm(rng.normal(size=(1, 4, 112, 32)).astype(np.float32), rng.normal(size=(3, 3, 32, 256)).astype(np.float32),
+                  stride=1, pad=1, in_dtype=X3, out_dtype=X3, device=gpu_device, k_order=1)
     with pytest.raises(L.HmmrError):           # a tile of the other K order
         conv_gemm(x, w, stride=1, pad=1, in_dtype=X3, out_dtype=X3, device=gpu_device, tile=9)
     with pytest.raises(L.HmmrError):           # built for split tensors

@@ -20,7 +20,7 @@ for d in sorted(glob.glob(root + "/cs_*")):
         e["c"][r["Counter_Name"]] = e["c"].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
     seq, prev = [], None
     for k, e in disp.items():
-        if "conv_gemm_kernel" not in e["name"]:
+        if "conv_gemm_kernel" not in e["name"] and "conv3x3_patch_kernel" not in e["name"]:
             continue
         key = (e["name"], e["grid"])
         if key != prev:
