@@ -834,6 +834,216 @@ __global__ __launch_bounds__(512, 1) void conv3x3_patch_kernel(const ConvArgs a)
     }
 }
 
+// ------------------------------------------------------------------------- //
+// The same layers WITHOUT a load segment (tile 11, 256x128): what profiles/r03m measured on the ping-pong schedule is that
+// an interval is as long as ONE wave needs to issue its ~100 address / ds_read / DMA instructions in program order
+// (~1040 cycles), not as long as the 24 MFMAs of its partner (768).  Here every wave keeps TWO fragment sets and reads
+// the fragments of K step kt+1 between the MFMAs of step kt, all eight waves run the same stream (the two waves of a
+// SIMD share its matrix pipe), and a K step is one barrier: the stage being read next was awaited at the end of the
+// previous step.  Filter ring of 4 stages (stage kt+3 is issued during step kt), two patches, K chunk-major, the patch
+// geometry and the epilogue of conv3x3_patch_kernel; same products in the same order per output element: same bits.
+template <typename TA, typename TO, int NPP>
+__global__ __launch_bounds__(512, 1) void conv3x3_pipe_kernel(const ConvArgs a) {
+    constexpr int BM = 256, BN = 128, WGM = 4, WGN = 2;
+    constexpr int NT = 512, RPP = 64, NSB = 4;
+    constexpr int EPS = elem_traits<TA>::EPS, BKE = 8 * EPS;
+    constexpr int TM = BM / WGM, TN = BN / WGN, FM = TM / 32, FN = TN / 32;
+    constexpr int PB = BN / RPP;
+    constexpr int B_BYTES = BN * 128, P_BYTES = NPP * RPP * 128, OFF_P = NSB * B_BYTES;
+    constexpr int NCHK = FragIO<TA>::CHUNKS;
+    static_assert(FM == 2 && FN == 2 && NCHK == 2, "written for 64x64 wave tiles of split operands");
+    typedef typename Frag<TA>::type frag_t;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int L = xcd_remap(blockIdx.x, a.n_tiles);
+    const int m0 = (L / a.tiles_n) * BM;
+    const int n0 = (L % a.tiles_n) * BN;
+    const int W = a.Win, C = 1 << a.cin_log2;
+    const int need = BM + 2 * W + 2;
+    constexpr int ZROW = NPP * RPP - 2;
+    const int base = m0 - W - 1;
+
+    const int pslot = tid & 7, r0 = tid >> 3;
+    const int lslot = pslot ^ ((r0 >> 1) & 7);
+    const TA* __restrict__ in = (const TA*)a.in;
+    const TA* pptr[NPP];
+#pragma unroll
+    for (int p = 0; p < NPP; ++p) {
+        const int r = RPP * p + r0, px = base + r;
+        pptr[p] = (r < need && px >= 0 && px < a.M) ? in + (long long)px * C + lslot * EPS : nullptr;
+    }
+    const TA* wptr = (const TA*)a.w + (long long)(n0 + r0) * a.K + lslot * EPS;
+    auto glds_patch = [&](int c, int buf) {
+        char* sp = smem + OFF_P + buf * P_BYTES + wave * 1024;
+#pragma unroll
+        for (int p = 0; p < NPP; ++p) {
+            const void* src = pptr[p] ? (const void*)(pptr[p] + c * BKE) : (const void*)g_zero_page;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sp + p * (RPP * 128)), 16, 0, 0);
+        }
+    };
+    auto glds_b = [&](int kt, int buf) {
+        char* sb = smem + buf * B_BYTES + wave * 1024;
+#pragma unroll
+        for (int p = 0; p < PB; ++p)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wptr + (long long)(RPP * p) * a.K + kt * BKE),
+                                             (lptr_t)(sb + p * (RPP * 128)), 16, 0, 0);
+    };
+
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int fswb = (lr >> 1) & 7;
+    const int b_row_off = (wn * TN + lr) * 128;
+    int prow[FM];
+    unsigned pmask[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        prow[i] = wm * TM + i * 32 + lr;
+        const int m = m0 + prow[i];
+        unsigned mk = 0u;
+        if (m < a.M) {
+            const int rem = m % a.HoWo, y = rem / W, x = rem - y * W;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                if ((unsigned)yy < (unsigned)a.Hin && (unsigned)xx < (unsigned)W) mk |= 1u << t;
+            }
+        }
+        pmask[i] = mk;
+    }
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nc = C / BKE, nk = 9 * nc;
+    frag_t fa[2][NCHK][FM], fb[2][NCHK][FN];
+    // one fragment (hi + lo: two ds_read_b128) of K step (tap t_, patch buffer pb_, filter stage sb_): piece q = 0 ... 7
+    auto read_piece = [&](frag_t (&da)[NCHK][FM], frag_t (&db)[NCHK][FN], int q, int t_, const char* sp_, const char* sb_) {
+        const int ch = q >> 2, w_ = q & 3;                  // per chunk: A row block 0, B 0, B 1, A row block 1
+        if (w_ == 0 || w_ == 3) {
+            const int i = w_ == 0 ? 0 : 1;
+            const int ky = (t_ * 11) >> 5;
+            const int tap_row = prow[i] + ky * W + (t_ - 3 * ky);
+            const int row = ((pmask[i] >> t_) & 1u) ? tap_row : ZROW + (tap_row & 1);
+            da[ch][i] = FragIO<TA>::read(sp_ + row * 128, ch, lh, (tap_row >> 1) & 7);
+        } else {
+            const int j = w_ - 1;
+            db[ch][j] = FragIO<TA>::read(sb_ + b_row_off + j * 32 * 128, ch, lh, fswb);
+        }
+    };
+    glds_patch(0, 0);
+#pragma unroll
+    for (int s_ = 0; s_ < NSB - 1; ++s_) glds_b(s_, s_);
+    __builtin_amdgcn_sched_barrier(0);
+    wait_vm_lgkm0<PB>();                                   // patch 0, stages 0 and 1 (only stage 2 may still be in flight)
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) read_piece(fa[0], fb[0], q, 0, smem + OFF_P, smem);
+    int t = 0, c = 0;
+    auto step = [&](auto cur_c, int kt) {
+        constexpr int CUR = decltype(cur_c)::value, NXT = CUR ^ 1;
+        // (the DMA issue in front of the MFMAs: in the middle of them it measured 1-2 % slower, profiles/r03n)
+        if (kt + 3 < nk) glds_b(kt + 3, (kt + 3) & 3);
+        if (t == 0 && c + 1 < nc) glds_patch(c + 1, (c + 1) & 1);
+        const int t1 = (t == 8) ? 0 : t + 1, cn = (t == 8) ? c + 1 : c;
+        const char* sp1 = smem + OFF_P + (cn & 1) * P_BYTES;
+        const char* sb1 = smem + ((kt + 1) & 3) * B_BYTES;
+        // fragments of step kt+1 (past the last step: a harmless read of stale LDS) between the MFMAs of step kt
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            read_piece(fa[NXT], fb[NXT], q, t1, sp1, sb1);
+            const int ch = q >> 2, i = (q >> 1) & 1, j = q & 1;
+            acc[i][j] = mma(fa[CUR][ch][i], fb[CUR][ch][j], acc[i][j]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // stage kt+2 (read during step kt+1) has landed: younger requests may stay in flight -- stage kt+3 and, through
+        // taps 0 and 1, the patch of the next chunk (issued during tap 0 behind that step's filter stage; in-order vmcnt)
+        if (kt + 2 < nk) {
+            const bool pend = t <= 1 && c + 1 < nc;
+            if (kt + 3 < nk) { if (pend) wait_vm_lgkm0<PB + NPP>(); else wait_vm_lgkm0<PB>(); }
+            else wait_vm_lgkm0<0>();
+        } else wait_vm_lgkm0<63>();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        t = t1; c = cn;
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+        step(std::integral_constant<int, 0>{}, kt);
+        if (kt + 1 < nk) step(std::integral_constant<int, 1>{}, kt + 1);
+    }
+
+    // ---- epilogue: accumulators -> LDS as fp32 [BM][BN] -> folded BN, ReLU, 8 channels per lane
+    float* sc = (float*)smem;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int col = wn * TN + j * 32 + lr;
+                sc[row * BN + col] = acc[i][j][r];
+            }
+    __syncthreads();
+    constexpr int VPR = BN / 8, NIT = (BM * VPR) / NT;
+    TO* __restrict__ out = (TO*)a.out;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = it * NT + tid;
+        const int row = idx / VPR, col = (idx % VPR) * 8;
+        const int m = m0 + row, n = n0 + col;
+        if (m >= a.M || n >= a.cout) continue;
+        float v[8];
+        load8(sc + row * BN + col, v);
+        if (a.scale && a.shift) {
+            float s[8], b[8]; load8(a.scale + n, s); load8(a.shift + n, b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], s[j], b[j]);
+        } else if (a.scale) {
+            float s[8]; load8(a.scale + n, s);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= s[j];
+        } else if (a.shift) {
+            float b[8]; load8(a.shift + n, b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += b[j];
+        }
+        if (a.relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        store8(out + (long long)m * a.ldo + n, v);
+    }
+}
+
+template <typename TA, typename TO, int NPP>
+static int launch_pipe(const ConvArgs& base, hipStream_t stream) {
+    ConvArgs a = base;
+    const int tiles_m = (a.M + 255) / 256;
+    a.tiles_n = (a.cout + 127) / 128;
+    a.n_tiles = tiles_m * a.tiles_n;
+    constexpr int kloop = 4 * 128 * 128 + 2 * NPP * 64 * 128, epi = 256 * 128 * 4;
+    constexpr int lds = kloop > epi ? kloop : epi;
+    static_assert(lds <= 160 * 1024, "LDS");
+    auto kern = conv3x3_pipe_kernel<TA, TO, NPP>;
+    static DeviceOnce once;
+    if (const unsigned long long bit = once.due()) {
+        HMMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        once.mark(bit);
+    }
+    hipLaunchKernelGGL(kern, dim3(a.n_tiles), dim3(512), lds, stream, a);
+    HMMR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 // rows of the patch of a BM-row tile: its pixels, a halo of W + 1 on either side, and the two zero rows
 static int patch_rows_bound(int bm, int h, int w) { (void)h; return bm + 2 * w + 2 + 2; }
 
@@ -859,8 +1069,7 @@ static int launch_patch(const ConvArgs& base, hipStream_t stream) {
 
 template <typename TA, typename TO>
 static int launch_patch_tiled(const ConvArgs& a, int tile, hipStream_t stream) {
-    if (tile == 0) tile = (a.cout % 256 == 0) ? 10 : 9;
-    const int bm = tile == 9 ? 256 : 128;
+    const int bm = tile == 10 ? 128 : 256;
     const int npp = (patch_rows_bound(bm, a.Hin, a.Win) + 63) / 64;
     if (tile == 9) {
         if (npp <= 5) return launch_patch<TA, TO, 256, 128, 4, 2, 5>(a, stream);
@@ -868,8 +1077,11 @@ static int launch_patch_tiled(const ConvArgs& a, int tile, hipStream_t stream) {
     } else if (tile == 10) {
         if (npp <= 3) return launch_patch<TA, TO, 128, 256, 2, 4, 3>(a, stream);
         if (npp <= 4) return launch_patch<TA, TO, 128, 256, 2, 4, 4>(a, stream);
+    } else if (tile == 11) {
+        if (npp <= 5) return launch_pipe<TA, TO, 5>(a, stream);
+        if (npp <= 6) return launch_pipe<TA, TO, 6>(a, stream);
     } else {
-        hmmr_set_error("hmmr_conv_gemm: k_order 1 runs tiles 9 (256x128) and 10 (128x256), not %d", tile);
+        hmmr_set_error("hmmr_conv_gemm: k_order 1 runs tiles 9 / 11 (256x128) and 10 (128x256), not %d", tile);
         return -1;
     }
     hmmr_set_error("hmmr_conv_gemm: k_order 1, tile %d: a %d x %d image needs a patch of %d x 64 rows, more than LDS holds",
@@ -1088,8 +1300,9 @@ extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
                      "hmmr_conv_gemm: k_order 1 is for 3x3 / stride 1 / pad 1 convolutions over a dense NHWC tensor with "
                      "cin a multiple of the 128-byte K step and a scale/shift/relu epilogue (no res, out2, out_b, pro_scale, in2, split_k)");
         HMMR_REQUIRE(d->in_dtype == HMMR_F16X3 && d->out_dtype == HMMR_F16X3, "hmmr_conv_gemm: k_order 1 is built for split (f16x3) tensors");
-        const int ptile = d->tile ? d->tile : (d->cout % 256 == 0 ? 10 : 9);
-        HMMR_REQUIRE((ptile == 9 ? d->cout % 128 : d->cout % 256) == 0, "hmmr_conv_gemm: k_order 1: cout must fill the tile's columns (filter rows are padded to 128)");
+        // library's choice: the 256x128 tile without a load segment where its patch fits LDS (images up to 62 pixels wide)
+        const int ptile = d->tile ? d->tile : (d->cout % 128 == 0 && 256 + 2 * d->win + 4 <= 6 * 64 ? 11 : d->cout % 256 == 0 ? 10 : 9);
+        HMMR_REQUIRE((ptile == 10 ? d->cout % 256 : d->cout % 128) == 0, "hmmr_conv_gemm: k_order 1: cout must fill the tile's columns (filter rows are padded to 128)");
         return launch_patch_tiled<bsplit_t, bsplit_t>(a, ptile, s);
     }
     const bool in16 = d->in_dtype == HMMR_BF16, in32 = d->in_dtype == HMMR_F32, inx3 = d->in_dtype == HMMR_F16X3;

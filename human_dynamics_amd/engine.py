@@ -183,12 +183,12 @@ class HmmrEngine(object):
     @staticmethod
     def _tile_for(lay, cand, cout):
         """hmmr_layer_t.tile for candidate `cand` on a layer with `cout` output columns: 0 (the library's choice) where
-        the tile does not fit; a layer packed chunk-major (k_order 1, the 3x3 patch kernel) runs tiles 9 / 10, the patch
-        forms of 7 / 8."""
+        the tile does not fit; a layer packed chunk-major (k_order 1, the 3x3 patch kernels) runs tiles 9 / 10, the patch
+        forms of 7 / 8, or 11, the 256x128 tile without a load segment."""
         if lay.k_order:
             cand = {7: 9, 8: 10}.get(cand, cand)
-            return cand if (cand == 9 and cout % 128 == 0) or (cand == 10 and cout % 256 == 0) else 0
-        if cand in (9, 10) or (cand in (1, 5, 7) and cout % 128) or (cand == 8 and cout % 256):
+            return cand if (cand in (9, 11) and cout % 128 == 0) or (cand == 10 and cout % 256 == 0) else 0
+        if cand in (9, 10, 11) or (cand in (1, 5, 7) and cout % 128) or (cand == 8 and cout % 256):
             return 0
         return cand
 

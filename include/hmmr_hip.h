@@ -103,7 +103,8 @@ typedef struct {
     int tile;              /* 0 = auto; 4-wave tiles: 1 = 128x128, 2 = 128x64, 3 = 64x64;
                               8-wave tiles: 5 = 128x128, 6 = 128x64 (two workgroups per CU, 2 LDS stages);
                               7 = 256x128, 8 = 128x256 (one workgroup per CU: 3-stage LDS ring, ping-pong wave groups);
-                              k_order 1 only: 9 = 256x128, 10 = 128x256 (the same structure, A operand out of an input patch) */
+                              k_order 1 only: 9 = 256x128, 10 = 128x256 (the same structure, A operand out of an input patch),
+                              11 = 256x128 without a load segment (two fragment sets per wave, one barrier per K step) */
     /* split-K (for GEMMs with few output tiles and a long K): split_k > 1 slices K into that many
      * contiguous ranges, each range leaves an fp32 partial plane in `ws`, and a second launch adds the
      * planes IN SLICE ORDER and applies the epilogue.  The caller fixes split_k per layer (never from
@@ -135,7 +136,7 @@ typedef struct {
      * kernel: a workgroup keeps the 128-byte channel chunk of every input pixel its tile touches (a PATCH: the tile's
      * pixels and a halo of win + 1 pixels on either side) in LDS and reads the nine taps of that chunk as nine shifted
      * fragment sets (out-of-image taps read a zero row), so an input
-     * line leaves L2 once per chunk instead of once per tap (tiles 9 / 10; scale/shift/relu epilogue only: no res,
+     * line leaves L2 once per chunk instead of once per tap (tiles 9 / 10 / 11; scale/shift/relu epilogue only: no res,
      * out2, out_b, pro_scale, in2, split_k).  The sum over k is the same set of products in another order: results
      * differ from k_order 0 by fp32 rounding of the accumulation only. */
     int k_order;

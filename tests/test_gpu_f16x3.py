@@ -137,7 +137,7 @@ def test_conv3x3_patch_kernel(case, gpu_device):
     shift = rng.normal(size=cout).astype(np.float32)
     kw = dict(stride=1, pad=1, scale=scale, shift=shift, relu=True, in_dtype=X3, out_dtype=X3, device=gpu_device)
     outs = {}
-    for tile in (0, 9, 10):
+    for tile in (0, 9, 10, 11):
         if tile == 10 and cout % 256:
             continue
         outs[tile], _ = conv_gemm(x, w, tile=tile, k_order=1, **kw)

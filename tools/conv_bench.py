@@ -40,7 +40,7 @@ def run(lib, name, n, h, cin, cout, k, stride, kind, dt, tile, iters=20):
     d.in_img_stride, d.in_row_stride, d.in_px_stride = h * h * cin, h * cin, cin
     d.kh = d.kw = k; d.sy = d.sx = stride; d.py = d.px = pad
     d.ho = d.wo = ho; d.cout = cout; d.ldo = cout; d.tile = tile
-    if tile in (9, 10):
+    if tile in (9, 10, 11):
         d.k_order = 1        # the 3x3 patch kernel (timing only: the random filter needs no re-packing)
     keep = [x, w, sc, sh, out]
     nbytes = x.numel() * x.element_size() / (stride * stride if k == 1 else 1) + out.numel() * out.element_size()
@@ -115,9 +115,9 @@ def main():
         if only and not any(o in name for o in only):
             continue
         for tile in TILES:
-            if (tile in (1, 5, 7, 9) and cout % 128) or (tile in (8, 10) and cout % 256):
+            if (tile in (1, 5, 7, 9, 11) and cout % 128) or (tile in (8, 10) and cout % 256):
                 continue
-            if tile in (9, 10) and not (k == 3 and stride == 1 and dt in ("f16x3", "split")):
+            if tile in (9, 10, 11) and not (k == 3 and stride == 1 and dt in ("f16x3", "split")):
                 continue
             rows.append(run(lib, name, n, h, cin, cout, k, stride, kind, dt, tile))
             print(json.dumps(rows[-1]), flush=True)
