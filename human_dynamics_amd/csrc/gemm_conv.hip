@@ -611,6 +611,68 @@ void conv_gemm_kernel(const ConvArgs a) {
     }
 }
 
+// Shared by the two 3x3 patch kernels below.
+// bit t of the result: tap t = ky*3 + kx of output pixel m (flattened [img][y][x]) lies inside its image
+__device__ __forceinline__ unsigned patch_tap_mask(int m, const ConvArgs& a) {
+    if (m >= a.M) return 0u;
+    const int rem = m % a.HoWo, y = rem / a.Wo, x = rem - y * a.Wo;
+    unsigned mk = 0u;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        if ((unsigned)yy < (unsigned)a.Hin && (unsigned)xx < (unsigned)a.Win) mk |= 1u << t;
+    }
+    return mk;
+}
+// accumulators of 64x64 wave tiles -> LDS as fp32 [BM][BN] -> folded BN (scale / shift), ReLU, 8 channels per lane
+template <typename TO, int BM, int BN, int WGM, int WGN>
+__device__ __forceinline__ void patch_epilogue(const ConvArgs& a, char* smem, const f32x16 (&acc)[2][2], int m0, int n0,
+                                               int tid, int wm, int wn, int lr, int lh) {
+    constexpr int NT = 512, TM = BM / WGM, TN = BN / WGN;
+    static_assert(TM == 64 && TN == 64, "64x64 wave tiles");
+    float* sc = (float*)smem;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int col = wn * TN + j * 32 + lr;
+                sc[row * BN + col] = acc[i][j][r];
+            }
+    __syncthreads();
+    constexpr int VPR = BN / 8, NIT = (BM * VPR) / NT;
+    TO* __restrict__ out = (TO*)a.out;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = it * NT + tid;
+        const int row = idx / VPR, col = (idx % VPR) * 8;
+        const int m = m0 + row, n = n0 + col;
+        if (m >= a.M || n >= a.cout) continue;
+        float v[8];
+        load8(sc + row * BN + col, v);
+        if (a.scale && a.shift) {
+            float s[8], b[8]; load8(a.scale + n, s); load8(a.shift + n, b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], s[j], b[j]);
+        } else if (a.scale) {
+            float s[8]; load8(a.scale + n, s);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= s[j];
+        } else if (a.shift) {
+            float b[8]; load8(a.shift + n, b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += b[j];
+        }
+        if (a.relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        store8(out + (long long)m * a.ldo + n, v);
+    }
+}
+
 // ------------------------------------------------------------------------- //
 // 3x3 / stride 1 / SAME convolutions out of an LDS-resident input PATCH (hmmr_conv_desc_t.k_order = 1; tiles 9, 10)
 // ------------------------------------------------------------------------- //
@@ -634,7 +696,7 @@ void conv_gemm_kernel(const ConvArgs a) {
 template <typename TA, typename TO, int BM, int BN, int WGM, int WGN, int NPP>
 __global__ __launch_bounds__(512, 1) void conv3x3_patch_kernel(const ConvArgs a) {
     static_assert(WGM * WGN == 8, "8-wave workgroups");
-    constexpr int NT = 512, RPP = 64, NSB = 3;
+    constexpr int RPP = 64, NSB = 3;
     constexpr int EPS = elem_traits<TA>::EPS, BKE = 8 * EPS;
     constexpr int TM = BM / WGM, TN = BN / WGN, FM = TM / 32, FN = TN / 32;
     constexpr int PB = BN / RPP;
@@ -691,17 +753,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_patch_kernel(const ConvArgs a)
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         prow[i] = wm * TM + i * 32 + lr;
-        const int m = m0 + prow[i];
-        unsigned mk = 0u;
-        if (m < a.M) {
-            const int rem = m % a.HoWo, y = rem / W, x = rem - y * W;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-                if ((unsigned)yy < (unsigned)a.Hin && (unsigned)xx < (unsigned)W) mk |= 1u << t;
-            }
-        }
-        pmask[i] = mk;
+        pmask[i] = patch_tap_mask(m0 + prow[i], a);
     }
 
     f32x16 acc[FM][FN];
@@ -790,48 +842,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_patch_kernel(const ConvArgs a)
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();
 
-    // ---- epilogue: accumulators -> LDS as fp32 [BM][BN] -> folded BN, ReLU, 8 channels per lane
-    float* sc = (float*)smem;
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int col = wn * TN + j * 32 + lr;
-                sc[row * BN + col] = acc[i][j][r];
-            }
-    __syncthreads();
-    constexpr int VPR = BN / 8, NIT = (BM * VPR) / NT;
-    TO* __restrict__ out = (TO*)a.out;
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int idx = it * NT + tid;
-        const int row = idx / VPR, col = (idx % VPR) * 8;
-        const int m = m0 + row, n = n0 + col;
-        if (m >= a.M || n >= a.cout) continue;
-        float v[8];
-        load8(sc + row * BN + col, v);
-        if (a.scale && a.shift) {
-            float s[8], b[8]; load8(a.scale + n, s); load8(a.shift + n, b);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], s[j], b[j]);
-        } else if (a.scale) {
-            float s[8]; load8(a.scale + n, s);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] *= s[j];
-        } else if (a.shift) {
-            float b[8]; load8(a.shift + n, b);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += b[j];
-        }
-        if (a.relu) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-        }
-        store8(out + (long long)m * a.ldo + n, v);
-    }
+    patch_epilogue<TO, BM, BN, WGM, WGN>(a, smem, acc, m0, n0, tid, wm, wn, lr, lh);
 }
 
 // ------------------------------------------------------------------------- //
@@ -845,7 +856,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_patch_kernel(const ConvArgs a)
 template <typename TA, typename TO, int NPP>
 __global__ __launch_bounds__(512, 1) void conv3x3_pipe_kernel(const ConvArgs a) {
     constexpr int BM = 256, BN = 128, WGM = 4, WGN = 2;
-    constexpr int NT = 512, RPP = 64, NSB = 4;
+    constexpr int RPP = 64, NSB = 4;
     constexpr int EPS = elem_traits<TA>::EPS, BKE = 8 * EPS;
     constexpr int TM = BM / WGM, TN = BN / WGN, FM = TM / 32, FN = TN / 32;
     constexpr int PB = BN / RPP;
@@ -901,17 +912,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pipe_kernel(const ConvArgs a) 
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         prow[i] = wm * TM + i * 32 + lr;
-        const int m = m0 + prow[i];
-        unsigned mk = 0u;
-        if (m < a.M) {
-            const int rem = m % a.HoWo, y = rem / W, x = rem - y * W;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-                if ((unsigned)yy < (unsigned)a.Hin && (unsigned)xx < (unsigned)W) mk |= 1u << t;
-            }
-        }
-        pmask[i] = mk;
+        pmask[i] = patch_tap_mask(m0 + prow[i], a);
     }
 
     f32x16 acc[FM][FN];
@@ -980,48 +981,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_pipe_kernel(const ConvArgs a) 
         if (kt + 1 < nk) step(std::integral_constant<int, 1>{}, kt + 1);
     }
 
-    // ---- epilogue: accumulators -> LDS as fp32 [BM][BN] -> folded BN, ReLU, 8 channels per lane
-    float* sc = (float*)smem;
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int col = wn * TN + j * 32 + lr;
-                sc[row * BN + col] = acc[i][j][r];
-            }
-    __syncthreads();
-    constexpr int VPR = BN / 8, NIT = (BM * VPR) / NT;
-    TO* __restrict__ out = (TO*)a.out;
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int idx = it * NT + tid;
-        const int row = idx / VPR, col = (idx % VPR) * 8;
-        const int m = m0 + row, n = n0 + col;
-        if (m >= a.M || n >= a.cout) continue;
-        float v[8];
-        load8(sc + row * BN + col, v);
-        if (a.scale && a.shift) {
-            float s[8], b[8]; load8(a.scale + n, s); load8(a.shift + n, b);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], s[j], b[j]);
-        } else if (a.scale) {
-            float s[8]; load8(a.scale + n, s);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] *= s[j];
-        } else if (a.shift) {
-            float b[8]; load8(a.shift + n, b);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += b[j];
-        }
-        if (a.relu) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-        }
-        store8(out + (long long)m * a.ldo + n, v);
-    }
+    patch_epilogue<TO, BM, BN, WGM, WGN>(a, smem, acc, m0, n0, tid, wm, wn, lr, lh);
 }
 
 template <typename TA, typename TO, int NPP>
