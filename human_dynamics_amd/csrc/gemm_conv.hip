@@ -1260,8 +1260,9 @@ extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
                      "hmmr_conv_gemm: k_order 1 is for 3x3 / stride 1 / pad 1 convolutions over a dense NHWC tensor with "
                      "cin a multiple of the 128-byte K step and a scale/shift/relu epilogue (no res, out2, out_b, pro_scale, in2, split_k)");
         HMMR_REQUIRE(d->in_dtype == HMMR_F16X3 && d->out_dtype == HMMR_F16X3, "hmmr_conv_gemm: k_order 1 is built for split (f16x3) tensors");
-        // library's choice: the 256x128 tile without a load segment where its patch fits LDS (images up to 62 pixels wide)
-        const int ptile = d->tile ? d->tile : (d->cout % 128 == 0 && 256 + 2 * d->win + 4 <= 6 * 64 ? 11 : d->cout % 256 == 0 ? 10 : 9);
+        // library's choice: the 256x128 ping-pong tile (inside the network the tuner prefers it to tile 11 on ten layers of eleven,
+        // profiles/r03p; tile 10 needs 256 output columns and a narrower image)
+        const int ptile = d->tile ? d->tile : 9;
         HMMR_REQUIRE((ptile == 10 ? d->cout % 256 : d->cout % 128) == 0, "hmmr_conv_gemm: k_order 1: cout must fill the tile's columns (filter rows are padded to 128)");
         return launch_patch_tiled<bsplit_t, bsplit_t>(a, ptile, s);
     }
