@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = devflags.get("LIB_PATH") or os.path.join(HERE, "libhmmr_hip.so")
 
 HMMR_F32, HMMR_BF16, HMMR_F16X3 = 0, 1, 2
-ABI_VERSION = 12
+ABI_VERSION = 13
 RESNET_UNITS = 16
 RESNET_PROF_SLOTS = 64
 MAX_TEMPORAL_BLOCKS = 8
@@ -41,6 +41,8 @@ class ConvDesc(C.Structure):
         ("pro_scale", _fp), ("pro_shift", _fp),
         ("out_b", _vp), ("ldo_b", C.c_int), ("n_split", C.c_int), ("relu_b", C.c_int),
         ("in2", _vp), ("cin2", C.c_int), ("k_order", C.c_int),
+        ("batch", C.c_int), ("batch_in_bytes", C.c_int64), ("batch_w_bytes", C.c_int64), ("batch_out_bytes", C.c_int64),
+        ("batch_res_bytes", C.c_int64), ("batch_scale_bytes", C.c_int64), ("batch_shift_bytes", C.c_int64),
     ]
 
 
@@ -61,7 +63,7 @@ class TailDesc(C.Structure):
 
 class Debug(C.Structure):
     """hmmr_debug_t: development switches, all zero = product defaults."""
-    _fields_ = [("stem_route", C.c_int), ("stem_no_conv1", C.c_int), ("gemm_probe", C.c_int), ("smpl_blend_mfma", C.c_int), ("reserved", C.c_int * 4)]
+    _fields_ = [("stem_route", C.c_int), ("stem_no_conv1", C.c_int), ("gemm_probe", C.c_int), ("smpl_blend_mfma", C.c_int), ("ief_no_group", C.c_int), ("reserved", C.c_int * 3)]
 
 
 class Layer(C.Structure):

@@ -54,7 +54,27 @@ struct ConvArgs {
     long long out_slice_stride;       // elements between the partial-sum planes of consecutive slices
     int probe;                        // always 0 in the product build (see HMMR_GEMM_PROBE below)
     const void* in2; int cin2, kt_split;   // second operand source: K steps >= kt_split read rows of in2 [M][cin2]
+    // grouped launch: `batch` problems of one shape, problem z (blockIdx.z) at these BYTE offsets from problem 0
+    int batch; long long bz_in, bz_w, bz_out, bz_res, bz_scale, bz_shift;
 };
+
+// The arguments of problem z of a grouped launch (hmmr_conv_desc_t.batch): every operand pointer moved by its stride.
+__device__ __forceinline__ ConvArgs batch_problem(const ConvArgs& a0, int z) {
+    ConvArgs a = a0;
+    if (a0.batch > 1) {
+        const long long zz = z;
+        a.in = (const char*)a0.in + zz * a0.bz_in;
+        a.w = (const char*)a0.w + zz * a0.bz_w;
+        if (a0.out) a.out = (char*)a0.out + zz * a0.bz_out;
+        if (a0.out2) a.out2 = (char*)a0.out2 + zz * a0.bz_out;
+        if (a0.res) a.res = (const char*)a0.res + zz * a0.bz_res;
+        if (a0.scale) a.scale = (const float*)((const char*)a0.scale + zz * a0.bz_scale);
+        if (a0.shift) a.shift = (const float*)((const char*)a0.shift + zz * a0.bz_shift);
+        if (a0.scale2) a.scale2 = (const float*)((const char*)a0.scale2 + zz * a0.bz_scale);
+        if (a0.shift2) a.shift2 = (const float*)((const char*)a0.shift2 + zz * a0.bz_shift);
+    }
+    return a;
+}
 
 // Development build only (-DHMMR_GEMM_PROBE, tools/probe_build.sh -> libhmmr_hip_probe.so): the K loop can drop its
 // MFMAs (1), its operand loads after the first stage (2) or its barriers (4), to measure which of the three bounds
@@ -165,7 +185,8 @@ template <int N> __device__ __forceinline__ void wait_vm_lgkm0() {
 //  every shape and tile, profiles/r03a_chunk_major_k.log; removed.)
 template <typename TA, typename TO, int BM, int BN, int WGM, int WGN, bool PRO, bool UTAP, int NSTAGE>
 __global__ __launch_bounds__(WGM * WGN * 64, NSTAGE >= 3 ? (WGM * WGN) / 4 : ((WGM * WGN == 8) ? 4 : 1))
-void conv_gemm_kernel(const ConvArgs a) {
+void conv_gemm_kernel(const ConvArgs a0) {
+    const ConvArgs a = batch_problem(a0, blockIdx.z);
     static_assert(NSTAGE >= 2 && NSTAGE <= 4, "2 stages (two workgroups per CU) or a 3/4-stage ring (one workgroup per CU)");
     static_assert(NSTAGE == 2 || WGM * WGN == 8, "the deep ring is written for 8-wave workgroups");
     static_assert(!PRO || UTAP, "the fused pre-activation needs one tap per K step");
@@ -1072,7 +1093,7 @@ static int launch_cfg(const ConvArgs& base, int slices, hipStream_t stream) {
     constexpr int BKE_ = 8 * elem_traits<TA>::EPS;
     const int nk = a.K / BKE_;
     a.kt_per_slice = (nk + slices - 1) / slices;
-    hipLaunchKernelGGL(kern, dim3(a.n_tiles, slices), dim3(WGM * WGN * 64), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(a.n_tiles, slices, a.batch), dim3(WGM * WGN * 64), lds, stream, a);
     HMMR_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -1117,8 +1138,10 @@ static int launch_typed(const ConvArgs& a, int tile, int slices, hipStream_t str
 // Split-K second pass: sum the S fp32 partial planes in slice order, then the same epilogue as
 // the GEMM kernel (scale/shift, residual, ReLU, optional second output).
 template <typename TO>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a, const float* __restrict__ part,
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a0, const float* __restrict__ part,
                                                             int slices, int ldw, long long plane) {
+    const ConvArgs a = batch_problem(a0, blockIdx.y);      // grouped launch: problem blockIdx.y, its planes behind the previous problem's
+    part += (long long)blockIdx.y * slices * plane;
     const int vpr = (a.cout + 7) / 8;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long long)a.M * vpr) return;
@@ -1247,6 +1270,13 @@ extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
     a.relu = d->relu; a.tiles_n = 0; a.n_tiles = 0;
     a.kt_per_slice = 0; a.out_slice_stride = 0; a.probe = 0;
     a.in2 = d->in2; a.cin2 = d->in2 ? d->cin2 : 0; a.kt_split = d->cin / bke;
+    a.batch = d->batch > 1 ? d->batch : 1;
+    a.bz_in = d->batch_in_bytes; a.bz_w = d->batch_w_bytes; a.bz_out = d->batch_out_bytes;
+    a.bz_res = d->batch_res_bytes; a.bz_scale = d->batch_scale_bytes; a.bz_shift = d->batch_shift_bytes;
+    HMMR_REQUIRE(a.batch == 1 || (a.batch <= 64 && !d->k_order && !d->out_b && !d->in2 && !d->pro_scale &&
+                                  ((d->batch_in_bytes | d->batch_w_bytes | d->batch_out_bytes | d->batch_res_bytes | d->batch_scale_bytes | d->batch_shift_bytes) & 15) == 0),
+                 "hmmr_conv_gemm: a grouped launch (batch > 1) takes up to 64 problems, strides that are multiples of 16 bytes, "
+                 "and no k_order / out_b / in2 / pro_scale");
 #ifdef HMMR_GEMM_PROBE
     a.probe = hmmr_debug_state()->gemm_probe;
 #endif
@@ -1277,9 +1307,10 @@ extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
         // pass 1: raw fp32 partial planes [slice][M][ldw]; pass 2: ordered sum + epilogue
         const int ldw = (d->cout + 127) / 128 * 128;
         const long long plane = (long long)a.M * ldw;
-        HMMR_REQUIRE(d->ws && d->ws_bytes >= hmmr_conv_splitk_workspace_bytes(a.M, d->cout, slices),
-                     "hmmr_conv_gemm: split-K workspace missing or too small");
+        HMMR_REQUIRE(d->ws && d->ws_bytes >= a.batch * hmmr_conv_splitk_workspace_bytes(a.M, d->cout, slices),
+                     "hmmr_conv_gemm: split-K workspace missing or too small (a grouped launch needs batch x the planes)");
         ConvArgs p = a;
+        p.bz_out = (long long)slices * plane * (long long)sizeof(float);      // problem z's planes behind problem z-1's
         p.scale = p.shift = nullptr; p.res = nullptr; p.out2 = nullptr; p.scale2 = p.shift2 = nullptr;
         // (a fused pre-activation, if any, stays: it acts on the A operand)
         p.relu = 0; p.out = d->ws; p.ldo = ldw; p.out_slice_stride = plane;
@@ -1289,9 +1320,10 @@ extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
         if (rc) return rc;
         const long long nvec = (long long)a.M * ((a.cout + 7) / 8);
         const unsigned grid = (unsigned)((nvec + 255) / 256);
-        if (out16) hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, a, (const float*)d->ws, slices, ldw, plane);
-        else if (outx3) hipLaunchKernelGGL(splitk_reduce_kernel<bsplit_t>, dim3(grid), dim3(256), 0, s, a, (const float*)d->ws, slices, ldw, plane);
-        else hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(grid), dim3(256), 0, s, a, (const float*)d->ws, slices, ldw, plane);
+        const dim3 rgrid(grid, a.batch);
+        if (out16) hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, rgrid, dim3(256), 0, s, a, (const float*)d->ws, slices, ldw, plane);
+        else if (outx3) hipLaunchKernelGGL(splitk_reduce_kernel<bsplit_t>, rgrid, dim3(256), 0, s, a, (const float*)d->ws, slices, ldw, plane);
+        else hipLaunchKernelGGL(splitk_reduce_kernel<float>, rgrid, dim3(256), 0, s, a, (const float*)d->ws, slices, ldw, plane);
         HMMR_CHECK_HIP(hipGetLastError());
         return 0;
     }

@@ -11,11 +11,12 @@
 
 #define GN_EPS 1e-6f
 // K = 3*2048 is long and M = b*t is short (640 rows for 32 windows): 4 K-slices quadruple the
-// number of workgroups.  Fixed per layer, never derived from b, so a window's result does not
-// depend on how many windows share the launch.
-#ifndef TEMPORAL_SPLIT_K
-#define TEMPORAL_SPLIT_K 4
-#endif
+// number of workgroups.  Fixed per layer and operand mode, never derived from b, so a window's result does not
+// depend on how many windows share the launch.  Split operands: 5 slices of the 128x256 ring tile (40 tiles x 5 = 200
+// workgroups on 256 CUs, 39 K steps each) measured 0.427 ms per f_movie pass of 32 windows against 0.477 for 4 slices
+// of the 256x128 tile (tools/stage_bench.py, round 3; 6 / 8 slices and the two-stage tiles are slower).
+#define TEMPORAL_SPLIT_K_MAX 5
+static inline int temporal_split_k(int dtype) { return dtype == HMMR_F16X3 ? 5 : 4; }
 
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
 #pragma unroll
@@ -93,7 +94,7 @@ extern "C" size_t hmmr_temporal_workspace_bytes(int b, int t, int dtype) {
     const size_t m = (size_t)b * t, e = dtype == HMMR_BF16 ? 2 : 4;
     // h (operand dtype) + h1 (fp32) + two fp32 trunk buffers + split-K partial planes
     return align_up(m * 2048 * e, 256) + 3 * align_up(m * 2048 * 4, 256) +
-           align_up(hmmr_conv_splitk_workspace_bytes((int)m, 2048, TEMPORAL_SPLIT_K), 256);
+           align_up(hmmr_conv_splitk_workspace_bytes((int)m, 2048, TEMPORAL_SPLIT_K_MAX), 256);
 }
 
 extern "C" int hmmr_temporal_fwd(const hmmr_temporal_weights_t* w, const float* phi, int b, int t,
@@ -111,7 +112,7 @@ extern "C" int hmmr_temporal_fwd(const hmmr_temporal_weights_t* w, const float* 
     net[0] = (float*)p;       p += align_up(m * C * 4, 256);
     net[1] = (float*)p;       p += align_up(m * C * 4, 256);
     void* skws = p;
-    const size_t skbytes = hmmr_conv_splitk_workspace_bytes((int)m, C, TEMPORAL_SPLIT_K);
+    const size_t skbytes = hmmr_conv_splitk_workspace_bytes((int)m, C, TEMPORAL_SPLIT_K_MAX);
     const float* cur = phi;
     for (int i = 0; i < w->num_blocks; ++i) {
         const hmmr_temporal_block_t& B = w->block[i];
@@ -123,7 +124,7 @@ extern "C" int hmmr_temporal_fwd(const hmmr_temporal_weights_t* w, const float* 
         d.n_img = b; d.hin = t; d.win = 1; d.cin = C;
         d.in_img_stride = (int64_t)t * C; d.in_row_stride = C; d.in_px_stride = C;
         d.kh = 3; d.kw = 1; d.sy = d.sx = 1; d.py = 1; d.px = 0; d.ho = t; d.wo = 1; d.cout = C; d.ldo = C;
-        d.split_k = TEMPORAL_SPLIT_K; d.ws = skws; d.ws_bytes = skbytes;
+        d.split_k = temporal_split_k(w->dtype); d.ws = skws; d.ws_bytes = skbytes;
         if (hmmr_conv_gemm(&d, stream)) return -2;
         if (hmmr_groupnorm_relu(h1, B.gn2_gamma, B.gn2_beta, b, t, C, 32, h, w->dtype, stream)) return -2;
         d.w = B.conv2.w; d.scale = B.conv2.scale; d.shift = B.conv2.shift; d.tile = B.conv2.tile;
@@ -141,7 +142,7 @@ extern "C" size_t hmmr_hallucinator_workspace_bytes(int m, int dtype) {
     if (m <= 0) return 0;
     const size_t e = dtype == HMMR_BF16 ? 2 : 4;
     return 3 * align_up((size_t)m * 2048 * e, 256) +
-           align_up(hmmr_conv_splitk_workspace_bytes(m, 2048, TEMPORAL_SPLIT_K), 256);
+           align_up(hmmr_conv_splitk_workspace_bytes(m, 2048, TEMPORAL_SPLIT_K_MAX), 256);
 }
 
 template <typename TO>
@@ -165,7 +166,7 @@ extern "C" int hmmr_hallucinator_fwd(const hmmr_hallucinator_weights_t* w, const
     void* h1 = p; p += align_up((size_t)m * C * e, 256);
     void* h2 = p; p += align_up((size_t)m * C * e, 256);
     void* sk = p;
-    const size_t skb = hmmr_conv_splitk_workspace_bytes(m, C, TEMPORAL_SPLIT_K);
+    const size_t skb = hmmr_conv_splitk_workspace_bytes(m, C, TEMPORAL_SPLIT_K_MAX);
     hipStream_t s = (hipStream_t)stream;
     const void* xin = phi;
     if (w->dtype != HMMR_F32) {
@@ -185,7 +186,7 @@ extern "C" int hmmr_hallucinator_fwd(const hmmr_hallucinator_weights_t* w, const
         d.in_img_stride = C; d.in_row_stride = C; d.in_px_stride = C;
         d.kh = d.kw = 1; d.sy = d.sx = 1; d.ho = d.wo = 1; d.cout = C; d.ldo = C;
         d.relu = relu; d.res = res; d.ldr = C;
-        d.split_k = TEMPORAL_SPLIT_K; d.ws = sk; d.ws_bytes = skb;
+        d.split_k = 4; d.ws = sk; d.ws_bytes = skb;            // (the hallucinator keeps 4 slices in every mode)
         return hmmr_conv_gemm(&d, s);
     };
     if (fc(xin, w->fc1, h1, w->dtype, 1, nullptr)) return -2;

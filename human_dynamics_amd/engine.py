@@ -26,11 +26,11 @@ DEFAULT_DTYPE = "f16x3"
 TILE_TABLES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tile_tables.json")
 
 
-def set_debug(stem_route=0, stem_no_conv1=0, gemm_probe=0, smpl_blend_mfma=0):
+def set_debug(stem_route=0, stem_no_conv1=0, gemm_probe=0, smpl_blend_mfma=0, ief_no_group=0):
     """Development switches of libhmmr_hip.so (hmmr_debug_t; process-wide, zeros = product defaults)."""
     d = L.Debug()
     d.stem_route, d.stem_no_conv1, d.gemm_probe = int(stem_route), int(stem_no_conv1), int(gemm_probe)
-    d.smpl_blend_mfma = int(smpl_blend_mfma)
+    d.smpl_blend_mfma, d.ief_no_group = int(smpl_blend_mfma), int(ief_no_group)
     L.load().hmmr_set_debug(C.byref(d))
 
 

@@ -284,8 +284,8 @@ def pack_temporal(w, dtype, store, num_conv_layers=3):
         b.gn2_gamma, b.gn2_beta = store.put(w[gn2 + "/gamma"]).data_ptr(), store.put(w[gn2 + "/beta"]).data_ptr()
         b.conv1 = _layer(store, pack_conv_weight(w[c1 + "/weights"]), dtype, shift=w[c1 + "/biases"])
         b.conv2 = _layer(store, pack_conv_weight(w[c2 + "/weights"]), dtype, shift=w[c2 + "/biases"])
-        if dtype == L.HMMR_F16X3:      # measured (tools/stage_bench.py, 32 windows): the ping-pong tile, 0.51 -> 0.44 ms per f_movie pass
-            b.conv1.tile = b.conv2.tile = 7
+        if dtype == L.HMMR_F16X3:      # measured (tools/stage_bench.py, 32 windows): the 128x256 ping-pong tile with 5 K slices (csrc/temporal.hip), 0.51 -> 0.43 ms per f_movie pass
+            b.conv1.tile = b.conv2.tile = 8
     return tw
 
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HMMR_ABI_VERSION 12      /* 12: hmmr_conv_desc_t / hmmr_layer_t k_order = 1: 3x3 SAME convolutions out of an LDS-resident input patch (tiles 9, 10) */
+#define HMMR_ABI_VERSION 13      /* 13: hmmr_conv_desc_t.batch (grouped launches); 12: k_order = 1, 3x3 SAME convolutions out of an LDS-resident input patch (tiles 9, 10, 11) */
 
 /* HMMR_F16X3: "split" tensors -- every group of 8 consecutive channels is 32 bytes, [hi x8][lo x8] with
  * hi = fp16(x), lo = fp16(x - hi), x clamped to +-65504 (4 bytes per element, 22 mantissa bits while lo is a normal
@@ -57,7 +57,8 @@ typedef struct hmmr_debug_s {
     int smpl_blend_mfma;   /* 1: the SMPL blend-shape product [m,218] x [218,3 x 6890] on the matrix cores in exact fp32
                               (smpl_verts_mfma_kernel, v_mfma_f32_32x32x2_f32) instead of the packed-FMA vector form
                               (smpl_verts_kernel, the default: measured 1.2x faster); results agree to one fp32 ulp */
-    int reserved[4];
+    int ief_no_group;      /* 1: hmmr_ief_fwd runs the delta regressors one after the other instead of as grouped launches (same bits) */
+    int reserved[3];
 } hmmr_debug_t;
 void hmmr_set_debug(const hmmr_debug_t* d);     /* NULL = defaults */
 void hmmr_get_debug(hmmr_debug_t* d);
@@ -140,6 +141,13 @@ typedef struct {
      * out2, out_b, pro_scale, in2, split_k).  The sum over k is the same set of products in another order: results
      * differ from k_order 0 by fp32 rounding of the accumulation only. */
     int k_order;
+    /* grouped launch: `batch` > 1 runs that many problems of this one shape as ONE launch (grid z); problem z reads and
+     * writes at these BYTE offsets (multiples of 16, negative allowed) from problem 0: `in`, `w`, `out` / `out2`, `res`,
+     * `scale` / `scale2` and `shift` / `shift2`.  A stride of 0 shares the operand.  With split_k, `ws` holds batch x the
+     * planes.  Not with k_order, out_b, in2, pro_scale.  Problem z's results are those of its own launch, bit for bit
+     * (the IEF's two delta regressors, src/models.py:343-361, run this way). */
+    int batch;
+    int64_t batch_in_bytes, batch_w_bytes, batch_out_bytes, batch_res_bytes, batch_scale_bytes, batch_shift_bytes;
 } hmmr_conv_desc_t;
 
 int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream);

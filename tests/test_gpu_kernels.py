@@ -307,6 +307,75 @@ def test_conv_gemm_fused_preactivation(tile, dt, gpu_device):
     assert np.abs(out - ref).max() < 3e-5 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("split_k", [0, 4])
+def test_conv_gemm_grouped_launch_equals_one_launch_per_problem(split_k, gpu_device):
+    """hmmr_conv_desc_t.batch: three problems of one shape as ONE launch (grid z), operands at byte strides -- one of them
+    0 (a shared input), one negative (filters stored in reverse order) -- bit for bit the three separate launches."""
+    import ctypes as C
+    from human_dynamics_amd import packing
+    lib = L.load()
+    g = torch.Generator().manual_seed(3)
+    B, m, k, cout = 3, 200, 1024, 1024
+    x = torch.randn((m, k), generator=g).to(gpu_device)
+    w = (torch.randn((B, cout, k), generator=g) / 32).to(gpu_device)
+    bias = torch.randn((B, cout), generator=g).to(gpu_device)
+    res = torch.randn((B, m, cout), generator=g).to(gpu_device)
+    out = torch.zeros((B, m, cout), device=gpu_device)
+    ref = torch.zeros_like(out)
+    nb = lib.hmmr_conv_splitk_workspace_bytes(m, cout, split_k) if split_k else 0
+    ws = torch.empty(max(B * int(nb), 16), dtype=torch.uint8, device=gpu_device)
+
+    def desc(z):
+        d = L.ConvDesc()
+        d.in_, d.w, d.out = x.data_ptr(), w[B - 1 - z].data_ptr(), ref[z].data_ptr()     # problem z uses filter B-1-z
+        d.shift, d.res, d.ldr, d.relu = bias[z].data_ptr(), res[z].data_ptr(), cout, 1
+        d.in_dtype = d.out_dtype = L.HMMR_F32
+        d.n_img, d.hin, d.win, d.cin = m, 1, 1, k
+        d.in_img_stride = d.in_row_stride = d.in_px_stride = k
+        d.kh = d.kw = d.sy = d.sx = d.ho = d.wo = 1
+        d.cout, d.ldo = cout, cout
+        if split_k:
+            d.split_k, d.ws, d.ws_bytes = split_k, ws.data_ptr(), int(nb)
+        return d
+    st = torch.cuda.current_stream().cuda_stream
+    for z in range(B):
+        d = desc(z)
+        L.check(lib.hmmr_conv_gemm(C.byref(d), st), "hmmr_conv_gemm")
+    d = desc(0)
+    d.out = out.data_ptr()
+    d.batch = B
+    d.batch_in_bytes, d.batch_w_bytes = 0, -cout * k * 4
+    d.batch_out_bytes = d.batch_res_bytes = m * cout * 4
+    d.batch_shift_bytes = cout * 4
+    if split_k:
+        d.ws_bytes = B * int(nb)
+    L.check(lib.hmmr_conv_gemm(C.byref(d), st), "hmmr_conv_gemm")
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref) and float(out.abs().max()) > 0
+    want = torch.relu(x.double() @ w[B - 1].double().T + bias[0].double() + res[0].double())      # ... and right
+    assert float((out[0].double() - want).abs().max()) < 2e-4
+    d.batch_w_bytes = 8                                       # strides are multiples of 16 bytes
+    with pytest.raises(L.HmmrError):
+        L.check(lib.hmmr_conv_gemm(C.byref(d), st), "hmmr_conv_gemm")
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16x3"])
+def test_ief_grouped_delta_regressors_equal_one_launch_each(dt, weights, gpu_device):
+    """hmmr_ief_fwd runs the two delta regressors as grouped launches (one per layer); hmmr_debug_t.ief_no_group runs them
+    one after the other: the same bits."""
+    from human_dynamics_amd import engine as E
+    eng = E.HmmrEngine(weights, None, dtype=dt, device=gpu_device)
+    strips = torch.randn((57, 2048), generator=torch.Generator().manual_seed(1)).to(gpu_device)
+    a = eng.ief(strips).clone()
+    E.set_debug(ief_no_group=1)
+    try:
+        b = eng.ief(strips).clone()
+    finally:
+        E.set_debug()
+    assert a.shape[0] == 3 and torch.equal(a, b)
+    assert not torch.equal(a[1], a[2])
+
+
 @pytest.mark.parametrize("dt", ["bf16", "f32", "f16x3"])
 def test_resnet_tile_choice_never_changes_a_bit(dt, weights, gpu_device):
     """hmmr_layer_t.tile (and therefore the per-batch-size autotuner) only moves work between
