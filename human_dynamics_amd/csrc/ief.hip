@@ -144,7 +144,6 @@ extern "C" int hmmr_ief_fwd_from(const hmmr_ief_weights_t* w, const float* strip
     const int nd_group = w->num_regressors - 1;
     struct Strides { long long w, scale, shift; };
     auto strides_of = [&](const hmmr_layer_t hmmr_ief_regressor_t::*lay, Strides& st) -> bool {
-        const hmmr_layer_t& l1 = w->reg[1].*lay;
         st = Strides{0, 0, 0};
         for (int r = 2; r < w->num_regressors; ++r) {
             const hmmr_layer_t& a = w->reg[r - 1].*lay; const hmmr_layer_t& b = w->reg[r].*lay;
@@ -155,7 +154,6 @@ extern "C" int hmmr_ief_fwd_from(const hmmr_ief_weights_t* w, const float* strip
             if (r > 2 && (cur.w != st.w || cur.scale != st.scale || cur.shift != st.shift)) return false;
             st = cur;
         }
-        (void)l1;
         return ((st.w | st.scale | st.shift) & 15) == 0;
     };
     Strides s_phi, s_th, s_fc2, s_fc3;
