@@ -189,3 +189,31 @@ def test_chunk_major_filter_pack():
     assert not any(off.unit[i].conv2.k_order for i in range(16))
     for dt in (_lib.HMMR_BF16, _lib.HMMR_F32):
         assert not any(packing.pack_resnet(ws, dt, packing.DeviceStore("cpu")).unit[i].conv2.k_order for i in range(16))
+
+
+def test_shipped_tile_tables_fit_their_layers():
+    """human_dynamics_amd/tile_tables.json: every entry names a layer of the ResNet and a tile that layer's launch accepts
+    (csrc/gemm_conv.hip: 128- / 256-column tiles need cout % 128 / 256 == 0; a layer packed chunk-major runs the patch tiles
+    9 / 10 / 11, every other layer the tiles 1 ... 8), for the three operand modes and the batch sizes the BASELINE
+    configurations produce.  HmmrEngine._tile_for is the same rule at run time (it maps what does not fit to 0)."""
+    import json
+    import os
+    from human_dynamics_amd import engine as E
+    tabs = json.load(open(os.path.join(os.path.dirname(E.__file__), "tile_tables.json")))
+    ws = assets.make_synthetic_weights(0)
+    sizes = set()
+    for dt in (_lib.HMMR_F32, _lib.HMMR_BF16, _lib.HMMR_F16X3):
+        rw = packing.pack_resnet(ws, dt, packing.DeviceStore("cpu"))
+        for key, tab in tabs.items():
+            if key.startswith("_") or int(key.split(":")[0]) != dt:
+                continue
+            sizes.add(int(key.split(":")[1]))
+            for lk, tile in tab.items():
+                u, nm = int(lk.split(":")[0]), lk.split(":")[1]
+                U = rw.unit[u]
+                assert 0 <= u < 16 and nm in ("conv1", "conv2", "conv3", "shortcut")
+                lay = U.c3sc if (nm == "conv3" and U.c3sc.w) else getattr(U, nm)
+                cout = U.depth + U.base if (nm == "shortcut" and U.sc_c1.w) else (U.base if nm in ("conv1", "conv2") else U.depth)
+                assert E.HmmrEngine._tile_for(lay, tile, cout) == tile, (key, lk, tile)
+                assert (tile in (0, 9, 10, 11)) if lay.k_order else (tile in (0, 1, 2, 3, 5, 6, 7, 8)), (key, lk, tile)
+    assert {40, 64, 65, 128, 129, 256, 257, 512, 513, 1024} <= sizes
