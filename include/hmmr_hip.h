@@ -326,6 +326,9 @@ typedef struct {
     int delta_from_start;              /* 1: use_delta_from_pred=False */
 } hmmr_ief_weights_t;
 
+/* One set of layer buffers per delta regressor (num_regressors - 1 of them, at least one): the delta regressors run as
+ * grouped launches, one per layer (hmmr_conv_desc_t.batch), when their filter banks / vectors lie at one common byte stride
+ * -- always the case for two of them -- and one after the other otherwise; same results either way. */
 size_t hmmr_ief_workspace_bytes(int m, int num_regressors, int dtype);
 /* omegas: [num_regressors][m][85] fp32.  The IEF starts from w->mean_theta in every row (tester.py:79-83, 181). */
 int hmmr_ief_fwd(const hmmr_ief_weights_t* w, const float* strips, int m, float* omegas,
