@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = devflags.get("LIB_PATH") or os.path.join(HERE, "libhmmr_hip.so")
 
 HMMR_F32, HMMR_BF16, HMMR_F16X3 = 0, 1, 2
-ABI_VERSION = 13
+ABI_VERSION = 14
 RESNET_UNITS = 16
 RESNET_PROF_SLOTS = 64
 MAX_TEMPORAL_BLOCKS = 8
@@ -58,6 +58,7 @@ class TailDesc(C.Structure):
         ("h1", _vp), ("hin", C.c_int), ("win", C.c_int), ("w2", _vp), ("scale2", _fp), ("shift2", _fp),
         ("xp", _vp), ("wsc", _vp), ("shift_sc", _fp),
         ("conv2_stride", C.c_int), ("out_pre", _vp),
+        ("pair_stream", _vp), ("c_xp", C.c_int),
     ]
 
 
@@ -72,7 +73,7 @@ class Layer(C.Structure):
 
 class ResnetUnit(C.Structure):
     _fields_ = [("conv1", Layer), ("conv2", Layer), ("conv3", Layer), ("shortcut", Layer), ("c3sc", Layer), ("sc_c1", Layer),
-                ("w3_frag", _vp), ("w1n_frag", _vp), ("pre_scale", _fp), ("pre_shift", _fp),
+                ("w3_frag", _vp), ("w1n_frag", _vp), ("pair_stream", _vp), ("pre_scale", _fp), ("pre_shift", _fp),
                 ("c_in", C.c_int), ("base", C.c_int), ("depth", C.c_int), ("stride", C.c_int),
                 ("fuse_preact", C.c_int), ("fuse_tail", C.c_int)]
 
@@ -135,6 +136,7 @@ SIGNATURES = {
                                 _fp, _fp, _fp, _fp, _vp, C.c_size_t, _vp]),
     "hmmr_crop_frames": (C.c_int, [_vp, _ip, C.c_int, C.c_int, C.c_int, _fp, _vp]),
     "hmmr_bottleneck_tail": (C.c_int, [C.POINTER(TailDesc), _vp]),
+    "hmmr_pair_stream_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "hmmr_render_handoff": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, _fp, C.c_int64, _fp, C.c_int, C.c_int, C.c_int,
                                       _fp, _fp, _fp, _vp]),
     "hmmr_eval_joints": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _vp]),

@@ -16,10 +16,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libhmmr_hip.so")
-SOURCES = ["api.cpp", "gemm_conv.hip", "stem.hip", "bottleneck.hip", "bottleneck_split.hip", "resnet.hip", "temporal.hip", "ief.hip", "smpl.hip", "eval_metrics.hip", "preprocess.hip", "handoff.hip"]
+SOURCES = ["api.cpp", "gemm_conv.hip", "stem.hip", "bottleneck.hip", "bottleneck_split.hip", "unit_pair.hip", "resnet.hip", "temporal.hip", "ief.hip", "smpl.hip", "eval_metrics.hip", "preprocess.hip", "handoff.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC,
          "-Wall", "-Wno-unused-function"]
+
+
+# per-file flags.  unit_pair.hip: a single wave per SIMD issues one vector instruction per ~8 cycles, so the instruction COUNT of its
+# epilogue is what bounds it; the SLP vectoriser packs pairs of its fp32 FMAs into v_pk_fma_f32 at the price of a v_mov per operand
+EXTRA_FLAGS = {"unit_pair.hip": ["-fno-slp-vectorize"]}
 
 
 def _newer(src, dst):
@@ -38,7 +43,7 @@ def build(force=False, verbose=True):
         objs.append(o)
         if force or _newer(s, o) or any(_newer(d, o) for d in _deps()):
             lang = ["-x", "hip"] if src.endswith(".hip") else []
-            jobs.append([HIPCC] + FLAGS + lang + ["-c", s, "-o", o])
+            jobs.append([HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + lang + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

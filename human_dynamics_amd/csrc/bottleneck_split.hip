@@ -40,29 +40,8 @@ struct SplitTailArgs {
     const float* scale2; const float* shift2;
 };
 
-struct wfrag { shalf8 hi, lo; };
-
-__device__ __forceinline__ f32x16 mma3(const wfrag& w, const shalf8& xh, const shalf8& xl, f32x16 c) {
-    c = mfma_split(w.hi, xl, c);
-    c = mfma_split(w.lo, xh, c);
-    return mfma_split(w.hi, xh, c);
-}
 __device__ __forceinline__ float bf_lo(unsigned v) { return shalf_lo(v); }
 __device__ __forceinline__ float bf_hi(unsigned v) { return shalf_hi(v); }
-
-// four fp32 values -> their split halves, 4 halves (8 bytes) each; clamped to the fp16 range like store8<bsplit_t>
-__device__ __forceinline__ void split4(const float (&v)[4], unsigned long long& hi, unsigned long long& lo) {
-    unsigned h[2], l[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const float c0 = split_clamp(v[2 * i]), c1 = split_clamp(v[2 * i + 1]);
-        const shalf_t a = (shalf_t)c0, b = (shalf_t)c1;
-        h[i] = shalf_pack(a, b);
-        l[i] = shalf_pack((shalf_t)(c0 - (float)a), (shalf_t)(c1 - (float)b));
-    }
-    hi = (unsigned long long)h[0] | ((unsigned long long)h[1] << 32);
-    lo = (unsigned long long)l[0] | ((unsigned long long)l[1] << 32);
-}
 
 // KS: 64-channel K sub-tiles of conv3 (1: h2 of block 1; 2: h2 of block 2, or block 1's {h2, xp} with the shortcut folded)
 // NCH = depth / 64, N2 = conv1' output channels, RES: a shortcut tensor is added (false: it is folded into conv3's K)
@@ -380,8 +359,11 @@ int launch_split_tail(const SplitTailArgs& a, hipStream_t stream) {
 
 }  // namespace
 
+int hmmr_unit_pair_split(const hmmr_tail_desc_t* d, hipStream_t stream);       // unit_pair.hip
+
 // hmmr_bottleneck_tail for HMMR_F16X3 (called from bottleneck.hip).  w3 / w1 are FRAGMENT-MAJOR here (hmmr_hip.h).
 int hmmr_bottleneck_tail_split(const hmmr_tail_desc_t* d, hipStream_t stream) {
+    if (d->pair_stream) return hmmr_unit_pair_split(d, stream);
     HMMR_REQUIRE((d->h2 != nullptr) != (d->h1 != nullptr) && d->w1 && d->out && d->out_h1 && d->pre_scale && d->pre_shift && d->scale1 &&
                  d->shift1 && !d->out_pre && !d->res_strided,
                  "hmmr_bottleneck_tail (f16x3): needs h2 or h1 (conv2 in front), the next conv1, out, out_h1 and a dense shortcut");

@@ -210,3 +210,26 @@ __device__ __forceinline__ u32x4 preact_slot_split(const u32x4& v, const f32x4& 
     const unsigned s0 = dpp_swap(is_lo ? ph[0] : pl[0]), s1 = dpp_swap(is_lo ? ph[1] : pl[1]);
     return is_lo ? u32x4{s0, s1, pl[0], pl[1]} : u32x4{ph[0], ph[1], s0, s1};
 }
+
+// ---- helpers shared by the fused unit kernels for split operands (bottleneck_split.hip, unit_pair.hip)
+// one MFMA A-operand fragment of a split filter bank: 32 rows x 16 K, hi and lo halves
+struct wfrag { shalf8 hi, lo; };
+// weights as the A operand, activations as B: gemm_conv.hip's product order (x.lo*w.hi, x.hi*w.lo, x.hi*w.hi) with the operands swapped
+__device__ __forceinline__ f32x16 mma3(const wfrag& w, const shalf8& xh, const shalf8& xl, f32x16 c) {
+    c = mfma_split(w.hi, xl, c);
+    c = mfma_split(w.lo, xh, c);
+    return mfma_split(w.hi, xh, c);
+}
+// four fp32 values -> their split halves, 4 halves (8 bytes) each; clamped to the fp16 range like store8<bsplit_t>
+__device__ __forceinline__ void split4(const float (&v)[4], unsigned long long& hi, unsigned long long& lo) {
+    unsigned h[2], l[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float c0 = split_clamp(v[2 * i]), c1 = split_clamp(v[2 * i + 1]);
+        const shalf_t a = (shalf_t)c0, b = (shalf_t)c1;
+        h[i] = shalf_pack(a, b);
+        l[i] = shalf_pack((shalf_t)(c0 - (float)a), (shalf_t)(c1 - (float)b));
+    }
+    hi = (unsigned long long)h[0] | ((unsigned long long)h[1] << 32);
+    lo = (unsigned long long)l[0] | ((unsigned long long)l[1] << 32);
+}

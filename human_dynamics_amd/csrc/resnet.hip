@@ -377,10 +377,11 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
             t.out = d.out; t.out_pre = d.out2; t.pre_scale = d.scale2; t.pre_shift = d.shift2;
             if (hmmr_bottleneck_tail(&t, s)) return -2;
         } else if (U.fuse_tail) {     // conv3 + add + the next unit's preact + conv1 in one launch (csrc/bottleneck.hip)
-            HMMR_REQUIRE(!last && (w->dtype == HMMR_BF16 || (w->dtype == HMMR_F16X3 && U.w3_frag && U.w1n_frag && U.fuse_tail <= 2)) &&
+            const bool pair = w->dtype == HMMR_F16X3 && U.pair_stream && U.fuse_tail == 1;      // csrc/unit_pair.hip
+            HMMR_REQUIRE(!last && (w->dtype == HMMR_BF16 || pair || (w->dtype == HMMR_F16X3 && U.w3_frag && U.w1n_frag && U.fuse_tail <= 2)) &&
                          U.stride == 1 && write_raw && !write_pre && next_fused &&
                          next_identity && w->unit[u + 1].base == U.base && w->unit[u + 1].c_in == U.depth &&
-                         ((U.base == 64 && U.depth == 256) || (U.base == 128 && U.depth == 512)),
+                         ((U.base == 64 && U.depth == 256) || (U.base == 128 && U.depth == 512) || (pair && U.base == 256 && U.depth == 1024)),
                          "resnet: unit %d cannot fuse its tail", u);
             const hmmr_resnet_unit_t& N = w->unit[u + 1];
             hmmr_tail_desc_t t = {};
@@ -393,9 +394,10 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
                 t.h2 = T2;
             }
             t.w3 = U.conv3.w; t.scale3 = U.conv3.scale; t.shift3 = U.conv3.shift;
-            if (w->dtype == HMMR_F16X3) {            // fragment-major filters; a folded shortcut rides in conv3's K
+            if (w->dtype == HMMR_F16X3) {            // fragment-major filters (or one fragment stream); a folded shortcut rides in conv3's K
                 t.w3 = U.w3_frag;
-                if (sc_in_c3) { t.scale3 = U.c3sc.scale; t.shift3 = U.c3sc.shift; t.xp = xin; }
+                if (pair) t.pair_stream = U.pair_stream;
+                if (sc_in_c3) { t.scale3 = U.c3sc.scale; t.shift3 = U.c3sc.shift; t.xp = xin; t.c_xp = U.c_in; }
             }
             if (sc_in_c3) {
             } else if (sc_in_tail) {
@@ -406,7 +408,7 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
             }
             t.ho = Ho; t.wo = Ho;
             t.out = xn; t.pre_scale = N.pre_scale; t.pre_shift = N.pre_shift;
-            t.w1 = w->dtype == HMMR_F16X3 ? U.w1n_frag : N.conv1.w;
+            t.w1 = w->dtype == HMMR_F16X3 ? U.w1n_frag : N.conv1.w;      // (not read with pair_stream)
             t.scale1 = N.conv1.scale; t.shift1 = N.conv1.shift; t.relu1 = 1; t.n2 = N.base;
             t.out_h1 = conv2_in_tail ? T2 : T1;
             if (hmmr_bottleneck_tail(&t, s)) return -2;

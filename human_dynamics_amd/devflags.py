@@ -24,6 +24,7 @@ FLAGS = {
     "PREACT_FIRST": ("0", "1: a block's first unit fuses its pre-activation too"),
     "FOLD_SC": ("", "0 | 1: conv shortcut folded into conv3's K (default: f16x3 only)"),
     "PATCH_3X3": ("1", "0: the stride-1 3x3 layers of blocks 2-4 keep the tap-major K order and the im2col gather (f16x3; differs by fp32 accumulation rounding)"),
+    "UNIT_PAIR": ("1", "0 | 1 | block2 | block3: the stride-1 units of blocks 2-3 as register-resident unit pairs (csrc/unit_pair.hip; f16x3)"),
     "AUTOTUNE": ("1", "0: no per-layer tile tuning pass (shipped table / library heuristic only)"),
     "TILE_TABLE": ("1", "0: ignore the shipped tile tables (tile_tables.json), tune or fall back to the heuristic"),
     "TILE_CACHE": ("", "json file the tuned tile tables are read from / written to (profiling runs)"),

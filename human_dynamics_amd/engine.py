@@ -74,7 +74,8 @@ class HmmrEngine(object):
 
     def __init__(self, weights, smpl, dtype=DEFAULT_DTYPE, device="cuda:0", num_conv_layers=3,
                  delta_t_values=(-5, 5), joint_type="cocoplus", resnet_chunk=0,
-                 temporal_dtype=None, ief_dtype=None, autotune=True, fold_sc=None, fuse_tail=None, patch_3x3=None):
+                 temporal_dtype=None, ief_dtype=None, autotune=True, fold_sc=None, fuse_tail=None, patch_3x3=None,
+                 unit_pair=None):
         self.lib = L.load()
         _debug_from_env()
         if not torch.cuda.is_available():
@@ -101,7 +102,9 @@ class HmmrEngine(object):
         w = weights if weights is not None else {}
         self.rw = (packing.pack_resnet(w, self.dtype, self.store, fuse_preact_blocks=fuse, fuse_tail=tail, fuse_sc=fsc,
                                        fuse_preact_first=pfirst, fold_sc=fold,
-                                       patch_3x3=(devflags.get("PATCH_3X3") != "0") if patch_3x3 is None else patch_3x3)
+                                       patch_3x3=(devflags.get("PATCH_3X3") != "0") if patch_3x3 is None else patch_3x3,
+                                       unit_pair=({"0": False, "1": True}.get(devflags.get("UNIT_PAIR"), devflags.get("UNIT_PAIR"))
+                                                  if unit_pair is None else unit_pair))
                    if "resnet_v2_50/conv1/weights" in w else None)
         self.tw = (packing.pack_temporal(w, self.temporal_dtype, self.store, num_conv_layers)
                    if assets.temporal_scopes(0)[1] + "/weights" in w else None)

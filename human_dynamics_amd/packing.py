@@ -120,6 +120,51 @@ def pack_frag_major(w_nk):
     return torch.stack([frag(hi), frag(lo)], dim=3).contiguous()   # [rb, kc, lane, 2, 8]
 
 
+def pair_is_a(i, na, ft):
+    """fragment i of an iteration's ft = na + nb fragments is a conv3 fragment (csrc/unit_pair.hip: pair_is_a)"""
+    return ((i + 1) * na) // ft > (i * na) // ft
+
+
+def pack_pair_stream(w3_nk, w1_nk):
+    """The filter stream of a fused unit pair (hmmr_tail_desc_t.pair_stream, csrc/unit_pair.hip): w3_nk [depth][K3] = this
+    unit's conv3 rows ([W3 | Wsc] along K with a folded shortcut), w1_nk [n2][depth] = the next unit's conv1 rows ->
+    fp16 [depth / 32 + 2][ft][2 (hi, lo plane)][64 lanes][8]: iteration `it` holds the K3 / 16 fragments of conv3 row block
+    `it` (zeros past the last one) and the n2 / 16 fragments of conv1' K step it - 2 (K chunk 2 (it - 2) + kcl, row block of;
+    fragment kb = kcl * (n2 / 32) + of; zeros for it < 2), interleaved by pair_is_a.  A fragment = the MFMA A operand of 32
+    rows x 16 K: lane = 32 * (k half) + row, 8 halves = W[32 rb + row][16 kc + 8 half .. + 7], rows scaled by row_pow2()."""
+    w3_nk = np.ascontiguousarray(w3_nk, dtype=np.float32)
+    w1_nk = np.ascontiguousarray(w1_nk, dtype=np.float32)
+    depth, K3 = w3_nk.shape
+    n2 = w1_nk.shape[0]
+    assert w1_nk.shape[1] == depth and depth % 32 == 0 and K3 % 16 == 0 and n2 % 32 == 0, (w3_nk.shape, w1_nk.shape)
+
+    def planar(w_nk):
+        t = torch.from_numpy(scale_rows(w_nk, row_pow2(w_nk)))
+        n, K = t.shape
+        hi = t.to(SPLIT_HALF)
+        lo = (t - hi.to(torch.float32)).to(SPLIT_HALF)
+
+        def frag(x):
+            x = x.reshape(n // 32, 32, K // 16, 2, 8)                # rb, row, kc, half, e
+            return x.permute(0, 2, 3, 1, 4).reshape(n // 32, K // 16, 64, 8)
+        return torch.stack([frag(hi), frag(lo)], dim=2)              # [rb, kc, plane, lane, 8]
+
+    f3, f1 = planar(w3_nk), planar(w1_nk)
+    nch, na, nf2 = depth // 32, K3 // 16, n2 // 32
+    nb = 2 * nf2
+    ft = na + nb
+    assert ft % 8 == 0, "an iteration must be a whole number of 8-fragment slabs"
+    out = torch.zeros((nch + 2, ft, 2, 64, 8), dtype=SPLIT_HALF)
+    ia = [i for i in range(ft) if pair_is_a(i, na, ft)]
+    ib = [i for i in range(ft) if not pair_is_a(i, na, ft)]
+    assert len(ia) == na and [(i * na) // ft for i in ia] == list(range(na))
+    out[:nch, ia] = f3                                               # conv3 row block it, K chunks in order
+    for kb, i in enumerate(ib):
+        kcl, of = divmod(kb, nf2)
+        out[2:, i] = f1[of, kcl::2]                                  # K chunk 2 (it - 2) + kcl for it = 2 .. nch + 1
+    return out.contiguous()
+
+
 def pack_stem_weight(w_hwio):
     """[7,7,3,64] -> [128][8*32]: k = ky*32 + kx*4 + c (kx = 7, c = 3 and ky = 7 are zero)."""
     out = np.zeros((64, 8, 8, 4), np.float32)
@@ -173,7 +218,7 @@ def _layer(store, w_packed, dtype, scale=None, shift=None):
 
 
 def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3", "block4"), fuse_tail=True,
-                fuse_sc=True, fuse_preact_first=False, fold_sc=None, patch_3x3=True):
+                fuse_sc=True, fuse_preact_first=False, fold_sc=None, patch_3x3=True, unit_pair=True):
     """fuse_preact_blocks: blocks whose units apply their `preact` BN+ReLU inside the operand
     staging of conv1/shortcut instead of reading a materialised preact tensor (csrc/resnet.hip;
     measured at batch 256: -4.5 % ResNet time with blocks 1-2 fused, neutral for blocks 3-4).
@@ -181,13 +226,19 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
     hmmr_bottleneck_tail launch (bf16; the stride-1 units of block1 and block2).
     patch_3x3 (f16x3 only): the stride-1 3x3 conv2 of blocks 2-4 packed chunk-major (hmmr_conv_desc_t.k_order = 1) and run
     by the patch kernel (csrc/gemm_conv.hip, tiles 9 / 10).  Block 1 keeps the tap-major order its fused tails reproduce bit
-    for bit; the stride-2 units keep the im2col gather."""
+    for bit; the stride-2 units keep the im2col gather.
+    unit_pair (f16x3 only; True | "block2" | "block3" | False): the stride-1 units of blocks 2-3 run conv3 + add + the next
+    unit's preact + conv1 as the register-resident unit pair of csrc/unit_pair.hip (one filter stream per unit); block3/unit_1
+    then keeps its conv shortcut as a launch (shortcut + conv1 as one column-split GEMM) instead of folding it into conv3."""
     if fold_sc is None:
         # fold every conv shortcut into its unit's conv3 (one GEMM over {h2, preact}: hmmr_resnet_unit_t.c3sc).  Default in
         # the f16x3 mode, where it removes the widest tensor of the unit (4 B/element) from HBM; the bf16 mode has its own
         # fused units, and in f32 mode it would move the accumulation order away from the layer-per-launch schedule.
         fold_sc = dtype == L.HMMR_F16X3
     bke = 64 if dtype == L.HMMR_BF16 else 32
+    pair_shapes = ()
+    if dtype == L.HMMR_F16X3 and unit_pair:
+        pair_shapes = {"block2": ((128, 512),), "block3": ((256, 1024),)}.get(unit_pair, ((128, 512), (256, 1024)))
     rw = L.ResnetWeights()
     rw.dtype = dtype
     rw.stem = _layer(store, pack_stem_weight(w["resnet_v2_50/conv1/weights"]), dtype,
@@ -215,6 +266,10 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
             u.shortcut = _layer(store, pack_conv_weight(w[scope + "/shortcut/weights"]), dtype,
                                 shift=w[scope + "/shortcut/biases"])
             folded = bool(fold_sc) and stride == 1 and not u.fuse_preact and base % bke == 0 and c_in % bke == 0
+            if (base, depth) == (256, 1024) and (base, depth) in pair_shapes:
+                # the unit pair keeps 32 px x K of conv3's operand in registers: K = 256 + 512 does not fit.  Decided by `unit_pair`
+                # alone (not by fuse_tail), so the layer-per-launch schedule of the same configuration rounds the same tensors
+                folded = False
             if folded:
                 both = np.concatenate([w[scope + "/conv3/weights"], w[scope + "/shortcut/weights"]], axis=2)   # along K
                 bias = (np.asarray(w[scope + "/conv3/biases"], np.float64) +
@@ -237,16 +292,22 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
         for i, (scope, c_in, base, depth, stride, has_sc) in enumerate(units[:-1]):
             u, nx = rw.unit[i], rw.unit[i + 1]
             nscope = units[i + 1][0]
-            ok = (stride == 1 and (base, depth) in ((64, 256), (128, 512)) and nx.c_in == depth and nx.base == base and
-                  nx.fuse_preact == 1 and not nx.shortcut.w and (not has_sc or (u.c3sc.w and c_in == 64 and base == 64)))
+            chain = stride == 1 and nx.c_in == depth and nx.base == base and nx.fuse_preact == 1 and not nx.shortcut.w
+            pair = (chain and (base, depth) in pair_shapes and fuse_tail not in ("block1",) and
+                    (not u.c3sc.w or (base, c_in) == (128, 256)))
+            ok = (chain and (base, depth) in ((64, 256), (128, 512)) and (not has_sc or (u.c3sc.w and c_in == 64 and base == 64)))
             if fuse_tail in ("block1",) and base != 64:
                 ok = False
-            if not ok:
+            if not (ok or pair):
                 continue
             w3 = np.asarray(w[scope + "/conv3/weights"], np.float32)[0, 0]              # [K][depth]
             if u.c3sc.w:
                 w3 = np.concatenate([w3, np.asarray(w[scope + "/shortcut/weights"], np.float32)[0, 0]], axis=0)
             w1n = np.asarray(w[nscope + "/conv1/weights"], np.float32)[0, 0]            # [depth][base]
+            if pair:
+                u.pair_stream = store.put_tensor(pack_pair_stream(w3.T, w1n.T)).data_ptr()
+                u.fuse_tail = 1
+                continue
             u.w3_frag = store.put_tensor(pack_frag_major(w3.T)).data_ptr()
             u.w1n_frag = store.put_tensor(pack_frag_major(w1n.T)).data_ptr()
             u.fuse_tail = 1

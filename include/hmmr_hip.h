@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HMMR_ABI_VERSION 13      /* 13: hmmr_conv_desc_t.batch (grouped launches); 12: k_order = 1, 3x3 SAME convolutions out of an LDS-resident input patch (tiles 9, 10, 11) */
+#define HMMR_ABI_VERSION 14      /* 14: hmmr_tail_desc_t.pair_stream / c_xp, hmmr_resnet_unit_t.pair_stream (the register-resident unit pair of blocks 2-3), hmmr_debug_t.no_unit_pair, hmmr_run_flags; 13: hmmr_conv_desc_t.batch (grouped launches); 12: k_order = 1, 3x3 SAME convolutions out of an LDS-resident input patch (tiles 9, 10, 11) */
 
 /* HMMR_F16X3: "split" tensors -- every group of 8 consecutive channels is 32 bytes, [hi x8][lo x8] with
  * hi = fp16(x), lo = fp16(x - hi), x clamped to +-65504 (4 bytes per element, 22 mantissa bits while lo is a normal
@@ -179,6 +179,8 @@ typedef struct {
                                   one column-split GEMM.  w == NULL: two launches. */
     const void* w3_frag;       /* f16x3 fused tail (fuse_tail == 1): this unit's conv3 filters ([W3 | Wsc] when c3sc is set) */
     const void* w1n_frag;      /* ... and the NEXT unit's conv1 filters, both FRAGMENT-MAJOR (hmmr_tail_desc_t); else NULL */
+    const void* pair_stream;   /* f16x3 fused tail of blocks 2-3 (fuse_tail == 1): this unit's conv3 filters ([W3 | Wsc] when c3sc is
+                                  set) and the NEXT unit's conv1 filters as ONE fragment stream (hmmr_tail_desc_t.pair_stream); else NULL */
     const float* pre_scale;    /* this unit's folded `preact` BN, [c_in] */
     const float* pre_shift;
     int c_in, base, depth, stride;
@@ -241,7 +243,20 @@ typedef struct {
      * (relu(out * pre_scale + pre_shift), what the next unit's conv1 AND conv shortcut read) are written */
     int conv2_stride;
     void* out_pre;                  /* [m][depth] or NULL */
+    /* HMMR_F16X3, (c_mid, depth, n2) = (256, 1024, 256) [block3] or (128, 512, 128) [block2]: the register-resident unit pair
+     * (csrc/unit_pair.hip).  w3 / w1 are not read; `pair_stream` holds both filter banks as the flat sequence of 2 KB MFMA
+     * A-operand fragments ([hi plane: 64 lanes x 16 B][lo plane]; lane = 32 * (k half) + row, the 16 bytes = the 8 halves of
+     * W[32 rb + row][16 kc + 8 half .. + 7], rows scaled like every split filter bank) the kernel consumes:
+     * depth / 32 + 2 iterations; iteration `it` holds the kc3 = (c_mid + c_xp) / 16 fragments of conv3 row block `it` (K chunks in
+     * order; zeros for it >= depth / 32) and the n2 / 16 fragments of conv1' K step it - 2 (K chunk 2 (it - 2) + {0, 1}, row blocks in
+     * order; zeros for it < 2), fragment i of an iteration being a conv3 fragment when ((i + 1) kc3) / ft > (i kc3) / ft, ft = the
+     * iteration's fragment count (hmmr_pair_stream_bytes; packing.pack_pair_stream).  With xp (c_xp = its channels, 256 for the
+     * block2 shape; res == NULL) conv3's K is {h2, xp} as in the block1 form.  h2 only (no conv2 in front).  Bit-identical to
+     * the launches it replaces. */
+    const void* pair_stream;
+    int c_xp;
 } hmmr_tail_desc_t;
+size_t hmmr_pair_stream_bytes(int kc3, int depth, int n2);
 int hmmr_bottleneck_tail(const hmmr_tail_desc_t* d, void* stream);
 
 size_t hmmr_resnet50_workspace_bytes(int n, int dtype);

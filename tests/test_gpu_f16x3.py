@@ -331,7 +331,7 @@ def test_resnet_folded_shortcut_is_the_separate_shortcut_up_to_its_rounding(weig
     from oracle import hmmr_oracle as O
     frames = assets.make_synthetic_frames(5, seed=9)
     folded = HmmrEngine(weights, None, dtype="f16x3", device=gpu_device, autotune=False)
-    assert [i for i in range(16) if folded.rw.unit[i].c3sc.w] == [0, 3, 7, 13]
+    assert [i for i in range(16) if folded.rw.unit[i].c3sc.w] == [0, 3, 13]       # (block3/unit_1 keeps its shortcut as a launch: its successor pair holds conv3's operand in registers)
     plain = HmmrEngine(weights, None, dtype="f16x3", device=gpu_device, autotune=False, fold_sc=False)
     assert not any(plain.rw.unit[i].c3sc.w for i in range(16))
     a, b = folded.resnet(frames, n_zero=1).cpu().numpy(), plain.resnet(frames, n_zero=1).cpu().numpy()
@@ -353,7 +353,9 @@ def test_resnet_split_fused_tails_equal_layer_per_launch(weights, gpu_device):
     from human_dynamics_amd.engine import HmmrEngine
     frames = assets.make_synthetic_frames(5, seed=17)
     fused = HmmrEngine(weights, None, dtype="f16x3", device=gpu_device, autotune=False)
-    assert [int(fused.rw.unit[i].fuse_tail) for i in range(16)] == [2, 2, 0, 0, 1, 1, 0] + [0] * 9
+    # units 1.1, 1.2: the block-1 tails with conv2 in front; 2.1-2.3 and 3.1-3.5: register-resident unit pairs (csrc/unit_pair.hip)
+    assert [int(fused.rw.unit[i].fuse_tail) for i in range(16)] == [2, 2, 0, 1, 1, 1, 0, 1, 1, 1, 1, 1, 0, 0, 0, 0]
+    assert [bool(fused.rw.unit[i].pair_stream) for i in range(16)] == [False] * 3 + [True] * 3 + [False] + [True] * 5 + [False] * 4
     plain = HmmrEngine(weights, None, dtype="f16x3", device=gpu_device, autotune=False, fuse_tail=False)
     assert not any(plain.rw.unit[i].fuse_tail for i in range(16))
     a, b = fused.resnet(frames, n_zero=1), plain.resnet(frames, n_zero=1)
@@ -362,3 +364,9 @@ def test_resnet_split_fused_tails_equal_layer_per_launch(weights, gpu_device):
     for variant in ("block1", "noconv2"):
         eng = HmmrEngine(weights, None, dtype="f16x3", device=gpu_device, autotune=False, fuse_tail=variant)
         assert torch.equal(eng.resnet(frames, n_zero=1), b), variant
+    # the round-3 schedule (LDS-panel tails in block 2, layer per launch in block 3, block3/unit_1's shortcut folded into its
+    # conv3) and the pairs one block at a time: each against the layer-per-launch schedule of the same folding decisions
+    for variant in (False, "block2", "block3"):
+        eng = HmmrEngine(weights, None, dtype="f16x3", device=gpu_device, autotune=False, unit_pair=variant)
+        ref = HmmrEngine(weights, None, dtype="f16x3", device=gpu_device, autotune=False, unit_pair=variant, fuse_tail=False)
+        assert torch.equal(eng.resnet(frames, n_zero=1), ref.resnet(frames, n_zero=1)), variant

@@ -121,7 +121,7 @@ def test_window_plan_matches_oracle():
 def test_ctypes_struct_sizes_are_plausible():
     # catches accidental field drift between include/hmmr_hip.h and _lib.py
     assert C.sizeof(_lib.Layer) == 32
-    assert C.sizeof(_lib.ResnetUnit) == 6 * 32 + 16 + 16 + 16 + 8
+    assert C.sizeof(_lib.ResnetUnit) == 6 * 32 + 24 + 16 + 16 + 8
     assert C.sizeof(_lib.ConvDesc) % 8 == 0
 
 
@@ -137,10 +137,16 @@ def test_packer_marks_the_fused_launches(weights):
     assert not any(rw.unit[i].c3sc.w for i in range(16))
     # f16x3: every conv shortcut is folded into its unit's conv3 (one GEMM over {h2, preact}); no column-split GEMMs then
     rwx = packing.pack_resnet(weights, _lib.HMMR_F16X3, packing.DeviceStore("cpu"))
-    assert [i for i in range(16) if rwx.unit[i].c3sc.w] == [0, 3, 7, 13] and not any(rwx.unit[i].sc_c1.w for i in range(16))
-    # ... and conv3 + add + the next conv1 run as one launch for the stride-1 units of blocks 1-2 with an identity successor
-    assert [rwx.unit[i].fuse_tail for i in range(16)] == [2, 2, 0, 0, 1, 1, 0] + [0] * 9      # block 1: conv2 inside as well
-    assert all(bool(rwx.unit[i].w3_frag) == bool(rwx.unit[i].fuse_tail) for i in range(16))
+    # (block3/unit_1 excepted: it heads a chain of register-resident unit pairs, csrc/unit_pair.hip, and runs shortcut + conv1 as one
+    #  column-split GEMM)
+    assert [i for i in range(16) if rwx.unit[i].c3sc.w] == [0, 3, 13] and [i for i in range(16) if rwx.unit[i].sc_c1.w] == [7]
+    # ... and conv3 + add + the next conv1 run as one launch for the stride-1 units of blocks 1-3 with an identity successor
+    assert [rwx.unit[i].fuse_tail for i in range(16)] == [2, 2, 0, 1, 1, 1, 0, 1, 1, 1, 1, 1, 0, 0, 0, 0]      # block 1: conv2 inside as well
+    assert [bool(rwx.unit[i].w3_frag) for i in range(16)] == [True, True] + [False] * 14              # block 1: LDS-panel tails, fragment-major filters
+    assert [bool(rwx.unit[i].pair_stream) for i in range(16)] == [False] * 3 + [True] * 3 + [False] + [True] * 5 + [False] * 4
+    old = packing.pack_resnet(weights, _lib.HMMR_F16X3, packing.DeviceStore("cpu"), unit_pair=False)      # the round-3 schedule
+    assert [i for i in range(16) if old.unit[i].c3sc.w] == [0, 3, 7, 13] and not any(old.unit[i].sc_c1.w for i in range(16))
+    assert [old.unit[i].fuse_tail for i in range(16)] == [2, 2, 0, 0, 1, 1, 0] + [0] * 9 and not any(old.unit[i].pair_stream for i in range(16))
     rw32 = packing.pack_resnet(weights, _lib.HMMR_F32, packing.DeviceStore("cpu"))
     assert sum(rw32.unit[i].fuse_tail for i in range(16)) == 0
     assert [i for i in range(16) if rw32.unit[i].sc_c1.w] == [7, 13]
