@@ -251,7 +251,6 @@ __global__ __launch_bounds__(256, NCH > 4 ? 2 : 3) void tail_split_kernel(const 
         if constexpr (RES) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) *(u32x4*)slot_of(OFF_P, rr + 16 * p) = rres[nc % AHEAD][p];
-            if (nc + AHEAD < NCH) load_res(nc + AHEAD, rres[nc % AHEAD]);
         }
         __syncthreads();
         // (2) conv3 chunk: D[channel][pixel]
@@ -311,6 +310,12 @@ __global__ __launch_bounds__(256, NCH > 4 ? 2 : 3) void tail_split_kernel(const 
         }
         __builtin_amdgcn_sched_barrier(0);
         if (nc + 1 < NCH) load_w1_chunk(nc + 1);
+        // the shortcut chunk two ahead is requested BEHIND the next chunk's filter fragments: a wave's loads return in order, and an
+        // L2-resident fragment issued behind this HBM request would only arrive with it (every chunk then waits an HBM round trip)
+        if constexpr (RES) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (nc + AHEAD < NCH) load_res(nc + AHEAD, rres[nc % AHEAD]);
+        }
         __syncthreads();                                             // P is free for the next chunk's pre-fill
     }
 

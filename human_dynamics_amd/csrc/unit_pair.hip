@@ -106,6 +106,45 @@ template <int CL, int NS, int EOPS> __device__ __forceinline__ void wait_pos(int
 
 struct xfrag { shalf8 hi, lo; };            // MFMA B-operand fragment of 32 pixels x 16 channels
 
+// LDS accesses of the loop as inline assembly.  hipcc waits lgkmcnt(0) wherever LDS data is first used -- never a counted wait -- which
+// drains this unit's fragment requests whenever an older value is touched (~100 cycles with the matrix pipe idle, every unit: profiles/
+// r04a).  These the compiler does not track: the loop places its own COUNTED waits (LDS operations of a wave complete in order).
+template <int OFF> __device__ __forceinline__ shalf8 lds_rd128h(unsigned addr) {
+    shalf8 v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF)); return v;
+}
+template <int OFF> __device__ __forceinline__ f32x4 lds_rd128f(unsigned addr) {
+    f32x4 v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF)); return v;
+}
+template <int OFF> __device__ __forceinline__ unsigned long long lds_rd64(unsigned addr) {
+    unsigned long long v; asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF)); return v;
+}
+template <int OFF> __device__ __forceinline__ void lds_wr64(unsigned addr, unsigned long long v) {
+    asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+// fragment f (0..7) of the slab at LDS address `base` (already + 16 * lane): hi plane, lo plane
+__device__ __forceinline__ wfrag lds_frag(unsigned base, int f) {      // f is a constant after unrolling
+    wfrag w;
+#define PAIR_F(k) if (f == k) { w.hi = lds_rd128h<k * 2048>(base); w.lo = lds_rd128h<k * 2048 + 1024>(base); }
+    PAIR_F(0) PAIR_F(1) PAIR_F(2) PAIR_F(3) PAIR_F(4) PAIR_F(5) PAIR_F(6) PAIR_F(7)
+#undef PAIR_F
+    return w;
+}
+// one plane (h: 0 = hi, 1 = lo) of fragment f
+__device__ __forceinline__ shalf8 lds_frag_half(unsigned base, int f, int h) {
+    shalf8 v = {};
+#define PAIR_F(k) if (f == k) { if (h == 0) v = lds_rd128h<k * 2048>(base); else v = lds_rd128h<k * 2048 + 1024>(base); }
+    PAIR_F(0) PAIR_F(1) PAIR_F(2) PAIR_F(3) PAIR_F(4) PAIR_F(5) PAIR_F(6) PAIR_F(7)
+#undef PAIR_F
+    return v;
+}
+// s_waitcnt lgkmcnt(n) alone, n a constant after unrolling
+__device__ __forceinline__ void wait_lgkm(int n) {
+#define PAIR_W(k) if (n == k) __builtin_amdgcn_s_waitcnt((63 & 15) | (7 << 4) | (k << 8) | ((63 >> 4) << 14));
+    PAIR_W(0) PAIR_W(1) PAIR_W(2) PAIR_W(3) PAIR_W(4) PAIR_W(5) PAIR_W(6) PAIR_W(7) PAIR_W(8) PAIR_W(9) PAIR_W(10) PAIR_W(11) PAIR_W(12)
+    PAIR_W(13) PAIR_W(14) PAIR_W(15)
+#undef PAIR_W
+}
+
 // mma3 (common.h) on two independent accumulators, their MFMAs issued alternately: neither dependent chain runs back to back
 __device__ __forceinline__ void mma3x2(const wfrag& w0, const xfrag& x0, f32x16& c0, const wfrag& w1, const xfrag& x1, f32x16& c1) {
     c0 = mfma_split(w0.hi, x0.lo, c0);
@@ -226,18 +265,7 @@ __global__ __launch_bounds__(256, 1) void unit_pair_kernel(const PairArgs a) {
     PAIR_STAMP(2);
 
     const int lane16 = lane * 16;
-    auto rd = [&](int slot_, int f) -> wfrag {
-        const char* p = smem + slot_ * SLAB + f * 2048 + lane16;
-        wfrag w;
-        w.hi = *(const shalf8*)p;
-        w.lo = *(const shalf8*)(p + 1024);
-        return w;
-    };
-
-    int slot = 0, dslab = NS - 1;
-    wfrag wq[2];                                               // the next two fragments
-    wq[0] = rd(0, 0);
-    wq[1] = rd(0, 1);
+    const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;      // LDS byte address of smem (0 unless something is linked in front)
     const int sw = (lr >> 1) & 7;
     const float one = a.one;                                   // 1.0f the compiler cannot fold: fma(h, one, l) is ONE v_fma_mix_f32
     // row pieces of the staging tile <-> global rows: piece q = rows 8q + rsub, this lane's 16 bytes = logical slot ls of the row
@@ -256,6 +284,7 @@ __global__ __launch_bounds__(256, 1) void unit_pair_kernel(const PairArgs a) {
         if constexpr (RES) rrow[q] = a.res + (long long)(ok ? m : 0) * a.ldr + ls * 4 + 32;
     }
     constexpr int NU = 4 * CL;                                 // units (two fragments, six MFMAs) per iteration
+    constexpr int LDU = NU >= 8 ? 2 : 1;                       // a group's LDS reads are requested this many units before its first piece
 #ifdef HMMR_GEMM_PROBE
     unsigned long long ut[NU + 3] = {};                        // probe bit 64: cycles per unit (+ iteration head, tail, step boundary), summed over the iterations
     unsigned long long tprev = 0;
@@ -263,33 +292,70 @@ __global__ __launch_bounds__(256, 1) void unit_pair_kernel(const PairArgs a) {
 #else
 #define PAIR_UT(k) do { } while (0)
 #endif
-    // what the epilogue of a chunk reads out of LDS (its constants, the shortcut chunk), per group of 8 channels: requested LDU units
-    // before the group's first piece (group 0: in the iteration before) and used from there on
+    // ---- LDS addresses of this lane
+    const unsigned fbase0 = lds0 + lane16;                                  // + slot * SLAB: fragment reads
+    const unsigned cbase0 = lds0 + OFF_C + lh * 16;                         // + chunk * 128: this lane's 4 channels of group 0 in scale3 (the other
+                                                                            //   groups / vectors: instruction offsets)
+    unsigned soff[4][2];                                                    // staging tile 0 of this wave: (pixel lr, group g, hi / lo plane, channels 4 lh ..)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) soff[g][pl] = lds0 + OFF_STG + wave * 8192 + lr * 128 + (((2 * g + pl) ^ sw) << 4) + 8 * lh;
+
+    // what the epilogue of a chunk reads out of LDS (its constants, the shortcut chunk), per group of 8 channels
     f32x4 cs3[4], cb3[4], cps[4], cpb[4];
     unsigned long long rh[RES ? 4 : 1], rl[RES ? 4 : 1];
-    auto group_loads = [&](int e_, int g) {
+    // element j of group g's reads: 0..3 = scale3, shift3, pre_scale, pre_shift of its 4 channels, 4 / 5 = the shortcut's hi / lo halves
+    auto group_load = [&](int e_, auto b_c, int g, int j) {    // b_c: the staging tile (e_ & 1), a compile-time constant
+        constexpr int B = decltype(b_c)::value;
         const int ec_ = e_ < 0 ? 0 : (e_ >= NCH ? NCH - 1 : e_);
-        const char* stg_ = stg_of(e_ & 1);
-        const int ch = ec_ * 32 + 8 * g + 4 * lh;
-        cs3[g] = *(const f32x4*)(sS3 + ch); cb3[g] = *(const f32x4*)(sB3 + ch);
-        cps[g] = *(const f32x4*)(sPS + ch); cpb[g] = *(const f32x4*)(sPB + ch);
-        if constexpr (RES) {
-            rh[g] = *(const unsigned long long*)(stg_ + lr * 128 + (((2 * g) ^ sw) << 4) + 8 * lh);
-            rl[g] = *(const unsigned long long*)(stg_ + lr * 128 + (((2 * g + 1) ^ sw) << 4) + 8 * lh);
-        }
+        const unsigned cb = cbase0 + ec_ * 128;
+#define PAIR_G(k) if (g == k) { \
+            if (j == 0) cs3[k] = lds_rd128f<k * 32>(cb); \
+            if (j == 1) cb3[k] = lds_rd128f<k * 32 + DEPTH * 4>(cb); \
+            if (j == 2) cps[k] = lds_rd128f<k * 32 + DEPTH * 8>(cb); \
+            if (j == 3) cpb[k] = lds_rd128f<k * 32 + DEPTH * 12>(cb); \
+            if constexpr (RES) { if (j == 4) rh[k] = lds_rd64<B * 4096>(soff[k][0]); if (j == 5) rl[k] = lds_rd64<B * 4096>(soff[k][1]); } }
+        PAIR_G(0) PAIR_G(1) PAIR_G(2) PAIR_G(3)
+#undef PAIR_G
     };
-    constexpr int LDU = NU >= 8 ? 2 : 1;
-    group_loads(-1, 0);
+    auto group_loads = [&](int e_, auto b_c, int g) {
+#pragma unroll
+        for (int j = 0; j < (RES ? 6 : 4); ++j) group_load(e_, b_c, g, j);
+    };
+    // LDS operations a unit issues behind its 4 fragment reads: a group's reads (B), a group's two trunk writes (C)
+    auto n_b = [](int v) -> int {
+        v = ((v % NU) + NU) % NU;
+        bool gl = v == NU - LDU;
+        for (int g = 1; g < 4; ++g) gl = gl || v == (g * NU) / 4 - LDU;
+        return gl ? (RES ? 6 : 4) : 0;
+    };
+    auto n_c = [](int v) -> int {
+        v = ((v % NU) + NU) % NU;
+        int n = 0;
+        for (int pc = 2; pc < 16; pc += 4) n += ((pc * NU) / 16 == v) ? 2 : 0;
+        return n;
+    };
+
+    int slot = 0, dslab = NS - 1;
+    wfrag wq[4][2];                                            // fragments of the units u, u+1, u+2 (slot u & 3): requested TWO units ahead
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { wq[u][0] = lds_frag(fbase0, 2 * u); wq[u][1] = lds_frag(fbase0, 2 * u + 1); }
+    group_loads(-1, std::integral_constant<int, 1>{}, 0);
+    wait_lgkm(0);
+    __builtin_amdgcn_sched_barrier(0);
+
     // One iteration: the MFMAs of conv3 chunk `it` (-> accN) and of conv1' K step it - 2 (-> acc2), the epilogue of chunk it - 1
-    // (accumulator accO) beside them.  Called for it = 0, 1 alternately with the two accumulators swapped, so neither is ever copied.
-    auto iteration = [&](int it, f32x16& accN, f32x16& accO) {
+    // (accumulator accO) beside them.  Called for even and odd `it` alternately with the two accumulators swapped, so neither is copied.
+    auto iteration = [&](int it, auto par_c, f32x16& accN, f32x16& accO) {
+        constexpr int PAR = decltype(par_c)::value;            // it & 1
+        constexpr int BE = 1 - PAR;                            // staging tile of chunk e = it - 1
 #ifdef HMMR_GEMM_PROBE
         if (PAIR_PROBE(a, 64)) tprev = __builtin_amdgcn_s_memtime();
 #endif
         const int e = it - 1;                                  // chunk whose epilogue runs in this iteration
         const bool ev = e >= 0 && e < NCH;
-        const int ec = e < 0 ? 0 : (e >= NCH ? NCH - 1 : e);
-        char* stg = stg_of(e & 1);
+        char* stg = stg_of(BE);
 #pragma unroll
         for (int r = 0; r < 16; ++r) accN[r] = 0.f;
         shalf2 nh[4][2], nl[4][2];                             // pre-activated chunk e as packed halves, D layout (group g = channels 8g + 4lh ..)
@@ -301,15 +367,6 @@ __global__ __launch_bounds__(256, 1) void unit_pair_kernel(const PairArgs a) {
         // so a unit of six MFMAs covers about two dozen (tools/probes/mfma_fillers.hip).
         auto epilogue_piece = [&](int pc) {
             const int g = pc >> 2, i = (pc >> 1) & 1;
-            if (PAIR_PROBE(a, 2048)) {                         // probe: the dataflow of the epilogue without its arithmetic (everything stays live)
-                if ((pc & 1) == 0) {
-                    oh[g][i] = __builtin_bit_cast(shalf2, __float_as_uint(accO[4 * g + 2 * i]));
-                    ol[g][i] = __builtin_bit_cast(shalf2, __float_as_uint(accO[4 * g + 2 * i + 1]));
-                } else {
-                    nh[g][i] = oh[g][i]; nl[g][i] = ol[g][i];
-                }
-                return;
-            }
             if ((pc & 1) == 0) {
                 shalf2 h2v, l2v;
                 if constexpr (RES) {
@@ -328,11 +385,13 @@ __global__ __launch_bounds__(256, 1) void unit_pair_kernel(const PairArgs a) {
                 const shalf2 pl = {(shalf_t)__builtin_fmaf((float)ph[0], -one, c[0]), (shalf_t)__builtin_fmaf((float)ph[1], -one, c[1])};
                 oh[g][i] = ph; ol[g][i] = pl;
                 if (i == 1 && !PAIR_PROBE(a, 1024)) {          // the group is complete: in place into the staging tile
-                    typedef __attribute__((ext_vector_type(4))) _Float16 shalf4;
-                    const shalf4 wh = {oh[g][0][0], oh[g][0][1], oh[g][1][0], oh[g][1][1]};
-                    const shalf4 wl = {ol[g][0][0], ol[g][0][1], ol[g][1][0], ol[g][1][1]};
-                    *(shalf4*)(stg + lr * 128 + (((2 * g) ^ sw) << 4) + 8 * lh) = wh;
-                    *(shalf4*)(stg + lr * 128 + (((2 * g + 1) ^ sw) << 4) + 8 * lh) = wl;
+                    const unsigned long long wh = (unsigned long long)__builtin_bit_cast(unsigned, oh[g][0]) |
+                                                  ((unsigned long long)__builtin_bit_cast(unsigned, oh[g][1]) << 32);
+                    const unsigned long long wl = (unsigned long long)__builtin_bit_cast(unsigned, ol[g][0]) |
+                                                  ((unsigned long long)__builtin_bit_cast(unsigned, ol[g][1]) << 32);
+#define PAIR_S(k) if (g == k) { lds_wr64<BE * 4096>(soff[k][0], wh); lds_wr64<BE * 4096>(soff[k][1], wl); }
+                    PAIR_S(0) PAIR_S(1) PAIR_S(2) PAIR_S(3)
+#undef PAIR_S
                 }
             } else {
                 const shalf2 ph = oh[g][i], pl = ol[g][i];
@@ -359,68 +418,85 @@ __global__ __launch_bounds__(256, 1) void unit_pair_kernel(const PairArgs a) {
             if (!PAIR_PROBE(a, 2)) dma_slab(dslab, prev);      // slab s + NS - 1 into the slot everybody left before this barrier
             dslab = dslab + 1 == TOTAL ? 0 : dslab + 1;
             const int nslot = slot + 1 == NS ? 0 : slot + 1;
+            const unsigned fcur = fbase0 + slot * SLAB, fnxt = fbase0 + nslot * SLAB;
             PAIR_UT(NU + 2);                                   // (wait + barrier + DMA issue)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {                      // two fragments at a time
                 const int i0 = p * 8 + 2 * u, i1 = i0 + 1;
                 const int uu = p * 4 + u;
-                // hipcc waits lgkmcnt(0) wherever LDS data is first used, never a counted wait: one such wait HERE, while every
-                // outstanding LDS read is a unit old, and nothing issued in this unit is used in it -- or a use sitting behind this
-                // unit's fragment reads would wait for those too (~100 cycles with the matrix pipe idle)
+                // ---- everything this unit uses has landed: its fragments (requested two units ago) and, if it runs a group's
+                // first piece, that group's reads (LDU units ago).  Issued since, and allowed to stay in flight: the writes of
+                // unit uu - 2 (LDU 2) and all of unit uu - 1.
                 __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_waitcnt((63 & 15) | (7 << 4) | (0 << 8) | ((63 >> 4) << 14));
+                wait_lgkm((LDU == 2 ? n_c(uu - 2) + 4 + n_b(uu - 1) : 0) + n_c(uu - 1));
                 __builtin_amdgcn_sched_barrier(0);
-                const wfrag w0 = wq[0], w1 = wq[1];
-                // prefetch the next two fragments (past the slab: the first two of slab s+1, published by this step's barrier)
-                if (!PAIR_PROBE(a, 32)) {
-                    wq[0] = u < 3 ? rd(slot, 2 * u + 2) : rd(nslot, 0);
-                    wq[1] = u < 3 ? rd(slot, 2 * u + 3) : rd(nslot, 1);
-                }
-                if (uu == NU - LDU && !PAIR_PROBE(a, 512)) {
-                    // group 0 of the NEXT iteration's epilogue: the shortcut chunk `it` was requested at the end of iteration
-                    // it - 1, and this wave has issued the 4 CL slab requests of this iteration since (in-order completion)
-                    if constexpr (RES) { __builtin_amdgcn_sched_barrier(0); wait_vm<4 * CL>(); }
-                    group_loads(it, 0);
-                }
-#pragma unroll
-                for (int g = 1; g < 4; ++g)
-                    if (uu == (g * NU) / 4 - LDU && !PAIR_PROBE(a, 512)) group_loads(e, g);
+                const wfrag w0 = wq[uu & 3][0], w1 = wq[uu & 3][1];
                 const bool a0 = pair_is_a(i0, NA, FT), a1 = pair_is_a(i1, NA, FT);
                 const int ka0 = pair_a_before(i0, NA, FT), ka1 = pair_a_before(i1, NA, FT);
                 const int kb0 = i0 - ka0, kb1 = i1 - ka1;          // conv1' fragment kb: K chunk kb / NF2 of the step, row block kb % NF2
-                if (PAIR_PROBE(a, 1)) {
-                } else if (a0 && a1) {                         // one accumulator: K order
-                    accN = mma3(w0, xh[ka0].hi, xh[ka0].lo, accN);
-                    accN = mma3(w1, xh[ka1].hi, xh[ka1].lo, accN);
-                } else if (a0) {                               // the three MFMAs of two independent accumulators, alternately
-                    mma3x2(w0, xh[ka0], accN, w1, th[kb1 / NF2], acc2[kb1 % NF2]);
-                } else if (a1) {
-                    mma3x2(w0, th[kb0 / NF2], acc2[kb0 % NF2], w1, xh[ka1], accN);
-                } else {
-                    mma3x2(w0, th[kb0 / NF2], acc2[kb0 % NF2], w1, th[kb1 / NF2], acc2[kb1 % NF2]);
+                // MFMA k of the unit: the three products (x.lo*w.hi, x.hi*w.lo, x.hi*w.hi) of the two fragments, alternately when
+                // they feed different accumulators (neither dependent chain runs back to back), else in K order
+                auto mfma_k = [&](int k) {
+                    const int fi = (a0 && a1) ? k / 3 : (k & 1), j = (a0 && a1) ? k % 3 : (k >> 1);
+                    const wfrag& w = fi ? w1 : w0;
+                    const bool isa = fi ? a1 : a0;
+                    const int ka = fi ? ka1 : ka0, kb = fi ? kb1 : kb0;
+                    const shalf8& wop = (j == 1) ? w.lo : w.hi;
+                    // (the empty asm ties the MFMA into the ordered chain of this unit's LDS requests: without it the instruction
+                    //  selector is free to emit the six MFMAs and the reads as two clumps, and the barriers below preserve that)
+                    if (isa) {
+                        const shalf8& xop = (j == 0) ? xh[ka].lo : xh[ka].hi;
+                        accN = mfma_split(wop, xop, accN);
+                        asm volatile("" : "+a"(accN));
+                    } else {
+                        const shalf8& xop = (j == 0) ? th[kb / NF2].lo : th[kb / NF2].hi;
+                        acc2[kb % NF2] = mfma_split(wop, xop, acc2[kb % NF2]);
+                        asm volatile("" : "+a"(acc2[kb % NF2]));
+                    }
+                };
+                // LDS read j of the unit: 0..3 = the two planes of the two fragments of unit uu + 2 (past the slab: out of slab s+1,
+                // published by this step's barrier); 4.. = a group's reads, if this unit carries them
+                const bool gl0 = uu == NU - LDU;
+                int glg = 0;
+#pragma unroll
+                for (int g = 1; g < 4; ++g) if (uu == (g * NU) / 4 - LDU) glg = g;
+                const int nrd = (PAIR_PROBE(a, 32) ? 0 : 4) + ((gl0 || glg) && !PAIR_PROBE(a, 512) ? (RES ? 6 : 4) : 0);
+                auto lds_read_j = [&](int j) {
+                    if (!PAIR_PROBE(a, 32)) {
+                        if (j < 4) {
+                            const int f = (u < 2 ? 2 * u + 4 : 2 * u - 4) + (j >> 1);
+                            shalf8 v = lds_frag_half(u < 2 ? fcur : fnxt, f, j & 1);
+                            if (j & 1) wq[(uu + 2) & 3][j >> 1].lo = v; else wq[(uu + 2) & 3][j >> 1].hi = v;
+                            return;
+                        }
+                        j -= 4;
+                    }
+                    if (gl0) {
+                        // group 0 of the NEXT iteration's epilogue: the shortcut chunk `it` was requested at the end of iteration
+                        // it - 1, and this wave has issued the 4 CL slab requests of this iteration since (in-order completion)
+                        if (RES && j == 4) wait_vm<4 * CL>();
+                        group_load(it, std::integral_constant<int, PAR>{}, 0, j);
+                    } else {
+                        group_load(e, std::integral_constant<int, BE>{}, glg, j);
+                    }
+                };
+                // one MFMA, then this gap's share of the reads (a ds_read_b128 holds the wave's LDS port for 16 cycles: more than two
+                // behind one MFMA leave the matrix pipe idle); vector and scalar instructions may move across the gaps
+                int jr = 0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    if (!PAIR_PROBE(a, 1)) mfma_k(k);
+                    const int r = (nrd * (k + 1)) / 6 - (nrd * k) / 6;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        if (q < r) lds_read_j(jr + q);
+                    jr += r;
+                    __builtin_amdgcn_sched_barrier(0x6);
                 }
                 // the epilogue of chunk e beside them: 16 pieces spread evenly over the NU units
 #pragma unroll
                 for (int pc = 0; pc < 16; ++pc)
                     if (uu == (pc * NU) / 16 && !PAIR_PROBE(a, 8) && !PAIR_PROBE(a, (pc & 1) ? 128 : 256)) epilogue_piece(pc);
-                // order inside the unit: one fragment read (ds_read_b128: 16 cycles of this wave's LDS port) and a few vector
-                // instructions behind each MFMA -- four reads issued back to back leave the matrix pipe idle for 30-60 cycles
-                // (profiles/r04a: 240-270 cycles per unit against 192 without the reads)
-                {
-                    bool gl = uu == NU - LDU;                  // this unit also carries a group's LDS reads (4 constants + 2 shortcut)
-#pragma unroll
-                    for (int g = 1; g < 4; ++g) gl = gl || uu == (g * NU) / 4 - LDU;
-                    const int nrd = 4 + (gl ? (RES ? 6 : 4) : 0);
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         // MFMA
-                        const int r = (nrd * (k + 1)) / 6 - (nrd * k) / 6;
-                        if (r == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS read
-                        if (r == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);         // VALU
-                    }
-                    __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);             // DS write (the group's trunk halves, if any)
-                }
                 __builtin_amdgcn_sched_barrier(0);             // a unit's work stays in its unit
                 PAIR_UT(uu);
             }
@@ -445,7 +521,8 @@ __global__ __launch_bounds__(256, 1) void unit_pair_kernel(const PairArgs a) {
         }
 
         // ---- end-of-iteration block: the trunk chunk e leaves as 16-byte row pieces, the shortcut chunk e+2 is requested into the tile.
-        // (every wave issues these 4 + 4 instructions in every iteration: the counted waits above rely on it)
+        // (every wave issues these 4 + 4 instructions in every iteration: the counted waits above rely on it.  The row reads are
+        //  ordinary loads: the compiler waits lgkmcnt(0) in front of the stores, so the next iteration starts with nothing in flight)
         if (PAIR_PROBE(a, 16)) return;
         PAIR_UT(NU + 1);                                       // (swaps)
         u32x4 xr[4];
@@ -474,8 +551,8 @@ __global__ __launch_bounds__(256, 1) void unit_pair_kernel(const PairArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) accB[r] = 0.f;
     for (int it = 0; it <= NCH + 1; it += 2) {
-        iteration(it, acc1, accB);
-        iteration(it + 1, accB, acc1);
+        iteration(it, std::integral_constant<int, 0>{}, acc1, accB);
+        iteration(it + 1, std::integral_constant<int, 1>{}, accB, acc1);
     }
 
     // ---- conv1' epilogue: BN (+ ReLU), split, through this wave's staging tile, coalesced stores
