@@ -120,7 +120,8 @@ def cpu_baseline(windows=16):
             "host_cores": os.cpu_count(),
             "sample": "%d windows x 20 frames through the fp32 PyTorch-CPU oracle (restatement of the "
                       "reference graph; TF 1.8 unavailable), reference-literal schedule: 8 output frames "
-                      "kept per 20-frame window, %.1f s" % (windows, dt)}
+                      "kept per 20-frame window, %.1f s, on %d threads = the CPU quota this process may use "
+                      "(sched_getaffinity / cgroup cpu.max), NOT the %d cores the host shows" % (windows, dt, cores, os.cpu_count())}
 
 
 def oracle_window(span_host, f0, n_total, weights, smpl):
@@ -135,6 +136,35 @@ def oracle_window(span_host, f0, n_total, weights, smpl):
             win[0, j] = span_host[f - f0]
     ref = O.OracleTester(weights, smpl, batch_size=1, dtype=torch.float64).predict(win)
     return {k: ref[k][0, 6:14] for k in ("verts", "joints", "omegas")}
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n, argv, script=None):
+    """Re-run this script (or `script`: the CPU test's stand-in) under torch.distributed.run with one process per GPU -- what
+    the driver's N > 1 command does; returns the launcher's exit code.  Rendezvous on 127.0.0.1: the container hostname
+    may not resolve."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), script or os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def resolve_workload(args, world):
+    """(strong, frames in the job) of a run on `world` ranks: N = 1 and --weak: a --frames shard per rank (BASELINE configs[3],
+    weak scaling); N > 1 by default: ONE 4096-frame video sharded over the ranks (BASELINE configs[4], strong scaling);
+    --video-frames picks the video length explicitly."""
+    if world > 1 and args.video_frames == 0 and not args.weak:
+        args.video_frames = 4096
+    strong = args.video_frames > 0
+    return strong, (args.video_frames if strong else args.frames * world)
 
 
 def run_mode(dtype, args, world, rank, device, weights, smpl, span, n_total, steps, warmup):
@@ -352,15 +382,20 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay the local pass as one hipGraph per step (measured equal to eager launches: "
                          "the step is GPU-bound, the host keeps 150 launches ahead)")
+    ap.add_argument("--weak", action="store_true",
+                    help="N > 1: weak scaling (every rank its own --frames shard) instead of the default, BASELINE configs[4]: "
+                         "ONE 4096-frame video sharded over the ranks")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` on its own: become the launcher (one rank per GPU over RCCL, the contract's command)
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    strong, n_total = resolve_workload(args, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible)")
     device = torch.device("cuda", local_rank)
@@ -373,8 +408,6 @@ def main():
 
     weights = assets.make_synthetic_weights(0)
     smpl = assets.make_synthetic_smpl(2)
-    strong = args.video_frames > 0
-    n_total = args.video_frames if strong else args.frames * world
     plan = hd.ShardPlan(n_total, 8, 20, 13, world, rank)
     # synthetic video, resident in HBM: this rank's span of real frames (shard + halo)
     gen = torch.Generator(device=device)
@@ -409,9 +442,39 @@ def main():
         all_gather_ms, gather_bytes = round(float(tg.item()), 3), int(full.numel() * 4)
         del loc, full
 
+    # the same per-rank shard as a 1-GPU job (no collective), every rank at once: value / (world x this) = the scaling efficiency
+    # of this run (the driver computes its own from the per-N lines)
+    scaling_eff, shard_fps, rccl_ranks = None, None, None
+    if world > 1:
+        rccl_ranks = dist.get_world_size()
+        n_loc = plan.o1 - plan.o0
+        solo = hd.ShardedPredictor(tester, n_loc, 0, 1, pipeline=not (args.no_pipeline or args.graph or args.serial),
+                                   step_streams=not args.no_step_streams)
+        span1 = span[plan.o0 - plan.f0:plan.o0 - plan.f0 + n_loc] if span.shape[0] >= n_loc else span
+        for _ in range(2):
+            solo.run(span1)
+        solo.finish()
+        torch.cuda.synchronize(device)
+        dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(max(2, args.steps // 2)):
+            solo.run(span1)
+        solo.finish()
+        torch.cuda.synchronize(device)
+        ts = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
+        dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+        shard_fps = n_loc * max(2, args.steps // 2) / float(ts.item())
+        scaling_eff = round(value / (world * shard_fps), 4)
+        del solo
+
     result = None
     if rank == 0:
         roofline = roofline_leg(tester, plan, span, args.dtype, args.frames if not strong else -1)
+        # the overlapped reading of the same FLOPs: the timed steps run the ResNet passes of consecutive steps on two streams
+        roofline["achieved_overlapped"] = round(RESNET_FLOPS_PER_FRAME * (plan.f1 - plan.f0 + 1) / (ms_per_step * 1e-3) / 1e12, 2)
+        roofline["frac_overlapped"] = round(roofline["achieved_overlapped"] / roofline["peak"], 4)
+        roofline["achieved_overlapped_note"] = ("ResNet FLOPs of one step / ms_per_step (the step also carries the f_movie / IEF / "
+                                                "SMPL tail on a second stream): the figure `value` corresponds to")
         single = world == 1
         # ---- the other operand modes, same workload, same steps (extras: never the headline).  Timed BEFORE any host-side
         # work of this script (oracle, PCIe legs): under the container's CPU quota the oracle's thread pool slows the launch
@@ -504,10 +567,14 @@ def main():
                            world, "packed records" if args.gather == "records" else "omegas (SMPL re-evaluated on every rank)",
                            "" if args.serial_gather else ", overlapped with the compute of the next step"))
                        if world > 1 else "single GPU"},
+            "saturated": bool(tester.engine.run_flags() & 1),      # hmmr_run_flags: a split store clamped a value to the fp16 range
             "per_gpu_fps": round(value / world, 1),
             "frames_total": n_total,
-            "all_gather_ms": all_gather_ms, "all_gather_bytes": gather_bytes,
-            "scaling_efficiency": None,        # computed by the driver from the per-N lines (tools/scale_table.py does the same)
+            "all_gather_ms": all_gather_ms, "all_gather_bytes": gather_bytes, "rccl_ranks": rccl_ranks,
+            # N > 1: value / (N x the fps of one rank's shard run as a 1-GPU job, all ranks at once, same run); the driver
+            # computes its own from the per-N lines (tools/scale_table.py does the same)
+            "scaling_efficiency": scaling_eff,
+            "single_gpu_fps_same_shard": round(shard_fps, 1) if shard_fps else None,
             "roofline": roofline,
             "init_untimed": {"conv_tile_tuning_ms_by_batch": {str(n_): ms_ for n_, ms_ in tester.engine.tune_log},
                              "note": "one pass per candidate tile and batch size on the first call, before the warm-up steps"},

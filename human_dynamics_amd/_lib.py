@@ -16,6 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = devflags.get("LIB_PATH") or os.path.join(HERE, "libhmmr_hip.so")
 
 HMMR_F32, HMMR_BF16, HMMR_F16X3 = 0, 1, 2
+FLAG_SATURATED = 1
 ABI_VERSION = 14
 RESNET_UNITS = 16
 RESNET_PROF_SLOTS = 64
@@ -116,6 +117,7 @@ class SmplConsts(C.Structure):
 SIGNATURES = {
     "hmmr_abi_version": (C.c_int, []),
     "hmmr_last_error": (C.c_char_p, []),
+    "hmmr_run_flags": (C.c_int, [C.POINTER(C.c_uint), C.c_int]),
     "hmmr_set_debug": (None, [C.POINTER(Debug)]),
     "hmmr_get_debug": (None, [C.POINTER(Debug)]),
     "hmmr_conv_gemm": (C.c_int, [C.POINTER(ConvDesc), _vp]),

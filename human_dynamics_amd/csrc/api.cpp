@@ -22,3 +22,22 @@ extern "C" void hmmr_get_debug(hmmr_debug_t* d) { if (d) *d = g_debug; }
 
 extern "C" int hmmr_abi_version(void) { return HMMR_ABI_VERSION; }
 extern "C" const char* hmmr_last_error(void) { return g_err; }
+
+// ---- run flags: every translation unit that splits values keeps a sticky device word (csrc/common.h) and registers its reader here
+typedef int (*hmmr_flag_reader_t)(unsigned* flags, int clear);
+static hmmr_flag_reader_t g_flag_readers[32];
+static int g_n_flag_readers = 0;
+void hmmr_register_flag_reader(hmmr_flag_reader_t fn) {
+    if (g_n_flag_readers < 32) g_flag_readers[g_n_flag_readers++] = fn;
+}
+extern "C" int hmmr_run_flags(unsigned* flags, int clear) {
+    if (!flags) { hmmr_set_error("hmmr_run_flags: null argument"); return -1; }
+    unsigned all = 0;
+    for (int i = 0; i < g_n_flag_readers; ++i) {
+        unsigned v = 0;
+        if (g_flag_readers[i](&v, clear)) { hmmr_set_error("hmmr_run_flags: reading the device flag word failed"); return -2; }
+        all |= v;
+    }
+    *flags = all;
+    return 0;
+}

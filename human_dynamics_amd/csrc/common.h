@@ -98,6 +98,37 @@ typedef f16x8 shalf8;
 typedef f16x2 shalf2;
 #define HMMR_SPLIT_MAX 65504.0f
 __device__ __forceinline__ float split_clamp(float v) { return __builtin_amdgcn_fmed3f(v, -HMMR_SPLIT_MAX, HMMR_SPLIT_MAX); }
+
+// ---- run flags (include/hmmr_hip.h: hmmr_run_flags).  The clamp above is silent by itself: a value beyond the fp16 range becomes
+// +-65504 and the network goes on.  Every place that splits a value checks it against the range first and raises a sticky flag word
+// (one per translation unit: no relocatable device code in this build; api.cpp ORs them).  The normal case costs the comparison;
+// only a saturating lane issues the atomic.
+#ifndef HMMR_FLAG_SATURATED
+#define HMMR_FLAG_SATURATED 1u      /* include/hmmr_hip.h */
+#endif
+static __device__ unsigned g_split_flags __attribute__((unused));
+__device__ __forceinline__ void split_flag(bool bad) {
+#ifndef HMMR_NO_SATURATION_CHECK      // (development A/B only: what the checks cost)
+    if (bad) atomicOr(&g_split_flags, HMMR_FLAG_SATURATED);
+#endif
+}
+__device__ __forceinline__ bool split_overflows(float v) { return __builtin_fabsf(v) > HMMR_SPLIT_MAX; }     // (+-inf included)
+typedef int (*hmmr_flag_reader_t)(unsigned* flags, int clear);
+void hmmr_register_flag_reader(hmmr_flag_reader_t fn);          // api.cpp
+namespace {
+int hmmr_tu_flags(unsigned* flags, int clear) {
+    unsigned v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_split_flags), sizeof(v)) != hipSuccess) return -2;
+    if (clear && v) {
+        const unsigned z = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_split_flags), &z, sizeof(z)) != hipSuccess) return -2;
+    }
+    *flags = v;
+    return 0;
+}
+struct HmmrFlagRegistration { HmmrFlagRegistration() { hmmr_register_flag_reader(&hmmr_tu_flags); } };
+static HmmrFlagRegistration g_flag_registration __attribute__((unused));
+}  // namespace
 // relu + clamp in one instruction
 __device__ __forceinline__ float split_relu(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, HMMR_SPLIT_MAX); }
 // one 32x32x16 MFMA on split halves
@@ -147,7 +178,28 @@ __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
     *(bf16x8*)p = a;
 }
 
+// the same with the range check left to the caller: satmax = the running maximum of |v| (four v_max3_f32 per call), for
+// split_flag(satmax > HMMR_SPLIT_MAX) once at the end of the kernel (the hot GEMM epilogues)
+template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8], float& satmax);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8], float&) { store8(p, v); }
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&v)[8], float&) { store8(p, v); }
+template <> __device__ __forceinline__ void store8<bsplit_t>(bsplit_t* p, const float (&v)[8], float& satmax) {
+    satmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(satmax, __builtin_fabsf(v[0])), __builtin_fmaxf(__builtin_fabsf(v[1]), __builtin_fabsf(v[2]))),
+                             __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[3]), __builtin_fabsf(v[4])),
+                                             __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[5]), __builtin_fabsf(v[6])), __builtin_fabsf(v[7]))));
+    shalf8 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float c = split_clamp(v[i]);
+        hi[i] = (shalf_t)c;
+        lo[i] = (shalf_t)(c - (float)hi[i]);
+    }
+    *(shalf8*)p = hi;
+    *((shalf8*)p + 1) = lo;
+}
 __device__ __forceinline__ void store8(bsplit_t* p, const float (&v)[8]) {
+    split_flag(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])), __builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3]))),
+                               __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[4]), __builtin_fabsf(v[5])), __builtin_fmaxf(__builtin_fabsf(v[6]), __builtin_fabsf(v[7])))) > HMMR_SPLIT_MAX);
     shalf8 hi, lo;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -221,7 +273,11 @@ __device__ __forceinline__ f32x16 mma3(const wfrag& w, const shalf8& xh, const s
     return mfma_split(w.hi, xh, c);
 }
 // four fp32 values -> their split halves, 4 halves (8 bytes) each; clamped to the fp16 range like store8<bsplit_t>
-__device__ __forceinline__ void split4(const float (&v)[4], unsigned long long& hi, unsigned long long& lo) {
+// satmax: running maximum of |v| over everything this thread has split (two v_max3_f32 per call; the caller raises the flag once,
+// with split_flag(satmax > HMMR_SPLIT_MAX), when it is done: these kernels are bound by their instruction count)
+__device__ __forceinline__ void split4(const float (&v)[4], unsigned long long& hi, unsigned long long& lo, float& satmax) {
+    satmax = __builtin_fmaxf(__builtin_fmaxf(satmax, __builtin_fabsf(v[3])),
+                             __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])), __builtin_fabsf(v[2])));
     unsigned h[2], l[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {

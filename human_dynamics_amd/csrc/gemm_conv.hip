@@ -572,6 +572,7 @@ void conv_gemm_kernel(const ConvArgs a0) {
 
     TO* __restrict__ out = a.out ? (TO*)a.out + (long long)blockIdx.y * a.out_slice_stride : nullptr;
     TO* __restrict__ out2 = (TO*)a.out2;
+    float satmax = 0.f;                           // split outputs: the largest |value| stored (common.h: hmmr_run_flags)
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int idx = it * NT + tid;
@@ -609,13 +610,13 @@ void conv_gemm_kernel(const ConvArgs a0) {
         }
         if (second) {
             TO* ob = (TO*)a.out_b + (long long)m * a.ldo_b + (n - a.n_split);
-            if (full) store8(ob, v);
+            if (full) store8<TO>(ob, v, satmax);
             else store_tail(ob, v, a.cout - n);
             continue;
         }
         const long long oo = (long long)m * a.ldo + n;
         if (out) {
-            if (full) store8(out + oo, v);
+            if (full) store8<TO>(out + oo, v, satmax);
             else store_tail(out + oo, v, a.cout - n);
         }
         if (out2) {
@@ -626,10 +627,11 @@ void conv_gemm_kernel(const ConvArgs a0) {
                 const float vr = stored_value<TO>(v[j]);
                 u[j] = fmaxf(fmaf(vr, s2[j], b2[j]), 0.f);
             }
-            if (full) store8(out2 + oo, u);
+            if (full) store8<TO>(out2 + oo, u, satmax);
             else store_tail(out2 + oo, u, a.cout - n);
         }
     }
+    if constexpr (std::is_same<TO, bsplit_t>::value) split_flag(satmax > HMMR_SPLIT_MAX);
 }
 
 // Shared by the two 3x3 patch kernels below.
@@ -665,6 +667,7 @@ __device__ __forceinline__ void patch_epilogue(const ConvArgs& a, char* smem, co
     __syncthreads();
     constexpr int VPR = BN / 8, NIT = (BM * VPR) / NT;
     TO* __restrict__ out = (TO*)a.out;
+    float satmax = 0.f;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int idx = it * NT + tid;
@@ -690,8 +693,9 @@ __device__ __forceinline__ void patch_epilogue(const ConvArgs& a, char* smem, co
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
         }
-        store8(out + (long long)m * a.ldo + n, v);
+        store8<TO>(out + (long long)m * a.ldo + n, v, satmax);
     }
+    if constexpr (std::is_same<TO, bsplit_t>::value) split_flag(satmax > HMMR_SPLIT_MAX);
 }
 
 // ------------------------------------------------------------------------- //

@@ -337,6 +337,7 @@ __global__ __launch_bounds__(256, 1) void unit_pair_kernel(const PairArgs a) {
         return n;
     };
 
+    float satm = 0.f;                                          // largest |trunk value| of this thread: the flag is raised once, at the end
     int slot = 0, dslab = NS - 1;
     wfrag wq[4][2];                                            // fragments of the units u, u+1, u+2 (slot u & 3): requested TWO units ahead
 #pragma unroll
@@ -373,13 +374,15 @@ __global__ __launch_bounds__(256, 1) void unit_pair_kernel(const PairArgs a) {
                     h2v = __builtin_bit_cast(shalf2, (unsigned)(rh[g] >> (32 * i)));
                     l2v = __builtin_bit_cast(shalf2, (unsigned)(rl[g] >> (32 * i)));
                 }
-                float c[2];
+                float c[2], vraw[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     float v = fmaf(accO[4 * g + 2 * i + j], cs3[g][2 * i + j], cb3[g][2 * i + j]);
                     if constexpr (RES) v += __builtin_fmaf((float)h2v[j], one, (float)l2v[j]);
                     c[j] = split_clamp(v);
+                    vraw[j] = v;
                 }
+                satm = __builtin_fmaxf(__builtin_fmaxf(satm, __builtin_fabsf(vraw[0])), __builtin_fabsf(vraw[1]));   // (one v_max3_f32: hmmr_run_flags)
                 shalf2 ph = {(shalf_t)c[0], (shalf_t)c[1]};
                 asm volatile("" : "+v"(ph));                   // (one v_cvt_pk_f16_f32; its halves are read in place below)
                 const shalf2 pl = {(shalf_t)__builtin_fmaf((float)ph[0], -one, c[0]), (shalf_t)__builtin_fmaf((float)ph[1], -one, c[1])};
@@ -561,6 +564,7 @@ __global__ __launch_bounds__(256, 1) void unit_pair_kernel(const PairArgs a) {
 #pragma unroll
     for (int j = 0; j < NF2; ++j) asm volatile("" : "+a"(acc2[j]));
     PAIR_STAMP(3);
+    split_flag(satm > HMMR_SPLIT_MAX);
 #ifdef HMMR_GEMM_PROBE
     if (PAIR_PROBE(a, 64) && a.ts && lane == 0 && blockIdx.x == 0 && wave == 0)
         for (int k = 0; k < NU + 3; ++k) a.ts[4096 * 4 * 8 + k] = ut[k];
@@ -569,6 +573,7 @@ __global__ __launch_bounds__(256, 1) void unit_pair_kernel(const PairArgs a) {
     __builtin_amdgcn_s_waitcnt(0);                             // (the last shortcut request must not land in the tile any more)
     PAIR_STAMP(4);
     char* stg = stg_of(0);
+    float satmax = 0.f;
 #pragma unroll
     for (int of = 0; of < NF2; ++of) {
 #pragma unroll
@@ -582,7 +587,7 @@ __global__ __launch_bounds__(256, 1) void unit_pair_kernel(const PairArgs a) {
                 if (a.relu1) v[j] = fmaxf(v[j], 0.f);
             }
             unsigned long long oh, ol;
-            split4(v, oh, ol);
+            split4(v, oh, ol, satmax);
             *(unsigned long long*)(stg + lr * 128 + (((2 * g) ^ sw) << 4) + 8 * lh) = oh;
             *(unsigned long long*)(stg + lr * 128 + (((2 * g + 1) ^ sw) << 4) + 8 * lh) = ol;
         }
@@ -594,6 +599,7 @@ __global__ __launch_bounds__(256, 1) void unit_pair_kernel(const PairArgs a) {
             if (m < a.M) *(u32x4*)(a.out_h1 + (long long)m * N2 + of * 32 + ls * 4) = x;
         }
     }
+    split_flag(satmax > HMMR_SPLIT_MAX);
     PAIR_STAMP(5);
 }
 

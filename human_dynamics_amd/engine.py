@@ -156,6 +156,15 @@ class HmmrEngine(object):
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    def run_flags(self, clear=False):
+        """Sticky run flags of this engine's device (hmmr_run_flags; _lib.FLAG_SATURATED: a split store clamped a value to the
+        fp16 range since the last clear).  Synchronises with the device."""
+        torch.cuda.synchronize(self.device)
+        with torch.cuda.device(self.device):
+            v = C.c_uint(0)
+            L.check(self.lib.hmmr_run_flags(C.byref(v), int(bool(clear))), "hmmr_run_flags")
+        return int(v.value)
+
     def to_device(self, a, dtype=torch.float32):
         if isinstance(a, torch.Tensor):
             return a.to(self.device, dtype).contiguous()

@@ -23,6 +23,7 @@ import os
 import numpy as np
 import torch
 
+from .. import _lib as L
 from .. import assets
 from ..engine import DEFAULT_DTYPE, HmmrEngine
 from ..models import (batch_pred_omega, get_hallucinator_model, get_image_encoder,
@@ -135,6 +136,11 @@ class Tester(object):
             self.engine, self.precision = precision.choose_engine(weights, smpl, device, pred_mode=self.pred_mode, **kw)
         else:
             self.engine = HmmrEngine(weights, smpl, dtype=dtype, device=device, **kw)
+        if self.precision is None:
+            from .. import precision
+            self.precision = {"operands": precision.describe(self.engine), "rungs": []}
+        self.precision["saturated"] = False
+        self._rebuild = (weights, smpl, device, kw)          # what the f32 rung is built from if a call saturates the split format
         self.smpl = SMPL(smpl, engine=self.engine)
         if self.engine.num_kps != config.num_kps:
             raise ValueError("config.num_kps=%d but the SMPL regressor has %d keypoints"
@@ -277,9 +283,37 @@ class Tester(object):
 
     def predict(self, images):
         """Runs forward pass of model.  images (BxTxHxWx3) -> dict of float32 ndarrays."""
-        out = self.predict_device(images)
-        torch.cuda.synchronize(self.engine.device)
-        return {k: v.float().cpu().numpy() for k, v in out.items()}
+        def run():
+            out = self.predict_device(images)
+            torch.cuda.synchronize(self.engine.device)
+            return {k: v.float().cpu().numpy() for k, v in out.items()}
+        return self._guard_saturation(run)
+
+    # ------------------------------------------------------------------------
+    def _uses_split_operands(self):
+        e = self.engine
+        return L.HMMR_F16X3 in (e.dtype, e.temporal_dtype, e.ief_dtype)
+
+    def _guard_saturation(self, run):
+        """Run a host-facing call; if any split (f16x3) store clamped a value to the fp16 range while it ran (libhmmr_hip.so's
+        sticky hmmr_run_flags: activations beyond +-65504, e.g. un-normalised frames or a checkpoint with very large trunk
+        activations), the results are not the network's: warn once, switch this Tester to exact-fp32 operands for good
+        (precision["saturated"] = True, precision["operands"] = "f32") and run the call again.  The dtype="auto" probe sees
+        synthetic frames only; this is the check on the caller's own data."""
+        if not self._uses_split_operands():
+            return run()
+        out = run()
+        if not (self.engine.run_flags(clear=True) & L.FLAG_SATURATED):
+            return out
+        import warnings
+        warnings.warn("human_dynamics_amd: an activation left the fp16 range of the f16x3 operand mode (clamped to +-65504) -- "
+                      "repeating the call with fp32 operands and keeping them for this Tester", RuntimeWarning, stacklevel=3)
+        weights, smpl, device, kw = self._rebuild
+        self.engine = HmmrEngine(weights, smpl, dtype="f32", device=device, **kw)
+        self.smpl = SMPL(smpl, engine=self.engine)
+        self._streamer = None
+        self.precision.update(saturated=True, operands="f32")
+        return run()
 
     # ------------------------------------------------------------------------
     def features(self, frames, chunk=256, n_zero=0):
@@ -359,6 +393,12 @@ class Tester(object):
         three-stream pipeline (copy-in / kernels / copy-out, evaluation/streaming.py; byte-identical to the
         one-shot path, `stream=False`).  want: optional subset of the output keys to compute copies for
         (e.g. ("joints", "omegas") skips the 250 KB/frame of vertices on the way back)."""
+        if self._uses_split_operands() and not getattr(self, "_in_guard", False):
+            self._in_guard = True
+            try:
+                return self._guard_saturation(lambda: self.predict_all_images(all_images, want, stream))
+            finally:
+                self._in_guard = False
         N = len(all_images)
         if not self.dedup:
             return self._predict_all_images_literal(all_images)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HMMR_ABI_VERSION 14      /* 14: hmmr_tail_desc_t.pair_stream / c_xp, hmmr_resnet_unit_t.pair_stream (the register-resident unit pair of blocks 2-3), hmmr_debug_t.no_unit_pair, hmmr_run_flags; 13: hmmr_conv_desc_t.batch (grouped launches); 12: k_order = 1, 3x3 SAME convolutions out of an LDS-resident input patch (tiles 9, 10, 11) */
+#define HMMR_ABI_VERSION 14      /* 14: hmmr_tail_desc_t.pair_stream / c_xp, hmmr_resnet_unit_t.pair_stream (the register-resident unit pair of blocks 2-3), hmmr_run_flags; 13: hmmr_conv_desc_t.batch (grouped launches); 12: k_order = 1, 3x3 SAME convolutions out of an LDS-resident input patch (tiles 9, 10, 11) */
 
 /* HMMR_F16X3: "split" tensors -- every group of 8 consecutive channels is 32 bytes, [hi x8][lo x8] with
  * hi = fp16(x), lo = fp16(x - hi), x clamped to +-65504 (4 bytes per element, 22 mantissa bits while lo is a normal
@@ -44,6 +44,13 @@ enum { HMMR_F32 = 0, HMMR_BF16 = 1, HMMR_F16X3 = 2 };
 
 int hmmr_abi_version(void);
 const char* hmmr_last_error(void);
+
+/* Sticky run flags of the CURRENT device, OR-ed over everything launched on it since the last clear.  HMMR_FLAG_SATURATED: a value
+ * beyond the fp16 range (+-65504, or +-inf) reached a split (HMMR_F16X3) store and was clamped -- the results of that call are not
+ * the network's; run it with fp32 operands instead (the Python mirror does: Tester.precision["saturated"]).  Synchronises with the
+ * device (a 4-byte copy per translation unit): call it where the results are read, not per launch.  clear != 0 resets the flags. */
+#define HMMR_FLAG_SATURATED 1u
+int hmmr_run_flags(unsigned* flags, int clear);
 
 /* Development switches for A/B measurements and tests.  Process-wide; all zero = the product defaults.  No
  * switch changes a result beyond what its comment says; the library never reads the environment. */

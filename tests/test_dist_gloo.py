@@ -197,3 +197,30 @@ def test_config5_plan_4096_frames():
             assert (p.f1 - p.f0) - (p.o1 - p.o0) <= 12
             tot += p.o1 - p.o0
         assert tot == 4096
+
+
+def test_bench_self_launch_and_default_workload(tmp_path):
+    """`python bench.py --gpus N` without a launcher re-runs itself under torch.distributed.run (one rank per GPU; bench.self_launch):
+    here with a stand-in script on 2 gloo ranks.  And the N > 1 default is BASELINE configs[4] (one 4096-frame video, strong
+    scaling), N = 1 a 256-frame shard (bench.resolve_workload)."""
+    import argparse
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    stub = tmp_path / "stub.py"
+    stub.write_text(
+        "import os, sys, torch, torch.distributed as dist\n"
+        "dist.init_process_group('gloo')\n"
+        "t = torch.tensor([float(dist.get_rank() + 1)])\n"
+        "dist.all_reduce(t)\n"
+        "open(os.path.join(sys.argv[1], 'rank%d' % dist.get_rank()), 'w').write('%d %d %s' % (dist.get_world_size(), int(t.item()), ' '.join(sys.argv[2:])))\n"
+        "dist.destroy_process_group()\n")
+    rc = bench.self_launch(2, [str(tmp_path), "--gpus", "2", "--steps", "3"], script=str(stub))
+    assert rc == 0
+    for r in (0, 1):
+        assert (tmp_path / ("rank%d" % r)).read_text() == "2 3 --gpus 2 --steps 3"
+    ns = lambda **kw: argparse.Namespace(**dict(dict(frames=256, video_frames=0, weak=False), **kw))
+    assert bench.resolve_workload(ns(), 1) == (False, 256)
+    assert bench.resolve_workload(ns(), 8) == (True, 4096)
+    assert bench.resolve_workload(ns(weak=True), 8) == (False, 2048)
+    assert bench.resolve_workload(ns(video_frames=1024), 2) == (True, 1024)

@@ -94,3 +94,40 @@ def test_tolerance_over_weight_sets(smpl_consts, gpu_device, kind, starts):
         assert max(ex3.values()) < precision.TOLERANCE, (kind, ex3)
         for k in KEYS:
             assert np.array_equal(ra[k], rx3[k])
+
+
+def test_saturating_frames_raise_the_flag_and_fall_back_to_f32(gpu_device):
+    """Runtime safety of the split format: frames scaled until block-1 activations leave the fp16 range (+-65504) are clamped
+    by every split store (csrc/common.h split_clamp) -- silently, before round 4.  Now the stores raise libhmmr_hip.so's sticky
+    flag (hmmr_run_flags), Tester notices it where the results are read, warns, repeats the call on exact-fp32 operands and
+    stays there: the result equals an f32 Tester's bit for bit, and ordinary frames do not raise anything."""
+    import warnings
+    from human_dynamics_amd import _lib as L
+    from human_dynamics_amd.evaluation.tester import Tester
+    w, s = assets.make_synthetic_weights(0), assets.make_synthetic_smpl(2)
+    frames = assets.make_synthetic_frames(20, seed=3)[None]
+
+    class Cfg(object):
+        load_path, batch_size, sequence_length, pred_mode, num_conv_layers = "synthetic:0", 1, 20, "pred", 3
+        delta_t_values, smpl_model_path, num_kps = ["-5", "5"], "synthetic:2", 25
+    t = Tester(Cfg(), weights=w, smpl=s, dtype="f16x3", device=gpu_device)
+    t.engine.run_flags(clear=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        ok = t.predict(frames)                                    # ordinary frames: no flag, no warning, still split operands
+    assert t.precision["saturated"] is False and t.engine.dtype == L.HMMR_F16X3 and np.isfinite(ok["verts"]).all()
+    assert t.engine.run_flags() == 0
+    big = frames * 3.0e4                                          # stem activations of ~1e5: beyond fp16
+    eng16 = t.engine
+    eng16.resnet(big[0])
+    assert eng16.run_flags(clear=True) & L.FLAG_SATURATED         # the raw engine call raises the flag ...
+    with pytest.warns(RuntimeWarning, match="fp16 range"):
+        got = t.predict(big)                                      # ... and the Tester acts on it
+    assert t.precision["saturated"] is True and t.precision["operands"] == "f32" and t.engine.dtype == L.HMMR_F32
+    ref = Tester(Cfg(), weights=w, smpl=s, dtype="f32", device=gpu_device).predict(big)
+    for k in ("verts", "joints", "omegas"):
+        assert np.array_equal(got[k], ref[k]), k
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        again = t.predict(frames)                                 # sticky: later calls run on f32 operands without further ado
+    assert np.abs(again["verts"] - ok["verts"]).max() < 1e-4
