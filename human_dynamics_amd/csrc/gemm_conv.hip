@@ -1063,8 +1063,10 @@ static int launch_patch_tiled(const ConvArgs& a, int tile, hipStream_t stream) {
         if (npp <= 3) return launch_patch<TA, TO, 128, 256, 2, 4, 3>(a, stream);
         if (npp <= 4) return launch_patch<TA, TO, 128, 256, 2, 4, 4>(a, stream);
     } else if (tile == 11) {
-        if (npp <= 5) return launch_pipe<TA, TO, 5>(a, stream);
-        if (npp <= 6) return launch_pipe<TA, TO, 6>(a, stream);
+        if constexpr (std::is_same<TA, bsplit_t>::value) {
+            if (npp <= 5) return launch_pipe<TA, TO, 5>(a, stream);
+            if (npp <= 6) return launch_pipe<TA, TO, 6>(a, stream);
+        }
     } else {
         hmmr_set_error("hmmr_conv_gemm: k_order 1 runs tiles 9 / 11 (256x128) and 10 (128x256), not %d", tile);
         return -1;
@@ -1293,11 +1295,16 @@ extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
                      !d->res && !d->out2 && !d->out_b && !d->pro_scale && !d->in2 && d->split_k <= 1 && d->out && d->cout % 8 == 0,
                      "hmmr_conv_gemm: k_order 1 is for 3x3 / stride 1 / pad 1 convolutions over a dense NHWC tensor with "
                      "cin a multiple of the 128-byte K step and a scale/shift/relu epilogue (no res, out2, out_b, pro_scale, in2, split_k)");
-        HMMR_REQUIRE(d->in_dtype == HMMR_F16X3 && d->out_dtype == HMMR_F16X3, "hmmr_conv_gemm: k_order 1 is built for split (f16x3) tensors");
+        const bool px3 = d->in_dtype == HMMR_F16X3 && d->out_dtype == HMMR_F16X3, pbf = d->in_dtype == HMMR_BF16 && d->out_dtype == HMMR_BF16;
+        HMMR_REQUIRE(px3 || pbf, "hmmr_conv_gemm: k_order 1 is built for split (f16x3) and bf16 tensors");
         // library's choice: the 256x128 ping-pong tile (inside the network the tuner prefers it to tile 11 on ten layers of eleven,
         // profiles/r03p; tile 10 needs 256 output columns and a narrower image)
         const int ptile = d->tile ? d->tile : 9;
         HMMR_REQUIRE((ptile == 10 ? d->cout % 256 : d->cout % 128) == 0, "hmmr_conv_gemm: k_order 1: cout must fill the tile's columns (filter rows are padded to 128)");
+        if (pbf) {
+            HMMR_REQUIRE(ptile != 11, "hmmr_conv_gemm: k_order 1, tile 11 (no load segment) is written for split operands; bf16 runs tiles 9 / 10");
+            return launch_patch_tiled<bf16_t, bf16_t>(a, ptile, s);
+        }
         return launch_patch_tiled<bsplit_t, bsplit_t>(a, ptile, s);
     }
     const bool in16 = d->in_dtype == HMMR_BF16, in32 = d->in_dtype == HMMR_F32, inx3 = d->in_dtype == HMMR_F16X3;

@@ -152,8 +152,13 @@ __global__ __launch_bounds__(VT) void smpl_verts_kernel(
     __shared__ __attribute__((aligned(16))) float smem[IB * LDA + NFEAT_PAD * IB];
     float (*sA)[LDA] = (float (*)[LDA])smem;
     float (*sF)[IB] = (float (*)[IB])(smem + IB * LDA);          // [k][instance]: 4 instances per ds_read_b128
-    const int v = blockIdx.x * VT + threadIdx.x;
-    const int i0 = blockIdx.y * IB;
+    // 1-D grid, instance blocks fastest, XCD-aware: the workgroups that share a vertex tile's basis slice (224 x 3 x 128 floats =
+    // 344 KB) are consecutive on ONE XCD and read it out of that XCD's L2.  (With the vertex tile as the fast index every instance
+    // block streamed the whole 17.9 MB basis again: 505 MB of fetch per 768 instances against 20 MB of constants, profiles/r03s.)
+    const int nib = (m + IB - 1) / IB;
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int v = (L / nib) * VT + threadIdx.x;
+    const int i0 = (L % nib) * IB;
     for (int e = threadIdx.x; e < IB * LDA; e += VT) {
         const int ii = e / LDA;
         sA[ii][e % LDA] = (i0 + ii < m) ? A[(long long)(i0 + ii) * LDA + (e % LDA)] : 0.f;
@@ -483,7 +488,7 @@ static int smpl_launch(const hmmr_smpl_consts_t* c, const float* theta, int ld_t
     // so the MFMA form can only win on operand delivery, and the packed-FMA kernel (two instances per v_pk_fma_f32, the
     // coefficients as LDS broadcasts) already has the cheaper one.  hmmr_debug_t.smpl_blend_mfma selects the MFMA form.
     if (!hmmr_debug_state()->smpl_blend_mfma)
-        hipLaunchKernelGGL(smpl_verts_kernel, dim3(vtiles, (m + IB - 1) / IB), dim3(VT), 0, s, c->dirs,
+        hipLaunchKernelGGL(smpl_verts_kernel, dim3(vtiles * ((m + IB - 1) / IB)), dim3(VT), 0, s, c->dirs,
                            c->vpad, (const float*)feat, (const float*)A, c->lbs_idx, c->lbs_w, c->lbs_nnz,
                            c->num_verts, m, verts, ld_verts, rm);
     else

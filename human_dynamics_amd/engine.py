@@ -193,12 +193,14 @@ class HmmrEngine(object):
         return getattr(U, nm)
 
     @staticmethod
-    def _tile_for(lay, cand, cout):
+    def _tile_for(lay, cand, cout, dtype=None):
         """hmmr_layer_t.tile for candidate `cand` on a layer with `cout` output columns: 0 (the library's choice) where
         the tile does not fit; a layer packed chunk-major (k_order 1, the 3x3 patch kernels) runs tiles 9 / 10, the patch
         forms of 7 / 8, or 11, the 256x128 tile without a load segment."""
         if lay.k_order:
             cand = {7: 9, 8: 10}.get(cand, cand)
+            if cand == 11 and dtype == L.HMMR_BF16:          # the tile without a load segment is written for split operands
+                return 0
             return cand if (cand in (9, 11) and cout % 128 == 0) or (cand == 10 and cout % 256 == 0) else 0
         if cand in (9, 10, 11) or (cand in (1, 5, 7) and cout % 128) or (cand == 8 and cout % 256):
             return 0
@@ -212,7 +214,7 @@ class HmmrEngine(object):
 
     def _set_tiles(self, table):
         for (u, nm), t in table.items():
-            self._layer_of(u, nm).tile = self._tile_for(self._layer_of(u, nm), int(t), self._layer_cout(u, nm))
+            self._layer_of(u, nm).tile = self._tile_for(self._layer_of(u, nm), int(t), self._layer_cout(u, nm), self.dtype)
 
     def _needs_tuning(self, nt):
         """A tuning pass is due for batch size nt: tuning is on, the size is worth it, it has no table of its own and (unless
@@ -242,7 +244,7 @@ class HmmrEngine(object):
         for cand in (0,) + self._TUNE_TILES:
             for slot, u, nm in layers:
                 lay = self._layer_of(u, nm)
-                lay.tile = self._tile_for(lay, cand, self._layer_cout(u, nm))
+                lay.tile = self._tile_for(lay, cand, self._layer_cout(u, nm), self.dtype)
             t = None
             for rep in range(reps):
                 pm = (C.c_float * L.RESNET_PROF_SLOTS)()
@@ -500,7 +502,7 @@ def conv_gemm(x, w_hwio, stride=1, pad=0, scale=None, shift=None, res=None, relu
     if second is not None:          # (x2 [n,h,w,cin2], w2 [1,1,cin2,cout]): a second 1x1 source appended along K (hmmr_conv_desc_t.in2)
         x2 = store.put(np.asarray(second[0], np.float32), packing.TORCH_DT[in_dtype])
         w_hwio = np.concatenate([np.asarray(w_hwio, np.float32), np.asarray(second[1], np.float32)], axis=2)
-    wp = packing.pack_conv_weight(np.asarray(w_hwio, np.float32), k_order)
+    wp = packing.pack_conv_weight(np.asarray(w_hwio, np.float32), k_order, chunk=64 if in_dtype == L.HMMR_BF16 else 32)
     if packing.TORCH_DT[in_dtype] is packing.SPLIT:     # as packing._layer: rows scaled by a power of two, undone by `scale`
         k = packing.row_pow2(wp)
         wp = packing.scale_rows(wp, k)

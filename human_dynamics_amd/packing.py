@@ -224,8 +224,8 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
     measured at batch 256: -4.5 % ResNet time with blocks 1-2 fused, neutral for blocks 3-4).
     fuse_tail: mark the units whose conv3 + add runs with the next unit's preact + conv1 as one
     hmmr_bottleneck_tail launch (bf16; the stride-1 units of block1 and block2).
-    patch_3x3 (f16x3 only): the stride-1 3x3 conv2 of blocks 2-4 packed chunk-major (hmmr_conv_desc_t.k_order = 1) and run
-    by the patch kernel (csrc/gemm_conv.hip, tiles 9 / 10).  Block 1 keeps the tap-major order its fused tails reproduce bit
+    patch_3x3 (f16x3: blocks 2-4; bf16: blocks 3-4): the stride-1 3x3 conv2 packed chunk-major (hmmr_conv_desc_t.k_order = 1) and run
+    by the patch kernel (csrc/gemm_conv.hip, tiles 9 / 10; 11 for f16x3).  Block 1 keeps the tap-major order its fused tails reproduce bit
     for bit; the stride-2 units keep the im2col gather.
     unit_pair (f16x3 only; True | "block2" | "block3" | False): the stride-1 units of blocks 2-3 run conv3 + add + the next
     unit's preact + conv1 as the register-resident unit pair of csrc/unit_pair.hip (one filter stream per unit); block3/unit_1
@@ -257,8 +257,9 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
         s, b = fold_bn(w, scope + "/conv1/BatchNorm")
         u.conv1 = _layer(store, pack_conv_weight(w[scope + "/conv1/weights"]), dtype, s, b)
         s, b = fold_bn(w, scope + "/conv2/BatchNorm")
-        kord = int(bool(patch_3x3) and dtype == L.HMMR_F16X3 and stride == 1 and base >= 128)
-        u.conv2 = _layer(store, pack_conv_weight(w[scope + "/conv2/weights"], kord), dtype, s, b)
+        # (bf16, round 4: blocks 3-4 only -- the conv2 of blocks 1-2 runs inside the fused bf16 units, which read the tap-major order)
+        kord = int(bool(patch_3x3) and stride == 1 and ((dtype == L.HMMR_F16X3 and base >= 128) or (dtype == L.HMMR_BF16 and base >= 256)))
+        u.conv2 = _layer(store, pack_conv_weight(w[scope + "/conv2/weights"], kord, chunk=bke), dtype, s, b)
         u.conv2.k_order = kord
         u.conv3 = _layer(store, pack_conv_weight(w[scope + "/conv3/weights"]), dtype,
                          shift=w[scope + "/conv3/biases"])

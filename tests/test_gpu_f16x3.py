@@ -164,8 +164,39 @@ def test_conv3x3_patch_kernel_refuses_what_it_is_not_built_for(gpu_device):
                   stride=1, pad=1, in_dtype=X3, out_dtype=X3, device=gpu_device, k_order=1)
     with pytest.raises(L.HmmrError):           # a tile of the other K order
         conv_gemm(x, w, stride=1, pad=1, in_dtype=X3, out_dtype=X3, device=gpu_device, tile=9)
-    with pytest.raises(L.HmmrError):           # built for split tensors
+    with pytest.raises(L.HmmrError):           # built for split and bf16 tensors
         conv_gemm(x, w, stride=1, pad=1, in_dtype=L.HMMR_F32, out_dtype=L.HMMR_F32, device=gpu_device, k_order=1)
+    with pytest.raises(L.HmmrError, match="tile 11"):          # the tile without a load segment: split operands only
+        conv_gemm(x, w, stride=1, pad=1, in_dtype=L.HMMR_BF16, out_dtype=L.HMMR_BF16, device=gpu_device, k_order=1, tile=11)
+
+
+@pytest.mark.parametrize("case", [c for c in PATCH_CASES if c[4] % 64 == 0], ids=[c[0] for c in PATCH_CASES if c[4] % 64 == 0])
+def test_conv3x3_patch_kernel_bf16(case, gpu_device):
+    """Round 4: the patch kernel for bf16 operands (64 channels per 128-byte chunk; blocks 3-4 of the bf16 mode): against a
+    float64 convolution of the same bf16-rounded operands, tiles 9 / 10 bit-identical, the im2col ring tiles within the rounding
+    of another accumulation order and of the bf16 output."""
+    from human_dynamics_amd.engine import conv_gemm
+    name, n, h, w_, cin, cout = case
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(name.encode()) % 1000 + 1)
+    bf = lambda a: torch.from_numpy(np.asarray(a, np.float32)).to(torch.bfloat16).float().numpy()
+    x = bf(rng.normal(size=(n, h, w_, cin)))
+    w = bf(rng.normal(size=(3, 3, cin, cout)) / np.sqrt(9 * cin))
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.normal(size=cout).astype(np.float32)
+    kw = dict(stride=1, pad=1, scale=scale, shift=shift, relu=True, in_dtype=L.HMMR_BF16, out_dtype=L.HMMR_F32 if False else L.HMMR_BF16, device=gpu_device)
+    outs = {}
+    for tile in (0, 9, 10):
+        if tile == 10 and cout % 256:
+            continue
+        outs[tile], _ = conv_gemm(x, w, tile=tile, k_order=1, **kw)
+    ref, _ = _ref_conv(x, w, 1, 1, scale, shift, None, True, None, None, 1)
+    mag = max(1.0, np.abs(ref).max())
+    for tile, out in outs.items():
+        assert np.abs(out - ref).max() < 6e-3 * mag, "%s tile %d" % (name, tile)          # (the output is stored as bf16)
+        assert np.array_equal(out, outs[0]), "%s: tile %d differs from the library's choice" % (name, tile)
+    ring, _ = conv_gemm(x, w, tile=0, **kw)
+    assert np.abs(outs[0] - ring).max() < 8e-3 * mag
 
 
 @pytest.mark.parametrize("tile", [0, 3, 5, 6, 1, 7])

@@ -193,8 +193,13 @@ def test_chunk_major_filter_pack():
     assert [on.unit[i].conv2.k_order for i in range(16)] == [0, 0, 0, 1, 1, 1, 0, 1, 1, 1, 1, 1, 0, 1, 1, 1]
     off = packing.pack_resnet(ws, _lib.HMMR_F16X3, packing.DeviceStore("cpu"), patch_3x3=False)
     assert not any(off.unit[i].conv2.k_order for i in range(16))
-    for dt in (_lib.HMMR_BF16, _lib.HMMR_F32):
-        assert not any(packing.pack_resnet(ws, dt, packing.DeviceStore("cpu")).unit[i].conv2.k_order for i in range(16))
+    # bf16 (round 4): blocks 3-4 only -- the conv2 of blocks 1-2 runs inside the fused bf16 units, which read the tap-major order
+    b16 = packing.pack_resnet(ws, _lib.HMMR_BF16, packing.DeviceStore("cpu"))
+    assert [b16.unit[i].conv2.k_order for i in range(16)] == [0] * 7 + [1, 1, 1, 1, 1, 0, 1, 1, 1]
+    assert not any(packing.pack_resnet(ws, _lib.HMMR_F32, packing.DeviceStore("cpu")).unit[i].conv2.k_order for i in range(16))
+    w64 = np.random.default_rng(1).normal(size=(3, 3, 128, 64)).astype(np.float32)
+    p64 = packing.pack_conv_weight(w64, 1, chunk=64)          # bf16: 64 elements per 128-byte K step
+    assert p64[5, ((70 // 64) * 9 + 4) * 64 + 70 % 64] == w64[1, 1, 70, 5]
 
 
 def test_shipped_tile_tables_fit_their_layers():
@@ -220,6 +225,6 @@ def test_shipped_tile_tables_fit_their_layers():
                 assert 0 <= u < 16 and nm in ("conv1", "conv2", "conv3", "shortcut")
                 lay = U.c3sc if (nm == "conv3" and U.c3sc.w) else getattr(U, nm)
                 cout = U.depth + U.base if (nm == "shortcut" and U.sc_c1.w) else (U.base if nm in ("conv1", "conv2") else U.depth)
-                assert E.HmmrEngine._tile_for(lay, tile, cout) == tile, (key, lk, tile)
+                assert E.HmmrEngine._tile_for(lay, tile, cout, dt) == tile, (key, lk, tile)
                 assert (tile in (0, 9, 10, 11)) if lay.k_order else (tile in (0, 1, 2, 3, 5, 6, 7, 8)), (key, lk, tile)
     assert {40, 64, 65, 128, 129, 256, 257, 512, 513, 1024} <= sizes
