@@ -110,7 +110,8 @@ class IefWeights(C.Structure):
 class SmplConsts(C.Structure):
     _fields_ = [("num_verts", C.c_int), ("num_kps", C.c_int), ("lbs_nnz", C.c_int), ("vpad", C.c_int),
                 ("dirs", _fp), ("j_template", _fp), ("j_shapedirs", _fp), ("parents", _ip),
-                ("lbs_idx", _ip), ("lbs_w", _fp), ("kreg_ptr", _ip), ("kreg_idx", _ip), ("kreg_val", _fp)]
+                ("lbs_idx", _ip), ("lbs_w", _fp), ("kreg_ptr", _ip), ("kreg_idx", _ip), ("kreg_val", _fp),
+                ("dirs_split", _vp)]
 
 
 # name -> (restype, argtypes); mirrors include/hmmr_hip.h one to one

@@ -354,6 +354,119 @@ __global__ __launch_bounds__(256, 2) void smpl_verts_mfma_kernel(
     }
 }
 
+// ---- kernel 2, split-fp16 matrix-core form (the default since round 4) --------------------------------------------- //
+// The same contraction [m, 218] x [218, 3 x 6890] with BOTH operands as fp16 hi/lo pairs and three v_mfma_f32_32x32x16_f16 per
+// product (x.lo*b.hi + x.hi*b.lo + x.hi*b.hi, fp32 accumulate) -- the ResNet's operand format (csrc/common.h) applied to the
+// dense part of the SMPL stage: 16 K per instruction instead of 2, i.e. ~5x the rate of the exact-fp32 MFMA / packed-FMA forms
+// at 22 operand bits (vertices within 1e-6 of the fp32 forms; the tolerance of the path is 1e-4).  The host packs the basis as
+// B-operand fragments (`dirs_split`: [K / 16][coordinate][hi, lo][k half][vertex][8 halves], pre-scaled by 2^13 so that the lo
+// halves of millimetre-sized blend-shape entries are normal fp16 numbers); the features are scaled by 2^8 and split into LDS here
+// (a feature beyond +-255 raises the saturation flag); the accumulator is scaled back by 2^-21 (exact).  D[instance][vertex]
+// per coordinate as in the exact-fp32 form: a lane ends up with its vertex's blended position for 16 instances and runs the
+// (4-sparse, vector-unit) skinning sum unchanged.  Same 1-D, XCD-aware grid as smpl_verts_kernel.
+static constexpr int KCH = LDF / 16;     // 14 K chunks of 16 (rows >= 218 of the basis are zero)
+static constexpr float DIRS_SPLIT_SCALE = 8192.f, FEAT_SPLIT_SCALE = 256.f;
+__global__ __launch_bounds__(256, 2) void smpl_verts_split_kernel(
+    const shalf8* __restrict__ dsplit, int vpad, const float* __restrict__ feat, const float* __restrict__ A,
+    const int* __restrict__ lbs_idx, const float* __restrict__ lbs_w, int nnz, int nv, int m,
+    float* __restrict__ verts, long long ld_verts, const RecMap rm) {
+    __shared__ __attribute__((aligned(16))) float smem[IBM * LDA + KCH * 2 * 2 * IBM * 4];
+    float (*sA)[LDA] = (float (*)[LDA])smem;
+    shalf8* sF = (shalf8*)(smem + IBM * LDA);                    // [kc][plane][k half][instance]: the A-operand fragments
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lc = lane & 31, lh = lane >> 5;
+    const int nib = (m + IBM - 1) / IBM;
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int v = (L / nib) * VT + wave * 32 + lc;               // this lane's vertex = its column of D (v < vpad always)
+    const int i0 = (L % nib) * IBM;
+    for (int e = threadIdx.x; e < IBM * LDA; e += 256) {
+        const int ii = e / LDA;
+        sA[ii][e % LDA] = (i0 + ii < m) ? A[(long long)(i0 + ii) * LDA + (e % LDA)] : 0.f;
+    }
+    bool sat = false;
+    for (int e = threadIdx.x; e < IBM * KCH * 2; e += 256) {     // one 8-wide K group of one instance per step
+        const int ii = e % IBM, g8 = e / IBM;                    // g8 = 2 kc + k half
+        const float* f = feat + (long long)(i0 + ii) * LDF + g8 * 8;        // (the scratch rows are sized for m rounded up to IBM)
+        shalf8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = f[j] * FEAT_SPLIT_SCALE;
+            sat = sat || (split_overflows(x) && i0 + ii < m);          // (rows beyond m are scratch)
+            const float c = split_clamp(x);
+            hi[j] = (shalf_t)c;
+            lo[j] = (shalf_t)(c - (float)hi[j]);
+        }
+        sF[((g8 >> 1) * 2 + 0) * 2 * IBM + (g8 & 1) * IBM + ii] = hi;
+        sF[((g8 >> 1) * 2 + 1) * 2 * IBM + (g8 & 1) * IBM + ii] = lo;
+    }
+    split_flag(sat);
+    f32x16 acc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+    // B fragments of chunk kc: [kc][c][plane][lh][vertex]
+    auto bptr = [&](int kc, int c, int pl) { return dsplit + ((long long)((kc * 3 + c) * 2 + pl) * 2 + lh) * vpad + v; };
+    shalf8 bh[2][3], bl[2][3];
+    auto fetch = [&](int kc, int set) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { bh[set][c] = *bptr(kc, c, 0); bl[set][c] = *bptr(kc, c, 1); }
+    };
+    fetch(0, 0);
+    __syncthreads();
+#pragma unroll
+    for (int kc = 0; kc < KCH; ++kc) {
+        if (kc + 1 < KCH) fetch(kc + 1, (kc + 1) & 1);
+        const shalf8 ah = sF[(kc * 2 + 0) * 2 * IBM + lh * IBM + lc], al = sF[(kc * 2 + 1) * 2 * IBM + lh * IBM + lc];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            acc[c] = mfma_split(al, bh[kc & 1][c], acc[c]);
+            acc[c] = mfma_split(ah, bl[kc & 1][c], acc[c]);
+            acc[c] = mfma_split(ah, bh[kc & 1][c], acc[c]);
+        }
+    }
+    if (v >= nv) return;
+    constexpr float UNSCALE = 1.0f / (DIRS_SPLIT_SCALE * FEAT_SPLIT_SCALE);
+    // skinning, as in smpl_verts_kernel: the lane holds instances i0 + 8 g + 4 lh + {0..3} in accumulator rows 4 g .. 4 g + 3
+    const int* vidx = lbs_idx + (long long)v * nnz;
+    const float* vw = lbs_w + (long long)v * nnz;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int ib = 8 * g + 4 * lh;
+        if (i0 + ib >= m) continue;
+        float T[4][12];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 12; ++e) T[q][e] = 0.f;
+        for (int z = 0; z < nnz; ++z) {
+            const int jj = vidx[z] * 12;
+            const float wv = vw[z];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4* a4 = (const f32x4*)&sA[ib + q][jj];
+                const f32x4 r0 = a4[0], r1 = a4[1], r2 = a4[2];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    T[q][e] = fmaf(wv, r0[e], T[q][e]);
+                    T[q][4 + e] = fmaf(wv, r1[e], T[q][4 + e]);
+                    T[q][8 + e] = fmaf(wv, r2[e], T[q][8 + e]);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (i0 + ib + q < m) {
+                const float x = acc[0][4 * g + q] * UNSCALE, y = acc[1][4 * g + q] * UNSCALE, z = acc[2][4 * g + q] * UNSCALE;
+                float* o = rec_ptr(verts, i0 + ib + q, ld_verts, rm, F_VERTS) + v * 3;
+                o[0] = T[q][0] * x + T[q][1] * y + T[q][2] * z + T[q][3];
+                o[1] = T[q][4] * x + T[q][5] * y + T[q][6] * z + T[q][7];
+                o[2] = T[q][8] * x + T[q][9] * y + T[q][10] * z + T[q][11];
+            }
+        }
+    }
+}
+
 // ---- kernel 3 ------------------------------------------------------------ //
 // joints = cocoplus_regressor^T verts (batch_smpl.py:154-157); kps = s*(xy + t) (projection.py:25-29)
 __global__ __launch_bounds__(256) void smpl_joints_kernel(
@@ -487,7 +600,15 @@ static int smpl_launch(const hmmr_smpl_consts_t* c, const float* theta, int ld_t
     // against 106.7 us for the matrix-core form below -- v_mfma_f32_32x32x2_f32 runs at the vector units' own fp32 rate,
     // so the MFMA form can only win on operand delivery, and the packed-FMA kernel (two instances per v_pk_fma_f32, the
     // coefficients as LDS broadcasts) already has the cheaper one.  hmmr_debug_t.smpl_blend_mfma selects the MFMA form.
-    if (!hmmr_debug_state()->smpl_blend_mfma)
+    // Round 4: with `dirs_split` packed, the blend product runs on the matrix cores with split-fp16 operands (three fp16 MFMAs per
+    // product, 16 K per instruction): smpl_verts_split_kernel.  hmmr_debug_t.smpl_blend_mfma: 0 = that default (the packed-FMA
+    // vector form when dirs_split is NULL), 1 = the exact-fp32 MFMA form, 2 = the packed-FMA vector form.
+    const int form = hmmr_debug_state()->smpl_blend_mfma;
+    if (form == 0 && c->dirs_split)
+        hipLaunchKernelGGL(smpl_verts_split_kernel, dim3(vtiles * ((m + IBM - 1) / IBM)), dim3(256), 0, s, (const shalf8*)c->dirs_split,
+                           c->vpad, (const float*)feat, (const float*)A, c->lbs_idx, c->lbs_w, c->lbs_nnz,
+                           c->num_verts, m, verts, ld_verts, rm);
+    else if (form != 1)
         hipLaunchKernelGGL(smpl_verts_kernel, dim3(vtiles * ((m + IB - 1) / IB)), dim3(VT), 0, s, c->dirs,
                            c->vpad, (const float*)feat, (const float*)A, c->lbs_idx, c->lbs_w, c->lbs_nnz,
                            c->num_verts, m, verts, ld_verts, rm);

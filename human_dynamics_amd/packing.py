@@ -435,6 +435,12 @@ def pack_smpl(smpl, store, joint_type="cocoplus"):
     sc = L.SmplConsts()
     sc.num_verts, sc.num_kps, sc.lbs_nnz, sc.vpad = nv, nk, nnz, vpad
     sc.dirs = store.put(dirs).data_ptr()
+    # the same basis as split-fp16 MFMA B-operand fragments (hmmr_smpl_consts_t.dirs_split): [K / 16][3][hi, lo][k half][vpad][8]
+    ds = torch.from_numpy(dirs.astype(np.float64) * 8192.0).to(torch.float32)            # exact: a power of two
+    hi = ds.to(SPLIT_HALF)
+    lo = (ds - hi.to(torch.float32)).to(SPLIT_HALF)
+    frag = lambda x: x.reshape(14, 2, 8, 3, vpad).permute(0, 3, 1, 4, 2)                # kc, c, h, v, e
+    sc.dirs_split = store.put_tensor(torch.stack([frag(hi), frag(lo)], dim=2).contiguous()).data_ptr()      # kc, c, plane, h, v, e
     sc.j_template = store.put(j_template.astype(np.float32)).data_ptr()
     sc.j_shapedirs = store.put(j_shapedirs.astype(np.float32)).data_ptr()
     sc.parents = store.put(np.asarray(smpl["parents"]).astype(np.int32), torch.int32).data_ptr()

@@ -61,9 +61,11 @@ typedef struct hmmr_debug_s {
     int gemm_probe;        /* read only by the -DHMMR_GEMM_PROBE development build (tools/probe_build.sh): the GEMM K loop
                               drops its MFMAs (1), its operand loads after the first stage (2) or its barriers (4), to see
                               which of the three bounds a shape; results are garbage then.  The product build ignores it. */
-    int smpl_blend_mfma;   /* 1: the SMPL blend-shape product [m,218] x [218,3 x 6890] on the matrix cores in exact fp32
-                              (smpl_verts_mfma_kernel, v_mfma_f32_32x32x2_f32) instead of the packed-FMA vector form
-                              (smpl_verts_kernel, the default: measured 1.2x faster); results agree to one fp32 ulp */
+    int smpl_blend_mfma;   /* the SMPL blend-shape product [m,218] x [218,3 x 6890]: 0 = the default, split-fp16 operands on the
+                              matrix cores (smpl_verts_split_kernel; needs hmmr_smpl_consts_t.dirs_split, else form 2);
+                              1 = exact fp32 on the matrix cores (smpl_verts_mfma_kernel, v_mfma_f32_32x32x2_f32);
+                              2 = the packed-FMA vector form (smpl_verts_kernel).  1 and 2 agree to one fp32 ulp, 0 with
+                              them to ~1e-7 m */
     int ief_no_group;      /* 1: hmmr_ief_fwd runs the delta regressors one after the other instead of as grouped launches (same bits) */
     int reserved[3];
 } hmmr_debug_t;
@@ -384,6 +386,11 @@ typedef struct {
     const int32_t* kreg_ptr;           /* CSR by keypoint of cocoplus_regressor^T: [num_kps+1] */
     const int32_t* kreg_idx;           /* vertex ids   */
     const float* kreg_val;
+    const void* dirs_split;            /* optional (NULL: the blend product runs on the vector units in fp32): `dirs` x 2^13 as fp16 hi/lo
+                                          MFMA B-operand fragments, [224 / 16][3][2 (hi, lo)][2 (k half)][vpad][8 halves]:
+                                          dirs_split[kc][c][plane][h][v][e] = plane(2^13 * dirs[16 kc + 8 h + e][c][v]), hi = fp16(x),
+                                          lo = fp16(x - hi) (packing.pack_smpl).  With it the blend shapes are a split-fp16 MFMA
+                                          product (three v_mfma_f32_32x32x16_f16 per operand pair, fp32 accumulate: 22 operand bits) */
 } hmmr_smpl_consts_t;
 
 size_t hmmr_smpl_workspace_bytes(int m);

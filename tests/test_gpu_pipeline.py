@@ -437,25 +437,34 @@ def test_one_smpl_launch_set_for_all_containers_equals_per_container_calls(weigh
 
 
 def test_smpl_blend_on_matrix_cores_agrees_with_the_vector_form(smpl_consts, gpu_device):
-    """smpl_verts_mfma_kernel (the dense blend-shape product [m,218] x [218,3 x 6890] as exact-fp32 MFMAs,
-    v_mfma_f32_32x32x2_f32; selectable through hmmr_debug_t.smpl_blend_mfma) against the default smpl_verts_kernel
-    (fmaf chains on the vector units): both are fp32 sums of the same exact products, they agree to rounding (measured
-    6e-8 = one ulp at the vertices' magnitude) -- ragged instance counts included (32-instance MFMA blocks, the last
-    vertex tile reaches past vertex 6889)."""
+    """The dense blend-shape product [m,218] x [218,3 x 6890] in its three forms (hmmr_debug_t.smpl_blend_mfma): 2 = fmaf chains
+    on the vector units (smpl_verts_kernel), 1 = exact-fp32 MFMAs (v_mfma_f32_32x32x2_f32: the same exact products, agrees
+    with 2 to one ulp, 6e-8 at the vertices' magnitude), 0 = the default since round 4, split-fp16 operands on the matrix cores
+    (three v_mfma_f32_32x32x16_f16 per product, 22 operand bits: within 1e-6 of the fp32 forms, two orders inside the path's
+    1e-4) -- ragged instance counts included (32-instance MFMA blocks, the last vertex tile reaches past vertex 6889)."""
     import torch
     from human_dynamics_amd.engine import HmmrEngine, set_debug
     eng = HmmrEngine(None, smpl_consts, device=gpu_device)
+    assert eng.sc.dirs_split
+    eng.run_flags(clear=True)
     rng = np.random.default_rng(8)
     for m in (1, 33, 70):
         theta = (rng.normal(size=(m, 72)) * 0.6).astype(np.float32)
         beta = rng.normal(size=(m, 10)).astype(np.float32)
         cams = rng.normal(size=(m, 3)).astype(np.float32)
-        ref = [t.clone() for t in eng.smpl(theta, beta, cams)]
+        out = {}
         try:
-            set_debug(smpl_blend_mfma=1)
-            got = [t.clone() for t in eng.smpl(theta, beta, cams)]
+            for form in (0, 1, 2):
+                set_debug(smpl_blend_mfma=form)
+                out[form] = [t.clone() for t in eng.smpl(theta, beta, cams)]
         finally:
             set_debug()
-        for a, b, name in zip(got, ref, ("verts", "joints", "kps", "Rs")):
+        for a, b, name in zip(out[1], out[2], ("verts", "joints", "kps", "Rs")):
             assert float((a - b).abs().max()) < 5e-7, (name, m, float((a - b).abs().max()))
-        assert torch.equal(got[3], ref[3])                # the rotations do not depend on the blend kernel
+        for a, b, name in zip(out[0], out[2], ("verts", "joints", "kps", "Rs")):
+            assert float((a - b).abs().max()) < 2e-6, (name, m, float((a - b).abs().max()))
+        assert torch.equal(out[1][3], out[2][3]) and torch.equal(out[0][3], out[2][3])      # the rotations do not depend on the blend kernel
+    assert eng.run_flags(clear=True) == 0
+    # a shape coefficient beyond the fp16 range of the scaled features (|beta| x 2^8 > 65504) raises the saturation flag
+    eng.smpl(np.zeros((1, 72), np.float32), np.full((1, 10), 300.0, np.float32), np.ones((1, 3), np.float32))
+    assert eng.run_flags(clear=True) & 1

@@ -15,7 +15,7 @@ for m in (256, 768):
     theta = torch.from_numpy((rng.normal(size=(m, 72)) * 0.5).astype(np.float32)).cuda()
     beta = torch.from_numpy(rng.normal(size=(m, 10)).astype(np.float32)).cuda()
     cams = torch.from_numpy(rng.normal(size=(m, 3)).astype(np.float32)).cuda()
-    for name, mf in (("valu (default)", 0), ("mfma", 1)):
+    for name, mf in (("split-fp16 mfma (default)", 0), ("exact-fp32 mfma", 1), ("packed-fma valu", 2)):
         set_debug(smpl_blend_mfma=mf)
         for _ in range(3):
             eng.smpl(theta, beta, cams)
