@@ -50,6 +50,12 @@ _debug_from_env.was_set = False
 
 def _dt(d):
     if isinstance(d, str):
+        if d == "bf16x3":              # rounds 1-2 called the split mode by its (then bf16) halves
+            import warnings
+            warnings.warn("dtype 'bf16x3' is now 'f16x3' (split operands with fp16 halves since round 3)", DeprecationWarning, stacklevel=3)
+            d = "f16x3"
+        if d not in DTYPES:
+            raise ValueError("unknown operand mode %r: use one of %s" % (d, ", ".join(sorted(set(DTYPES)))))
         return DTYPES[d]
     return int(d)
 
@@ -69,8 +75,8 @@ class _Workspace(object):
 class HmmrEngine(object):
     """weights: dict of checkpoint-named arrays (assets.py); smpl: dict in the
     src/tf_smpl layout.  dtype: GEMM operand mode of ResNet / temporal / IEF: 'f16x3' (default: split-fp16 hi/lo
-    operands, three bf16 MFMAs per product -- the mode inside the reference tolerance), 'bf16' or 'f32'; SMPL is
-    always fp32."""
+    operands, three fp16 MFMAs per product -- the mode inside the reference tolerance), 'bf16' or 'f32'; SMPL is
+    always fp32 at its boundaries (its blend-shape product runs on split-fp16 MFMAs)."""
 
     def __init__(self, weights, smpl, dtype=DEFAULT_DTYPE, device="cuda:0", num_conv_layers=3,
                  delta_t_values=(-5, 5), joint_type="cocoplus", resnet_chunk=0,
@@ -402,10 +408,10 @@ class HmmrEngine(object):
             if start.shape[0] == 1:
                 start = start.expand(m, 85).contiguous()
             assert start.shape == (m, 85), start.shape
-        self.iw.delta_from_start = int(not use_delta_from_pred)
-        L.check(self.lib.hmmr_ief_fwd_from(C.byref(self.iw), strips.data_ptr(), L.ptr(start), m, out.data_ptr(),
-                                           ws.data_ptr(), nbytes, self._stream()), "hmmr_ief_fwd")
-        self.iw.delta_from_start = 0
+        iw = L.IefWeights.from_buffer_copy(self.iw)          # a per-call copy of the (host) struct: the shared one is never toggled
+        iw.delta_from_start = int(not use_delta_from_pred)
+        L.check(self.lib.hmmr_ief_fwd_from(C.byref(iw), strips.data_ptr(), L.ptr(start), m, out.data_ptr(),
+                                           ws.data_ptr(), nbytes, self._stream()), "hmmr_ief_fwd_from")
         return out
 
     @property

@@ -259,6 +259,10 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
         s, b = fold_bn(w, scope + "/conv2/BatchNorm")
         # (bf16, round 4: blocks 3-4 only -- the conv2 of blocks 1-2 runs inside the fused bf16 units, which read the tap-major order)
         kord = int(bool(patch_3x3) and stride == 1 and ((dtype == L.HMMR_F16X3 and base >= 128) or (dtype == L.HMMR_BF16 and base >= 256)))
+        # (a chunk-major layer cannot fall back to the im2col gather: its 128-pixel patch -- tile + halo of W + 1 on either side --
+        #  must fit the 4 x 64 rows the 128x256 tile keeps in LDS.  ResNet-50 on 224 x 224 crops: W <= 28)
+        if kord and 128 + 2 * (224 // {64: 4, 128: 8, 256: 16, 512: 32}[base]) + 4 > 4 * 64:
+            kord = 0
         u.conv2 = _layer(store, pack_conv_weight(w[scope + "/conv2/weights"], kord, chunk=bke), dtype, s, b)
         u.conv2.k_order = kord
         u.conv3 = _layer(store, pack_conv_weight(w[scope + "/conv3/weights"]), dtype,

@@ -58,28 +58,64 @@ def probe_outputs(engine, frames, T=20, pred_mode="pred"):
     return {"verts": torch.stack(verts), "joints": torch.stack(joints)}
 
 
+_DECISIONS = {}          # weights fingerprint -> (rung index, report): one probe per weight set and process
+
+
+def weights_fingerprint(weights, pred_mode):
+    """A cheap identity of a weight set: names, shapes and two moments of every array (float64 sums)."""
+    import hashlib
+    h = hashlib.sha1(pred_mode.encode())
+    for k in sorted(weights):
+        a = np.asarray(weights[k])
+        h.update(k.encode()); h.update(str(a.shape).encode())
+        h.update(np.array([a.sum(dtype=np.float64), np.abs(a).sum(dtype=np.float64)]).tobytes())
+    return h.hexdigest()
+
+
 def choose_engine(weights, smpl, device, pred_mode="pred", **engine_kw):
     """Walk LADDER; returns (engine, report).  report = {'operands', 'probe_tolerance', 'rungs': [{'operands', 'verts',
-    'joints', 'accepted'}]} -- what bench.py prints and Tester.precision holds."""
+    'joints', 'accepted'}]} -- what bench.py prints and Tester.precision holds.  The decision is cached per weight set (a second
+    Tester on the same weights builds its rung directly), and in a torch.distributed job rank 0 decides for everybody: every rank
+    then runs the same operand mode even on a borderline weight set."""
+    import copy
+    import torch.distributed as dist
+
+    def make(rung):
+        return HmmrEngine(weights, smpl, dtype=rung[0], temporal_dtype=rung[1], ief_dtype=rung[2], device=device, **engine_kw)
+    key = weights_fingerprint(weights, pred_mode)
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if key not in _DECISIONS and multi and dist.get_rank() != 0:
+        box = [None]
+        dist.broadcast_object_list(box, src=0)               # rank 0's decision (below)
+        _DECISIONS[key] = box[0]
+    if key in _DECISIONS:
+        idx, report = _DECISIONS[key]
+        return make(LADDER[idx]), dict(copy.deepcopy(report), cached=True)
+    chosen, report, idx = _probe(weights, smpl, device, pred_mode, make)
+    _DECISIONS[key] = (idx, copy.deepcopy(report))
+    if multi:
+        dist.broadcast_object_list([_DECISIONS[key]], src=0)
+    return chosen, report
+
+
+def _probe(weights, smpl, device, pred_mode, make):
     dev = torch.device(device)
     structured = assets.make_synthetic_frames(20 * (PROBE_WINDOWS - PROBE_WINDOWS // 2), seed=4242)
     noise = np.random.Generator(np.random.PCG64(4243)).uniform(-1.0, 1.0, (20 * (PROBE_WINDOWS // 2), 224, 224, 3)).astype(np.float32)
     frames = torch.from_numpy(np.concatenate([structured, noise])).to(dev)
     tol = PROBE_FRACTION * TOLERANCE
 
-    def make(rung):
-        return HmmrEngine(weights, smpl, dtype=rung[0], temporal_dtype=rung[1], ief_dtype=rung[2], device=device, **engine_kw)
     ref_engine = make(LADDER[-1])
     ref = probe_outputs(ref_engine, frames, pred_mode=pred_mode)
-    rungs, chosen = [], None
-    for rung in LADDER[:-1]:
+    rungs, chosen, idx = [], None, len(LADDER) - 1
+    for ri, rung in enumerate(LADDER[:-1]):
         eng = make(rung)
         got = probe_outputs(eng, frames, pred_mode=pred_mode)
         errs = {k: float((got[k] - ref[k]).abs().max()) for k in ("verts", "joints")}
         ok = bool(np.isfinite(list(errs.values())).all() and max(errs.values()) <= tol)
         rungs.append(dict(operands=describe(eng), accepted=ok, **errs))
         if ok:
-            chosen = eng
+            chosen, idx = eng, ri
             break
         del eng, got
         torch.cuda.empty_cache()
@@ -91,4 +127,4 @@ def choose_engine(weights, smpl, device, pred_mode="pred", **engine_kw):
     del ref
     torch.cuda.empty_cache()
     return chosen, {"operands": describe(chosen), "probe_tolerance": tol, "probe_frames": 20 * PROBE_WINDOWS,
-                    "against": "the f32 rung (exact fp32 MFMA) on the same device", "rungs": rungs}
+                    "against": "the f32 rung (exact fp32 MFMA) on the same device", "rungs": rungs}, idx
