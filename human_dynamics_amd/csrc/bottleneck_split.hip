@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256, NCH > 4 ? 2 : 3) void tail_split_kernel(const 
         grow[p] = rok[p] ? m : 0;                    // tail rows read row 0 and are never stored
     }
 
-    float satmax = 0.f;                              // largest |value| this thread splits (common.h: hmmr_run_flags)
+    unsigned long long satmask = 0ull;               // lanes of this wave that split a value beyond the fp16 range (common.h: hmmr_run_flags)
     float* sScale3 = (float*)(smem + OFF_C);
     float* sBias3 = sScale3 + depth;
     float* sPreS = sBias3 + depth;
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256, NCH > 4 ? 2 : 3) void tail_split_kernel(const 
             for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(acc0[4 * g + j], s4[j], b4[j]), 0.f);
             char* q = smem + OFF_H2 + prow + (((n >> 3) ^ fsw) << 4) + 8 * lh;
             unsigned long long oh, ol;
-            split4(v, oh, ol, satmax);
+            split4(v, oh, ol, satmask);
             *(unsigned long long*)q = oh;
             *(unsigned long long*)(q + PLANE) = ol;
         }
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256, NCH > 4 ? 2 : 3) void tail_split_kernel(const 
                 v[3] += bf_hi((unsigned)(h >> 32)) + bf_hi((unsigned)(l >> 32));
             }
             unsigned long long oh, ol;
-            split4(v, oh, ol, satmax);
+            split4(v, oh, ol, satmask);
             *(unsigned long long*)ph = oh;
             *(unsigned long long*)(ph + PLANE) = ol;
         }
@@ -335,11 +335,11 @@ __global__ __launch_bounds__(256, NCH > 4 ? 2 : 3) void tail_split_kernel(const 
             }
             char* ph = smem + OFF_H2 + (n2 >> 6) * 2 * PLANE + prow + ((((n2 & 63) >> 3) ^ fsw) << 4) + 8 * lh;
             unsigned long long oh, ol;
-            split4(v, oh, ol, satmax);
+            split4(v, oh, ol, satmask);
             *(unsigned long long*)ph = oh;
             *(unsigned long long*)(ph + PLANE) = ol;
         }
-    split_flag(satmax > HMMR_SPLIT_MAX);
+    split_flag(satmask != 0ull);
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < J2; ++t)

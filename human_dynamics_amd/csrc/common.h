@@ -273,6 +273,9 @@ __device__ __forceinline__ f32x16 mma3(const wfrag& w, const shalf8& xh, const s
     return mfma_split(w.hi, xh, c);
 }
 // four fp32 values -> their split halves, 4 halves (8 bytes) each; clamped to the fp16 range like store8<bsplit_t>
+// the same with the check accumulated in a SCALAR register pair (a wave-wide mask of the lanes that saw a value beyond the range;
+// v_cmp + s_or, no vector register stays live: the block-1 tails have none to spare) -- raise with split_flag(satmask != 0)
+__device__ __forceinline__ void split4(const float (&v)[4], unsigned long long& hi, unsigned long long& lo, unsigned long long& satmask);
 // satmax: running maximum of |v| over everything this thread has split (two v_max3_f32 per call; the caller raises the flag once,
 // with split_flag(satmax > HMMR_SPLIT_MAX), when it is done: these kernels are bound by their instruction count)
 __device__ __forceinline__ void split4(const float (&v)[4], unsigned long long& hi, unsigned long long& lo, float& satmax) {
@@ -288,4 +291,11 @@ __device__ __forceinline__ void split4(const float (&v)[4], unsigned long long& 
     }
     hi = (unsigned long long)h[0] | ((unsigned long long)h[1] << 32);
     lo = (unsigned long long)l[0] | ((unsigned long long)l[1] << 32);
+}
+
+__device__ __forceinline__ void split4(const float (&v)[4], unsigned long long& hi, unsigned long long& lo, unsigned long long& satmask) {
+    const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])), __builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
+    satmask |= __builtin_amdgcn_ballot_w64(m > HMMR_SPLIT_MAX);
+    float unused = 0.f;
+    split4(v, hi, lo, unused);
 }

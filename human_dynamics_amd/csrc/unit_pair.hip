@@ -572,14 +572,27 @@ __global__ __launch_bounds__(256, 1) void unit_pair_kernel(const PairArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(0);                             // (the last shortcut request must not land in the tile any more)
     PAIR_STAMP(4);
+    // conv1's folded BN constants: through the (now idle) ring, one global round trip for the workgroup instead of one per row block
+    __syncthreads();                                           // every wave has left the loop: the ring is free
+    float* sS1 = (float*)smem;
+    float* sB1 = sS1 + N2;
+    for (int i = tid; i < N2; i += 256) { sS1[i] = a.scale1[i]; sB1[i] = a.shift1[i]; }
+    __syncthreads();
     char* stg = stg_of(0);
     float satmax = 0.f;
+    bsplit_t* hrow[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = 8 * q + rsub, m = mbase + r;
+        const int ls = pslot ^ ((r >> 1) & 7);
+        hrow[q] = m < a.M ? a.out_h1 + (long long)m * N2 + ls * 4 : (bsplit_t*)g_pair_dump + lane * 4;
+    }
 #pragma unroll
     for (int of = 0; of < NF2; ++of) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int n2 = of * 32 + 8 * g + 4 * lh;
-            const f32x4 s4 = *(const f32x4*)(a.scale1 + n2), b4 = *(const f32x4*)(a.shift1 + n2);
+            const f32x4 s4 = *(const f32x4*)(sS1 + n2), b4 = *(const f32x4*)(sB1 + n2);
             float v[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -588,15 +601,17 @@ __global__ __launch_bounds__(256, 1) void unit_pair_kernel(const PairArgs a) {
             }
             unsigned long long oh, ol;
             split4(v, oh, ol, satmax);
-            *(unsigned long long*)(stg + lr * 128 + (((2 * g) ^ sw) << 4) + 8 * lh) = oh;
-            *(unsigned long long*)(stg + lr * 128 + (((2 * g + 1) ^ sw) << 4) + 8 * lh) = ol;
+            *(unsigned long long*)(stg + (of & 1) * 4096 + lr * 128 + (((2 * g) ^ sw) << 4) + 8 * lh) = oh;
+            *(unsigned long long*)(stg + (of & 1) * 4096 + lr * 128 + (((2 * g + 1) ^ sw) << 4) + 8 * lh) = ol;
         }
+        // (the two staging tiles alternate: the row reads of block `of` do not hold up the writes of block of + 1)
+        u32x4 xr[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xr[q] = *(const u32x4*)(stg + (of & 1) * 4096 + q * 1024 + lane16);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int r = 8 * q + rsub, m = mbase + r;
-            const int ls = pslot ^ ((r >> 1) & 7);
-            const u32x4 x = *(const u32x4*)(stg + q * 1024 + lane16);
-            if (m < a.M) *(u32x4*)(a.out_h1 + (long long)m * N2 + of * 32 + ls * 4) = x;
+            const int m = mbase + 8 * q + rsub;
+            *(u32x4*)(hrow[q] + (m < a.M ? of * 32 : 0)) = xr[q];
         }
     }
     split_flag(satmax > HMMR_SPLIT_MAX);
