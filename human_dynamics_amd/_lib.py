@@ -17,7 +17,7 @@ LIB_PATH = devflags.get("LIB_PATH") or os.path.join(HERE, "libhmmr_hip.so")
 
 HMMR_F32, HMMR_BF16, HMMR_F16X3 = 0, 1, 2
 FLAG_SATURATED = 1
-ABI_VERSION = 14
+ABI_VERSION = 15
 RESNET_UNITS = 16
 RESNET_PROF_SLOTS = 64
 MAX_TEMPORAL_BLOCKS = 8
@@ -140,6 +140,7 @@ SIGNATURES = {
     "hmmr_crop_frames": (C.c_int, [_vp, _ip, C.c_int, C.c_int, C.c_int, _fp, _vp]),
     "hmmr_bottleneck_tail": (C.c_int, [C.POINTER(TailDesc), _vp]),
     "hmmr_pair_stream_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "hmmr_conv3x3_stream_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "hmmr_render_handoff": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, _fp, C.c_int64, _fp, C.c_int, C.c_int, C.c_int,
                                       _fp, _fp, _fp, _vp]),
     "hmmr_eval_joints": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _vp]),

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libhmmr_hip.so")
-SOURCES = ["api.cpp", "gemm_conv.hip", "stem.hip", "bottleneck.hip", "bottleneck_split.hip", "unit_pair.hip", "resnet.hip", "temporal.hip", "ief.hip", "smpl.hip", "eval_metrics.hip", "preprocess.hip", "handoff.hip"]
+SOURCES = ["api.cpp", "gemm_conv.hip", "conv3x3_stream.hip", "stem.hip", "bottleneck.hip", "bottleneck_split.hip", "unit_pair.hip", "resnet.hip", "temporal.hip", "ief.hip", "smpl.hip", "eval_metrics.hip", "preprocess.hip", "handoff.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC,
          "-Wall", "-Wno-unused-function"]
@@ -24,7 +24,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "
 
 # per-file flags.  unit_pair.hip: a single wave per SIMD issues one vector instruction per ~8 cycles, so the instruction COUNT of its
 # epilogue is what bounds it; the SLP vectoriser packs pairs of its fp32 FMAs into v_pk_fma_f32 at the price of a v_mov per operand
-EXTRA_FLAGS = {"unit_pair.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"unit_pair.hip": ["-fno-slp-vectorize"], "conv3x3_stream.hip": ["-fno-slp-vectorize"]}
 
 
 def _newer(src, dst):

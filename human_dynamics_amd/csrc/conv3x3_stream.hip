@@ -1,0 +1,369 @@
+// 3x3 / stride 1 / SAME convolutions of the ResNet's conv2 layers for gfx950, f16x3 ("split") operands, as ONE MFMA STREAM PER SIMD
+// (hmmr_conv_desc_t.k_order = 2; tiles 12 ...).  slim resnet_v2.bottleneck `conv2` as invoked at src/models.py:65-75.
+//
+// What the 8-wave patch tiles of gemm_conv.hip (k_order 1) measure: the matrix pipes are busy 45 % of a launch, 394 workgroups go to
+// 256 CUs (block 3), and a launch without its MFMAs is still 80 % as long -- two waves per SIMD that meet at a barrier every 24
+// MFMAs spend their time on their own skeleton.  This kernel is built the way csrc/unit_pair.hip is:
+//   * ONE wave per SIMD (4-wave workgroups, one per CU) with all 512 registers: FM x FN accumulators of 32 x 32 in the AGPR half
+//     (up to 16), two sets of operand fragments in the VGPR half.  A K step (one tap x 16 channels) is 3 FM FN MFMAs -- 42 for
+//     the 7 x 2 wave tile -- and ONE barrier; the (FM + FN) x 2 fragment reads of the next step sit between them, at most one
+//     ds_read_b128 per MFMA pair.  LDS reads per MFMA are half those of a 64 x 64 wave tile;
+//   * the tile is R x 32 pixels by 128 output channels with R chosen per layer so that the launch is a whole number of rounds of
+//     256 workgroups (R = 14: 226 tiles in block 3, 450 in block 2; the 256 x 128 tile: 394 and 788);
+//   * filters: the host packs them as the stream of MFMA A-operand fragments the kernel consumes (packing.pack_conv3x3_stream:
+//     [128-channel tile][K step][4 row blocks][hi plane | lo plane] of 1 KB, lane-linear), the waves DMA a K step (8 KB) into
+//     a 4-slab ring four steps ahead (global_load_lds; waits are COUNTED s_waitcnt vmcnt(N)); reads are conflict-free with no
+//     address arithmetic at all (ring slot and row block are instruction offsets);
+//   * pixels: K is chunk-major in 16-channel chunks (K step kt = chunk kt / 9, tap kt % 9).  A chunk of every input pixel the tile
+//     can touch is DMA'd once into a PATCH (two buffers: chunk c + 1 lands while chunk c is consumed), stored as a hi plane and a
+//     lo plane of 32-byte rows (two 16-byte k halves, swapped in rows with bit 3 set: the 16 lanes of a ds_read_b128 group hit 16
+//     distinct slots).  Patch row r holds input pixel m0 - (W + 1) + r of the flattened [img][y][x] order, so tap (ky, kx) of tile
+//     pixel i is row i + ky W + kx for EVERY pixel: one address per step, the FM row blocks are instruction offsets.  SAME padding
+//     is an address select: per row block four wave masks in SCALAR registers (pixels in the top / bottom row, left / right
+//     column); a lane whose tap is outside its image reads a zero row of the same bank instead (one v_cndmask per fragment).
+// Products and their order per output element: (w.hi x.lo, w.lo x.hi, w.hi x.hi) per K step, K steps in stream order -- the
+// same for every tile shape, so every tile of this kernel produces the same bits (they differ from k_order 0 / 1 by the fp32
+// rounding of a different summation order only).
+#include <type_traits>
+
+#include "common.h"
+#include "hmmr_hip.h"
+
+namespace {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ u32x4 g_s3_dump[64];            // 1 KB: where the stores of rows beyond M go
+
+struct S3Args {
+    const char* in;                         // [M][C] split rows
+    const char* wstream;                    // packing.pack_conv3x3_stream
+    const float* scale; const float* shift; // [cout]
+    bsplit_t* out; int ldo;
+    int M, H, W, C, nc;                     // nc = C / 16
+    int relu, tiles_n, n_tiles;
+    long long nt_stride;                    // bytes of one 128-channel tile of the stream: 9 nc x 8 KB
+    unsigned long long* ts;                 // probe build: s_memtime stamps, or NULL
+};
+
+// Development build only (tools/s3_probe_build.sh): drop the MFMAs (1), the fragment reads (2), the DMA requests and their waits (4),
+// the loop's barrier (8) or the per-step address arithmetic (16) at COMPILE time, and stamp s_memtime around the phases.  Results are
+// garbage in those modes; the product build compiles the switches away.
+#ifndef S3_PROBE_BITS
+#define S3_PROBE_BITS 0
+#endif
+#define S3_PROBE(bit) (((S3_PROBE_BITS) & (bit)) != 0)
+#ifdef HMMR_GEMM_PROBE
+#define S3_STAMP(k) do { if (a.ts) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) a.ts[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = t_; } } while (0)
+#else
+#define S3_STAMP(k) do { } while (0)
+#endif
+
+// s_waitcnt vmcnt(N) lgkmcnt(0) (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14])
+template <int N> __device__ __forceinline__ void s3_wait() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (0 << 8) | ((N >> 4) << 14));
+}
+
+// the loop's LDS reads as inline assembly: the compiler does not track them (it would wait lgkmcnt(0) at the first use of any of
+// them); the step ends with one lgkmcnt(0) of its own
+template <int OFF> __device__ __forceinline__ shalf8 s3_rd(unsigned addr) {
+    shalf8 v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF)); return v;
+}
+
+struct xfrag { shalf8 hi, lo; };            // MFMA B-operand fragment: 32 pixels x 16 channels
+
+constexpr int S3_NS = 4;                    // ring slabs
+constexpr int S3_SLAB = 8192;               // one K step of a 128-channel tile: 4 row blocks x (hi 1 KB | lo 1 KB)
+
+
+// FM x FN accumulators per wave, WGM x WGN waves: the tile is 32 WGM FM pixels x 128 channels (WGN FN = 4)
+template <int FM, int FN, int WGM, int WGN>
+__global__ __launch_bounds__(256, 1) void conv3x3_stream_kernel(const S3Args a) {
+    static_assert(WGM * WGN == 4 && WGN * FN == 4 && FM * FN <= 16, "4 waves, 128 channels, at most 16 accumulators");
+    constexpr int R = WGM * FM, BM = 32 * R;
+    constexpr int NPP = (BM + 58 + 63) / 64;                    // 64-row pieces of a patch (W <= 28: BM + 2 W + 2 rows)
+    constexpr int NS = S3_NS, SLAB = S3_SLAB, RING = NS * SLAB;
+    constexpr int ZROWS = 32 * (FM - 1) + 16;                   // zero rows behind the data rows of every plane
+    constexpr int PLANE = (NPP * 64 + ZROWS) * 32, PBUF = 2 * PLANE;
+    constexpr int NR = 2 * (FM + FN), NSLOT = 3 * FM;
+    static_assert(PLANE + 1024 * (FM - 1) + 16 < 65536, "instruction offsets");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    S3_STAMP(0);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int L = xcd_remap(blockIdx.x, a.n_tiles);
+    const int mt = L / a.tiles_n, nt = L - mt * a.tiles_n;
+    const int m0 = mt * BM;
+    const int W = a.W, HW = a.H * a.W;
+    const int base = m0 - W - 1;                                // input pixel of patch row 0
+    const int nc = a.nc, nk = 9 * nc;
+    const int wm = wave / WGN, wn = wave - wm * WGN;
+    const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;
+
+    // ---- zero rows of the four planes (never written again)
+    for (int i = tid; i < 4 * ZROWS * 2; i += 256) {
+        const int pl = i / (ZROWS * 2), o = i - pl * (ZROWS * 2);
+        *(u32x4*)(smem + RING + pl * PLANE + NPP * 64 * 32 + o * 16) = u32x4{0u, 0u, 0u, 0u};
+    }
+
+    // ---- patch DMA: piece q of this wave = plane wave >> 1, rows 64 q + 32 (wave & 1) .. + 31, two lanes per row.  Rows outside
+    // the tensor read its first / last pixel instead: only out-of-image taps (which read a zero row) and pixels >= M ever see them
+    const int pplane = wave >> 1;
+    const char* pptr[NPP];
+#pragma unroll
+    for (int q = 0; q < NPP; ++q) {
+        const int r = 64 * q + 32 * (wave & 1) + (lane >> 1);
+        int px = base + r;
+        px = px < 0 ? 0 : (px >= a.M ? a.M - 1 : px);
+        const int half = (lane & 1) ^ ((r >> 3) & 1);
+        pptr[q] = a.in + ((long long)px * a.C) * 4 + half * 32 + pplane * 16;
+    }
+    auto patch_dma = [&](int c, int buf) {
+        char* dst = smem + RING + buf * PBUF + pplane * PLANE + (wave & 1) * 1024;
+#pragma unroll
+        for (int q = 0; q < NPP; ++q)
+            __builtin_amdgcn_global_load_lds((gptr_t)(pptr[q] + c * 64), (lptr_t)(dst + q * 2048), 16, 0, 0);
+    };
+    // ---- filter stream: K step s -> ring slot s & 3; each wave moves a quarter (one row block: hi and lo plane)
+    const char* gw = a.wstream + (long long)nt * a.nt_stride + wave * 2048 + lane * 16;
+    auto ring_dma = [&](int s, int slot) {
+        const char* src = gw + (long long)s * SLAB;
+        char* dst = smem + slot * SLAB + wave * 2048;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);          // (the instruction offset moves both addresses)
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 1024, 0);
+    };
+
+    // ---- image borders: nibble i of `eb` = this lane's pixel of row block i lies in the top / bottom row, left / right column
+    unsigned eb = 0;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int m = m0 + (wm * FM + i) * 32 + lr;
+        const int rem = m % HW, y = rem / W, x = rem - y * W;
+        eb |= (unsigned)((y == 0) | ((y == a.H - 1) << 1) | ((x == 0) << 2) | ((x == W - 1) << 3)) << (4 * i);
+    }
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            asm volatile("" : "+a"(acc[i][j]));
+        }
+
+    const unsigned vW = lds0 + wn * FN * 2048 + lane * 16;      // filter fragments: + slot * SLAB + j * 2048 (+ 1024: lo plane)
+    const int rb0 = wm * FM * 32 + lr;                          // patch row of tap (0, 0) of this lane's pixel in row block 0
+    xfrag fx[2][FM];
+    wfrag fw[2][FN];
+
+    // addresses of the pixel fragments of (tap t_, patch buffer buf_): A0 = the tap's own row, A0 + DZ = the zero row of its bank;
+    // bit 4 i + 3 of `inv`: the tap of this lane's pixel of row block i lies outside its image (SAME padding)
+    unsigned A0 = 0, DZ = 0, inv = 0;
+    auto tap_setup = [&](int t_, int buf_) {
+        const int ky = (t_ * 11) >> 5, kx = t_ - 3 * ky;
+        const int rowp = rb0 + ky * W + kx;
+        const unsigned slot = (unsigned)((lh ^ (rowp >> 3)) & 1) << 4;
+        A0 = lds0 + RING + buf_ * PBUF + rowp * 32 + slot;
+        DZ = (NPP * 64 + (rowp & 15) - rowp) * 32;
+        // nibble (top, bottom, left, right) of the borders tap t_ leaves the image over: ky == 0, ky == 2, kx == 0, kx == 2
+        const unsigned sel = (unsigned)((0xA26804915ull >> (4 * t_)) & 15u) * 0x11111111u;
+        unsigned v = eb & sel;
+        v |= v << 1;
+        v |= v << 2;
+        inv = v;
+    };
+    // read number r of a step's NR fragment halves into set `set` (filters first); slot_ = the ring slot of that step
+    auto read_one = [&](int set, int r, int slot_) {            // set, r, slot_ are constants after unrolling
+        if (r < 2 * FN) {
+            const int j = r >> 1, pl = r & 1;
+#define S3_F(SL, J, PL) if (slot_ == SL && j == J && pl == PL) { shalf8 v = s3_rd<SL * SLAB + J * 2048 + PL * 1024>(vW); if (PL) fw[set][J].lo = v; else fw[set][J].hi = v; }
+#define S3_FJ(SL, J) S3_F(SL, J, 0) S3_F(SL, J, 1)
+#define S3_FS(SL) S3_FJ(SL, 0) if constexpr (FN > 1) { S3_FJ(SL, 1) } if constexpr (FN > 2) { S3_FJ(SL, 2) S3_FJ(SL, 3) }
+            S3_FS(0) S3_FS(1) S3_FS(2) S3_FS(3)
+#undef S3_FS
+#undef S3_FJ
+#undef S3_F
+        } else {
+            const int i = (r - 2 * FN) >> 1, pl = (r - 2 * FN) & 1;
+            const unsigned ad = __builtin_amdgcn_ubfe(inv, 4 * i + 3, 1) * (DZ & 0xffffffu) + A0;
+#define S3_X(I) if constexpr (I < FM) { if (i == I) { if (pl) fx[set][I].lo = s3_rd<PLANE + I * 1024>(ad); else fx[set][I].hi = s3_rd<I * 1024>(ad); } }
+            S3_X(0) S3_X(1) S3_X(2) S3_X(3) S3_X(4) S3_X(5) S3_X(6) S3_X(7) S3_X(8) S3_X(9) S3_X(10) S3_X(11) S3_X(12) S3_X(13) S3_X(14) S3_X(15)
+#undef S3_X
+        }
+    };
+
+    // ---- prologue: patch 0, ring stages 0 .. 3
+    patch_dma(0, 0);
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_) ring_dma(s_, s_);
+    __builtin_amdgcn_sched_barrier(0);
+    s3_wait<2 * (NS - 1)>();                                    // patch 0 and stage 0 have landed
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    tap_setup(0, 0);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) read_one(0, r, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    s3_wait<2 * (NS - 2)>();                                    // ... stage 1 too, and the fragments of step 0
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    S3_STAMP(1);
+
+    int t = 0, c = 0;
+    // One K step.  The MFMAs come in 3 FM groups of FN (independent accumulators back to back); everything else sits in the gaps
+    // behind them, so the matrix pipe never waits for the wave's own bookkeeping: gap 0 = the DMA requests (ring stage kt + 4
+    // into the slot of stage kt, whose fragments were read during step kt - 1; with tap 0, the next chunk's patch), gap 1 = the
+    // addresses of the next step's pixel fragments, gaps 2 ... = that step's fragment reads, spread evenly
+    auto step = [&](auto sub_c, int kt) {
+        constexpr int SUB = decltype(sub_c)::value, CUR = SUB & 1, NXT = CUR ^ 1, SNEXT = (SUB + 1) & 3;
+        constexpr int NRS = NSLOT - 2;
+        const bool more = kt + NS < nk;
+        const bool pat = t == 0 && c + 1 < nc;
+        const int t1 = (t == 8) ? 0 : t + 1, c1 = (t == 8) ? c + 1 : c;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const shalf8& wa = p == 1 ? fw[CUR][j].lo : fw[CUR][j].hi;
+                    const shalf8& xb = p == 0 ? fx[CUR][i].lo : fx[CUR][i].hi;
+                    if (!S3_PROBE(1)) acc[i][j] = mfma_split(wa, xb, acc[i][j]);
+                }
+                const int sl = 3 * i + p;
+                if (sl == 0 && !S3_PROBE(4)) {
+                    if (more) ring_dma(kt + NS, SUB);
+                    if (pat) patch_dma(c + 1, (c + 1) & 1);
+                }
+                if (sl == 1 && !S3_PROBE(16)) tap_setup(t1, c1 & 1);               // (past the last step: a harmless read of stale LDS)
+#pragma unroll
+                for (int r = 0; r < NR; ++r)
+                    if (2 + (r * NRS) / NR == sl && !S3_PROBE(2)) read_one(NXT, r, SNEXT);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        // stage kt + 2 (read during step kt + 1) has landed; younger requests stay in flight: stages kt + 3 and kt + 4 and, through
+        // taps 0 .. 2, the patch of the next chunk (issued behind the ring stage of tap 0; vmcnt retires in order)
+        if (S3_PROBE(4)) __builtin_amdgcn_s_waitcnt(63 | (7 << 4) | (0 << 8) | (3 << 14));      // lgkmcnt(0) alone
+        else if (more) { if (t <= 2 && c + 1 < nc) s3_wait<4 + NPP>(); else s3_wait<4>(); }
+        else s3_wait<0>();
+        __builtin_amdgcn_sched_barrier(0);
+        if (!S3_PROBE(8)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        t = t1; c = c1;
+    };
+    for (int kt = 0; kt < nk; kt += 4) {
+        step(std::integral_constant<int, 0>{}, kt);
+        step(std::integral_constant<int, 1>{}, kt + 1);
+        step(std::integral_constant<int, 2>{}, kt + 2);
+        step(std::integral_constant<int, 3>{}, kt + 3);
+    }
+    S3_STAMP(2);
+
+    // ---- epilogue: D layout (lane = pixel, 4 consecutive channels per register group) -> folded BN, ReLU, split -> this wave's
+    // staging tiles (rows of 128 B, slot XOR-swizzled by (row >> 1) & 7; the ring is idle) -> 16-byte row stores
+    char* stg = smem + wave * 8192;
+    const int rsub = lane >> 3, pslot = lane & 7, sw = (lr >> 1) & 7;
+    const int nb = nt * 128 + wn * FN * 32;
+    float satmax = 0.f;
+    int blk = 0;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int mb = m0 + (wm * FM + i) * 32;
+        bsplit_t* orow[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = 8 * q + rsub, m = mb + r;
+            const int ls = pslot ^ ((r >> 1) & 7);
+            orow[q] = m < a.M ? a.out + (long long)m * a.ldo + nb + ls * 4 : (bsplit_t*)g_s3_dump + lane * 4;
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j, ++blk) {
+            char* tile = stg + (blk & 1) * 4096;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = nb + j * 32 + 8 * g + 4 * lh;
+                const f32x4 s4 = *(const f32x4*)(a.scale + n), b4 = *(const f32x4*)(a.shift + n);
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = fmaf(acc[i][j][4 * g + e], s4[e], b4[e]);
+                    if (a.relu) v[e] = fmaxf(v[e], 0.f);
+                }
+                unsigned long long oh, ol;
+                split4(v, oh, ol, satmax);
+                *(unsigned long long*)(tile + lr * 128 + (((2 * g) ^ sw) << 4) + 8 * lh) = oh;
+                *(unsigned long long*)(tile + lr * 128 + (((2 * g + 1) ^ sw) << 4) + 8 * lh) = ol;
+            }
+            u32x4 xr[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xr[q] = *(const u32x4*)(tile + q * 1024 + lane * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = mb + 8 * q + rsub;
+                *(u32x4*)(orow[q] + (m < a.M ? j * 32 : 0)) = xr[q];
+            }
+        }
+    }
+    split_flag(satmax > HMMR_SPLIT_MAX);
+    S3_STAMP(3);
+}
+
+template <int FM, int FN, int WGM, int WGN>
+int launch_s3(const S3Args& base, int cout, hipStream_t stream) {
+    S3Args a = base;
+    constexpr int BM = 32 * WGM * FM, NPP = (BM + 58 + 63) / 64;
+    constexpr int lds = S3_NS * S3_SLAB + 4 * (NPP * 64 + 32 * (FM - 1) + 16) * 32;
+    static_assert(lds <= 160 * 1024, "LDS");
+    a.tiles_n = cout / 128;
+    a.n_tiles = ((a.M + BM - 1) / BM) * a.tiles_n;
+    auto kern = conv3x3_stream_kernel<FM, FN, WGM, WGN>;
+    static DeviceOnce once;
+    if (const unsigned long long bit = once.due()) {
+        HMMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        once.mark(bit);
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)a.n_tiles), dim3(256), lds, stream, a);
+    HMMR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+// bytes of the filter stream of a 3x3 layer (packing.pack_conv3x3_stream): per 128 output channels, 9 cin / 16 K steps of 8 KB
+extern "C" size_t hmmr_conv3x3_stream_bytes(int cin, int cout) {
+    return (size_t)((cout + 127) / 128) * (size_t)(9 * (cin / 16)) * S3_SLAB;
+}
+
+// hmmr_conv_gemm with k_order = 2 (called from gemm_conv.hip, which has checked the descriptor's geometry)
+int hmmr_conv3x3_stream(const hmmr_conv_desc_t* d, hipStream_t stream) {
+    HMMR_REQUIRE(d->in_dtype == HMMR_F16X3 && d->out_dtype == HMMR_F16X3, "hmmr_conv_gemm: k_order 2 is built for split (f16x3) tensors");
+    HMMR_REQUIRE(d->cin % 64 == 0 && d->cout % 128 == 0 && d->win <= 28 && d->scale && d->shift,
+                 "hmmr_conv_gemm: k_order 2 needs cin %% 64 == 0, cout %% 128 == 0, an image at most 28 pixels wide and scale + shift");
+    S3Args a = {};
+    a.in = (const char*)d->in; a.wstream = (const char*)d->w; a.scale = d->scale; a.shift = d->shift;
+    a.out = (bsplit_t*)d->out; a.ldo = d->ldo;
+    a.M = d->n_img * d->ho * d->wo; a.H = d->hin; a.W = d->win; a.C = d->cin; a.nc = d->cin / 16;
+    a.relu = d->relu;
+    a.nt_stride = (long long)9 * a.nc * S3_SLAB;
+#ifdef HMMR_GEMM_PROBE
+    a.ts = (unsigned long long*)(((unsigned long long)(unsigned)hmmr_debug_state()->reserved[1] << 32) | (unsigned)hmmr_debug_state()->reserved[0]);
+#endif
+    switch (d->tile) {
+    case 0:
+    case 12: return launch_s3<7, 2, 2, 2>(a, d->cout, stream);       // 448 pixels
+    case 13: return launch_s3<4, 2, 2, 2>(a, d->cout, stream);       // 256
+    case 14: return launch_s3<8, 2, 2, 2>(a, d->cout, stream);       // 512
+    case 15: return launch_s3<6, 2, 2, 2>(a, d->cout, stream);       // 384
+    case 16: return launch_s3<5, 2, 2, 2>(a, d->cout, stream);       // 320
+    case 17: return launch_s3<4, 4, 4, 1>(a, d->cout, stream);       // 512, waves split the pixels
+    case 18: return launch_s3<3, 4, 4, 1>(a, d->cout, stream);       // 384
+    default: break;
+    }
+    hmmr_set_error("hmmr_conv_gemm: k_order 2 runs tiles 12 .. 18, not %d", d->tile);
+    return -1;
+}

@@ -1224,6 +1224,8 @@ static int ilog2_exact(int v) {
     return ((1 << l) == v) ? l : -1;
 }
 
+int hmmr_conv3x3_stream(const hmmr_conv_desc_t* d, hipStream_t stream);     // conv3x3_stream.hip
+
 extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
     HMMR_REQUIRE(d && d->in && d->w && (d->out || d->out2), "hmmr_conv_gemm: null operand");
     const int esz = d->in_dtype == HMMR_BF16 ? 2 : 4;
@@ -1289,12 +1291,13 @@ extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
     if (a.M <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     if (d->k_order) {
-        HMMR_REQUIRE(d->k_order == 1 && d->kh == 3 && d->kw == 3 && d->sy == 1 && d->sx == 1 && d->py == 1 && d->px == 1 &&
+        HMMR_REQUIRE((d->k_order == 1 || d->k_order == 2) && d->kh == 3 && d->kw == 3 && d->sy == 1 && d->sx == 1 && d->py == 1 && d->px == 1 &&
                      d->ho == d->hin && d->wo == d->win && d->in_px_stride == d->cin && d->in_row_stride == d->win * d->cin &&
                      d->in_img_stride == (int64_t)d->hin * d->win * d->cin && (d->cin * esz) % 128 == 0 &&
                      !d->res && !d->out2 && !d->out_b && !d->pro_scale && !d->in2 && d->split_k <= 1 && d->out && d->cout % 8 == 0,
                      "hmmr_conv_gemm: k_order 1 is for 3x3 / stride 1 / pad 1 convolutions over a dense NHWC tensor with "
                      "cin a multiple of the 128-byte K step and a scale/shift/relu epilogue (no res, out2, out_b, pro_scale, in2, split_k)");
+        if (d->k_order == 2) return hmmr_conv3x3_stream(d, s);
         const bool px3 = d->in_dtype == HMMR_F16X3 && d->out_dtype == HMMR_F16X3, pbf = d->in_dtype == HMMR_BF16 && d->out_dtype == HMMR_BF16;
         HMMR_REQUIRE(px3 || pbf, "hmmr_conv_gemm: k_order 1 is built for split (f16x3) and bf16 tensors");
         // library's choice: the 256x128 ping-pong tile (inside the network the tuner prefers it to tile 11 on ten layers of eleven,

@@ -23,7 +23,7 @@ FLAGS = {
     "FUSE_SC": ("1", "0 | 1 | all: shortcut + conv1 as one column-split GEMM (1: blocks 3-4)"),
     "PREACT_FIRST": ("0", "1: a block's first unit fuses its pre-activation too"),
     "FOLD_SC": ("", "0 | 1: conv shortcut folded into conv3's K (default: f16x3 only)"),
-    "PATCH_3X3": ("1", "0: the stride-1 3x3 layers of blocks 2-4 keep the tap-major K order and the im2col gather (f16x3; differs by fp32 accumulation rounding)"),
+    "PATCH_3X3": ("2", "the stride-1 3x3 layers of blocks 2-4 (f16x3): 2 = the one-wave-per-SIMD stream kernel (k_order 2), 1 = the 8-wave patch kernels (k_order 1), 0 = tap-major K order and the im2col gather; the three differ by fp32 accumulation rounding"),
     "UNIT_PAIR": ("1", "0 | 1 | block2 | block3: the stride-1 units of blocks 2-3 as register-resident unit pairs (csrc/unit_pair.hip; f16x3)"),
     "AUTOTUNE": ("1", "0: no per-layer tile tuning pass (shipped table / library heuristic only)"),
     "TILE_TABLE": ("1", "0: ignore the shipped tile tables (tile_tables.json), tune or fall back to the heuristic"),

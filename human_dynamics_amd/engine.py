@@ -108,7 +108,7 @@ class HmmrEngine(object):
         w = weights if weights is not None else {}
         self.rw = (packing.pack_resnet(w, self.dtype, self.store, fuse_preact_blocks=fuse, fuse_tail=tail, fuse_sc=fsc,
                                        fuse_preact_first=pfirst, fold_sc=fold,
-                                       patch_3x3=(devflags.get("PATCH_3X3") != "0") if patch_3x3 is None else patch_3x3,
+                                       patch_3x3=int(devflags.get("PATCH_3X3")) if patch_3x3 is None else patch_3x3,
                                        unit_pair=({"0": False, "1": True}.get(devflags.get("UNIT_PAIR"), devflags.get("UNIT_PAIR"))
                                                   if unit_pair is None else unit_pair))
                    if "resnet_v2_50/conv1/weights" in w else None)
@@ -202,7 +202,10 @@ class HmmrEngine(object):
     def _tile_for(lay, cand, cout, dtype=None):
         """hmmr_layer_t.tile for candidate `cand` on a layer with `cout` output columns: 0 (the library's choice) where
         the tile does not fit; a layer packed chunk-major (k_order 1, the 3x3 patch kernels) runs tiles 9 / 10, the patch
-        forms of 7 / 8, or 11, the 256x128 tile without a load segment."""
+        forms of 7 / 8, or 11, the 256x128 tile without a load segment; a k_order 2 layer (csrc/conv3x3_stream.hip) takes the
+        tuner's candidates as its own tile shapes 13 .. 18."""
+        if lay.k_order == 2:                                 # the stream kernel's tiles: 12 (the library's choice) .. 18
+            return {5: 13, 6: 14, 3: 15, 1: 16, 2: 17, 7: 18}.get(cand, cand if 12 <= cand <= 18 else 0)
         if lay.k_order:
             cand = {7: 9, 8: 10}.get(cand, cand)
             if cand == 11 and dtype == L.HMMR_BF16:          # the tile without a load segment is written for split operands
@@ -508,15 +511,22 @@ def conv_gemm(x, w_hwio, stride=1, pad=0, scale=None, shift=None, res=None, relu
     if second is not None:          # (x2 [n,h,w,cin2], w2 [1,1,cin2,cout]): a second 1x1 source appended along K (hmmr_conv_desc_t.in2)
         x2 = store.put(np.asarray(second[0], np.float32), packing.TORCH_DT[in_dtype])
         w_hwio = np.concatenate([np.asarray(w_hwio, np.float32), np.asarray(second[1], np.float32)], axis=2)
-    wp = packing.pack_conv_weight(np.asarray(w_hwio, np.float32), k_order, chunk=64 if in_dtype == L.HMMR_BF16 else 32)
-    if packing.TORCH_DT[in_dtype] is packing.SPLIT:     # as packing._layer: rows scaled by a power of two, undone by `scale`
+    wp = packing.pack_conv_weight(np.asarray(w_hwio, np.float32), k_order if k_order != 2 else 0, chunk=64 if in_dtype == L.HMMR_BF16 else 32)
+    if k_order == 2:                                    # the filter stream of csrc/conv3x3_stream.hip (as packing._layer_stream3x3)
+        k = packing.row_pow2(wp[:cout])
+        sc = np.ones(cout, np.float64) if scale is None else np.asarray(scale, np.float64)
+        scale = (sc * np.exp2(-k.astype(np.float64))).astype(np.float32)
+        shift = np.zeros(cout, np.float32) if shift is None else shift
+        wt = store.put_tensor(packing.pack_conv3x3_stream(np.asarray(w_hwio, np.float32), k))
+    elif packing.TORCH_DT[in_dtype] is packing.SPLIT:   # as packing._layer: rows scaled by a power of two, undone by `scale`
         k = packing.row_pow2(wp)
         wp = packing.scale_rows(wp, k)
         sc = np.ones(wp.shape[0], np.float64)
         if scale is not None:
             sc[:len(scale)] = np.asarray(scale, np.float64)
         scale = (sc * np.exp2(-k.astype(np.float64))).astype(np.float32)
-    wt = store.put(wp, packing.TORCH_DT[in_dtype])
+    if k_order != 2:
+        wt = store.put(wp, packing.TORCH_DT[in_dtype])
     ldo = (cout + 7) // 8 * 8
     out = packing.empty_act((n, ho, wo, ldo), out_dtype, dev, zero=True)
     d = L.ConvDesc()

@@ -120,6 +120,26 @@ def pack_frag_major(w_nk):
     return torch.stack([frag(hi), frag(lo)], dim=3).contiguous()   # [rb, kc, lane, 2, 8]
 
 
+def pack_conv3x3_stream(w_hwio, k=None):
+    """[3,3,cin,cout] -> fp16 [cout / 128][9 cin / 16][4][2 (hi, lo plane)][64 lanes][8]: the filter stream of a k_order 2 layer
+    (hmmr_conv_desc_t.k_order, csrc/conv3x3_stream.hip).  K step kt = (ci // 16) * 9 + ky * 3 + kx of a 128-channel tile is 8 KB:
+    row blocks 0 .. 3, each the MFMA A operand of 32 rows x 16 K as a hi and a lo plane (lane = 32 * (k half) + row, 8 halves =
+    W[ky, kx, 16 (ci // 16) + 8 half .. + 7, 128 tile + 32 block + row]), rows scaled by 2^k (row_pow2 of the rows)."""
+    w = np.asarray(w_hwio, np.float64)
+    kh, kw, cin, cout = w.shape
+    assert (kh, kw) == (3, 3) and cin % 16 == 0 and cout % 128 == 0, w.shape
+    if k is None:
+        k = row_pow2(w.reshape(9 * cin, cout).T)
+    t = torch.from_numpy((w * np.exp2(np.asarray(k, np.float64))).astype(np.float32))
+    hi = t.to(SPLIT_HALF)
+    lo = (t - hi.to(torch.float32)).to(SPLIT_HALF)
+
+    def frag(x):
+        x = x.reshape(9, cin // 16, 2, 8, cout // 128, 4, 32)            # tap, c16, half, e, tile, rb, row
+        return x.permute(4, 1, 0, 5, 2, 6, 3).reshape(cout // 128, 9 * (cin // 16), 4, 64, 8)
+    return torch.stack([frag(hi), frag(lo)], dim=3).contiguous()          # [tile, kt, rb, plane, lane, 8]
+
+
 def pair_is_a(i, na, ft):
     """fragment i of an iteration's ft = na + nb fragments is a conv3 fragment (csrc/unit_pair.hip: pair_is_a)"""
     return ((i + 1) * na) // ft > (i * na) // ft
@@ -217,16 +237,29 @@ def _layer(store, w_packed, dtype, scale=None, shift=None):
     return lay
 
 
+def _layer_stream3x3(store, w_hwio, scale, shift):
+    """hmmr_layer_t of a k_order 2 conv2 (f16x3): the filter stream instead of a matrix, the same row scaling as _layer."""
+    rows = pack_conv_weight(w_hwio)[:w_hwio.shape[3]]
+    k = row_pow2(rows)
+    lay = L.Layer()
+    lay.w = store.put_tensor(pack_conv3x3_stream(w_hwio, k)).data_ptr()
+    lay.scale = store.vec((np.asarray(scale, np.float64) * np.exp2(-k.astype(np.float64))).astype(np.float32)).data_ptr()
+    lay.shift = store.vec(shift).data_ptr()
+    lay.k_order = 2
+    return lay
+
+
 def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3", "block4"), fuse_tail=True,
-                fuse_sc=True, fuse_preact_first=False, fold_sc=None, patch_3x3=True, unit_pair=True):
+                fuse_sc=True, fuse_preact_first=False, fold_sc=None, patch_3x3=2, unit_pair=True):
     """fuse_preact_blocks: blocks whose units apply their `preact` BN+ReLU inside the operand
     staging of conv1/shortcut instead of reading a materialised preact tensor (csrc/resnet.hip;
     measured at batch 256: -4.5 % ResNet time with blocks 1-2 fused, neutral for blocks 3-4).
     fuse_tail: mark the units whose conv3 + add runs with the next unit's preact + conv1 as one
     hmmr_bottleneck_tail launch (bf16; the stride-1 units of block1 and block2).
-    patch_3x3 (f16x3: blocks 2-4; bf16: blocks 3-4): the stride-1 3x3 conv2 packed chunk-major (hmmr_conv_desc_t.k_order = 1) and run
-    by the patch kernel (csrc/gemm_conv.hip, tiles 9 / 10; 11 for f16x3).  Block 1 keeps the tap-major order its fused tails reproduce bit
-    for bit; the stride-2 units keep the im2col gather.
+    patch_3x3 (f16x3: blocks 2-4; bf16: blocks 3-4): the stride-1 3x3 conv2 out of an LDS-resident input patch.  2 (default): f16x3
+    layers get hmmr_conv_desc_t.k_order = 2, the filter stream of the one-wave-per-SIMD kernel (csrc/conv3x3_stream.hip, tiles 12 .. 18);
+    1 / True (and bf16 always): k_order = 1, chunk-major rows for the 8-wave patch kernels (csrc/gemm_conv.hip, tiles 9 / 10; 11 for f16x3).
+    Block 1 keeps the tap-major order its fused tails reproduce bit for bit; the stride-2 units keep the im2col gather.
     unit_pair (f16x3 only; True | "block2" | "block3" | False): the stride-1 units of blocks 2-3 run conv3 + add + the next
     unit's preact + conv1 as the register-resident unit pair of csrc/unit_pair.hip (one filter stream per unit); block3/unit_1
     then keeps its conv shortcut as a launch (shortcut + conv1 as one column-split GEMM) instead of folding it into conv3."""
@@ -263,8 +296,11 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
         #  must fit the 4 x 64 rows the 128x256 tile keeps in LDS.  ResNet-50 on 224 x 224 crops: W <= 28)
         if kord and 128 + 2 * (224 // {64: 4, 128: 8, 256: 16, 512: 32}[base]) + 4 > 4 * 64:
             kord = 0
-        u.conv2 = _layer(store, pack_conv_weight(w[scope + "/conv2/weights"], kord, chunk=bke), dtype, s, b)
-        u.conv2.k_order = kord
+        if kord and dtype == L.HMMR_F16X3 and patch_3x3 == 2 and patch_3x3 is not True:
+            u.conv2 = _layer_stream3x3(store, np.asarray(w[scope + "/conv2/weights"], np.float32), s, b)
+        else:
+            u.conv2 = _layer(store, pack_conv_weight(w[scope + "/conv2/weights"], kord, chunk=bke), dtype, s, b)
+            u.conv2.k_order = kord
         u.conv3 = _layer(store, pack_conv_weight(w[scope + "/conv3/weights"]), dtype,
                          shift=w[scope + "/conv3/biases"])
         if has_sc:

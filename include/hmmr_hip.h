@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HMMR_ABI_VERSION 14      /* 14: hmmr_tail_desc_t.pair_stream / c_xp, hmmr_resnet_unit_t.pair_stream (the register-resident unit pair of blocks 2-3), hmmr_run_flags; 13: hmmr_conv_desc_t.batch (grouped launches); 12: k_order = 1, 3x3 SAME convolutions out of an LDS-resident input patch (tiles 9, 10, 11) */
+#define HMMR_ABI_VERSION 15      /* 15: k_order = 2 (the one-wave-per-SIMD 3x3 stream kernel, tiles 12 .. 18), hmmr_conv3x3_stream_bytes; 14: hmmr_tail_desc_t.pair_stream / c_xp, hmmr_resnet_unit_t.pair_stream (the register-resident unit pair of blocks 2-3), hmmr_run_flags; 13: hmmr_conv_desc_t.batch (grouped launches); 12: k_order = 1, 3x3 SAME convolutions out of an LDS-resident input patch (tiles 9, 10, 11) */
 
 /* HMMR_F16X3: "split" tensors -- every group of 8 consecutive channels is 32 bytes, [hi x8][lo x8] with
  * hi = fp16(x), lo = fp16(x - hi), x clamped to +-65504 (4 bytes per element, 22 mantissa bits while lo is a normal
@@ -114,7 +114,10 @@ typedef struct {
                               8-wave tiles: 5 = 128x128, 6 = 128x64 (two workgroups per CU, 2 LDS stages);
                               7 = 256x128, 8 = 128x256 (one workgroup per CU: 3-stage LDS ring, ping-pong wave groups);
                               k_order 1 only: 9 = 256x128, 10 = 128x256 (the same structure, A operand out of an input patch),
-                              11 = 256x128 without a load segment (two fragment sets per wave, one barrier per K step) */
+                              11 = 256x128 without a load segment (two fragment sets per wave, one barrier per K step);
+                              k_order 2 only (csrc/conv3x3_stream.hip; 4 waves, one per SIMD, 128 output channels per tile): 12 = 448 pixels
+                              (wave tile 7 x 2 accumulators of 32 x 32), 13 = 256 (4 x 2), 14 = 512 (8 x 2), 15 = 384 (6 x 2), 16 = 320 (5 x 2);
+                              17 = 512, 18 = 384 pixels with the waves splitting the pixels (4 x 4 / 3 x 4) */
     /* split-K (for GEMMs with few output tiles and a long K): split_k > 1 slices K into that many
      * contiguous ranges, each range leaves an fp32 partial plane in `ws`, and a second launch adds the
      * planes IN SLICE ORDER and applies the epilogue.  The caller fixes split_k per layer (never from
@@ -148,7 +151,12 @@ typedef struct {
      * fragment sets (out-of-image taps read a zero row), so an input
      * line leaves L2 once per chunk instead of once per tap (tiles 9 / 10 / 11; scale/shift/relu epilogue only: no res,
      * out2, out_b, pro_scale, in2, split_k).  The sum over k is the same set of products in another order: results
-     * differ from k_order 0 by fp32 rounding of the accumulation only. */
+     * differ from k_order 0 by fp32 rounding of the accumulation only.
+     * 2: `w` is not a matrix but the FILTER STREAM of packing.pack_conv3x3_stream (hmmr_conv3x3_stream_bytes(cin, cout) bytes):
+     * per 128 output channels, K steps kt = (ci / 16) * 9 + ky*3 + kx of 8 KB = 4 row blocks x (hi plane | lo plane) of MFMA
+     * A-operand fragments (lane = 32 * (k half) + row; 8 halves = W[row][16 (ci / 16) + 8 half .. + 7] of that tap), rows scaled
+     * like every split filter bank.  Same convolutions and epilogue as k_order 1, split (f16x3) tensors only, cin % 64 == 0,
+     * cout % 128 == 0, win <= 28; tiles 12 .. 18 (csrc/conv3x3_stream.hip).  Every tile produces the same bits. */
     int k_order;
     /* grouped launch: `batch` > 1 runs that many problems of this one shape as ONE launch (grid z); problem z reads and
      * writes at these BYTE offsets (multiples of 16, negative allowed) from problem 0: `in`, `w`, `out` / `out2`, `res`,
@@ -266,6 +274,8 @@ typedef struct {
     int c_xp;
 } hmmr_tail_desc_t;
 size_t hmmr_pair_stream_bytes(int kc3, int depth, int n2);
+/* bytes of the filter stream of a k_order 2 layer: (cout / 128) x 9 (cin / 16) K steps of 8 KB */
+size_t hmmr_conv3x3_stream_bytes(int cin, int cout);
 int hmmr_bottleneck_tail(const hmmr_tail_desc_t* d, void* stream);
 
 size_t hmmr_resnet50_workspace_bytes(int n, int dtype);
