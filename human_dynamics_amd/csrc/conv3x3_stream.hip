@@ -34,7 +34,7 @@ namespace {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-__device__ u32x4 g_s3_dump[64];            // 1 KB: where the stores of rows beyond M go
+__device__ u32x4 g_s3_dump[64 + 32];       // where the stores of rows beyond M go (a lane's 16 bytes, up to 4 row blocks of 128 B further)
 
 struct S3Args {
     const char* in;                         // [M][C] split rows
@@ -48,7 +48,7 @@ struct S3Args {
 };
 
 // Development build only (tools/s3_probe_build.sh): drop the MFMAs (1), the fragment reads (2), the DMA requests and their waits (4),
-// the loop's barrier (8) or the per-step address arithmetic (16) at COMPILE time, and stamp s_memtime around the phases.  Results are
+// the loop's barrier (8), the per-step address arithmetic (16), the waits on vector memory alone (32) or the patch requests alone (64) at COMPILE time, and stamp s_memtime around the phases.  Results are
 // garbage in those modes; the product build compiles the switches away.
 #ifndef S3_PROBE_BITS
 #define S3_PROBE_BITS 0
@@ -74,9 +74,10 @@ template <int OFF> __device__ __forceinline__ shalf8 s3_rd(unsigned addr) {
 
 struct xfrag { shalf8 hi, lo; };            // MFMA B-operand fragment: 32 pixels x 16 channels
 
-constexpr int S3_NS = 4;                    // ring slabs
+constexpr int S3_NS = 6;                    // ring slabs
 constexpr int S3_SLAB = 8192;               // one K step of a 128-channel tile: 4 row blocks x (hi 1 KB | lo 1 KB)
 
+template <int V> using s3_ic = std::integral_constant<int, V>;
 
 // FM x FN accumulators per wave, WGM x WGN waves: the tile is 32 WGM FM pixels x 128 channels (WGN FN = 4)
 template <int FM, int FN, int WGM, int WGN>
@@ -85,12 +86,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_stream_kernel(const S3Args a) 
     constexpr int R = WGM * FM, BM = 32 * R;
     constexpr int NPP = (BM + 58 + 63) / 64;                    // 64-row pieces of a patch (W <= 28: BM + 2 W + 2 rows)
     constexpr int NS = S3_NS, SLAB = S3_SLAB, RING = NS * SLAB;
-    constexpr int ZROWS = 32 * (FM - 1) + 16;                   // zero rows behind the data rows of every plane
-    constexpr int PLANE = (NPP * 64 + ZROWS) * 32, PBUF = 2 * PLANE;
-    constexpr int NR = 2 * (FM + FN), NSLOT = 3 * FM;
-    static_assert(PLANE + 1024 * (FM - 1) + 16 < 65536, "instruction offsets");
+    constexpr int ZROWS = 32 * (FM - 1) + 16;                   // zero rows behind the data rows of every quarter plane
+    constexpr int QP = (NPP * 64 + ZROWS) * 16, PBUF = 4 * QP;  // quarter plane: 16 bytes per row; [hi k0][hi k1][lo k0][lo k1]
+    constexpr int NR = 2 * (FM + FN), NG = 3 * FM * FN;         // fragment reads and MFMAs (= gaps) of a step
+    static_assert(2 * QP + 512 * (FM - 1) + 16 < 65536 && QP % 256 == 0 && RING % 256 == 0, "instruction offsets, bank arithmetic");
+    static_assert(NR <= NG - 4, "one fragment read per gap");
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(256))) char smem[];
     S3_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -104,31 +106,21 @@ __global__ __launch_bounds__(256, 1) void conv3x3_stream_kernel(const S3Args a) 
     const int wm = wave / WGN, wn = wave - wm * WGN;
     const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;
 
-    // ---- zero rows of the four planes (never written again)
-    for (int i = tid; i < 4 * ZROWS * 2; i += 256) {
-        const int pl = i / (ZROWS * 2), o = i - pl * (ZROWS * 2);
-        *(u32x4*)(smem + RING + pl * PLANE + NPP * 64 * 32 + o * 16) = u32x4{0u, 0u, 0u, 0u};
-    }
-
-    // ---- patch DMA: piece q of this wave = plane wave >> 1, rows 64 q + 32 (wave & 1) .. + 31, two lanes per row.  Rows outside
-    // the tensor read its first / last pixel instead: only out-of-image taps (which read a zero row) and pixels >= M ever see them
-    const int pplane = wave >> 1;
+    // ---- patch DMA: piece q of this wave = quarter plane `wave` (LDS order hi k0, hi k1, lo k0, lo k1 = bytes 0, 32, 16, 48 of a
+    // pixel's 64-byte chunk), rows 64 q .. 64 q + 63, one lane per row.  Rows outside the tensor read its first / last pixel
+    // instead: only out-of-image taps (which read a zero row) and pixels >= M ever see them
     const char* pptr[NPP];
 #pragma unroll
     for (int q = 0; q < NPP; ++q) {
-        const int r = 64 * q + 32 * (wave & 1) + (lane >> 1);
-        int px = base + r;
+        int px = base + 64 * q + lane;
         px = px < 0 ? 0 : (px >= a.M ? a.M - 1 : px);
-        const int half = (lane & 1) ^ ((r >> 3) & 1);
-        pptr[q] = a.in + ((long long)px * a.C) * 4 + half * 32 + pplane * 16;
+        pptr[q] = a.in + ((long long)px * a.C) * 4 + (wave & 1) * 32 + (wave >> 1) * 16;
     }
-    auto patch_dma = [&](int c, int buf) {
-        char* dst = smem + RING + buf * PBUF + pplane * PLANE + (wave & 1) * 1024;
-#pragma unroll
-        for (int q = 0; q < NPP; ++q)
-            __builtin_amdgcn_global_load_lds((gptr_t)(pptr[q] + c * 64), (lptr_t)(dst + q * 2048), 16, 0, 0);
+    auto patch_piece = [&](int q, int c, int buf) {             // q is a constant after unrolling
+        char* dst = smem + RING + buf * PBUF + wave * QP;
+        __builtin_amdgcn_global_load_lds((gptr_t)(pptr[q] + c * 64), (lptr_t)(dst + q * 1024), 16, 0, 0);
     };
-    // ---- filter stream: K step s -> ring slot s & 3; each wave moves a quarter (one row block: hi and lo plane)
+    // ---- filter stream: K step s -> ring slot s % 6; each wave moves a quarter (one row block: hi and lo plane)
     const char* gw = a.wstream + (long long)nt * a.nt_stride + wave * 2048 + lane * 16;
     auto ring_dma = [&](int s, int slot) {
         const char* src = gw + (long long)s * SLAB;
@@ -136,14 +128,31 @@ __global__ __launch_bounds__(256, 1) void conv3x3_stream_kernel(const S3Args a) 
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);          // (the instruction offset moves both addresses)
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 1024, 0);
     };
+#pragma unroll
+    for (int q = 0; q < NPP; ++q) patch_piece(q, 0, 0);
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_) ring_dma(s_, s_);
 
-    // ---- image borders: nibble i of `eb` = this lane's pixel of row block i lies in the top / bottom row, left / right column
-    unsigned eb = 0;
+    // ---- zero rows of the eight quarter planes (never written again)
+    for (int i = tid; i < 8 * ZROWS; i += 256) {
+        const int pl = i / ZROWS, o = i - pl * ZROWS;
+        *(u32x4*)(smem + RING + pl * QP + NPP * 64 * 16 + o * 16) = u32x4{0u, 0u, 0u, 0u};
+    }
+    // ---- this tile's folded BN constants (128 scales, 128 shifts) behind the patch buffers: the epilogue reads them from LDS
+    {
+        float* cst = (float*)(smem + RING + 2 * PBUF);
+        cst[tid] = tid < 128 ? a.scale[nt * 128 + tid] : a.shift[nt * 128 + tid - 128];
+    }
+    // ---- wave masks (32 bits: both k halves of a wave hold the same 32 pixels) of the pixels on an image border, per row block
+    unsigned mtop[FM], mbot[FM], mlef[FM], mrig[FM];
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int m = m0 + (wm * FM + i) * 32 + lr;
         const int rem = m % HW, y = rem / W, x = rem - y * W;
-        eb |= (unsigned)((y == 0) | ((y == a.H - 1) << 1) | ((x == 0) << 2) | ((x == W - 1) << 3)) << (4 * i);
+        mtop[i] = (unsigned)__builtin_amdgcn_ballot_w64(y == 0);
+        mbot[i] = (unsigned)__builtin_amdgcn_ballot_w64(y == a.H - 1);
+        mlef[i] = (unsigned)__builtin_amdgcn_ballot_w64(x == 0);
+        mrig[i] = (unsigned)__builtin_amdgcn_ballot_w64(x == W - 1);
     }
 
     f32x16 acc[FM][FN];
@@ -157,118 +166,127 @@ __global__ __launch_bounds__(256, 1) void conv3x3_stream_kernel(const S3Args a) 
         }
 
     const unsigned vW = lds0 + wn * FN * 2048 + lane * 16;      // filter fragments: + slot * SLAB + j * 2048 (+ 1024: lo plane)
-    const int rb0 = wm * FM * 32 + lr;                          // patch row of tap (0, 0) of this lane's pixel in row block 0
+    // pixel fragments: row (rb0 + tap shift) of quarter plane lh (hi; the lo plane 2 QP behind it), row block i 512 bytes further
+    const unsigned A00[2] = {lds0 + RING + lh * QP + (wm * FM * 32 + lr) * 16, lds0 + RING + PBUF + lh * QP + (wm * FM * 32 + lr) * 16};
+    const unsigned ZC[2] = {lds0 + RING + lh * QP + NPP * 64 * 16, lds0 + RING + PBUF + lh * QP + NPP * 64 * 16};
+    const int W16 = 16 * W;
     xfrag fx[2][FM];
     wfrag fw[2][FN];
+    unsigned A0 = 0, Zb = 0, adcur = 0;
 
-    // addresses of the pixel fragments of (tap t_, patch buffer buf_): A0 = the tap's own row, A0 + DZ = the zero row of its bank;
-    // bit 4 i + 3 of `inv`: the tap of this lane's pixel of row block i lies outside its image (SAME padding)
-    unsigned A0 = 0, DZ = 0, inv = 0;
-    auto tap_setup = [&](int t_, int buf_) {
-        const int ky = (t_ * 11) >> 5, kx = t_ - 3 * ky;
-        const int rowp = rb0 + ky * W + kx;
-        const unsigned slot = (unsigned)((lh ^ (rowp >> 3)) & 1) << 4;
-        A0 = lds0 + RING + buf_ * PBUF + rowp * 32 + slot;
-        DZ = (NPP * 64 + (rowp & 15) - rowp) * 32;
-        // nibble (top, bottom, left, right) of the borders tap t_ leaves the image over: ky == 0, ky == 2, kx == 0, kx == 2
-        const unsigned sel = (unsigned)((0xA26804915ull >> (4 * t_)) & 15u) * 0x11111111u;
-        unsigned v = eb & sel;
-        v |= v << 1;
-        v |= v << 2;
-        inv = v;
-    };
-    // read number r of a step's NR fragment halves into set `set` (filters first); slot_ = the ring slot of that step
-    auto read_one = [&](int set, int r, int slot_) {            // set, r, slot_ are constants after unrolling
+    // read number r of the NR fragment halves of the step with tap TAP_ (filters first) into set `set`; slot_ = that step's ring slot
+    auto read_one = [&](auto tap_c, int set, int r, int slot_) {           // set, r, slot_ are constants after unrolling
+        constexpr int TAP_ = decltype(tap_c)::value, KY = TAP_ / 3, KX = TAP_ % 3;
         if (r < 2 * FN) {
             const int j = r >> 1, pl = r & 1;
 #define S3_F(SL, J, PL) if (slot_ == SL && j == J && pl == PL) { shalf8 v = s3_rd<SL * SLAB + J * 2048 + PL * 1024>(vW); if (PL) fw[set][J].lo = v; else fw[set][J].hi = v; }
 #define S3_FJ(SL, J) S3_F(SL, J, 0) S3_F(SL, J, 1)
 #define S3_FS(SL) S3_FJ(SL, 0) if constexpr (FN > 1) { S3_FJ(SL, 1) } if constexpr (FN > 2) { S3_FJ(SL, 2) S3_FJ(SL, 3) }
-            S3_FS(0) S3_FS(1) S3_FS(2) S3_FS(3)
+            S3_FS(0) S3_FS(1) S3_FS(2) S3_FS(3) S3_FS(4) S3_FS(5)
 #undef S3_FS
 #undef S3_FJ
 #undef S3_F
         } else {
             const int i = (r - 2 * FN) >> 1, pl = (r - 2 * FN) & 1;
-            const unsigned ad = __builtin_amdgcn_ubfe(inv, 4 * i + 3, 1) * (DZ & 0xffffffu) + A0;
-#define S3_X(I) if constexpr (I < FM) { if (i == I) { if (pl) fx[set][I].lo = s3_rd<PLANE + I * 1024>(ad); else fx[set][I].hi = s3_rd<I * 1024>(ad); } }
+            if (pl == 0) {
+                // SAME padding: lanes whose tap leaves the image read the zero row of their bank
+                if (KY == 1 && KX == 1) adcur = A0;
+                else {
+                    const int ii = i < FM ? i : 0;
+                    const unsigned my = KY == 0 ? mtop[ii] : (KY == 2 ? mbot[ii] : 0u);
+                    const unsigned mx = KX == 0 ? mlef[ii] : (KX == 2 ? mrig[ii] : 0u);
+                    asm volatile("s_mov_b32 vcc_lo, %1\n\ts_mov_b32 vcc_hi, %1\n\tv_cndmask_b32 %0, %2, %3, vcc"
+                                 : "=v"(adcur) : "s"(my | mx), "v"(A0), "v"(Zb) : "vcc");
+                }
+            }
+#define S3_X(I) if constexpr (I < FM) { if (i == I) { if (pl) fx[set][I].lo = s3_rd<2 * QP + I * 512>(adcur); else fx[set][I].hi = s3_rd<I * 512>(adcur); } }
             S3_X(0) S3_X(1) S3_X(2) S3_X(3) S3_X(4) S3_X(5) S3_X(6) S3_X(7) S3_X(8) S3_X(9) S3_X(10) S3_X(11) S3_X(12) S3_X(13) S3_X(14) S3_X(15)
 #undef S3_X
         }
     };
+    auto tap_setup = [&](auto tap_c, int buf_) {                // buf_ is a constant after unrolling
+        constexpr int TAP_ = decltype(tap_c)::value, KY = TAP_ / 3, KX = TAP_ % 3;
+        A0 = A00[buf_] + (unsigned)(KY * W16 + KX * 16);
+        Zb = (A0 & 0xF0u) | ZC[buf_];                           // (every base is a multiple of 256: bits 4-7 are the row's)
+    };
 
-    // ---- prologue: patch 0, ring stages 0 .. 3
-    patch_dma(0, 0);
-#pragma unroll
-    for (int s_ = 0; s_ < NS; ++s_) ring_dma(s_, s_);
+    // ---- prologue: patch 0 and stage 0, then the fragments of step 0
     __builtin_amdgcn_sched_barrier(0);
-    s3_wait<2 * (NS - 1)>();                                    // patch 0 and stage 0 have landed
+    s3_wait<2 * (NS - 1)>();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    tap_setup(0, 0);
+    tap_setup(s3_ic<0>{}, 0);
 #pragma unroll
-    for (int r = 0; r < NR; ++r) read_one(0, r, 0);
+    for (int r = 0; r < NR; ++r) read_one(s3_ic<0>{}, 0, r, 0);
     __builtin_amdgcn_sched_barrier(0);
     s3_wait<2 * (NS - 2)>();                                    // ... stage 1 too, and the fragments of step 0
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     S3_STAMP(1);
 
-    int t = 0, c = 0;
-    // One K step.  The MFMAs come in 3 FM groups of FN (independent accumulators back to back); everything else sits in the gaps
-    // behind them, so the matrix pipe never waits for the wave's own bookkeeping: gap 0 = the DMA requests (ring stage kt + 4
-    // into the slot of stage kt, whose fragments were read during step kt - 1; with tap 0, the next chunk's patch), gap 1 = the
-    // addresses of the next step's pixel fragments, gaps 2 ... = that step's fragment reads, spread evenly
-    auto step = [&](auto sub_c, int kt) {
-        constexpr int SUB = decltype(sub_c)::value, CUR = SUB & 1, NXT = CUR ^ 1, SNEXT = (SUB + 1) & 3;
-        constexpr int NRS = NSLOT - 2;
+    // One K step, S = its position in a pair of chunks (18 steps: tap S % 9, ring slot S % 6, fragment set S & 1, patch buffer S / 9).
+    // Every MFMA is followed by a gap that holds at most a few other instructions, so the matrix pipe never waits for the wave's
+    // own bookkeeping: gap 0 = the ring's DMA (stage kt + 6 into the slot of stage kt, whose fragments were read during step
+    // kt - 1), gap 1 = the addresses of the next step's pixel fragments, gaps 2 ... = that step's fragment reads, spread evenly;
+    // with tap 0, the patch of the next chunk goes out one piece per gap
+    auto step = [&](auto s_c, int kt, int c) {
+        constexpr int S = decltype(s_c)::value, TAP = S % 9, SUB = S % NS, CUR = S & 1, NXT = CUR ^ 1;
+        constexpr int S1 = (S + 1) % 18, TAP1 = S1 % 9, SNEXT = S1 % NS, BUF1 = S1 / 9, BUFP = (S / 9) ^ 1;
         const bool more = kt + NS < nk;
-        const bool pat = t == 0 && c + 1 < nc;
-        const int t1 = (t == 8) ? 0 : t + 1, c1 = (t == 8) ? c + 1 : c;
+        const bool pat = TAP == 0 && c + 1 < nc;
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
+            for (int p = 0; p < 3; ++p)
 #pragma unroll
                 for (int j = 0; j < FN; ++j) {
                     const shalf8& wa = p == 1 ? fw[CUR][j].lo : fw[CUR][j].hi;
                     const shalf8& xb = p == 0 ? fx[CUR][i].lo : fx[CUR][i].hi;
                     if (!S3_PROBE(1)) acc[i][j] = mfma_split(wa, xb, acc[i][j]);
-                }
-                const int sl = 3 * i + p;
-                if (sl == 0 && !S3_PROBE(4)) {
-                    if (more) ring_dma(kt + NS, SUB);
-                    if (pat) patch_dma(c + 1, (c + 1) & 1);
-                }
-                if (sl == 1 && !S3_PROBE(16)) tap_setup(t1, c1 & 1);               // (past the last step: a harmless read of stale LDS)
+                    const int g = (3 * i + p) * FN + j;
+                    if (g == 0 && more && !S3_PROBE(4)) ring_dma(kt + NS, SUB);
+                    if (g == 1 && !S3_PROBE(16)) tap_setup(s3_ic<TAP1>{}, BUF1);           // (past the last step: a harmless read of stale LDS)
+                    if (TAP == 0 && g >= 2 && g < 2 + NPP && pat && !S3_PROBE(4) && !S3_PROBE(64)) patch_piece(g - 2 < NPP ? g - 2 : 0, c + 1, BUFP);
 #pragma unroll
-                for (int r = 0; r < NR; ++r)
-                    if (2 + (r * NRS) / NR == sl && !S3_PROBE(2)) read_one(NXT, r, SNEXT);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        // stage kt + 2 (read during step kt + 1) has landed; younger requests stay in flight: stages kt + 3 and kt + 4 and, through
-        // taps 0 .. 2, the patch of the next chunk (issued behind the ring stage of tap 0; vmcnt retires in order)
-        if (S3_PROBE(4)) __builtin_amdgcn_s_waitcnt(63 | (7 << 4) | (0 << 8) | (3 << 14));      // lgkmcnt(0) alone
-        else if (more) { if (t <= 2 && c + 1 < nc) s3_wait<4 + NPP>(); else s3_wait<4>(); }
+                    for (int r = 0; r < NR; ++r)
+                        if (2 + (r * (NG - 4)) / NR == g && !S3_PROBE(2)) read_one(s3_ic<TAP1>{}, NXT, r, SNEXT);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        // stage kt + 2 (read during step kt + 1) has landed; younger requests stay in flight: stages kt + 3 .. kt + 6 and, through
+        // taps 0 .. 4, the patch of the next chunk (issued behind the ring stage of tap 0; vmcnt retires in order)
+        if (S3_PROBE(4) || S3_PROBE(32)) __builtin_amdgcn_s_waitcnt(63 | (7 << 4) | (0 << 8) | (3 << 14));      // lgkmcnt(0) alone
+        else if (more) { if (TAP <= 4 && c + 1 < nc && !S3_PROBE(64)) s3_wait<2 * (NS - 2) + NPP>(); else s3_wait<2 * (NS - 2)>(); }
         else s3_wait<0>();
         __builtin_amdgcn_sched_barrier(0);
         if (!S3_PROBE(8)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        t = t1; c = c1;
     };
-    for (int kt = 0; kt < nk; kt += 4) {
-        step(std::integral_constant<int, 0>{}, kt);
-        step(std::integral_constant<int, 1>{}, kt + 1);
-        step(std::integral_constant<int, 2>{}, kt + 2);
-        step(std::integral_constant<int, 3>{}, kt + 3);
-    }
+    auto chunk_pair = [&](int kt0, int c0, auto... S) { (step(S, kt0 + decltype(S)::value, c0 + decltype(S)::value / 9), ...); };
+    for (int c0 = 0; c0 < nc; c0 += 2)
+        chunk_pair(18 * (c0 >> 1), c0, s3_ic<0>{}, s3_ic<1>{}, s3_ic<2>{}, s3_ic<3>{}, s3_ic<4>{}, s3_ic<5>{}, s3_ic<6>{}, s3_ic<7>{}, s3_ic<8>{},
+                   s3_ic<9>{}, s3_ic<10>{}, s3_ic<11>{}, s3_ic<12>{}, s3_ic<13>{}, s3_ic<14>{}, s3_ic<15>{}, s3_ic<16>{}, s3_ic<17>{});
     S3_STAMP(2);
 
     // ---- epilogue: D layout (lane = pixel, 4 consecutive channels per register group) -> folded BN, ReLU, split -> this wave's
-    // staging tiles (rows of 128 B, slot XOR-swizzled by (row >> 1) & 7; the ring is idle) -> 16-byte row stores
+    // staging tiles (rows of 128 B, slot XOR-swizzled by (row >> 1) & 7; the ring is idle) -> 16-byte row stores.  One wave per
+    // SIMD: every instruction here is exposed, so the arithmetic is 4.5 instructions per value -- fma, one med3 (ReLU and the
+    // fp16 clamp together), half a packed convert for the hi halves, one v_fma_mix per lo half (c - hi, rounded to fp16, written
+    // straight into its half of the pair), half a max3 for the saturation flag
     char* stg = smem + wave * 8192;
     const int rsub = lane >> 3, pslot = lane & 7, sw = (lr >> 1) & 7;
     const int nb = nt * 128 + wn * FN * 32;
+    const float lo_clamp = a.relu ? 0.f : -HMMR_SPLIT_MAX;
+    f32x4 s4[FN][4], b4[FN][4];
+    {
+        const float* cst = (const float*)(smem + RING + 2 * PBUF) + wn * FN * 32 + 4 * lh;
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                s4[j][g] = *(const f32x4*)(cst + j * 32 + 8 * g);
+                b4[j][g] = *(const f32x4*)(cst + 128 + j * 32 + 8 * g);
+            }
+    }
     float satmax = 0.f;
     int blk = 0;
 #pragma unroll
@@ -286,16 +304,23 @@ __global__ __launch_bounds__(256, 1) void conv3x3_stream_kernel(const S3Args a) 
             char* tile = stg + (blk & 1) * 4096;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int n = nb + j * 32 + 8 * g + 4 * lh;
-                const f32x4 s4 = *(const f32x4*)(a.scale + n), b4 = *(const f32x4*)(a.shift + n);
-                float v[4];
+                float c[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    v[e] = fmaf(acc[i][j][4 * g + e], s4[e], b4[e]);
-                    if (a.relu) v[e] = fmaxf(v[e], 0.f);
+                    const float v = fmaf(acc[i][j][4 * g + e], s4[j][g][e], b4[j][g][e]);
+                    satmax = __builtin_fmaxf(satmax, __builtin_fabsf(v));
+                    c[e] = __builtin_amdgcn_fmed3f(v, lo_clamp, HMMR_SPLIT_MAX);
                 }
-                unsigned long long oh, ol;
-                split4(v, oh, ol, satmax);
+                const unsigned h01 = __builtin_bit_cast(unsigned, shalf2{(shalf_t)c[0], (shalf_t)c[1]});
+                const unsigned h23 = __builtin_bit_cast(unsigned, shalf2{(shalf_t)c[2], (shalf_t)c[3]});
+                // lo = fp16(c - hi): c - hi is exact in fp32, so the mixed-precision fma rounds once, like the cast of split4 (common.h)
+                unsigned l01, l23;
+                asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l01) : "v"(h01), "v"(c[0]));
+                asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l01) : "v"(h01), "v"(c[1]));
+                asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l23) : "v"(h23), "v"(c[2]));
+                asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l23) : "v"(h23), "v"(c[3]));
+                const unsigned long long oh = (unsigned long long)h01 | ((unsigned long long)h23 << 32);
+                const unsigned long long ol = (unsigned long long)l01 | ((unsigned long long)l23 << 32);
                 *(unsigned long long*)(tile + lr * 128 + (((2 * g) ^ sw) << 4) + 8 * lh) = oh;
                 *(unsigned long long*)(tile + lr * 128 + (((2 * g + 1) ^ sw) << 4) + 8 * lh) = ol;
             }
@@ -303,10 +328,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_stream_kernel(const S3Args a) 
 #pragma unroll
             for (int q = 0; q < 4; ++q) xr[q] = *(const u32x4*)(tile + q * 1024 + lane * 16);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int m = mb + 8 * q + rsub;
-                *(u32x4*)(orow[q] + (m < a.M ? j * 32 : 0)) = xr[q];
-            }
+            for (int q = 0; q < 4; ++q) *(u32x4*)(orow[q] + j * 32) = xr[q];
         }
     }
     split_flag(satmax > HMMR_SPLIT_MAX);
@@ -317,7 +339,7 @@ template <int FM, int FN, int WGM, int WGN>
 int launch_s3(const S3Args& base, int cout, hipStream_t stream) {
     S3Args a = base;
     constexpr int BM = 32 * WGM * FM, NPP = (BM + 58 + 63) / 64;
-    constexpr int lds = S3_NS * S3_SLAB + 4 * (NPP * 64 + 32 * (FM - 1) + 16) * 32;
+    constexpr int lds = S3_NS * S3_SLAB + 8 * (NPP * 64 + 32 * (FM - 1) + 16) * 16 + 1024;
     static_assert(lds <= 160 * 1024, "LDS");
     a.tiles_n = cout / 128;
     a.n_tiles = ((a.M + BM - 1) / BM) * a.tiles_n;
@@ -342,8 +364,8 @@ extern "C" size_t hmmr_conv3x3_stream_bytes(int cin, int cout) {
 // hmmr_conv_gemm with k_order = 2 (called from gemm_conv.hip, which has checked the descriptor's geometry)
 int hmmr_conv3x3_stream(const hmmr_conv_desc_t* d, hipStream_t stream) {
     HMMR_REQUIRE(d->in_dtype == HMMR_F16X3 && d->out_dtype == HMMR_F16X3, "hmmr_conv_gemm: k_order 2 is built for split (f16x3) tensors");
-    HMMR_REQUIRE(d->cin % 64 == 0 && d->cout % 128 == 0 && d->win <= 28 && d->scale && d->shift,
-                 "hmmr_conv_gemm: k_order 2 needs cin %% 64 == 0, cout %% 128 == 0, an image at most 28 pixels wide and scale + shift");
+    HMMR_REQUIRE(d->cin % 32 == 0 && d->cout % 128 == 0 && d->win <= 28 && d->scale && d->shift,
+                 "hmmr_conv_gemm: k_order 2 needs cin %% 32 == 0, cout %% 128 == 0, an image at most 28 pixels wide and scale + shift");
     S3Args a = {};
     a.in = (const char*)d->in; a.wstream = (const char*)d->w; a.scale = d->scale; a.shift = d->shift;
     a.out = (bsplit_t*)d->out; a.ldo = d->ldo;
@@ -353,8 +375,19 @@ int hmmr_conv3x3_stream(const hmmr_conv_desc_t* d, hipStream_t stream) {
 #ifdef HMMR_GEMM_PROBE
     a.ts = (unsigned long long*)(((unsigned long long)(unsigned)hmmr_debug_state()->reserved[1] << 32) | (unsigned)hmmr_debug_state()->reserved[0]);
 #endif
-    switch (d->tile) {
-    case 0:
+    int tile = d->tile;
+    if (!tile) {
+        // the library's choice: fewest rounds of 256 workgroups x (row blocks per tile + ~1.5 for a tile's prologue and epilogue)
+        static const int cand[4][2] = {{12, 14}, {13, 8}, {15, 12}, {16, 10}};
+        const long long rbs = (a.M + 31) / 32, nts = d->cout / 128;
+        double best = 0;
+        for (const auto& cd : cand) {
+            const long long tiles = ((rbs + cd[1] - 1) / cd[1]) * nts;
+            const double cost = (double)((tiles + 255) / 256) * (cd[1] + 1.5);
+            if (!tile || cost < best) { tile = cd[0]; best = cost; }
+        }
+    }
+    switch (tile) {
     case 12: return launch_s3<7, 2, 2, 2>(a, d->cout, stream);       // 448 pixels
     case 13: return launch_s3<4, 2, 2, 2>(a, d->cout, stream);       // 256
     case 14: return launch_s3<8, 2, 2, 2>(a, d->cout, stream);       // 512
@@ -364,6 +397,6 @@ int hmmr_conv3x3_stream(const hmmr_conv_desc_t* d, hipStream_t stream) {
     case 18: return launch_s3<3, 4, 4, 1>(a, d->cout, stream);       // 384
     default: break;
     }
-    hmmr_set_error("hmmr_conv_gemm: k_order 2 runs tiles 12 .. 18, not %d", d->tile);
+    hmmr_set_error("hmmr_conv_gemm: k_order 2 runs tiles 12 .. 18, not %d", tile);
     return -1;
 }

@@ -155,7 +155,7 @@ typedef struct {
      * 2: `w` is not a matrix but the FILTER STREAM of packing.pack_conv3x3_stream (hmmr_conv3x3_stream_bytes(cin, cout) bytes):
      * per 128 output channels, K steps kt = (ci / 16) * 9 + ky*3 + kx of 8 KB = 4 row blocks x (hi plane | lo plane) of MFMA
      * A-operand fragments (lane = 32 * (k half) + row; 8 halves = W[row][16 (ci / 16) + 8 half .. + 7] of that tap), rows scaled
-     * like every split filter bank.  Same convolutions and epilogue as k_order 1, split (f16x3) tensors only, cin % 64 == 0,
+     * like every split filter bank.  Same convolutions and epilogue as k_order 1, split (f16x3) tensors only, cin % 32 == 0,
      * cout % 128 == 0, win <= 28; tiles 12 .. 18 (csrc/conv3x3_stream.hip).  Every tile produces the same bits. */
     int k_order;
     /* grouped launch: `batch` > 1 runs that many problems of this one shape as ONE launch (grid z); problem z reads and

@@ -150,6 +150,44 @@ def test_conv3x3_patch_kernel(case, gpu_device):
     assert np.abs(outs[0] - ring).max() < 2e-5 * mag
 
 
+@pytest.mark.parametrize("case", PATCH_CASES, ids=[c[0] for c in PATCH_CASES])
+def test_conv3x3_stream_kernel(case, gpu_device):
+    """The one-wave-per-SIMD 3x3 kernel (hmmr_conv_desc_t.k_order = 2, csrc/conv3x3_stream.hip: filters as a fragment stream, pixels out
+    of an LDS patch in 16-channel chunks, SAME padding as an address select) against a float64 convolution of the same 16-bit operands
+    and against the patch kernel (another accumulation order).  Its seven tile shapes agree bit for bit; without ReLU too."""
+    from human_dynamics_amd.engine import conv_gemm
+    name, n, h, w_, cin, cout = case
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(name.encode()) % 1000)
+    x = rng.normal(size=(n, h, w_, cin)).astype(np.float32)
+    w = (rng.normal(size=(3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.normal(size=cout).astype(np.float32)
+    for relu in (True, False):
+        kw = dict(stride=1, pad=1, scale=scale, shift=shift, relu=relu, in_dtype=X3, out_dtype=X3, device=gpu_device)
+        outs = {tile: conv_gemm(x, w, tile=tile, k_order=2, **kw)[0] for tile in ((0, 12, 13, 14, 15, 16, 17, 18) if relu else (0, 13))}
+        ref, _ = _ref_conv(_split_round(x), _split_round_w(w), 1, 1, scale, shift, None, relu, None, None, 1)
+        mag = max(1.0, np.abs(ref).max())
+        for tile, out in outs.items():
+            assert np.abs(out - ref).max() < 2e-5 * mag, "%s tile %d" % (name, tile)
+            assert np.array_equal(out, outs[0]), "%s: tile %d differs from the library's choice" % (name, tile)
+        patch, _ = conv_gemm(x, w, tile=0, k_order=1, **kw)
+        assert np.abs(outs[0] - patch).max() < 2e-5 * mag
+
+
+def test_conv3x3_stream_kernel_refuses_what_it_is_not_built_for(gpu_device):
+    from human_dynamics_amd.engine import conv_gemm
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(2, 14, 14, 64)).astype(np.float32)
+    w = rng.normal(size=(3, 3, 64, 256)).astype(np.float32)
+    for kw in (dict(stride=2, pad=1), dict(stride=1, pad=0), dict(stride=1, pad=1, tile=9), dict(stride=1, pad=1, tile=5),
+               dict(stride=1, pad=1, res=np.zeros((2, 14, 14, 256), np.float32))):
+        with pytest.raises(L.HmmrError):
+            conv_gemm(x, w, in_dtype=X3, out_dtype=X3, device=gpu_device, k_order=2, **kw)
+    with pytest.raises(L.HmmrError, match="28 pixels"):
+        conv_gemm(rng.normal(size=(1, 4, 56, 64)).astype(np.float32), w, stride=1, pad=1, in_dtype=X3, out_dtype=X3, device=gpu_device, k_order=2)
+
+
 def test_conv3x3_patch_kernel_refuses_what_it_is_not_built_for(gpu_device):
     from human_dynamics_amd.engine import conv_gemm
     rng = np.random.default_rng(0)

@@ -189,8 +189,11 @@ def test_chunk_major_filter_pack():
         assert p0[co, tap * 128 + ci] == w[ky, kx, ci, co]
         assert p1[co, ((ci // 32) * 9 + tap) * 32 + ci % 32] == w[ky, kx, ci, co]
     ws = assets.make_synthetic_weights(0)
-    on = packing.pack_resnet(ws, _lib.HMMR_F16X3, packing.DeviceStore("cpu"))
+    on = packing.pack_resnet(ws, _lib.HMMR_F16X3, packing.DeviceStore("cpu"), patch_3x3=1)
     assert [on.unit[i].conv2.k_order for i in range(16)] == [0, 0, 0, 1, 1, 1, 0, 1, 1, 1, 1, 1, 0, 1, 1, 1]
+    # the default: the same layers as the filter stream of the one-wave-per-SIMD kernel (k_order 2, csrc/conv3x3_stream.hip)
+    st = packing.pack_resnet(ws, _lib.HMMR_F16X3, packing.DeviceStore("cpu"))
+    assert [st.unit[i].conv2.k_order for i in range(16)] == [0, 0, 0, 2, 2, 2, 0, 2, 2, 2, 2, 2, 0, 2, 2, 2]
     off = packing.pack_resnet(ws, _lib.HMMR_F16X3, packing.DeviceStore("cpu"), patch_3x3=False)
     assert not any(off.unit[i].conv2.k_order for i in range(16))
     # bf16 (round 4): blocks 3-4 only -- the conv2 of blocks 1-2 runs inside the fused bf16 units, which read the tap-major order
@@ -200,6 +203,21 @@ def test_chunk_major_filter_pack():
     w64 = np.random.default_rng(1).normal(size=(3, 3, 128, 64)).astype(np.float32)
     p64 = packing.pack_conv_weight(w64, 1, chunk=64)          # bf16: 64 elements per 128-byte K step
     assert p64[5, ((70 // 64) * 9 + 4) * 64 + 70 % 64] == w64[1, 1, 70, 5]
+
+
+def test_conv3x3_stream_pack():
+    """packing.pack_conv3x3_stream: K step kt = (ci // 16) * 9 + tap of a 128-channel tile = 4 row blocks x (hi | lo plane) of MFMA
+    A-operand fragments, lane = 32 * (k half) + row (hmmr_conv_desc_t.k_order = 2); hi + lo reproduce the scaled filter to 2^-22."""
+    w = np.random.default_rng(2).normal(size=(3, 3, 64, 256)).astype(np.float32)
+    k = packing.row_pow2(packing.pack_conv_weight(w))
+    st = packing.pack_conv3x3_stream(w, k)
+    assert tuple(st.shape) == (2, 36, 4, 2, 64, 8) and st.dtype == torch.float16
+    for ky, kx, ci, co in ((0, 0, 0, 0), (1, 2, 37, 5), (2, 2, 63, 255), (0, 1, 17, 130)):
+        tile, rb, row = co // 128, (co % 128) // 32, co % 32
+        kt, half, e = (ci // 16) * 9 + ky * 3 + kx, (ci % 16) // 8, ci % 8
+        got = float(st[tile, kt, rb, 0, 32 * half + row, e]) + float(st[tile, kt, rb, 1, 32 * half + row, e])
+        want = float(w[ky, kx, ci, co]) * 2.0 ** int(k[co])
+        assert abs(got - want) <= abs(want) * 2.0 ** -21
 
 
 def test_shipped_tile_tables_fit_their_layers():
@@ -226,5 +244,6 @@ def test_shipped_tile_tables_fit_their_layers():
                 lay = U.c3sc if (nm == "conv3" and U.c3sc.w) else getattr(U, nm)
                 cout = U.depth + U.base if (nm == "shortcut" and U.sc_c1.w) else (U.base if nm in ("conv1", "conv2") else U.depth)
                 assert E.HmmrEngine._tile_for(lay, tile, cout, dt) == tile, (key, lk, tile)
-                assert (tile in (0, 9, 10, 11)) if lay.k_order else (tile in (0, 1, 2, 3, 5, 6, 7, 8)), (key, lk, tile)
+                ok = {0: (0, 1, 2, 3, 5, 6, 7, 8), 1: (0, 9, 10, 11), 2: (0, 12, 13, 14, 15, 16, 17, 18)}[lay.k_order]
+                assert tile in ok, (key, lk, tile)
     assert {40, 64, 65, 128, 129, 256, 257, 512, 513, 1024} <= sizes
