@@ -74,18 +74,19 @@ template <int OFF> __device__ __forceinline__ shalf8 s3_rd(unsigned addr) {
 
 struct xfrag { shalf8 hi, lo; };            // MFMA B-operand fragment: 32 pixels x 16 channels
 
-constexpr int S3_NS = 6;                    // ring slabs
-constexpr int S3_SLAB = 8192;               // one K step of a 128-channel tile: 4 row blocks x (hi 1 KB | lo 1 KB)
+constexpr int S3_NS = 6;                    // ring slabs; a slab = one K step of a tile's NB row blocks (32 channels each) x (hi 1 KB | lo 1 KB)
 
 template <int V> using s3_ic = std::integral_constant<int, V>;
 
-// FM x FN accumulators per wave, WGM x WGN waves: the tile is 32 WGM FM pixels x 128 channels (WGN FN = 4)
-template <int FM, int FN, int WGM, int WGN>
+// FM x FN accumulators per wave, WGM x WGN waves: the tile is 32 WGM FM pixels x 32 WGN FN channels (128 or 64); WMAX: the widest image
+template <int FM, int FN, int WGM, int WGN, int WMAX>
 __global__ __launch_bounds__(256, 1) void conv3x3_stream_kernel(const S3Args a) {
-    static_assert(WGM * WGN == 4 && WGN * FN == 4 && FM * FN <= 16, "4 waves, 128 channels, at most 16 accumulators");
+    constexpr int NB = WGN * FN;                                // row blocks of 32 output channels per tile
+    static_assert(WGM * WGN == 4 && (NB == 4 || NB == 2) && FM * FN <= 16, "4 waves, 128 or 64 channels, at most 16 accumulators");
     constexpr int R = WGM * FM, BM = 32 * R;
-    constexpr int NPP = (BM + 58 + 63) / 64;                    // 64-row pieces of a patch (W <= 28: BM + 2 W + 2 rows)
-    constexpr int NS = S3_NS, SLAB = S3_SLAB, RING = NS * SLAB;
+    constexpr int NPP = (BM + 2 * WMAX + 2 + 63) / 64;          // 64-row pieces of a patch (BM + 2 W + 2 rows)
+    constexpr int NS = S3_NS, SLAB = NB * 2048, RING = NS * SLAB;
+    constexpr int RW = NB / 2;                                  // 1 KB pieces of a slab each wave moves
     constexpr int ZROWS = 32 * (FM - 1) + 16;                   // zero rows behind the data rows of every quarter plane
     constexpr int QP = (NPP * 64 + ZROWS) * 16, PBUF = 4 * QP;  // quarter plane: 16 bytes per row; [hi k0][hi k1][lo k0][lo k1]
     constexpr int NR = 2 * (FM + FN), NG = 3 * FM * FN;         // fragment reads and MFMAs (= gaps) of a step
@@ -120,13 +121,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_stream_kernel(const S3Args a) 
         char* dst = smem + RING + buf * PBUF + wave * QP;
         __builtin_amdgcn_global_load_lds((gptr_t)(pptr[q] + c * 64), (lptr_t)(dst + q * 1024), 16, 0, 0);
     };
-    // ---- filter stream: K step s -> ring slot s % 6; each wave moves a quarter (one row block: hi and lo plane)
-    const char* gw = a.wstream + (long long)nt * a.nt_stride + wave * 2048 + lane * 16;
+    // ---- filter stream: K step s -> ring slot s % 6; each wave moves a quarter (128 channels: one row block, hi and lo plane)
+    const char* gw = a.wstream + (long long)nt * a.nt_stride + wave * (RW * 1024) + lane * 16;
     auto ring_dma = [&](int s, int slot) {
         const char* src = gw + (long long)s * SLAB;
-        char* dst = smem + slot * SLAB + wave * 2048;
+        char* dst = smem + slot * SLAB + wave * (RW * 1024);
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);          // (the instruction offset moves both addresses)
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 1024, 0);
+        if constexpr (RW == 2) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 1024, 0);
     };
 #pragma unroll
     for (int q = 0; q < NPP; ++q) patch_piece(q, 0, 0);
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_stream_kernel(const S3Args a) 
     // ---- this tile's folded BN constants (128 scales, 128 shifts) behind the patch buffers: the epilogue reads them from LDS
     {
         float* cst = (float*)(smem + RING + 2 * PBUF);
-        cst[tid] = tid < 128 ? a.scale[nt * 128 + tid] : a.shift[nt * 128 + tid - 128];
+        if (tid < 64 * NB) cst[tid] = tid < 32 * NB ? a.scale[nt * (32 * NB) + tid] : a.shift[nt * (32 * NB) + tid - 32 * NB];
     }
     // ---- wave masks (32 bits: both k halves of a wave hold the same 32 pixels) of the pixels on an image border, per row block
     unsigned mtop[FM], mbot[FM], mlef[FM], mrig[FM];
@@ -212,14 +213,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_stream_kernel(const S3Args a) 
 
     // ---- prologue: patch 0 and stage 0, then the fragments of step 0
     __builtin_amdgcn_sched_barrier(0);
-    s3_wait<2 * (NS - 1)>();
+    s3_wait<RW * (NS - 1)>();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     tap_setup(s3_ic<0>{}, 0);
 #pragma unroll
     for (int r = 0; r < NR; ++r) read_one(s3_ic<0>{}, 0, r, 0);
     __builtin_amdgcn_sched_barrier(0);
-    s3_wait<2 * (NS - 2)>();                                    // ... stage 1 too, and the fragments of step 0
+    s3_wait<RW * (NS - 2)>();                                   // ... stage 1 too, and the fragments of step 0
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     S3_STAMP(1);
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_stream_kernel(const S3Args a) 
         // stage kt + 2 (read during step kt + 1) has landed; younger requests stay in flight: stages kt + 3 .. kt + 6 and, through
         // taps 0 .. 4, the patch of the next chunk (issued behind the ring stage of tap 0; vmcnt retires in order)
         if (S3_PROBE(4) || S3_PROBE(32)) __builtin_amdgcn_s_waitcnt(63 | (7 << 4) | (0 << 8) | (3 << 14));      // lgkmcnt(0) alone
-        else if (more) { if (TAP <= 4 && c + 1 < nc && !S3_PROBE(64)) s3_wait<2 * (NS - 2) + NPP>(); else s3_wait<2 * (NS - 2)>(); }
+        else if (more) { if (TAP <= 4 && c + 1 < nc && !S3_PROBE(64)) s3_wait<RW * (NS - 2) + NPP>(); else s3_wait<RW * (NS - 2)>(); }
         else s3_wait<0>();
         __builtin_amdgcn_sched_barrier(0);
         if (!S3_PROBE(8)) __builtin_amdgcn_s_barrier();
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_stream_kernel(const S3Args a) 
     // straight into its half of the pair), half a max3 for the saturation flag
     char* stg = smem + wave * 8192;
     const int rsub = lane >> 3, pslot = lane & 7, sw = (lr >> 1) & 7;
-    const int nb = nt * 128 + wn * FN * 32;
+    const int nb = nt * (32 * NB) + wn * FN * 32;
     const float lo_clamp = a.relu ? 0.f : -HMMR_SPLIT_MAX;
     f32x4 s4[FN][4], b4[FN][4];
     {
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_stream_kernel(const S3Args a) 
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 s4[j][g] = *(const f32x4*)(cst + j * 32 + 8 * g);
-                b4[j][g] = *(const f32x4*)(cst + 128 + j * 32 + 8 * g);
+                b4[j][g] = *(const f32x4*)(cst + 32 * NB + j * 32 + 8 * g);
             }
     }
     float satmax = 0.f;
@@ -335,15 +336,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_stream_kernel(const S3Args a) 
     S3_STAMP(3);
 }
 
-template <int FM, int FN, int WGM, int WGN>
+template <int FM, int FN, int WGM, int WGN, int WMAX>
 int launch_s3(const S3Args& base, int cout, hipStream_t stream) {
     S3Args a = base;
-    constexpr int BM = 32 * WGM * FM, NPP = (BM + 58 + 63) / 64;
-    constexpr int lds = S3_NS * S3_SLAB + 8 * (NPP * 64 + 32 * (FM - 1) + 16) * 16 + 1024;
+    constexpr int NB = WGN * FN, BM = 32 * WGM * FM, NPP = (BM + 2 * WMAX + 2 + 63) / 64;
+    constexpr int lds = S3_NS * NB * 2048 + 8 * (NPP * 64 + 32 * (FM - 1) + 16) * 16 + 1024;
     static_assert(lds <= 160 * 1024, "LDS");
-    a.tiles_n = cout / 128;
+    a.tiles_n = cout / (32 * NB);
     a.n_tiles = ((a.M + BM - 1) / BM) * a.tiles_n;
-    auto kern = conv3x3_stream_kernel<FM, FN, WGM, WGN>;
+    a.nt_stride = (long long)9 * a.nc * (NB * 2048);
+    auto kern = conv3x3_stream_kernel<FM, FN, WGM, WGN, WMAX>;
     static DeviceOnce once;
     if (const unsigned long long bit = once.due()) {
         HMMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -356,47 +358,53 @@ int launch_s3(const S3Args& base, int cout, hipStream_t stream) {
 
 }  // namespace
 
-// bytes of the filter stream of a 3x3 layer (packing.pack_conv3x3_stream): per 128 output channels, 9 cin / 16 K steps of 8 KB
+// bytes of the filter stream of a 3x3 layer (packing.pack_conv3x3_stream): per tile of 128 output channels (64 when cout is 64), 9 cin / 16
+// K steps of 2 KB per 32 channels
 extern "C" size_t hmmr_conv3x3_stream_bytes(int cin, int cout) {
-    return (size_t)((cout + 127) / 128) * (size_t)(9 * (cin / 16)) * S3_SLAB;
+    return (size_t)(cout / 32) * (size_t)(9 * (cin / 16)) * 2048;
 }
 
 // hmmr_conv_gemm with k_order = 2 (called from gemm_conv.hip, which has checked the descriptor's geometry)
 int hmmr_conv3x3_stream(const hmmr_conv_desc_t* d, hipStream_t stream) {
     HMMR_REQUIRE(d->in_dtype == HMMR_F16X3 && d->out_dtype == HMMR_F16X3, "hmmr_conv_gemm: k_order 2 is built for split (f16x3) tensors");
-    HMMR_REQUIRE(d->cin % 32 == 0 && d->cout % 128 == 0 && d->win <= 28 && d->scale && d->shift,
-                 "hmmr_conv_gemm: k_order 2 needs cin %% 32 == 0, cout %% 128 == 0, an image at most 28 pixels wide and scale + shift");
+    HMMR_REQUIRE(d->cin % 32 == 0 && (d->cout % 128 == 0 || d->cout == 64) && d->win <= 56 && d->scale && d->shift,
+                 "hmmr_conv_gemm: k_order 2 needs cin %% 32 == 0, cout %% 128 == 0 (or cout = 64), an image at most 56 pixels wide and scale + shift");
     S3Args a = {};
     a.in = (const char*)d->in; a.wstream = (const char*)d->w; a.scale = d->scale; a.shift = d->shift;
     a.out = (bsplit_t*)d->out; a.ldo = d->ldo;
     a.M = d->n_img * d->ho * d->wo; a.H = d->hin; a.W = d->win; a.C = d->cin; a.nc = d->cin / 16;
     a.relu = d->relu;
-    a.nt_stride = (long long)9 * a.nc * S3_SLAB;
 #ifdef HMMR_GEMM_PROBE
     a.ts = (unsigned long long*)(((unsigned long long)(unsigned)hmmr_debug_state()->reserved[1] << 32) | (unsigned)hmmr_debug_state()->reserved[0]);
 #endif
     int tile = d->tile;
+    const bool narrow = d->cout == 64, wide = d->win > 28;
     if (!tile) {
         // the library's choice: fewest rounds of 256 workgroups x (row blocks per tile + ~1.5 for a tile's prologue and epilogue)
-        static const int cand[4][2] = {{12, 14}, {13, 8}, {15, 12}, {16, 10}};
-        const long long rbs = (a.M + 31) / 32, nts = d->cout / 128;
+        static const int cand[6][3] = {{12, 14, 0}, {13, 8, 0}, {15, 12, 0}, {16, 10, 0}, {19, 20, 1}, {20, 16, 1}};
+        const long long rbs = (a.M + 31) / 32, nts = narrow ? 1 : d->cout / 128;
         double best = 0;
         for (const auto& cd : cand) {
+            if ((cd[2] != 0) != narrow) continue;
             const long long tiles = ((rbs + cd[1] - 1) / cd[1]) * nts;
             const double cost = (double)((tiles + 255) / 256) * (cd[1] + 1.5);
             if (!tile || cost < best) { tile = cd[0]; best = cost; }
         }
     }
+    HMMR_REQUIRE((tile >= 19) == narrow && (!wide || narrow), "hmmr_conv_gemm: k_order 2: tiles 12 .. 18 take cout %% 128 == 0 and images up to 28 pixels wide, "
+                 "tiles 19 / 20 cout = 64 and up to 56 (tile %d, cout %d, win %d)", tile, d->cout, d->win);
     switch (tile) {
-    case 12: return launch_s3<7, 2, 2, 2>(a, d->cout, stream);       // 448 pixels
-    case 13: return launch_s3<4, 2, 2, 2>(a, d->cout, stream);       // 256
-    case 14: return launch_s3<8, 2, 2, 2>(a, d->cout, stream);       // 512
-    case 15: return launch_s3<6, 2, 2, 2>(a, d->cout, stream);       // 384
-    case 16: return launch_s3<5, 2, 2, 2>(a, d->cout, stream);       // 320
-    case 17: return launch_s3<4, 4, 4, 1>(a, d->cout, stream);       // 512, waves split the pixels
-    case 18: return launch_s3<3, 4, 4, 1>(a, d->cout, stream);       // 384
+    case 12: return launch_s3<7, 2, 2, 2, 28>(a, d->cout, stream);       // 448 pixels
+    case 13: return launch_s3<4, 2, 2, 2, 28>(a, d->cout, stream);       // 256
+    case 14: return launch_s3<8, 2, 2, 2, 28>(a, d->cout, stream);       // 512
+    case 15: return launch_s3<6, 2, 2, 2, 28>(a, d->cout, stream);       // 384
+    case 16: return launch_s3<5, 2, 2, 2, 28>(a, d->cout, stream);       // 320
+    case 17: return launch_s3<4, 4, 4, 1, 28>(a, d->cout, stream);       // 512, waves split the pixels
+    case 18: return launch_s3<3, 4, 4, 1, 28>(a, d->cout, stream);       // 384
+    case 19: return launch_s3<5, 2, 4, 1, 56>(a, d->cout, stream);       // 640 pixels x 64 channels
+    case 20: return launch_s3<4, 2, 4, 1, 56>(a, d->cout, stream);       // 512 x 64
     default: break;
     }
-    hmmr_set_error("hmmr_conv_gemm: k_order 2 runs tiles 12 .. 18, not %d", tile);
+    hmmr_set_error("hmmr_conv_gemm: k_order 2 runs tiles 12 .. 20, not %d", tile);
     return -1;
 }

@@ -81,7 +81,7 @@ class HmmrEngine(object):
     def __init__(self, weights, smpl, dtype=DEFAULT_DTYPE, device="cuda:0", num_conv_layers=3,
                  delta_t_values=(-5, 5), joint_type="cocoplus", resnet_chunk=0,
                  temporal_dtype=None, ief_dtype=None, autotune=True, fold_sc=None, fuse_tail=None, patch_3x3=None,
-                 unit_pair=None):
+                 unit_pair=None, b1_stream=None):
         self.lib = L.load()
         _debug_from_env()
         if not torch.cuda.is_available():
@@ -110,7 +110,8 @@ class HmmrEngine(object):
                                        fuse_preact_first=pfirst, fold_sc=fold,
                                        patch_3x3=int(devflags.get("PATCH_3X3")) if patch_3x3 is None else patch_3x3,
                                        unit_pair=({"0": False, "1": True}.get(devflags.get("UNIT_PAIR"), devflags.get("UNIT_PAIR"))
-                                                  if unit_pair is None else unit_pair))
+                                                  if unit_pair is None else unit_pair),
+                                       b1_stream=(devflags.get("B1_STREAM") == "1") if b1_stream is None else b1_stream)
                    if "resnet_v2_50/conv1/weights" in w else None)
         self.tw = (packing.pack_temporal(w, self.temporal_dtype, self.store, num_conv_layers)
                    if assets.temporal_scopes(0)[1] + "/weights" in w else None)
@@ -204,7 +205,9 @@ class HmmrEngine(object):
         the tile does not fit; a layer packed chunk-major (k_order 1, the 3x3 patch kernels) runs tiles 9 / 10, the patch
         forms of 7 / 8, or 11, the 256x128 tile without a load segment; a k_order 2 layer (csrc/conv3x3_stream.hip) takes the
         tuner's candidates as its own tile shapes 13 .. 18."""
-        if lay.k_order == 2:                                 # the stream kernel's tiles: 12 (the library's choice) .. 18
+        if lay.k_order == 2:                                 # the stream kernel's tiles: 12 .. 18 (128-channel tiles), 19 / 20 (64 channels)
+            if cout == 64:
+                return {5: 19, 6: 20}.get(cand, cand if cand in (19, 20) else 0)
             return {5: 13, 6: 14, 3: 15, 1: 16, 2: 17, 7: 18}.get(cand, cand if 12 <= cand <= 18 else 0)
         if lay.k_order:
             cand = {7: 9, 8: 10}.get(cand, cand)

@@ -124,10 +124,12 @@ def pack_conv3x3_stream(w_hwio, k=None):
     """[3,3,cin,cout] -> fp16 [cout / 128][9 cin / 16][4][2 (hi, lo plane)][64 lanes][8]: the filter stream of a k_order 2 layer
     (hmmr_conv_desc_t.k_order, csrc/conv3x3_stream.hip).  K step kt = (ci // 16) * 9 + ky * 3 + kx of a 128-channel tile is 8 KB:
     row blocks 0 .. 3, each the MFMA A operand of 32 rows x 16 K as a hi and a lo plane (lane = 32 * (k half) + row, 8 halves =
-    W[ky, kx, 16 (ci // 16) + 8 half .. + 7, 128 tile + 32 block + row]), rows scaled by 2^k (row_pow2 of the rows)."""
+    W[ky, kx, 16 (ci // 16) + 8 half .. + 7, 128 tile + 32 block + row]), rows scaled by 2^k (row_pow2 of the rows).  cout = 64: one
+    tile of two row blocks ([1][9 cin / 16][2][2][64][8])."""
     w = np.asarray(w_hwio, np.float64)
     kh, kw, cin, cout = w.shape
-    assert (kh, kw) == (3, 3) and cin % 16 == 0 and cout % 128 == 0, w.shape
+    assert (kh, kw) == (3, 3) and cin % 16 == 0 and (cout % 128 == 0 or cout == 64), w.shape
+    tw = 128 if cout % 128 == 0 else 64
     if k is None:
         k = row_pow2(w.reshape(9 * cin, cout).T)
     t = torch.from_numpy((w * np.exp2(np.asarray(k, np.float64))).astype(np.float32))
@@ -135,8 +137,8 @@ def pack_conv3x3_stream(w_hwio, k=None):
     lo = (t - hi.to(torch.float32)).to(SPLIT_HALF)
 
     def frag(x):
-        x = x.reshape(9, cin // 16, 2, 8, cout // 128, 4, 32)            # tap, c16, half, e, tile, rb, row
-        return x.permute(4, 1, 0, 5, 2, 6, 3).reshape(cout // 128, 9 * (cin // 16), 4, 64, 8)
+        x = x.reshape(9, cin // 16, 2, 8, cout // tw, tw // 32, 32)      # tap, c16, half, e, tile, rb, row
+        return x.permute(4, 1, 0, 5, 2, 6, 3).reshape(cout // tw, 9 * (cin // 16), tw // 32, 64, 8)
     return torch.stack([frag(hi), frag(lo)], dim=3).contiguous()          # [tile, kt, rb, plane, lane, 8]
 
 
@@ -250,7 +252,7 @@ def _layer_stream3x3(store, w_hwio, scale, shift):
 
 
 def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3", "block4"), fuse_tail=True,
-                fuse_sc=True, fuse_preact_first=False, fold_sc=None, patch_3x3=2, unit_pair=True):
+                fuse_sc=True, fuse_preact_first=False, fold_sc=None, patch_3x3=2, unit_pair=True, b1_stream=False):
     """fuse_preact_blocks: blocks whose units apply their `preact` BN+ReLU inside the operand
     staging of conv1/shortcut instead of reading a materialised preact tensor (csrc/resnet.hip;
     measured at batch 256: -4.5 % ResNet time with blocks 1-2 fused, neutral for blocks 3-4).
@@ -259,7 +261,10 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
     patch_3x3 (f16x3: blocks 2-4; bf16: blocks 3-4): the stride-1 3x3 conv2 out of an LDS-resident input patch.  2 (default): f16x3
     layers get hmmr_conv_desc_t.k_order = 2, the filter stream of the one-wave-per-SIMD kernel (csrc/conv3x3_stream.hip, tiles 12 .. 18);
     1 / True (and bf16 always): k_order = 1, chunk-major rows for the 8-wave patch kernels (csrc/gemm_conv.hip, tiles 9 / 10; 11 for f16x3).
-    Block 1 keeps the tap-major order its fused tails reproduce bit for bit; the stride-2 units keep the im2col gather.
+    b1_stream (with patch_3x3 = 2, f16x3; default off): the conv2 of block1/unit_1 and unit_2 is a k_order 2 launch too (64-channel tiles,
+    56-pixel images) and their fused tails start at conv3 (hmmr_resnet_unit_t.fuse_tail = 1); False: conv2 runs inside those tails,
+    tap-major.  Measured equal (profiles/r04c: 0.188 + 0.434 ms against 0.632 ms per unit), so the form with 0.4 GB less HBM traffic stays.
+    The stride-2 units keep the im2col gather.
     unit_pair (f16x3 only; True | "block2" | "block3" | False): the stride-1 units of blocks 2-3 run conv3 + add + the next
     unit's preact + conv1 as the register-resident unit pair of csrc/unit_pair.hip (one filter stream per unit); block3/unit_1
     then keeps its conv shortcut as a launch (shortcut + conv1 as one column-split GEMM) instead of folding it into conv3."""
@@ -291,12 +296,14 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
         u.conv1 = _layer(store, pack_conv_weight(w[scope + "/conv1/weights"]), dtype, s, b)
         s, b = fold_bn(w, scope + "/conv2/BatchNorm")
         # (bf16, round 4: blocks 3-4 only -- the conv2 of blocks 1-2 runs inside the fused bf16 units, which read the tap-major order)
-        kord = int(bool(patch_3x3) and stride == 1 and ((dtype == L.HMMR_F16X3 and base >= 128) or (dtype == L.HMMR_BF16 and base >= 256)))
+        stream = dtype == L.HMMR_F16X3 and patch_3x3 == 2 and patch_3x3 is not True
+        kord = int(bool(patch_3x3) and stride == 1 and ((dtype == L.HMMR_F16X3 and (base >= 128 or (stream and b1_stream))) or
+                                                         (dtype == L.HMMR_BF16 and base >= 256)))
         # (a chunk-major layer cannot fall back to the im2col gather: its 128-pixel patch -- tile + halo of W + 1 on either side --
         #  must fit the 4 x 64 rows the 128x256 tile keeps in LDS.  ResNet-50 on 224 x 224 crops: W <= 28)
-        if kord and 128 + 2 * (224 // {64: 4, 128: 8, 256: 16, 512: 32}[base]) + 4 > 4 * 64:
+        if kord and not stream and 128 + 2 * (224 // {64: 4, 128: 8, 256: 16, 512: 32}[base]) + 4 > 4 * 64:
             kord = 0
-        if kord and dtype == L.HMMR_F16X3 and patch_3x3 == 2 and patch_3x3 is not True:
+        if kord and stream:
             u.conv2 = _layer_stream3x3(store, np.asarray(w[scope + "/conv2/weights"], np.float32), s, b)
         else:
             u.conv2 = _layer(store, pack_conv_weight(w[scope + "/conv2/weights"], kord, chunk=bke), dtype, s, b)
@@ -352,7 +359,7 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
             u.w3_frag = store.put_tensor(pack_frag_major(w3.T)).data_ptr()
             u.w1n_frag = store.put_tensor(pack_frag_major(w1n.T)).data_ptr()
             u.fuse_tail = 1
-            if base == 64 and fuse_tail != "noconv2":        # block 1 (56 x 56 = 7 x 7 tiles of 8 x 8): conv2 inside as well
+            if base == 64 and fuse_tail != "noconv2" and u.conv2.k_order != 2:   # block 1 (56 x 56 = 7 x 7 tiles of 8 x 8): conv2 inside as well
                 u.fuse_tail = 2
     for i in range(L.RESNET_UNITS - 1):
         u, nx = rw.unit[i], rw.unit[i + 1]

@@ -150,7 +150,13 @@ def test_conv3x3_patch_kernel(case, gpu_device):
     assert np.abs(outs[0] - ring).max() < 2e-5 * mag
 
 
-@pytest.mark.parametrize("case", PATCH_CASES, ids=[c[0] for c in PATCH_CASES])
+STREAM_CASES = PATCH_CASES + [
+    ("b1_56x56", 2, 56, 56, 64, 64),            # 64-channel tiles (19 / 20), the widest image
+    ("b1_one_5x7", 1, 5, 7, 64, 64),
+]
+
+
+@pytest.mark.parametrize("case", STREAM_CASES, ids=[c[0] for c in STREAM_CASES])
 def test_conv3x3_stream_kernel(case, gpu_device):
     """The one-wave-per-SIMD 3x3 kernel (hmmr_conv_desc_t.k_order = 2, csrc/conv3x3_stream.hip: filters as a fragment stream, pixels out
     of an LDS patch in 16-channel chunks, SAME padding as an address select) against a float64 convolution of the same 16-bit operands
@@ -165,14 +171,15 @@ def test_conv3x3_stream_kernel(case, gpu_device):
     shift = rng.normal(size=cout).astype(np.float32)
     for relu in (True, False):
         kw = dict(stride=1, pad=1, scale=scale, shift=shift, relu=relu, in_dtype=X3, out_dtype=X3, device=gpu_device)
-        outs = {tile: conv_gemm(x, w, tile=tile, k_order=2, **kw)[0] for tile in ((0, 12, 13, 14, 15, 16, 17, 18) if relu else (0, 13))}
+        tiles = ((0, 19, 20) if relu else (0, 20)) if cout == 64 else ((0, 12, 13, 14, 15, 16, 17, 18) if relu else (0, 13))
+        outs = {tile: conv_gemm(x, w, tile=tile, k_order=2, **kw)[0] for tile in tiles}
         ref, _ = _ref_conv(_split_round(x), _split_round_w(w), 1, 1, scale, shift, None, relu, None, None, 1)
         mag = max(1.0, np.abs(ref).max())
         for tile, out in outs.items():
             assert np.abs(out - ref).max() < 2e-5 * mag, "%s tile %d" % (name, tile)
             assert np.array_equal(out, outs[0]), "%s: tile %d differs from the library's choice" % (name, tile)
-        patch, _ = conv_gemm(x, w, tile=0, k_order=1, **kw)
-        assert np.abs(outs[0] - patch).max() < 2e-5 * mag
+        other, _ = conv_gemm(x, w, tile=0, k_order=0 if cout == 64 else 1, **kw)
+        assert np.abs(outs[0] - other).max() < 2e-5 * mag
 
 
 def test_conv3x3_stream_kernel_refuses_what_it_is_not_built_for(gpu_device):
@@ -184,8 +191,10 @@ def test_conv3x3_stream_kernel_refuses_what_it_is_not_built_for(gpu_device):
                dict(stride=1, pad=1, res=np.zeros((2, 14, 14, 256), np.float32))):
         with pytest.raises(L.HmmrError):
             conv_gemm(x, w, in_dtype=X3, out_dtype=X3, device=gpu_device, k_order=2, **kw)
-    with pytest.raises(L.HmmrError, match="28 pixels"):
+    with pytest.raises(L.HmmrError, match="28 pixels"):        # 128-channel tiles: images up to 28 pixels wide
         conv_gemm(rng.normal(size=(1, 4, 56, 64)).astype(np.float32), w, stride=1, pad=1, in_dtype=X3, out_dtype=X3, device=gpu_device, k_order=2)
+    with pytest.raises(L.HmmrError):                           # a 64-channel layer on a 128-channel tile
+        conv_gemm(x, w[..., :64], stride=1, pad=1, in_dtype=X3, out_dtype=X3, device=gpu_device, k_order=2, tile=12)
 
 
 def test_conv3x3_patch_kernel_refuses_what_it_is_not_built_for(gpu_device):

@@ -142,6 +142,9 @@ def test_packer_marks_the_fused_launches(weights):
     assert [i for i in range(16) if rwx.unit[i].c3sc.w] == [0, 3, 13] and [i for i in range(16) if rwx.unit[i].sc_c1.w] == [7]
     # ... and conv3 + add + the next conv1 run as one launch for the stride-1 units of blocks 1-3 with an identity successor
     assert [rwx.unit[i].fuse_tail for i in range(16)] == [2, 2, 0, 1, 1, 1, 0, 1, 1, 1, 1, 1, 0, 0, 0, 0]      # block 1: conv2 inside as well
+    # (b1_stream: block 1's conv2 as a launch of the 3x3 stream kernel, csrc/conv3x3_stream.hip, the tails start at conv3)
+    b1s = packing.pack_resnet(weights, _lib.HMMR_F16X3, packing.DeviceStore("cpu"), b1_stream=True)
+    assert [b1s.unit[i].fuse_tail for i in range(3)] == [1, 1, 0] and [b1s.unit[i].conv2.k_order for i in range(3)] == [2, 2, 0]
     assert [bool(rwx.unit[i].w3_frag) for i in range(16)] == [True, True] + [False] * 14              # block 1: LDS-panel tails, fragment-major filters
     assert [bool(rwx.unit[i].pair_stream) for i in range(16)] == [False] * 3 + [True] * 3 + [False] + [True] * 5 + [False] * 4
     old = packing.pack_resnet(weights, _lib.HMMR_F16X3, packing.DeviceStore("cpu"), unit_pair=False)      # the round-3 schedule
@@ -244,6 +247,6 @@ def test_shipped_tile_tables_fit_their_layers():
                 lay = U.c3sc if (nm == "conv3" and U.c3sc.w) else getattr(U, nm)
                 cout = U.depth + U.base if (nm == "shortcut" and U.sc_c1.w) else (U.base if nm in ("conv1", "conv2") else U.depth)
                 assert E.HmmrEngine._tile_for(lay, tile, cout, dt) == tile, (key, lk, tile)
-                ok = {0: (0, 1, 2, 3, 5, 6, 7, 8), 1: (0, 9, 10, 11), 2: (0, 12, 13, 14, 15, 16, 17, 18)}[lay.k_order]
+                ok = {0: (0, 1, 2, 3, 5, 6, 7, 8), 1: (0, 9, 10, 11), 2: (0, 12, 13, 14, 15, 16, 17, 18, 19, 20)}[lay.k_order]
                 assert tile in ok, (key, lk, tile)
     assert {40, 64, 65, 128, 129, 256, 257, 512, 513, 1024} <= sizes

@@ -20,7 +20,9 @@ if "probe" in L.LIB_PATH:
 blk = sys.argv[1] if len(sys.argv) > 1 else "b3"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 257
 tiles = [int(t) for t in sys.argv[3:]] or [12, 13, 14, 15, 16, 17, 18]
-cch, hw = {"b2": (128, 28), "b3": (256, 14), "b4": (512, 7)}[blk]
+cch, hw = {"b1": (64, 56), "b2": (128, 28), "b3": (256, 14), "b4": (512, 7)}[blk]
+if blk == "b1" and len(sys.argv) <= 3:
+    tiles = [19, 20]
 dev = "cuda"
 X3 = L.HMMR_F16X3
 g = torch.Generator(device="cpu").manual_seed(5)
@@ -41,7 +43,8 @@ def run(k_order, tile, reps=10):
     # engine.conv_gemm packs and launches once; re-launch the same descriptor for the timing
     store = packing.DeviceStore(dev)
     wp = packing.pack_conv_weight(w, k_order if k_order != 2 else 0)
-    k = packing.row_pow2(wp[:cch])
+    wp = wp[:cch]
+    k = packing.row_pow2(wp)
     scale = store.vec((sc.astype(np.float64) * np.exp2(-k.astype(np.float64))).astype(np.float32))
     shift = store.vec(sh)
     wt = store.put_tensor(packing.pack_conv3x3_stream(w, k)) if k_order == 2 else store.put(packing.scale_rows(wp, k), packing.SPLIT)
@@ -67,8 +70,8 @@ def run(k_order, tile, reps=10):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     if ts is not None and k_order == 2:
-        bm = {12: 448, 13: 256, 14: 512, 15: 384, 16: 320, 17: 512, 18: 384}[tile]
-        nb = ((n * hw * hw + bm - 1) // bm) * (cch // 128)
+        bm = {12: 448, 13: 256, 14: 512, 15: 384, 16: 320, 17: 512, 18: 384, 19: 640, 20: 512}[tile]
+        nb = ((n * hw * hw + bm - 1) // bm) * max(1, cch // 128)
         t = ts[:nb].cpu().numpy().astype(np.float64)
         t0 = t[:, :, 0].min()
         print("      stamps (100 MHz ticks) over %d workgroups: start spread %.0f | prologue %.0f | loop %.0f (min %.0f max %.0f) | epilogue %.0f | span %.0f" % (
@@ -78,8 +81,8 @@ def run(k_order, tile, reps=10):
 
 
 fl = 2.0 * n * hw * hw * 9 * cch * cch
-o11, ms11 = run(1, 11)
-print("%s, %d frames (%d px): k_order 1 tile 11  %.4f ms = %.0f TFLOP/s" % (blk, n, n * hw * hw, ms11, fl / ms11 / 1e9))
+o11, ms11 = run(1, 11) if blk != "b1" else run(0, 0)
+print("%s, %d frames (%d px): %s  %.4f ms = %.0f TFLOP/s" % (blk, n, n * hw * hw, "k_order 1 tile 11" if blk != "b1" else "k_order 0", ms11, fl / ms11 / 1e9))
 first = None
 for t in tiles:
     o, ms = run(2, t)
