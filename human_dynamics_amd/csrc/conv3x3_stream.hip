@@ -48,7 +48,7 @@ struct S3Args {
 };
 
 // Development build only (tools/s3_probe_build.sh): drop the MFMAs (1), the fragment reads (2), the DMA requests and their waits (4),
-// the loop's barrier (8), the per-step address arithmetic (16), the waits on vector memory alone (32) or the patch requests alone (64) at COMPILE time, and stamp s_memtime around the phases.  Results are
+// the loop's barrier (8), the per-step address arithmetic (16), the waits on vector memory alone (32) or the patch requests alone (64) at COMPILE time; 128: the patch requests read coalesced (wrong) bytes, and stamp s_memtime around the phases.  Results are
 // garbage in those modes; the product build compiles the switches away.
 #ifndef S3_PROBE_BITS
 #define S3_PROBE_BITS 0
@@ -87,10 +87,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_stream_kernel(const S3Args a) 
     constexpr int NPP = (BM + 2 * WMAX + 2 + 63) / 64;          // 64-row pieces of a patch (BM + 2 W + 2 rows)
     constexpr int NS = S3_NS, SLAB = NB * 2048, RING = NS * SLAB;
     constexpr int RW = NB / 2;                                  // 1 KB pieces of a slab each wave moves
-    constexpr int ZROWS = 32 * (FM - 1) + 16;                   // zero rows behind the data rows of every quarter plane
-    constexpr int QP = (NPP * 64 + ZROWS) * 16, PBUF = 4 * QP;  // quarter plane: 16 bytes per row; [hi k0][hi k1][lo k0][lo k1]
+    constexpr int ZROWS = 32 * (FM - 1) + 16;                   // zero rows behind the data rows of a patch buffer
+    constexpr int PBUF = (NPP * 64 + ZROWS) * 64;               // patch rows of 64 bytes: [hi k0][lo k0][hi k1][lo k1], slots XOR-swizzled by (row >> 2) & 3
     constexpr int NR = 2 * (FM + FN), NG = 3 * FM * FN;         // fragment reads and MFMAs (= gaps) of a step
-    static_assert(2 * QP + 512 * (FM - 1) + 16 < 65536 && QP % 256 == 0 && RING % 256 == 0, "instruction offsets, bank arithmetic");
+    static_assert(2048 * (FM - 1) + 16 < 65536, "instruction offsets");
     static_assert(NR <= NG - 4, "one fragment read per gap");
 
     extern __shared__ __attribute__((aligned(256))) char smem[];
@@ -107,19 +107,21 @@ __global__ __launch_bounds__(256, 1) void conv3x3_stream_kernel(const S3Args a) 
     const int wm = wave / WGN, wn = wave - wm * WGN;
     const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;
 
-    // ---- patch DMA: piece q of this wave = quarter plane `wave` (LDS order hi k0, hi k1, lo k0, lo k1 = bytes 0, 32, 16, 48 of a
-    // pixel's 64-byte chunk), rows 64 q .. 64 q + 63, one lane per row.  Rows outside the tensor read its first / last pixel
-    // instead: only out-of-image taps (which read a zero row) and pixels >= M ever see them
+    // ---- patch DMA: piece q of this wave = rows 64 q + 16 wave .. + 15, four lanes per row (one coalesced 64-byte chunk; as quarter
+    // planes with one lane per row the same bytes cost four times the L1 transactions and 5 % of the kernel, profiles/r04d).  Rows
+    // outside the tensor read its first / last pixel instead: only out-of-image taps (which read a zero row) and pixels >= M see them
     const char* pptr[NPP];
 #pragma unroll
     for (int q = 0; q < NPP; ++q) {
-        int px = base + 64 * q + lane;
+        const int r = 64 * q + 16 * wave + (lane >> 2);
+        int px = base + r;
         px = px < 0 ? 0 : (px >= a.M ? a.M - 1 : px);
-        pptr[q] = a.in + ((long long)px * a.C) * 4 + (wave & 1) * 32 + (wave >> 1) * 16;
+        pptr[q] = a.in + ((long long)px * a.C) * 4 + (((lane & 3) ^ ((r >> 2) & 3)) << 4);
+        if (S3_PROBE(128)) pptr[q] = a.in + ((long long)(px & ~15) * a.C) * 4 + lane * 16;     // (probe: a coalesced KB of the wrong bytes)
     }
     auto patch_piece = [&](int q, int c, int buf) {             // q is a constant after unrolling
-        char* dst = smem + RING + buf * PBUF + wave * QP;
-        __builtin_amdgcn_global_load_lds((gptr_t)(pptr[q] + c * 64), (lptr_t)(dst + q * 1024), 16, 0, 0);
+        char* dst = smem + RING + buf * PBUF + wave * 1024;
+        __builtin_amdgcn_global_load_lds((gptr_t)(pptr[q] + c * 64), (lptr_t)(dst + q * 4096), 16, 0, 0);
     };
     // ---- filter stream: K step s -> ring slot s % 6; each wave moves a quarter (128 channels: one row block, hi and lo plane)
     const char* gw = a.wstream + (long long)nt * a.nt_stride + wave * (RW * 1024) + lane * 16;
@@ -134,10 +136,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_stream_kernel(const S3Args a) 
 #pragma unroll
     for (int s_ = 0; s_ < NS; ++s_) ring_dma(s_, s_);
 
-    // ---- zero rows of the eight quarter planes (never written again)
-    for (int i = tid; i < 8 * ZROWS; i += 256) {
-        const int pl = i / ZROWS, o = i - pl * ZROWS;
-        *(u32x4*)(smem + RING + pl * QP + NPP * 64 * 16 + o * 16) = u32x4{0u, 0u, 0u, 0u};
+    // ---- zero rows of the two patch buffers (never written again)
+    for (int i = tid; i < 2 * ZROWS * 4; i += 256) {
+        const int pl = i / (ZROWS * 4), o = i - pl * (ZROWS * 4);
+        *(u32x4*)(smem + RING + pl * PBUF + NPP * 64 * 64 + o * 16) = u32x4{0u, 0u, 0u, 0u};
     }
     // ---- this tile's folded BN constants (128 scales, 128 shifts) behind the patch buffers: the epilogue reads them from LDS
     {
@@ -167,13 +169,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_stream_kernel(const S3Args a) 
         }
 
     const unsigned vW = lds0 + wn * FN * 2048 + lane * 16;      // filter fragments: + slot * SLAB + j * 2048 (+ 1024: lo plane)
-    // pixel fragments: row (rb0 + tap shift) of quarter plane lh (hi; the lo plane 2 QP behind it), row block i 512 bytes further
-    const unsigned A00[2] = {lds0 + RING + lh * QP + (wm * FM * 32 + lr) * 16, lds0 + RING + PBUF + lh * QP + (wm * FM * 32 + lr) * 16};
-    const unsigned ZC[2] = {lds0 + RING + lh * QP + NPP * 64 * 16, lds0 + RING + PBUF + lh * QP + NPP * 64 * 16};
-    const int W16 = 16 * W;
+    // pixel fragments: row rb0 + tap shift of a patch buffer, slots 2 lh (hi) and 2 lh + 1 (lo) before the swizzle; row block i 2 KB further
+    const int rb0 = wm * FM * 32 + lr;
+    const unsigned lh2 = 2 * lh;
     xfrag fx[2][FM];
     wfrag fw[2][FN];
-    unsigned A0 = 0, Zb = 0, adcur = 0;
+    unsigned A0 = 0, A0l = 0, Zb = 0, Zbl = 0, adcur = 0, adcurl = 0;
 
     // read number r of the NR fragment halves of the step with tap TAP_ (filters first) into set `set`; slot_ = that step's ring slot
     auto read_one = [&](auto tap_c, int set, int r, int slot_) {           // set, r, slot_ are constants after unrolling
@@ -191,24 +192,29 @@ __global__ __launch_bounds__(256, 1) void conv3x3_stream_kernel(const S3Args a) 
             const int i = (r - 2 * FN) >> 1, pl = (r - 2 * FN) & 1;
             if (pl == 0) {
                 // SAME padding: lanes whose tap leaves the image read the zero row of their bank
-                if (KY == 1 && KX == 1) adcur = A0;
+                if (KY == 1 && KX == 1) { adcur = A0; adcurl = A0l; }
                 else {
                     const int ii = i < FM ? i : 0;
                     const unsigned my = KY == 0 ? mtop[ii] : (KY == 2 ? mbot[ii] : 0u);
                     const unsigned mx = KX == 0 ? mlef[ii] : (KX == 2 ? mrig[ii] : 0u);
-                    asm volatile("s_mov_b32 vcc_lo, %1\n\ts_mov_b32 vcc_hi, %1\n\tv_cndmask_b32 %0, %2, %3, vcc"
-                                 : "=v"(adcur) : "s"(my | mx), "v"(A0), "v"(Zb) : "vcc");
+                    asm volatile("s_mov_b32 vcc_lo, %2\n\ts_mov_b32 vcc_hi, %2\n\tv_cndmask_b32 %0, %3, %4, vcc\n\tv_cndmask_b32 %1, %5, %6, vcc"
+                                 : "=&v"(adcur), "=v"(adcurl) : "s"(my | mx), "v"(A0), "v"(Zb), "v"(A0l), "v"(Zbl) : "vcc");
                 }
             }
-#define S3_X(I) if constexpr (I < FM) { if (i == I) { if (pl) fx[set][I].lo = s3_rd<2 * QP + I * 512>(adcur); else fx[set][I].hi = s3_rd<I * 512>(adcur); } }
+#define S3_X(I) if constexpr (I < FM) { if (i == I) { if (pl) fx[set][I].lo = s3_rd<I * 2048>(adcurl); else fx[set][I].hi = s3_rd<I * 2048>(adcur); } }
             S3_X(0) S3_X(1) S3_X(2) S3_X(3) S3_X(4) S3_X(5) S3_X(6) S3_X(7) S3_X(8) S3_X(9) S3_X(10) S3_X(11) S3_X(12) S3_X(13) S3_X(14) S3_X(15)
 #undef S3_X
         }
     };
     auto tap_setup = [&](auto tap_c, int buf_) {                // buf_ is a constant after unrolling
         constexpr int TAP_ = decltype(tap_c)::value, KY = TAP_ / 3, KX = TAP_ % 3;
-        A0 = A00[buf_] + (unsigned)(KY * W16 + KX * 16);
-        Zb = (A0 & 0xF0u) | ZC[buf_];                           // (every base is a multiple of 256: bits 4-7 are the row's)
+        const unsigned rowp = (unsigned)(rb0 + KY * W + KX);
+        const unsigned ph = (lh2 ^ ((rowp >> 2) & 3u)) << 4;    // this lane's hi slot in that row (the lo slot: ^ 16)
+        const unsigned pb = lds0 + RING + buf_ * PBUF;
+        A0 = pb + rowp * 64 + ph;
+        A0l = A0 ^ 16u;
+        Zb = pb + NPP * 64 * 64 + (rowp & 3u) * 64 + ph;       // the zero row of the same bank (row & 3 and the slot are what the bank is made of)
+        Zbl = Zb ^ 16u;
     };
 
     // ---- prologue: patch 0 and stage 0, then the fragments of step 0
