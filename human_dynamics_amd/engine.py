@@ -208,7 +208,7 @@ class HmmrEngine(object):
         if lay.k_order == 2:                                 # the stream kernel's tiles: 12 .. 18 (128-channel tiles), 19 / 20 (64 channels)
             if cout == 64:
                 return {5: 19, 6: 20}.get(cand, cand if cand in (19, 20) else 0)
-            return {5: 13, 6: 14, 3: 15, 1: 16, 2: 17, 7: 18}.get(cand, cand if 12 <= cand <= 18 else 0)
+            return {5: 13, 6: 14, 3: 15, 1: 16, 2: 17, 7: 18, 8: 12}.get(cand, cand if 12 <= cand <= 18 else 0)
         if lay.k_order:
             cand = {7: 9, 8: 10}.get(cand, cand)
             if cand == 11 and dtype == L.HMMR_BF16:          # the tile without a load segment is written for split operands

@@ -57,6 +57,7 @@ class HostStreamer(object):
         self.s_out = torch.cuda.Stream(device=self.dev)
         self.s_tail = torch.cuda.Stream(device=self.dev)       # the ~150 small launches of a chunk's tail run under the next ResNet
         self._pin, self._dev_in, self._geom, self._dev_f32 = {}, {}, None, None
+        self._phi_zero = None
         self.layout, self.rec_len = tester.record_layout()
         # staging copies (pageable user array -> pinned buffer) run on a small private pool of plain memcpy workers
         # (NumPy releases the GIL): torch's intra-op pool would wake one spinning thread per core for every chunk,
@@ -134,10 +135,16 @@ class HostStreamer(object):
         in_free = [None, None]          # compute finished reading dev_in[slot]
         out_free = [None, None]         # copy-out finished reading recs[slot]
         ar_T = torch.arange(T, device=dev)
-        eng.resnet(torch.empty((0, 224, 224, 3), dtype=torch.float32, device=dev), n_zero=1, out=phi[N:N + 1])                                 # the zero padding image, once, up front
         import time as _time
         from .. import devflags
         trace = [] if devflags.get("STREAM_TRACE") else None
+        t_entry = _time.perf_counter()
+        # the zero padding image: its features are a property of the weights (every frame is encoded independently of its batch,
+        # tests/test_gpu_f16x3.py::test_resnet_split_batch_independence), so one 1-image pass per streamer serves every call
+        if self._phi_zero is None:
+            self._phi_zero = torch.empty((1, 2048), dtype=torch.float32, device=dev)
+            eng.resnet(torch.empty((0, 224, 224, 3), dtype=torch.float32, device=dev), n_zero=1, out=self._phi_zero)
+        phi[N:N + 1].copy_(self._phi_zero)
         tr = (lambda tag: trace.append((tag, _time.perf_counter()))) if trace is not None else (lambda tag: None)
         gpu_marks = [] if trace is not None else None          # (tag, event): device-side timeline of the same call
 
@@ -219,7 +226,9 @@ class HostStreamer(object):
                 # tail of output frames [o0, o1): their windows reach margin frames into chunk k, encoded just above
                 with torch.cuda.stream(self.s_tail):
                     self.s_tail.wait_event(enc[min(k, n_chunks - 1)])
-                    self._tail(k - 1, N, phi, recs, out_free, host, fields, keys, ar_T)
+                    # (a one-chunk video's tail as two halves, the first half's download under the second: measured SLOWER, 0.88 ms per
+                    #  half against 1.0 ms for the whole -- the tail is ~60 short launches -- profiles/r04e_host_surface.log)
+                    self._tail((k - 1) % 2, (k - 1) * C, min(N, k * C), N, phi, recs, out_free, host, fields, keys, ar_T)
                 tr(" tail queued")
         self.s_tail.synchronize()
         for f in out_free:
@@ -229,20 +238,21 @@ class HostStreamer(object):
         cur.synchronize()
         tr("done")
         if trace is not None:
+            print("entry -> first trace point: %.2f ms" % ((trace[0][1] - t_entry) * 1e3))
             t0 = trace[0][1]
             print("\n".join("%8.2f ms %s" % ((t - t0) * 1e3, tag) for tag, t in trace))
             print("\n".join("%8.2f ms (device) %s" % (gpu_marks[0][1].elapsed_time(e), tag) for tag, e in gpu_marks[1:]))
         return {k: host[k].numpy() for k in keys}
 
-    def _tail(self, j, N, phi, recs, out_free, host, fields, keys, ar_T):
+    def _tail(self, slot, o0, o1, N, phi, recs, out_free, host, fields, keys, ar_T):
+        """output frames [o0, o1) (o0 a multiple of g): windows -> records in recs[slot] -> the downloader thread"""
         t, eng, dev = self.t, self.eng, self.dev
         C, g, margin = self.chunk, self.g, self.margin
         cur = torch.cuda.current_stream(dev)
-        o0, o1 = j * C, min(N, (j + 1) * C)
+        j = o0
         w0, w1 = o0 // g, (o1 + g - 1) // g
         f = (torch.arange(w0, w1, device=dev)[:, None] * g - margin) + ar_T[None, :]
         idx = torch.where((f >= 0) & (f < N), f, torch.full_like(f, N))
-        slot = j % 2
         if out_free[slot] is not None:
             cur.wait_event(out_free[slot].result())                 # the previous copy-out of this buffer is done
         rec = recs[slot]
