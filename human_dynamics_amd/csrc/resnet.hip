@@ -288,11 +288,16 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
         T* pn = P[pcur ^ 1];
         hmmr_conv_desc_t d;
         const bool sc_c1 = U.shortcut.w && U.sc_c1.w && !h1_ready && U.stride == 1;
-        const bool sc_in_tail = U.fuse_tail == 3;        // the conv shortcut is computed inside the fused tail
+        // a register-resident unit pair (csrc/unit_pair.hip) is one round of 128-pixel workgroups with a ~20 k-cycle prologue however few
+        // pixels there are: below ~12 k pixels (61 frames in block 3) the two launches it replaces are faster (profiles/r04_unit_pair_check.log:
+        // 0.064 against 0.096 ms at 33 frames), and they produce the same bits, so a short batch simply takes them
+        const bool pair_off = w->dtype == HMMR_F16X3 && U.pair_stream && U.fuse_tail == 1 && (long long)n * Ho * Ho < 12000;
+        const int fuse_tail = pair_off ? 0 : U.fuse_tail;
+        const bool sc_in_tail = fuse_tail == 3;          // the conv shortcut is computed inside the fused tail
         // the conv shortcut is folded into conv3: ONE GEMM over {h2, preact} with [W3 | Wsc] (hmmr_conv_desc_t.in2);
         // the shortcut tensor (the widest tensor of the unit) is neither written nor read back
         const bool sc_in_c3 = U.c3sc.w != nullptr;
-        HMMR_REQUIRE(!sc_in_c3 || (U.shortcut.w && !fused && U.stride == 1 && U.fuse_tail <= 2 && !U.sc_c1.w),
+        HMMR_REQUIRE(!sc_in_c3 || (U.shortcut.w && !fused && U.stride == 1 && fuse_tail <= 2 && !U.sc_c1.w),
                      "resnet: unit %d cannot fold its shortcut into conv3", u);
         if (sc_in_c3) {
             if (prof_mark(pf)) return -2;
@@ -330,7 +335,7 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
         if (prof_mark(pf)) return -2;
         // conv2: 3x3 conv2d_same(stride): pad 1/1 both for stride 1 (SAME) and stride 2 (explicit pad + VALID);
         // with fuse_tail == 2 it runs inside the fused tail below
-        const bool conv2_in_tail = U.fuse_tail >= 2;     // (4: the single-phase tail of a stride-2 unit)
+        const bool conv2_in_tail = fuse_tail >= 2;       // (4: the single-phase tail of a stride-2 unit)
         if (!conv2_in_tail) {
             d = hmmr_conv_desc_t{};
             d.in = T1; d.w = U.conv2.w; d.scale = U.conv2.scale; d.shift = U.conv2.shift; d.relu = 1; d.tile = U.conv2.tile;
@@ -363,7 +368,7 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
             HMMR_REQUIRE(d.scale2 && d.shift2, "resnet: unit %d lacks its preact BN", u + 1);
         }
         h1_ready = false;
-        if (U.fuse_tail == 4) {       // stride-2 last unit of a block: conv2 + conv3 + add in one launch, no next conv1
+        if (fuse_tail == 4) {         // stride-2 last unit of a block: conv2 + conv3 + add in one launch, no next conv1
             HMMR_REQUIRE(!last && w->dtype == HMMR_BF16 && U.conv2.scale && U.conv2.shift && !U.shortcut.w &&
                          ((U.base == 64 && U.depth == 256) || (U.base == 128 && U.depth == 512)),
                          "resnet: unit %d cannot run as a single-phase tail", u);
@@ -376,9 +381,9 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
             t.res_row_stride = d.res_row_stride; t.res_px_stride = d.res_px_stride;
             t.out = d.out; t.out_pre = d.out2; t.pre_scale = d.scale2; t.pre_shift = d.shift2;
             if (hmmr_bottleneck_tail(&t, s)) return -2;
-        } else if (U.fuse_tail) {     // conv3 + add + the next unit's preact + conv1 in one launch (csrc/bottleneck.hip)
-            const bool pair = w->dtype == HMMR_F16X3 && U.pair_stream && U.fuse_tail == 1;      // csrc/unit_pair.hip
-            HMMR_REQUIRE(!last && (w->dtype == HMMR_BF16 || pair || (w->dtype == HMMR_F16X3 && U.w3_frag && U.w1n_frag && U.fuse_tail <= 2)) &&
+        } else if (fuse_tail) {       // conv3 + add + the next unit's preact + conv1 in one launch (csrc/bottleneck.hip)
+            const bool pair = w->dtype == HMMR_F16X3 && U.pair_stream && fuse_tail == 1;        // csrc/unit_pair.hip
+            HMMR_REQUIRE(!last && (w->dtype == HMMR_BF16 || pair || (w->dtype == HMMR_F16X3 && U.w3_frag && U.w1n_frag && fuse_tail <= 2)) &&
                          U.stride == 1 && write_raw && !write_pre && next_fused &&
                          next_identity && w->unit[u + 1].base == U.base && w->unit[u + 1].c_in == U.depth &&
                          ((U.base == 64 && U.depth == 256) || (U.base == 128 && U.depth == 512) || (pair && U.base == 256 && U.depth == 1024)),

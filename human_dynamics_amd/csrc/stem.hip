@@ -15,6 +15,9 @@
 //   4. conv + bias is staged in LDS in the activation type (the rounding point of the unfused path),
 //      then each lane max-pools 3x3/2 windows of 8 channels, applies scale/shift + ReLU, and writes
 //      16 B (bf16) / 32 B (fp32) of a 128/256-B pixel row.
+#include <type_traits>
+#include <utility>
+
 #include "common.h"
 #include "hmmr_hip.h"
 
@@ -335,22 +338,53 @@ __global__ __launch_bounds__(X3_NT) void stem_fused_split_kernel(const float* __
         abase[i] = ((2 * cy) * IPW + 2 * cx) * 8 + lh * 16;
     }
     const int bbase = lr * X3_WROW + lh * 16;
-#pragma unroll 1
-    for (int ky = 0; ky < 7; ++ky) {
+    // The 14 K steps (7 taps x 2 chunks of 16) with the six fragment reads of step s + 1 in flight under the six MFMAs of step s.
+    // The reads are inline assembly: left to itself hipcc issues each step's reads right in front of their first use and waits for
+    // them with the matrix pipe idle, 30 times per wave (round 4; per accumulator the order of the products is unchanged: same bits).
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)smem;
+    const unsigned aw = lds0 + 2 * X3_PLANE + bbase;            // filters: hi plane (+ X3_WPLANE: lo), + ky * 64 + c * 32
+    unsigned ap[MPW];                                           // patch: hi plane (+ X3_PLANE: lo), + ky * IPW * 8 + c * 32
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const shalf8 bh = *(const shalf8*)(s_wh + bbase + ky * 64 + c * 32);
-            const shalf8 bl = *(const shalf8*)(s_wl + bbase + ky * 64 + c * 32);
+    for (int i = 0; i < MPW; ++i) ap[i] = lds0 + abase[i];
+    shalf8 fb[2][2], fa[2][MPW][2];                             // [set][...][hi, lo]
+#define STEM_RD(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF))
+    auto load_step = [&](auto s_c, int set) {
+        constexpr int S = decltype(s_c)::value, KY = S >> 1, C = S & 1;
+        shalf8& bh = fb[set][0];
+        shalf8& bl = fb[set][1];
+        STEM_RD(bh, aw, KY * 64 + C * 32);
+        STEM_RD(bl, aw, X3_WPLANE + KY * 64 + C * 32);
 #pragma unroll
-            for (int i = 0; i < MPW; ++i) {
-                const shalf8 ah = *(const shalf8*)(s_ph + abase[i] + ky * IPW * 8 + c * 32);
-                const shalf8 al = *(const shalf8*)(s_pl + abase[i] + ky * IPW * 8 + c * 32);
-                acc[i] = mfma_split(al, bh, acc[i]);
-                acc[i] = mfma_split(ah, bl, acc[i]);
-                acc[i] = mfma_split(ah, bh, acc[i]);
-            }
+        for (int i = 0; i < MPW; ++i) {
+            shalf8& ah = fa[set][i][0];
+            shalf8& al = fa[set][i][1];
+            const unsigned ad = ap[i];
+            STEM_RD(ah, ad, KY * IPW * 8 + C * 32);
+            STEM_RD(al, ad, X3_PLANE + KY * IPW * 8 + C * 32);
         }
-    }
+    };
+    auto k_step = [&](auto s_c) {
+        constexpr int S = decltype(s_c)::value, CUR = S & 1;
+        if constexpr (S + 1 < 14) load_step(std::integral_constant<int, (S + 1 < 14 ? S + 1 : 13)>{}, CUR ^ 1);
+#pragma unroll
+        for (int i = 0; i < MPW; ++i) {
+            acc[i] = mfma_split(fa[CUR][i][1], fb[CUR][0], acc[i]);
+            acc[i] = mfma_split(fa[CUR][i][0], fb[CUR][1], acc[i]);
+            acc[i] = mfma_split(fa[CUR][i][0], fb[CUR][0], acc[i]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(63 | (7 << 4) | (0 << 8) | (3 << 14));      // lgkmcnt(0): the next step's fragments
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    load_step(std::integral_constant<int, 0>{}, 0);
+    __builtin_amdgcn_s_waitcnt(63 | (7 << 4) | (0 << 8) | (3 << 14));
+    __builtin_amdgcn_sched_barrier(0);
+    auto k_steps = [&](auto... S) { (k_step(S), ...); };
+    k_steps(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{},
+            std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{}, std::integral_constant<int, 6>{}, std::integral_constant<int, 7>{},
+            std::integral_constant<int, 8>{}, std::integral_constant<int, 9>{}, std::integral_constant<int, 10>{}, std::integral_constant<int, 11>{},
+            std::integral_constant<int, 12>{}, std::integral_constant<int, 13>{});
+#undef STEM_RD
     __syncthreads();                              // every wave is done with the filters: reuse as staging
 
     // ---- 4a. conv + bias, rounded to what split storage holds, -> LDS fp32 [pixel][32]
