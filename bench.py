@@ -329,7 +329,34 @@ def roofline_leg(tester, plan, span, dtype, frames):
             traffic_commit = js.get("commit")            # stamped by tools/collect_profiles.py: the kernels the counters saw
             families = {k: v.get("mfma_util") for k, v in js.get("families", {}).items()} or None
             break
+    # what the matrix pipes of THIS box sustain when they do nothing else (csrc/probe.hip): one wave per SIMD on every CU issuing
+    # v_mfma_f32_32x32x16_f16 back to back for ~0.3 ms, best of five launches -- the chip clocks well below 2.4 GHz under that load
+    sustained = None
+    if dtype in ("f16x3", "bf16"):
+        try:
+            from human_dynamics_amd import _lib as L
+            cus = torch.cuda.get_device_properties(device).multi_processor_count
+            n8 = 2500                                     # 20 000 MFMAs per wave: ~0.35 ms
+            best = None
+            for _ in range(6):
+                p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                p0.record()
+                L.check(eng.lib.hmmr_mfma_rate_probe(cus, n8, None, torch.cuda.current_stream(device).cuda_stream), "hmmr_mfma_rate_probe")
+                p1.record()
+                torch.cuda.synchronize(device)
+                ms_ = p0.elapsed_time(p1)
+                best = ms_ if best is None else min(best, ms_)
+            rate = cus * 4 * 8 * n8 * 32768.0 / (best * 1e-3)
+            sustained = {"tflops": round(rate / 1e12, 1), "instruction": "v_mfma_f32_32x32x16_f16, one wave per SIMD, nothing else issued",
+                         "frac_of_nominal": round(rate / PEAK_BF16, 4),
+                         "ceiling_for_this_mode": round(rate / mfma_per_product / 1e12, 1),
+                         "frac_of_sustained": round(achieved * mfma_per_product / rate, 4),
+                         "note": "measured on this box in this run: the power cap, not the 2.4 GHz nominal clock, sets what a dense "
+                                 "fp16 MFMA stream reaches; `frac` above stays against the nominal peak"}
+        except Exception as e:                            # the probe is a reporting aid: never fail the bench over it
+            sustained = {"error": repr(e)}
     return {"bound": "mfma",
+            "mfma_sustained": sustained,
             "kernel": "conv_gemm_kernel%s (ResNet-v2-50, %s operands: %d MFMA launches/pass, %d of them fused bottleneck units)"
                       % ({"bf16": " / bottleneck_tail_kernel / stem_fused_kernel", "f16x3": " / conv3x3_stream_kernel / unit_pair_kernel / tail_split_kernel / stem_fused_split_kernel"}.get(dtype, ""), dtype, n_conv, n_tails),
             "achieved": round(achieved / 1e12, 2), "peak": round(peak / 1e12, 1), "unit": "TFLOP/s",

@@ -141,6 +141,7 @@ SIGNATURES = {
     "hmmr_bottleneck_tail": (C.c_int, [C.POINTER(TailDesc), _vp]),
     "hmmr_pair_stream_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "hmmr_conv3x3_stream_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "hmmr_mfma_rate_probe": (C.c_int, [C.c_int, C.c_int, _fp, _vp]),
     "hmmr_render_handoff": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, _fp, C.c_int64, _fp, C.c_int, C.c_int, C.c_int,
                                       _fp, _fp, _fp, _vp]),
     "hmmr_eval_joints": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _vp]),

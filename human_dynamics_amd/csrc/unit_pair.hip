@@ -168,7 +168,6 @@ __global__ __launch_bounds__(256, 1) void unit_pair_kernel(const PairArgs a) {
     constexpr int OFF_STG = NS * SLAB;                         // [4 waves][2][4 KB]: 32 px x 32 channels x 4 B
     constexpr int OFF_C = OFF_STG + 4 * 2 * 4096;              // scale3, shift3, pre_scale, pre_shift: [DEPTH] floats each
     constexpr int EOPS = RES ? 8 : 4;
-    constexpr int EOFF = CL > 1 ? 1 : 0;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     PAIR_STAMP(0);

@@ -274,6 +274,9 @@ typedef struct {
     int c_xp;
 } hmmr_tail_desc_t;
 size_t hmmr_pair_stream_bytes(int kc3, int depth, int n2);
+/* measurement aid (bench.py's `roofline.mfma_sustained`): one launch of `workgroups` x 4 waves, one wave per SIMD, each issuing 8 * n8
+ * v_mfma_f32_32x32x16_f16 (32768 FLOP each) on four independent accumulators and nothing else.  out: NULL or workgroups * 256 floats. */
+int hmmr_mfma_rate_probe(int workgroups, int n8, float* out, void* stream);
 /* bytes of the filter stream of a k_order 2 layer: (cout / 128) x 9 (cin / 16) K steps of 8 KB */
 size_t hmmr_conv3x3_stream_bytes(int cin, int cout);
 int hmmr_bottleneck_tail(const hmmr_tail_desc_t* d, void* stream);
