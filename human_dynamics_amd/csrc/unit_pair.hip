@@ -180,12 +180,16 @@ __global__ __launch_bounds__(256, 1) void unit_pair_kernel(const PairArgs a) {
     float* sB3 = sS3 + DEPTH;
     float* sPS = sB3 + DEPTH;
     float* sPB = sPS + DEPTH;
-    for (int i = tid; i < DEPTH; i += 256) {
-        sS3[i] = a.scale3 ? a.scale3[i] : 1.0f;
-        sB3[i] = a.shift3 ? a.shift3[i] : 0.0f;
-        sPS[i] = a.pre_scale[i];
-        sPB[i] = a.pre_shift[i];
-    }
+    // the constants: four floats of each array per thread, REQUESTED here and stored behind the ring's and the panel's requests -- as a
+    // loop of scalar loads (one global round trip per 256 channels before anything else was in flight) this was half of the prologue
+    static_assert(DEPTH <= 1024 && DEPTH % 4 == 0, "one f32x4 per thread");
+    const int ci4 = tid * 4, cl4 = ci4 < DEPTH ? ci4 : DEPTH - 4;     // (unconditional requests: a load under a branch makes hipcc wait vmcnt(0))
+    f32x4 c_s3 = *(const f32x4*)((a.scale3 ? a.scale3 : a.pre_scale) + cl4);
+    f32x4 c_b3 = *(const f32x4*)((a.shift3 ? a.shift3 : a.pre_shift) + cl4);
+    const f32x4 c_ps = *(const f32x4*)(a.pre_scale + cl4);
+    const f32x4 c_pb = *(const f32x4*)(a.pre_shift + cl4);
+    static_assert(N2 <= 256, "one conv1' constant pair per thread");
+    float c_s1 = a.scale1[tid < N2 ? tid : 0], c_b1 = a.shift1[tid < N2 ? tid : 0];     // (for the h1' epilogue: no round trip at the end)
 
     // ---- the filter stream: slab `slab` -> ring slot; each wave moves a quarter (4 x 1 KB)
     // (uniform base + one 32-bit lane offset: the scalar-base addressing mode, no vector address arithmetic per request)
@@ -236,6 +240,11 @@ __global__ __launch_bounds__(256, 1) void unit_pair_kernel(const PairArgs a) {
                                           : a.src[1] + row * a.src_ld[1] + (2 * (kc - KC3A) + lh) * 8;
             xh[kc].hi = *(const shalf8*)p;
             xh[kc].lo = *((const shalf8*)p + 1);
+        }
+        if (!a.scale3) c_s3 = f32x4{1.f, 1.f, 1.f, 1.f};
+        if (!a.shift3) c_b3 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ci4 < DEPTH) {
+            *(f32x4*)(sS3 + ci4) = c_s3; *(f32x4*)(sB3 + ci4) = c_b3; *(f32x4*)(sPS + ci4) = c_ps; *(f32x4*)(sPB + ci4) = c_pb;
         }
         // the panel is read by MFMAs only (B operand): keep it in the AGPR half of the register file, where the conv1' accumulators
         // already are -- left to itself the allocator parks part of it there anyway and copies it back before every use
@@ -575,7 +584,8 @@ __global__ __launch_bounds__(256, 1) void unit_pair_kernel(const PairArgs a) {
     __syncthreads();                                           // every wave has left the loop: the ring is free
     float* sS1 = (float*)smem;
     float* sB1 = sS1 + N2;
-    for (int i = tid; i < N2; i += 256) { sS1[i] = a.scale1[i]; sB1[i] = a.shift1[i]; }
+    asm volatile("" : "+v"(c_s1), "+v"(c_b1));                 // (requested in the prologue)
+    if (tid < N2) { sS1[tid] = c_s1; sB1[tid] = c_b1; }
     __syncthreads();
     char* stg = stg_of(0);
     float satmax = 0.f;
