@@ -221,6 +221,12 @@ def test_conv3x3_stream_pack():
         got = float(st[tile, kt, rb, 0, 32 * half + row, e]) + float(st[tile, kt, rb, 1, 32 * half + row, e])
         want = float(w[ky, kx, ci, co]) * 2.0 ** int(k[co])
         assert abs(got - want) <= abs(want) * 2.0 ** -21
+    # the size the library expects (hmmr_conv3x3_stream_bytes: host arithmetic, no device needed); cout = 64: one tile of two row blocks
+    lib = _lib.load()
+    assert st.numel() * 2 == lib.hmmr_conv3x3_stream_bytes(64, 256)
+    w64 = np.random.default_rng(3).normal(size=(3, 3, 64, 64)).astype(np.float32)
+    s64 = packing.pack_conv3x3_stream(w64)
+    assert tuple(s64.shape) == (1, 36, 2, 2, 64, 8) and s64.numel() * 2 == lib.hmmr_conv3x3_stream_bytes(64, 64)
 
 
 def test_shipped_tile_tables_fit_their_layers():
