@@ -40,7 +40,7 @@ struct S3Args {
     const char* in;                         // [M][C] split rows
     const char* wstream;                    // packing.pack_conv3x3_stream
     const float* scale; const float* shift; // [cout]
-    bsplit_t* out; int ldo;
+    void* out; int ldo;                     // bsplit_t (split) or bf16_t rows
     int M, H, W, C, nc;                     // nc = C / 16
     int relu, tiles_n, n_tiles;
     long long nt_stride;                    // bytes of one 128-channel tile of the stream: 9 nc x 8 KB
@@ -79,8 +79,13 @@ constexpr int S3_NS = 6;                    // ring slabs; a slab = one K step o
 template <int V> using s3_ic = std::integral_constant<int, V>;
 
 // FM x FN accumulators per wave, WGM x WGN waves: the tile is 32 WGM FM pixels x 32 WGN FN channels (128 or 64); WMAX: the widest image
-template <int FM, int FN, int WGM, int WGN, int WMAX>
+// SPLIT: f16x3 operands (a K step = 16 channels as hi and lo halves: three MFMAs per product); false: bf16 operands (the same 64-byte
+// patch rows and 2 KB fragments hold 32 channels = two 16-wide MFMA chunks: two MFMAs per accumulator and step, the "hi" / "lo" reads
+// of the split form are chunk 0 / chunk 1 here)
+template <int FM, int FN, int WGM, int WGN, int WMAX, bool SPLIT = true>
 __global__ __launch_bounds__(256, 1) void conv3x3_stream_kernel(const S3Args a) {
+    constexpr int NP = SPLIT ? 3 : 2;                           // MFMAs per accumulator and step
+    constexpr int ESZ = SPLIT ? 4 : 2;                          // bytes per channel of a tensor row
     constexpr int NB = WGN * FN;                                // row blocks of 32 output channels per tile
     static_assert(WGM * WGN == 4 && (NB == 4 || NB == 2) && FM * FN <= 16, "4 waves, 128 or 64 channels, at most 16 accumulators");
     constexpr int R = WGM * FM, BM = 32 * R;
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_stream_kernel(const S3Args a) 
     constexpr int RW = NB / 2;                                  // 1 KB pieces of a slab each wave moves
     constexpr int ZROWS = 32 * (FM - 1) + 16;                   // zero rows behind the data rows of a patch buffer
     constexpr int PBUF = (NPP * 64 + ZROWS) * 64;               // patch rows of 64 bytes: [hi k0][lo k0][hi k1][lo k1], slots XOR-swizzled by (row >> 2) & 3
-    constexpr int NR = 2 * (FM + FN), NG = 3 * FM * FN;         // fragment reads and MFMAs (= gaps) of a step
+    constexpr int NR = 2 * (FM + FN), NG = NP * FM * FN;         // fragment reads and MFMAs (= gaps) of a step
     static_assert(2048 * (FM - 1) + 16 < 65536, "instruction offsets");
     static_assert(NR <= NG - 4, "one fragment read per gap");
 
@@ -116,8 +121,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_stream_kernel(const S3Args a) 
         const int r = 64 * q + 16 * wave + (lane >> 2);
         int px = base + r;
         px = px < 0 ? 0 : (px >= a.M ? a.M - 1 : px);
-        pptr[q] = a.in + ((long long)px * a.C) * 4 + (((lane & 3) ^ ((r >> 2) & 3)) << 4);
-        if (S3_PROBE(128)) pptr[q] = a.in + ((long long)(px & ~15) * a.C) * 4 + lane * 16;     // (probe: a coalesced KB of the wrong bytes)
+        pptr[q] = a.in + ((long long)px * a.C) * ESZ + (((lane & 3) ^ ((r >> 2) & 3)) << 4);
+        if (S3_PROBE(128)) pptr[q] = a.in + ((long long)(px & ~15) * a.C) * ESZ + lane * 16;     // (probe: a coalesced KB of the wrong bytes)
     }
     auto patch_piece = [&](int q, int c, int buf) {             // q is a constant after unrolling
         char* dst = smem + RING + buf * PBUF + wave * 1024;
@@ -171,7 +176,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_stream_kernel(const S3Args a) 
     const unsigned vW = lds0 + wn * FN * 2048 + lane * 16;      // filter fragments: + slot * SLAB + j * 2048 (+ 1024: lo plane)
     // pixel fragments: row rb0 + tap shift of a patch buffer, slots 2 lh (hi) and 2 lh + 1 (lo) before the swizzle; row block i 2 KB further
     const int rb0 = wm * FM * 32 + lr;
-    const unsigned lh2 = 2 * lh;
+    const unsigned lh2 = SPLIT ? 2 * lh : lh;                   // the first read's slot before the swizzle (split: hi of k half lh; bf16: k half lh of chunk 0)
+    constexpr unsigned XL = SPLIT ? 16u : 32u;                  // ... and the second read's: ^ XL (split: the lo slot; bf16: chunk 1)
     xfrag fx[2][FM];
     wfrag fw[2][FN];
     unsigned A0 = 0, A0l = 0, Zb = 0, Zbl = 0, adcur = 0, adcurl = 0;
@@ -212,9 +218,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_stream_kernel(const S3Args a) 
         const unsigned ph = (lh2 ^ ((rowp >> 2) & 3u)) << 4;    // this lane's hi slot in that row (the lo slot: ^ 16)
         const unsigned pb = lds0 + RING + buf_ * PBUF;
         A0 = pb + rowp * 64 + ph;
-        A0l = A0 ^ 16u;
+        A0l = A0 ^ XL;
         Zb = pb + NPP * 64 * 64 + (rowp & 3u) * 64 + ph;       // the zero row of the same bank (row & 3 and the slot are what the bank is made of)
-        Zbl = Zb ^ 16u;
+        Zbl = Zb ^ XL;
     };
 
     // ---- prologue: patch 0 and stage 0, then the fragments of step 0
@@ -244,13 +250,19 @@ __global__ __launch_bounds__(256, 1) void conv3x3_stream_kernel(const S3Args a) 
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+            for (int p = 0; p < NP; ++p)
 #pragma unroll
                 for (int j = 0; j < FN; ++j) {
-                    const shalf8& wa = p == 1 ? fw[CUR][j].lo : fw[CUR][j].hi;
-                    const shalf8& xb = p == 0 ? fx[CUR][i].lo : fx[CUR][i].hi;
-                    if (!S3_PROBE(1)) acc[i][j] = mfma_split(wa, xb, acc[i][j]);
-                    const int g = (3 * i + p) * FN + j;
+                    if constexpr (SPLIT) {
+                        const shalf8& wa = p == 1 ? fw[CUR][j].lo : fw[CUR][j].hi;
+                        const shalf8& xb = p == 0 ? fx[CUR][i].lo : fx[CUR][i].hi;
+                        if (!S3_PROBE(1)) acc[i][j] = mfma_split(wa, xb, acc[i][j]);
+                    } else {
+                        const shalf8& wa = p ? fw[CUR][j].lo : fw[CUR][j].hi;
+                        const shalf8& xb = p ? fx[CUR][i].lo : fx[CUR][i].hi;
+                        if (!S3_PROBE(1)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa), __builtin_bit_cast(bf16x8, xb), acc[i][j], 0, 0, 0);
+                    }
+                    const int g = (NP * i + p) * FN + j;
                     if (g == 0 && more && !S3_PROBE(4)) ring_dma(kt + NS, SUB);
                     if (g == 1 && !S3_PROBE(16)) tap_setup(s3_ic<TAP1>{}, BUF1);           // (past the last step: a harmless read of stale LDS)
                     if (TAP == 0 && g >= 2 && g < 2 + NPP && pat && !S3_PROBE(4) && !S3_PROBE(64)) patch_piece(g - 2 < NPP ? g - 2 : 0, c + 1, BUFP);
@@ -294,56 +306,94 @@ __global__ __launch_bounds__(256, 1) void conv3x3_stream_kernel(const S3Args a) 
                 b4[j][g] = *(const f32x4*)(cst + 32 * NB + j * 32 + 8 * g);
             }
     }
-    float satmax = 0.f;
-    int blk = 0;
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-        const int mb = m0 + (wm * FM + i) * 32;
-        bsplit_t* orow[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int r = 8 * q + rsub, m = mb + r;
-            const int ls = pslot ^ ((r >> 1) & 7);
-            orow[q] = m < a.M ? a.out + (long long)m * a.ldo + nb + ls * 4 : (bsplit_t*)g_s3_dump + lane * 4;
-        }
-#pragma unroll
-        for (int j = 0; j < FN; ++j, ++blk) {
-            char* tile = stg + (blk & 1) * 4096;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float c[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = fmaf(acc[i][j][4 * g + e], s4[j][g][e], b4[j][g][e]);
-                    satmax = __builtin_fmaxf(satmax, __builtin_fabsf(v));
-                    c[e] = __builtin_amdgcn_fmed3f(v, lo_clamp, HMMR_SPLIT_MAX);
-                }
-                const unsigned h01 = __builtin_bit_cast(unsigned, shalf2{(shalf_t)c[0], (shalf_t)c[1]});
-                const unsigned h23 = __builtin_bit_cast(unsigned, shalf2{(shalf_t)c[2], (shalf_t)c[3]});
-                // lo = fp16(c - hi): c - hi is exact in fp32, so the mixed-precision fma rounds once, like the cast of split4 (common.h)
-                unsigned l01, l23;
-                asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l01) : "v"(h01), "v"(c[0]));
-                asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l01) : "v"(h01), "v"(c[1]));
-                asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l23) : "v"(h23), "v"(c[2]));
-                asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l23) : "v"(h23), "v"(c[3]));
-                const unsigned long long oh = (unsigned long long)h01 | ((unsigned long long)h23 << 32);
-                const unsigned long long ol = (unsigned long long)l01 | ((unsigned long long)l23 << 32);
-                *(unsigned long long*)(tile + lr * 128 + (((2 * g) ^ sw) << 4) + 8 * lh) = oh;
-                *(unsigned long long*)(tile + lr * 128 + (((2 * g + 1) ^ sw) << 4) + 8 * lh) = ol;
+    if constexpr (SPLIT) {
+        float satmax = 0.f;
+        int blk = 0;
+    #pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int mb = m0 + (wm * FM + i) * 32;
+            bsplit_t* orow[4];
+    #pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = 8 * q + rsub, m = mb + r;
+                const int ls = pslot ^ ((r >> 1) & 7);
+                orow[q] = m < a.M ? (bsplit_t*)a.out + (long long)m * a.ldo + nb + ls * 4 : (bsplit_t*)g_s3_dump + lane * 4;
             }
-            u32x4 xr[4];
+    #pragma unroll
+            for (int j = 0; j < FN; ++j, ++blk) {
+                char* tile = stg + (blk & 1) * 4096;
+    #pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float c[4];
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = fmaf(acc[i][j][4 * g + e], s4[j][g][e], b4[j][g][e]);
+                        satmax = __builtin_fmaxf(satmax, __builtin_fabsf(v));
+                        c[e] = __builtin_amdgcn_fmed3f(v, lo_clamp, HMMR_SPLIT_MAX);
+                    }
+                    const unsigned h01 = __builtin_bit_cast(unsigned, shalf2{(shalf_t)c[0], (shalf_t)c[1]});
+                    const unsigned h23 = __builtin_bit_cast(unsigned, shalf2{(shalf_t)c[2], (shalf_t)c[3]});
+                    // lo = fp16(c - hi): c - hi is exact in fp32, so the mixed-precision fma rounds once, like the cast of split4 (common.h)
+                    unsigned l01, l23;
+                    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l01) : "v"(h01), "v"(c[0]));
+                    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l01) : "v"(h01), "v"(c[1]));
+                    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l23) : "v"(h23), "v"(c[2]));
+                    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l23) : "v"(h23), "v"(c[3]));
+                    const unsigned long long oh = (unsigned long long)h01 | ((unsigned long long)h23 << 32);
+                    const unsigned long long ol = (unsigned long long)l01 | ((unsigned long long)l23 << 32);
+                    *(unsigned long long*)(tile + lr * 128 + (((2 * g) ^ sw) << 4) + 8 * lh) = oh;
+                    *(unsigned long long*)(tile + lr * 128 + (((2 * g + 1) ^ sw) << 4) + 8 * lh) = ol;
+                }
+                u32x4 xr[4];
+    #pragma unroll
+                for (int q = 0; q < 4; ++q) xr[q] = *(const u32x4*)(tile + q * 1024 + lane * 16);
+    #pragma unroll
+                for (int q = 0; q < 4; ++q) *(u32x4*)(orow[q] + j * 32) = xr[q];
+            }
+        }
+    split_flag(satmax > HMMR_SPLIT_MAX);
+    } else {
+        // bf16 rows: 32 channels = 64 bytes per pixel and accumulator; lane (pixel lr, k half lh) holds channels 8 g + 4 lh .. + 3 of group g
+        // as 8 bytes; a 2 KB staging tile per accumulator, rows of 64 B, 16-byte slot g XOR (row >> 2) & 3
+        int blk = 0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) xr[q] = *(const u32x4*)(tile + q * 1024 + lane * 16);
+        for (int i = 0; i < FM; ++i) {
+            const int mb = m0 + (wm * FM + i) * 32;
+            bf16_t* orow[2];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) *(u32x4*)(orow[q] + j * 32) = xr[q];
+            for (int q = 0; q < 2; ++q) {
+                const int r = 16 * q + (lane >> 2), m = mb + r;
+                const int ls = (lane & 3) ^ ((r >> 2) & 3);
+                orow[q] = m < a.M ? (bf16_t*)a.out + (long long)m * a.ldo + nb + ls * 8 : (bf16_t*)g_s3_dump + lane * 8;
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j, ++blk) {
+                char* tile = stg + (blk & 1) * 4096;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = fmaf(acc[i][j][4 * g + e], s4[j][g][e], b4[j][g][e]);
+                        if (a.relu) v = fmaxf(v, 0.f);
+                        o[e] = (bf16_t)v;
+                    }
+                    *(bf16x4*)(tile + lr * 64 + ((g ^ ((lr >> 2) & 3)) << 4) + 8 * lh) = o;
+                }
+                u32x4 xr[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) xr[q] = *(const u32x4*)(tile + q * 1024 + lane * 16);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) *(u32x4*)(orow[q] + j * 32) = xr[q];
+            }
         }
     }
-    split_flag(satmax > HMMR_SPLIT_MAX);
     S3_STAMP(3);
 }
 
-template <int FM, int FN, int WGM, int WGN, int WMAX>
-int launch_s3(const S3Args& base, int cout, hipStream_t stream) {
+template <int FM, int FN, int WGM, int WGN, int WMAX, bool SPLIT>
+int launch_s3_t(const S3Args& base, int cout, hipStream_t stream) {
     S3Args a = base;
     constexpr int NB = WGN * FN, BM = 32 * WGM * FM, NPP = (BM + 2 * WMAX + 2 + 63) / 64;
     constexpr int lds = S3_NS * NB * 2048 + 8 * (NPP * 64 + 32 * (FM - 1) + 16) * 16 + 1024;
@@ -351,7 +401,7 @@ int launch_s3(const S3Args& base, int cout, hipStream_t stream) {
     a.tiles_n = cout / (32 * NB);
     a.n_tiles = ((a.M + BM - 1) / BM) * a.tiles_n;
     a.nt_stride = (long long)9 * a.nc * (NB * 2048);
-    auto kern = conv3x3_stream_kernel<FM, FN, WGM, WGN, WMAX>;
+    auto kern = conv3x3_stream_kernel<FM, FN, WGM, WGN, WMAX, SPLIT>;
     static DeviceOnce once;
     if (const unsigned long long bit = once.due()) {
         HMMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -360,6 +410,11 @@ int launch_s3(const S3Args& base, int cout, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3((unsigned)a.n_tiles), dim3(256), lds, stream, a);
     HMMR_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+template <int FM, int FN, int WGM, int WGN, int WMAX>
+int launch_s3(const S3Args& a, int cout, bool split, hipStream_t stream) {
+    return split ? launch_s3_t<FM, FN, WGM, WGN, WMAX, true>(a, cout, stream) : launch_s3_t<FM, FN, WGM, WGN, WMAX, false>(a, cout, stream);
 }
 
 }  // namespace
@@ -372,13 +427,15 @@ extern "C" size_t hmmr_conv3x3_stream_bytes(int cin, int cout) {
 
 // hmmr_conv_gemm with k_order = 2 (called from gemm_conv.hip, which has checked the descriptor's geometry)
 int hmmr_conv3x3_stream(const hmmr_conv_desc_t* d, hipStream_t stream) {
-    HMMR_REQUIRE(d->in_dtype == HMMR_F16X3 && d->out_dtype == HMMR_F16X3, "hmmr_conv_gemm: k_order 2 is built for split (f16x3) tensors");
+    const bool split = d->in_dtype == HMMR_F16X3 && d->out_dtype == HMMR_F16X3;
+    HMMR_REQUIRE(split || (d->in_dtype == HMMR_BF16 && d->out_dtype == HMMR_BF16), "hmmr_conv_gemm: k_order 2 is built for split (f16x3) and bf16 tensors");
+    HMMR_REQUIRE(split || d->cin % 64 == 0, "hmmr_conv_gemm: k_order 2 with bf16 tensors needs cin %% 64 == 0 (K steps of 32 channels, taken in pairs)");
     HMMR_REQUIRE(d->cin % 32 == 0 && (d->cout % 128 == 0 || d->cout == 64) && d->win <= 56 && d->scale && d->shift,
                  "hmmr_conv_gemm: k_order 2 needs cin %% 32 == 0, cout %% 128 == 0 (or cout = 64), an image at most 56 pixels wide and scale + shift");
     S3Args a = {};
     a.in = (const char*)d->in; a.wstream = (const char*)d->w; a.scale = d->scale; a.shift = d->shift;
-    a.out = (bsplit_t*)d->out; a.ldo = d->ldo;
-    a.M = d->n_img * d->ho * d->wo; a.H = d->hin; a.W = d->win; a.C = d->cin; a.nc = d->cin / 16;
+    a.out = d->out; a.ldo = d->ldo;
+    a.M = d->n_img * d->ho * d->wo; a.H = d->hin; a.W = d->win; a.C = d->cin; a.nc = split ? d->cin / 16 : d->cin / 32;      // K chunks: 64 bytes of a pixel's row
     a.relu = d->relu;
 #ifdef HMMR_GEMM_PROBE
     a.ts = (unsigned long long*)(((unsigned long long)(unsigned)hmmr_debug_state()->reserved[1] << 32) | (unsigned)hmmr_debug_state()->reserved[0]);
@@ -400,15 +457,15 @@ int hmmr_conv3x3_stream(const hmmr_conv_desc_t* d, hipStream_t stream) {
     HMMR_REQUIRE((tile >= 19) == narrow && (!wide || narrow), "hmmr_conv_gemm: k_order 2: tiles 12 .. 18 take cout %% 128 == 0 and images up to 28 pixels wide, "
                  "tiles 19 / 20 cout = 64 and up to 56 (tile %d, cout %d, win %d)", tile, d->cout, d->win);
     switch (tile) {
-    case 12: return launch_s3<7, 2, 2, 2, 28>(a, d->cout, stream);       // 448 pixels
-    case 13: return launch_s3<4, 2, 2, 2, 28>(a, d->cout, stream);       // 256
-    case 14: return launch_s3<8, 2, 2, 2, 28>(a, d->cout, stream);       // 512
-    case 15: return launch_s3<6, 2, 2, 2, 28>(a, d->cout, stream);       // 384
-    case 16: return launch_s3<5, 2, 2, 2, 28>(a, d->cout, stream);       // 320
-    case 17: return launch_s3<4, 4, 4, 1, 28>(a, d->cout, stream);       // 512, waves split the pixels
-    case 18: return launch_s3<3, 4, 4, 1, 28>(a, d->cout, stream);       // 384
-    case 19: return launch_s3<5, 2, 4, 1, 56>(a, d->cout, stream);       // 640 pixels x 64 channels
-    case 20: return launch_s3<4, 2, 4, 1, 56>(a, d->cout, stream);       // 512 x 64
+    case 12: return launch_s3<7, 2, 2, 2, 28>(a, d->cout, split, stream);       // 448 pixels
+    case 13: return launch_s3<4, 2, 2, 2, 28>(a, d->cout, split, stream);       // 256
+    case 14: return launch_s3<8, 2, 2, 2, 28>(a, d->cout, split, stream);       // 512
+    case 15: return launch_s3<6, 2, 2, 2, 28>(a, d->cout, split, stream);       // 384
+    case 16: return launch_s3<5, 2, 2, 2, 28>(a, d->cout, split, stream);       // 320
+    case 17: return launch_s3<4, 4, 4, 1, 28>(a, d->cout, split, stream);       // 512, waves split the pixels
+    case 18: return launch_s3<3, 4, 4, 1, 28>(a, d->cout, split, stream);       // 384
+    case 19: return launch_s3<5, 2, 4, 1, 56>(a, d->cout, split, stream);       // 640 pixels x 64 channels
+    case 20: return launch_s3<4, 2, 4, 1, 56>(a, d->cout, split, stream);       // 512 x 64
     default: break;
     }
     hmmr_set_error("hmmr_conv_gemm: k_order 2 runs tiles 12 .. 20, not %d", tile);

@@ -515,7 +515,11 @@ def conv_gemm(x, w_hwio, stride=1, pad=0, scale=None, shift=None, res=None, relu
         x2 = store.put(np.asarray(second[0], np.float32), packing.TORCH_DT[in_dtype])
         w_hwio = np.concatenate([np.asarray(w_hwio, np.float32), np.asarray(second[1], np.float32)], axis=2)
     wp = packing.pack_conv_weight(np.asarray(w_hwio, np.float32), k_order if k_order != 2 else 0, chunk=64 if in_dtype == L.HMMR_BF16 else 32)
-    if k_order == 2:                                    # the filter stream of csrc/conv3x3_stream.hip (as packing._layer_stream3x3)
+    if k_order == 2 and in_dtype == L.HMMR_BF16:        # the filter stream of csrc/conv3x3_stream.hip, bf16 form
+        scale = np.ones(cout, np.float32) if scale is None else scale
+        shift = np.zeros(cout, np.float32) if shift is None else shift
+        wt = store.put_tensor(packing.pack_conv3x3_stream(np.asarray(w_hwio, np.float32), bf16=True))
+    elif k_order == 2:                                  # ... split form (as packing._layer_stream3x3)
         k = packing.row_pow2(wp[:cout])
         sc = np.ones(cout, np.float64) if scale is None else np.asarray(scale, np.float64)
         scale = (sc * np.exp2(-k.astype(np.float64))).astype(np.float32)

@@ -120,16 +120,23 @@ def pack_frag_major(w_nk):
     return torch.stack([frag(hi), frag(lo)], dim=3).contiguous()   # [rb, kc, lane, 2, 8]
 
 
-def pack_conv3x3_stream(w_hwio, k=None):
+def pack_conv3x3_stream(w_hwio, k=None, bf16=False):
     """[3,3,cin,cout] -> fp16 [cout / 128][9 cin / 16][4][2 (hi, lo plane)][64 lanes][8]: the filter stream of a k_order 2 layer
     (hmmr_conv_desc_t.k_order, csrc/conv3x3_stream.hip).  K step kt = (ci // 16) * 9 + ky * 3 + kx of a 128-channel tile is 8 KB:
     row blocks 0 .. 3, each the MFMA A operand of 32 rows x 16 K as a hi and a lo plane (lane = 32 * (k half) + row, 8 halves =
     W[ky, kx, 16 (ci // 16) + 8 half .. + 7, 128 tile + 32 block + row]), rows scaled by 2^k (row_pow2 of the rows).  cout = 64: one
-    tile of two row blocks ([1][9 cin / 16][2][2][64][8])."""
+    tile of two row blocks ([1][9 cin / 16][2][2][64][8]).
+    bf16=True (bf16 tensors): bfloat16 [cout / 128][9 cin / 32][4][2][64][8] -- a K step is (ci // 32) * 9 + tap, its two planes are the
+    two 16-wide MFMA chunks of those 32 channels (8 values = W[.., 32 (ci // 32) + 16 plane + 8 half .. + 7, ..]); no row scaling."""
     w = np.asarray(w_hwio, np.float64)
     kh, kw, cin, cout = w.shape
     assert (kh, kw) == (3, 3) and cin % 16 == 0 and (cout % 128 == 0 or cout == 64), w.shape
     tw = 128 if cout % 128 == 0 else 64
+    if bf16:
+        assert cin % 32 == 0, w.shape
+        t = torch.from_numpy(w.astype(np.float32)).to(torch.bfloat16)
+        x = t.reshape(9, cin // 32, 2, 2, 8, cout // tw, tw // 32, 32)       # tap, c32, plane, half, e, tile, rb, row
+        return x.permute(5, 1, 0, 6, 2, 3, 7, 4).reshape(cout // tw, 9 * (cin // 32), tw // 32, 2, 64, 8).contiguous()
     if k is None:
         k = row_pow2(w.reshape(9 * cin, cout).T)
     t = torch.from_numpy((w * np.exp2(np.asarray(k, np.float64))).astype(np.float32))
@@ -239,13 +246,17 @@ def _layer(store, w_packed, dtype, scale=None, shift=None):
     return lay
 
 
-def _layer_stream3x3(store, w_hwio, scale, shift):
-    """hmmr_layer_t of a k_order 2 conv2 (f16x3): the filter stream instead of a matrix, the same row scaling as _layer."""
-    rows = pack_conv_weight(w_hwio)[:w_hwio.shape[3]]
-    k = row_pow2(rows)
+def _layer_stream3x3(store, w_hwio, scale, shift, bf16=False):
+    """hmmr_layer_t of a k_order 2 conv2: the filter stream instead of a matrix; f16x3: the same row scaling as _layer."""
     lay = L.Layer()
-    lay.w = store.put_tensor(pack_conv3x3_stream(w_hwio, k)).data_ptr()
-    lay.scale = store.vec((np.asarray(scale, np.float64) * np.exp2(-k.astype(np.float64))).astype(np.float32)).data_ptr()
+    if bf16:
+        lay.w = store.put_tensor(pack_conv3x3_stream(w_hwio, bf16=True)).data_ptr()
+        lay.scale = store.vec(scale).data_ptr()
+    else:
+        rows = pack_conv_weight(w_hwio)[:w_hwio.shape[3]]
+        k = row_pow2(rows)
+        lay.w = store.put_tensor(pack_conv3x3_stream(w_hwio, k)).data_ptr()
+        lay.scale = store.vec((np.asarray(scale, np.float64) * np.exp2(-k.astype(np.float64))).astype(np.float32)).data_ptr()
     lay.shift = store.vec(shift).data_ptr()
     lay.k_order = 2
     return lay
@@ -258,9 +269,9 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
     measured at batch 256: -4.5 % ResNet time with blocks 1-2 fused, neutral for blocks 3-4).
     fuse_tail: mark the units whose conv3 + add runs with the next unit's preact + conv1 as one
     hmmr_bottleneck_tail launch (bf16; the stride-1 units of block1 and block2).
-    patch_3x3 (f16x3: blocks 2-4; bf16: blocks 3-4): the stride-1 3x3 conv2 out of an LDS-resident input patch.  2 (default): f16x3
+    patch_3x3 (f16x3: blocks 2-4; bf16: blocks 3-4): the stride-1 3x3 conv2 out of an LDS-resident input patch.  2 (default): the
     layers get hmmr_conv_desc_t.k_order = 2, the filter stream of the one-wave-per-SIMD kernel (csrc/conv3x3_stream.hip, tiles 12 .. 18);
-    1 / True (and bf16 always): k_order = 1, chunk-major rows for the 8-wave patch kernels (csrc/gemm_conv.hip, tiles 9 / 10; 11 for f16x3).
+    1 / True: k_order = 1, chunk-major rows for the 8-wave patch kernels (csrc/gemm_conv.hip, tiles 9 / 10; 11 for f16x3).
     b1_stream (with patch_3x3 = 2, f16x3; default off): the conv2 of block1/unit_1 and unit_2 is a k_order 2 launch too (64-channel tiles,
     56-pixel images) and their fused tails start at conv3 (hmmr_resnet_unit_t.fuse_tail = 1); False: conv2 runs inside those tails,
     tap-major.  Measured equal (profiles/r04c: 0.188 + 0.434 ms against 0.632 ms per unit), so the form with 0.4 GB less HBM traffic stays.
@@ -296,7 +307,7 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
         u.conv1 = _layer(store, pack_conv_weight(w[scope + "/conv1/weights"]), dtype, s, b)
         s, b = fold_bn(w, scope + "/conv2/BatchNorm")
         # (bf16, round 4: blocks 3-4 only -- the conv2 of blocks 1-2 runs inside the fused bf16 units, which read the tap-major order)
-        stream = dtype == L.HMMR_F16X3 and patch_3x3 == 2 and patch_3x3 is not True
+        stream = dtype in (L.HMMR_F16X3, L.HMMR_BF16) and patch_3x3 == 2 and patch_3x3 is not True
         kord = int(bool(patch_3x3) and stride == 1 and ((dtype == L.HMMR_F16X3 and (base >= 128 or (stream and b1_stream))) or
                                                          (dtype == L.HMMR_BF16 and base >= 256)))
         # (a chunk-major layer cannot fall back to the im2col gather: its 128-pixel patch -- tile + halo of W + 1 on either side --
@@ -304,7 +315,7 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
         if kord and not stream and 128 + 2 * (224 // {64: 4, 128: 8, 256: 16, 512: 32}[base]) + 4 > 4 * 64:
             kord = 0
         if kord and stream:
-            u.conv2 = _layer_stream3x3(store, np.asarray(w[scope + "/conv2/weights"], np.float32), s, b)
+            u.conv2 = _layer_stream3x3(store, np.asarray(w[scope + "/conv2/weights"], np.float32), s, b, bf16=dtype == L.HMMR_BF16)
         else:
             u.conv2 = _layer(store, pack_conv_weight(w[scope + "/conv2/weights"], kord, chunk=bke), dtype, s, b)
             u.conv2.k_order = kord

@@ -155,7 +155,8 @@ typedef struct {
      * 2: `w` is not a matrix but the FILTER STREAM of packing.pack_conv3x3_stream (hmmr_conv3x3_stream_bytes(cin, cout) bytes):
      * per 128 output channels, K steps kt = (ci / 16) * 9 + ky*3 + kx of 8 KB = 4 row blocks x (hi plane | lo plane) of MFMA
      * A-operand fragments (lane = 32 * (k half) + row; 8 halves = W[row][16 (ci / 16) + 8 half .. + 7] of that tap), rows scaled
-     * like every split filter bank.  Same convolutions and epilogue as k_order 1, split (f16x3) tensors only, cin % 32 == 0,
+     * like every split filter bank.  Same convolutions and epilogue as k_order 1; split (f16x3) tensors, cin % 32 == 0 -- or bf16 tensors (K steps of 32
+     * channels `(ci / 32) * 9 + tap`, the two planes = the two 16-wide MFMA chunks, no row scaling), cin % 64 == 0 --,
      * cout % 128 == 0, win <= 28; tiles 12 .. 18 (csrc/conv3x3_stream.hip).  Every tile produces the same bits. */
     int k_order;
     /* grouped launch: `batch` > 1 runs that many problems of this one shape as ONE launch (grid z); problem z reads and
@@ -277,7 +278,8 @@ size_t hmmr_pair_stream_bytes(int kc3, int depth, int n2);
 /* measurement aid (bench.py's `roofline.mfma_sustained`): one launch of `workgroups` x 4 waves, one wave per SIMD, each issuing 8 * n8
  * v_mfma_f32_32x32x16_f16 (32768 FLOP each) on four independent accumulators and nothing else.  out: NULL or workgroups * 256 floats. */
 int hmmr_mfma_rate_probe(int workgroups, int n8, float* out, void* stream);
-/* bytes of the filter stream of a k_order 2 layer: (cout / 128) x 9 (cin / 16) K steps of 8 KB */
+/* bytes of the filter stream of a k_order 2 layer of split tensors: (cout / 128) x 9 (cin / 16) K steps of 8 KB (bf16 tensors: half of it,
+ * 9 (cin / 32) K steps) */
 size_t hmmr_conv3x3_stream_bytes(int cin, int cout);
 int hmmr_bottleneck_tail(const hmmr_tail_desc_t* d, void* stream);
 

@@ -246,6 +246,32 @@ def test_conv3x3_patch_kernel_bf16(case, gpu_device):
     assert np.abs(outs[0] - ring).max() < 8e-3 * mag
 
 
+@pytest.mark.parametrize("case", [c for c in PATCH_CASES if c[4] % 64 == 0], ids=[c[0] for c in PATCH_CASES if c[4] % 64 == 0])
+def test_conv3x3_stream_kernel_bf16(case, gpu_device):
+    """The stream kernel's bf16 instantiation (k_order 2 with bf16 tensors: K steps of 32 channels, two MFMAs per accumulator and step):
+    against a float64 convolution of the same bf16-rounded operands; its tiles agree bit for bit; the patch kernel (another accumulation
+    order) within the rounding of the bf16 output."""
+    from human_dynamics_amd.engine import conv_gemm
+    name, n, h, w_, cin, cout = case
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(name.encode()) % 1000 + 2)
+    bf = lambda a: torch.from_numpy(np.asarray(a, np.float32)).to(torch.bfloat16).float().numpy()
+    x = bf(rng.normal(size=(n, h, w_, cin)))
+    w = bf(rng.normal(size=(3, 3, cin, cout)) / np.sqrt(9 * cin))
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.normal(size=cout).astype(np.float32)
+    for relu in (True, False):
+        kw = dict(stride=1, pad=1, scale=scale, shift=shift, relu=relu, in_dtype=L.HMMR_BF16, out_dtype=L.HMMR_BF16, device=gpu_device)
+        outs = {tile: conv_gemm(x, w, tile=tile, k_order=2, **kw)[0] for tile in ((0, 12, 13, 14, 15, 16, 17, 18) if relu else (0, 13))}
+        ref, _ = _ref_conv(x, w, 1, 1, scale, shift, None, relu, None, None, 1)
+        mag = max(1.0, np.abs(ref).max())
+        for tile, out in outs.items():
+            assert np.abs(out - ref).max() < 6e-3 * mag, "%s tile %d" % (name, tile)          # (the output is stored as bf16)
+            assert np.array_equal(out, outs[0]), "%s: tile %d differs from the library's choice" % (name, tile)
+        patch, _ = conv_gemm(x, w, tile=0, k_order=1, **kw)
+        assert np.abs(outs[0] - patch).max() < 8e-3 * mag
+
+
 @pytest.mark.parametrize("tile", [0, 3, 5, 6, 1, 7])
 def test_conv_gemm_split_fused_preactivation(tile, gpu_device):
     """A = relu(x*scale[ci] + shift[ci]) applied while staging a split operand (hi and lo halves sit in

@@ -200,8 +200,10 @@ def test_chunk_major_filter_pack():
     off = packing.pack_resnet(ws, _lib.HMMR_F16X3, packing.DeviceStore("cpu"), patch_3x3=False)
     assert not any(off.unit[i].conv2.k_order for i in range(16))
     # bf16 (round 4): blocks 3-4 only -- the conv2 of blocks 1-2 runs inside the fused bf16 units, which read the tap-major order
-    b16 = packing.pack_resnet(ws, _lib.HMMR_BF16, packing.DeviceStore("cpu"))
+    b16 = packing.pack_resnet(ws, _lib.HMMR_BF16, packing.DeviceStore("cpu"), patch_3x3=1)
     assert [b16.unit[i].conv2.k_order for i in range(16)] == [0] * 7 + [1, 1, 1, 1, 1, 0, 1, 1, 1]
+    b16s = packing.pack_resnet(ws, _lib.HMMR_BF16, packing.DeviceStore("cpu"))              # default: the stream kernel's bf16 form
+    assert [b16s.unit[i].conv2.k_order for i in range(16)] == [0] * 7 + [2, 2, 2, 2, 2, 0, 2, 2, 2]
     assert not any(packing.pack_resnet(ws, _lib.HMMR_F32, packing.DeviceStore("cpu")).unit[i].conv2.k_order for i in range(16))
     w64 = np.random.default_rng(1).normal(size=(3, 3, 128, 64)).astype(np.float32)
     p64 = packing.pack_conv_weight(w64, 1, chunk=64)          # bf16: 64 elements per 128-byte K step
@@ -227,6 +229,13 @@ def test_conv3x3_stream_pack():
     w64 = np.random.default_rng(3).normal(size=(3, 3, 64, 64)).astype(np.float32)
     s64 = packing.pack_conv3x3_stream(w64)
     assert tuple(s64.shape) == (1, 36, 2, 2, 64, 8) and s64.numel() * 2 == lib.hmmr_conv3x3_stream_bytes(64, 64)
+    # bf16 tensors: K steps of 32 channels, the planes = the two 16-wide MFMA chunks, half the bytes
+    sb = packing.pack_conv3x3_stream(w, bf16=True)
+    assert tuple(sb.shape) == (2, 18, 4, 2, 64, 8) and sb.dtype == torch.bfloat16 and sb.numel() * 2 * 2 == lib.hmmr_conv3x3_stream_bytes(64, 256)
+    for ky, kx, ci, co in ((0, 0, 0, 0), (1, 2, 37, 5), (2, 2, 63, 255), (0, 1, 17, 130)):
+        tile, rb, row = co // 128, (co % 128) // 32, co % 32
+        kt, plane, half, e = (ci // 32) * 9 + ky * 3 + kx, (ci % 32) // 16, (ci % 16) // 8, ci % 8
+        assert float(sb[tile, kt, rb, plane, 32 * half + row, e]) == float(torch.tensor(w[ky, kx, ci, co]).to(torch.bfloat16))
 
 
 def test_shipped_tile_tables_fit_their_layers():
