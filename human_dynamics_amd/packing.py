@@ -308,8 +308,11 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
         s, b = fold_bn(w, scope + "/conv2/BatchNorm")
         # (bf16, round 4: blocks 3-4 only -- the conv2 of blocks 1-2 runs inside the fused bf16 units, which read the tap-major order)
         stream = dtype in (L.HMMR_F16X3, L.HMMR_BF16) and patch_3x3 == 2 and patch_3x3 is not True
+        # (bf16: the conv2 of blocks 1-2 runs inside the fused bf16 units, which read the tap-major order -- unless fuse_tail="conv2b1"
+        #  keeps block 2's outside, as launches of the stream kernel)
+        b16_min = 128 if (stream and fuse_tail == "conv2b1") else 256
         kord = int(bool(patch_3x3) and stride == 1 and ((dtype == L.HMMR_F16X3 and (base >= 128 or (stream and b1_stream))) or
-                                                         (dtype == L.HMMR_BF16 and base >= 256)))
+                                                         (dtype == L.HMMR_BF16 and base >= b16_min)))
         # (a chunk-major layer cannot fall back to the im2col gather: its 128-pixel patch -- tile + halo of W + 1 on either side --
         #  must fit the 4 x 64 rows the 128x256 tile keeps in LDS.  ResNet-50 on 224 x 224 crops: W <= 28)
         if kord and not stream and 128 + 2 * (224 // {64: 4, 128: 8, 256: 16, 512: 32}[base]) + 4 > 4 * 64:
