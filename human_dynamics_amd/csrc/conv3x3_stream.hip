@@ -444,17 +444,17 @@ int hmmr_conv3x3_stream(const hmmr_conv_desc_t* d, hipStream_t stream) {
     const bool narrow = d->cout == 64, wide = d->win > 28;
     if (!tile) {
         // the library's choice: fewest rounds of 256 workgroups x (row blocks per tile + ~1.5 for a tile's prologue and epilogue)
-        static const int cand[6][3] = {{12, 14, 0}, {13, 8, 0}, {15, 12, 0}, {16, 10, 0}, {19, 20, 1}, {20, 16, 1}};
+        static const int cand[7][3] = {{12, 14, 0}, {13, 8, 0}, {15, 12, 0}, {16, 10, 0}, {21, 7, 0}, {19, 20, 1}, {20, 16, 1}};
         const long long rbs = (a.M + 31) / 32, nts = narrow ? 1 : d->cout / 128;
         double best = 0;
         for (const auto& cd : cand) {
-            if ((cd[2] != 0) != narrow) continue;
+            if ((cd[2] != 0) != narrow || (cd[0] == 21 && !split)) continue;
             const long long tiles = ((rbs + cd[1] - 1) / cd[1]) * nts;
             const double cost = (double)((tiles + 255) / 256) * (cd[1] + 1.5);
             if (!tile || cost < best) { tile = cd[0]; best = cost; }
         }
     }
-    HMMR_REQUIRE((tile >= 19) == narrow && (!wide || narrow), "hmmr_conv_gemm: k_order 2: tiles 12 .. 18 take cout %% 128 == 0 and images up to 28 pixels wide, "
+    HMMR_REQUIRE((tile == 19 || tile == 20) == narrow && (!wide || narrow), "hmmr_conv_gemm: k_order 2: tiles 12 .. 18 take cout %% 128 == 0 and images up to 28 pixels wide, "
                  "tiles 19 / 20 cout = 64 and up to 56 (tile %d, cout %d, win %d)", tile, d->cout, d->win);
     switch (tile) {
     case 12: return launch_s3<7, 2, 2, 2, 28>(a, d->cout, split, stream);       // 448 pixels
@@ -466,8 +466,12 @@ int hmmr_conv3x3_stream(const hmmr_conv_desc_t* d, hipStream_t stream) {
     case 18: return launch_s3<3, 4, 4, 1, 28>(a, d->cout, split, stream);       // 384
     case 19: return launch_s3<5, 2, 4, 1, 56>(a, d->cout, split, stream);       // 640 pixels x 64 channels
     case 20: return launch_s3<4, 2, 4, 1, 56>(a, d->cout, split, stream);       // 512 x 64
+    case 21:                                                                    // 224 pixels, every wave all of them and 32 of the 128 channels
+        HMMR_REQUIRE(split, "hmmr_conv_gemm: k_order 2, tile 21 (7 x 1 accumulators per wave) is built for split tensors: with two MFMAs per step "
+                     "the bf16 form has no room for its 16 fragment reads");
+        return launch_s3_t<7, 1, 1, 4, 28, true>(a, d->cout, stream);
     default: break;
     }
-    hmmr_set_error("hmmr_conv_gemm: k_order 2 runs tiles 12 .. 20, not %d", tile);
+    hmmr_set_error("hmmr_conv_gemm: k_order 2 runs tiles 12 .. 21, not %d", tile);
     return -1;
 }

@@ -205,10 +205,11 @@ class HmmrEngine(object):
         the tile does not fit; a layer packed chunk-major (k_order 1, the 3x3 patch kernels) runs tiles 9 / 10, the patch
         forms of 7 / 8, or 11, the 256x128 tile without a load segment; a k_order 2 layer (csrc/conv3x3_stream.hip) takes the
         tuner's candidates as its own tile shapes 13 .. 18."""
-        if lay.k_order == 2:                                 # the stream kernel's tiles: 12 .. 18 (128-channel tiles), 19 / 20 (64 channels)
+        if lay.k_order == 2:                                 # the stream kernel's tiles: 12 .. 18 and 21 (128-channel tiles), 19 / 20 (64 channels)
             if cout == 64:
                 return {5: 19, 6: 20}.get(cand, cand if cand in (19, 20) else 0)
-            return {5: 13, 6: 14, 3: 15, 1: 16, 2: 17, 7: 18, 8: 12}.get(cand, cand if 12 <= cand <= 18 else 0)
+            t = {5: 13, 6: 14, 3: 15, 1: 16, 2: 17, 7: 18, 8: 12, 11: 21}.get(cand, cand if (12 <= cand <= 18 or cand == 21) else 0)
+            return 0 if (t == 21 and dtype == L.HMMR_BF16) else t       # (the 7 x 1 wave tile is built for split tensors)
         if lay.k_order:
             cand = {7: 9, 8: 10}.get(cand, cand)
             if cand == 11 and dtype == L.HMMR_BF16:          # the tile without a load segment is written for split operands

@@ -117,7 +117,8 @@ typedef struct {
                               11 = 256x128 without a load segment (two fragment sets per wave, one barrier per K step);
                               k_order 2 only (csrc/conv3x3_stream.hip; 4 waves, one per SIMD, 128 output channels per tile): 12 = 448 pixels
                               (wave tile 7 x 2 accumulators of 32 x 32), 13 = 256 (4 x 2), 14 = 512 (8 x 2), 15 = 384 (6 x 2), 16 = 320 (5 x 2);
-                              17 = 512, 18 = 384 pixels with the waves splitting the pixels (4 x 4 / 3 x 4) */
+                              17 = 512, 18 = 384 pixels with the waves splitting the pixels (4 x 4 / 3 x 4); 19 = 640, 20 = 512 pixels x 64 channels
+                              (cout = 64, images up to 56 pixels wide); 21 = 224 pixels, every wave all of them and 32 channels (7 x 1; split only) */
     /* split-K (for GEMMs with few output tiles and a long K): split_k > 1 slices K into that many
      * contiguous ranges, each range leaves an fp32 partial plane in `ws`, and a second launch adds the
      * planes IN SLICE ORDER and applies the epilogue.  The caller fixes split_k per layer (never from
@@ -157,7 +158,7 @@ typedef struct {
      * A-operand fragments (lane = 32 * (k half) + row; 8 halves = W[row][16 (ci / 16) + 8 half .. + 7] of that tap), rows scaled
      * like every split filter bank.  Same convolutions and epilogue as k_order 1; split (f16x3) tensors, cin % 32 == 0 -- or bf16 tensors (K steps of 32
      * channels `(ci / 32) * 9 + tap`, the two planes = the two 16-wide MFMA chunks, no row scaling), cin % 64 == 0 --,
-     * cout % 128 == 0, win <= 28; tiles 12 .. 18 (csrc/conv3x3_stream.hip).  Every tile produces the same bits. */
+     * cout % 128 == 0 and win <= 28 (tiles 12 .. 18, 21) or cout = 64 and win <= 56 (tiles 19 / 20) (csrc/conv3x3_stream.hip).  Every tile produces the same bits. */
     int k_order;
     /* grouped launch: `batch` > 1 runs that many problems of this one shape as ONE launch (grid z); problem z reads and
      * writes at these BYTE offsets (multiples of 16, negative allowed) from problem 0: `in`, `w`, `out` / `out2`, `res`,

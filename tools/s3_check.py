@@ -70,7 +70,7 @@ def run(k_order, tile, reps=10):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     if ts is not None and k_order == 2:
-        bm = {12: 448, 13: 256, 14: 512, 15: 384, 16: 320, 17: 512, 18: 384, 19: 640, 20: 512}[tile]
+        bm = {12: 448, 13: 256, 14: 512, 15: 384, 16: 320, 17: 512, 18: 384, 19: 640, 20: 512, 21: 224}[tile]
         nb = ((n * hw * hw + bm - 1) // bm) * max(1, cch // 128)
         t = ts[:nb].cpu().numpy().astype(np.float64)
         t0 = t[:, :, 0].min()
