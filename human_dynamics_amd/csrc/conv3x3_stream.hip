@@ -1,5 +1,5 @@
 // 3x3 / stride 1 / SAME convolutions of the ResNet's conv2 layers for gfx950, f16x3 ("split") operands, as ONE MFMA STREAM PER SIMD
-// (hmmr_conv_desc_t.k_order = 2; tiles 12 ...).  slim resnet_v2.bottleneck `conv2` as invoked at src/models.py:65-75.
+// (hmmr_conv_desc_t.k_order = 2; tiles 12 .. 21).  slim resnet_v2.bottleneck `conv2` as invoked at src/models.py:65-75.
 //
 // What the 8-wave patch tiles of gemm_conv.hip (k_order 1) measure: the matrix pipes are busy 45 % of a launch, 394 workgroups go to
 // 256 CUs (block 3), and a launch without its MFMAs is still 80 % as long -- two waves per SIMD that meet at a barrier every 24
@@ -12,15 +12,20 @@
 //     256 workgroups (R = 14: 226 tiles in block 3, 450 in block 2; the 256 x 128 tile: 394 and 788);
 //   * filters: the host packs them as the stream of MFMA A-operand fragments the kernel consumes (packing.pack_conv3x3_stream:
 //     [128-channel tile][K step][4 row blocks][hi plane | lo plane] of 1 KB, lane-linear), the waves DMA a K step (8 KB) into
-//     a 4-slab ring four steps ahead (global_load_lds; waits are COUNTED s_waitcnt vmcnt(N)); reads are conflict-free with no
+//     a 6-slab ring six steps ahead (global_load_lds; waits are COUNTED s_waitcnt vmcnt(N)); reads are conflict-free with no
 //     address arithmetic at all (ring slot and row block are instruction offsets);
 //   * pixels: K is chunk-major in 16-channel chunks (K step kt = chunk kt / 9, tap kt % 9).  A chunk of every input pixel the tile
-//     can touch is DMA'd once into a PATCH (two buffers: chunk c + 1 lands while chunk c is consumed), stored as a hi plane and a
-//     lo plane of 32-byte rows (two 16-byte k halves, swapped in rows with bit 3 set: the 16 lanes of a ds_read_b128 group hit 16
-//     distinct slots).  Patch row r holds input pixel m0 - (W + 1) + r of the flattened [img][y][x] order, so tap (ky, kx) of tile
-//     pixel i is row i + ky W + kx for EVERY pixel: one address per step, the FM row blocks are instruction offsets.  SAME padding
-//     is an address select: per row block four wave masks in SCALAR registers (pixels in the top / bottom row, left / right
-//     column); a lane whose tap is outside its image reads a zero row of the same bank instead (one v_cndmask per fragment).
+//     can touch is DMA'd once into a PATCH (two buffers: chunk c + 1 lands while chunk c is consumed): rows of 64 bytes
+//     [hi k0-7 | lo k0-7 | hi k8-15 | lo k8-15], four lanes per row = one coalesced chunk, the 16-byte slots XOR-swizzled with
+//     (row >> 2) & 3 (the 16 lanes of a ds_read_b128 group hit 16 distinct slots for any tap shift).  Patch row r holds input pixel
+//     m0 - (W + 1) + r of the flattened [img][y][x] order, so tap (ky, kx) of tile pixel i is row i + ky W + kx for EVERY pixel: one
+//     address pair per step, the FM row blocks are instruction offsets.  The taps are unrolled (18 steps = two chunks: ring slot,
+//     fragment set, patch buffer and tap are compile-time).  SAME padding is an address select: per row block four 32-bit wave masks
+//     in SCALAR registers (pixels in the top / bottom row, left / right column); a lane whose tap is outside its image reads a zero
+//     row of the same bank instead (s_mov vcc + two v_cndmask per fragment, nothing for the centre tap);
+//   * bf16 tensors (SPLIT = false): the same rows and fragments hold 32 channels = two 16-wide MFMA chunks; two MFMAs per
+//     accumulator and step, K steps of 32 channels, bf16 rows out.
+// DESIGN.md section 4.1.2 has the probe studies (profiles/r04a / r04b / r04d) behind each of these choices.
 // Products and their order per output element: (w.hi x.lo, w.lo x.hi, w.hi x.hi) per K step, K steps in stream order -- the
 // same for every tile shape, so every tile of this kernel produces the same bits (they differ from k_order 0 / 1 by the fp32
 // rounding of a different summation order only).
