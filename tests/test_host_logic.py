@@ -238,6 +238,20 @@ def test_conv3x3_stream_pack():
         assert float(sb[tile, kt, rb, plane, 32 * half + row, e]) == float(torch.tensor(w[ky, kx, ci, co]).to(torch.bfloat16))
 
 
+def test_tuner_candidates_map_onto_the_stream_kernels_tiles():
+    """HmmrEngine._tile_for: a k_order 2 layer (csrc/conv3x3_stream.hip) takes the tuner's candidate ids as its own tile shapes; the 7 x 1
+    wave tile (21) is split-only, the 64-channel tiles (19 / 20) belong to 64-channel layers; what does not fit maps to 0 (the library's
+    choice: fewest rounds of 256 workgroups)."""
+    from human_dynamics_amd import engine as E
+    lay = _lib.Layer()
+    lay.k_order = 2
+    f = E.HmmrEngine._tile_for
+    assert [f(lay, c, 256, _lib.HMMR_F16X3) for c in (0, 5, 6, 3, 1, 2, 7, 8, 11)] == [0, 13, 14, 15, 16, 17, 18, 12, 21]
+    assert f(lay, 21, 256, _lib.HMMR_F16X3) == 21 and f(lay, 21, 256, _lib.HMMR_BF16) == 0 and f(lay, 11, 512, _lib.HMMR_BF16) == 0
+    assert f(lay, 9, 256, _lib.HMMR_F16X3) == 0 and f(lay, 12, 256, _lib.HMMR_BF16) == 12
+    assert [f(lay, c, 64, _lib.HMMR_F16X3) for c in (0, 5, 6, 19, 20, 12)] == [0, 19, 20, 19, 20, 0]
+
+
 def test_shipped_tile_tables_fit_their_layers():
     """human_dynamics_amd/tile_tables.json: every entry names a layer of the ResNet and a tile that layer's launch accepts
     (csrc/gemm_conv.hip: 128- / 256-column tiles need cout % 128 / 256 == 0; a layer packed chunk-major runs the patch tiles
