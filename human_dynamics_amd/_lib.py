@@ -17,7 +17,7 @@ LIB_PATH = devflags.get("LIB_PATH") or os.path.join(HERE, "libhmmr_hip.so")
 
 HMMR_F32, HMMR_BF16, HMMR_F16X3 = 0, 1, 2
 FLAG_SATURATED = 1
-ABI_VERSION = 15
+ABI_VERSION = 16
 RESNET_UNITS = 16
 RESNET_PROF_SLOTS = 64
 MAX_TEMPORAL_BLOCKS = 8
@@ -59,13 +59,19 @@ class TailDesc(C.Structure):
         ("h1", _vp), ("hin", C.c_int), ("win", C.c_int), ("w2", _vp), ("scale2", _fp), ("shift2", _fp),
         ("xp", _vp), ("wsc", _vp), ("shift_sc", _fp),
         ("conv2_stride", C.c_int), ("out_pre", _vp),
-        ("pair_stream", _vp), ("c_xp", C.c_int),
+        ("pair_stream", _vp), ("c_xp", C.c_int), ("unit_stream", _vp),
     ]
 
 
 class Debug(C.Structure):
     """hmmr_debug_t: development switches, all zero = product defaults."""
-    _fields_ = [("stem_route", C.c_int), ("stem_no_conv1", C.c_int), ("gemm_probe", C.c_int), ("smpl_blend_mfma", C.c_int), ("ief_no_group", C.c_int), ("reserved", C.c_int * 3)]
+    _fields_ = [("stem_route", C.c_int), ("stem_no_conv1", C.c_int), ("gemm_probe", C.c_int), ("smpl_blend_mfma", C.c_int), ("ief_no_group", C.c_int), ("reserved", C.c_int * 3),
+                ("pair_min_pixels", C.c_int)]
+
+
+class LaunchCounts(C.Structure):
+    """hmmr_launch_counts_t: how often each fused-unit kernel was launched since the last clear."""
+    _fields_ = [("unit_pair", C.c_ulonglong), ("b1_unit", C.c_ulonglong), ("tail_split", C.c_ulonglong), ("conv3x3_stream", C.c_ulonglong)]
 
 
 class Layer(C.Structure):
@@ -74,7 +80,7 @@ class Layer(C.Structure):
 
 class ResnetUnit(C.Structure):
     _fields_ = [("conv1", Layer), ("conv2", Layer), ("conv3", Layer), ("shortcut", Layer), ("c3sc", Layer), ("sc_c1", Layer),
-                ("w3_frag", _vp), ("w1n_frag", _vp), ("pair_stream", _vp), ("pre_scale", _fp), ("pre_shift", _fp),
+                ("w3_frag", _vp), ("w1n_frag", _vp), ("pair_stream", _vp), ("unit_stream", _vp), ("pre_scale", _fp), ("pre_shift", _fp),
                 ("c_in", C.c_int), ("base", C.c_int), ("depth", C.c_int), ("stride", C.c_int),
                 ("fuse_preact", C.c_int), ("fuse_tail", C.c_int)]
 
@@ -121,6 +127,7 @@ SIGNATURES = {
     "hmmr_run_flags": (C.c_int, [C.POINTER(C.c_uint), C.c_int]),
     "hmmr_set_debug": (None, [C.POINTER(Debug)]),
     "hmmr_get_debug": (None, [C.POINTER(Debug)]),
+    "hmmr_launch_counts": (None, [C.POINTER(LaunchCounts), C.c_int]),
     "hmmr_conv_gemm": (C.c_int, [C.POINTER(ConvDesc), _vp]),
     "hmmr_conv_splitk_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "hmmr_resnet50_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
@@ -140,6 +147,7 @@ SIGNATURES = {
     "hmmr_crop_frames": (C.c_int, [_vp, _ip, C.c_int, C.c_int, C.c_int, _fp, _vp]),
     "hmmr_bottleneck_tail": (C.c_int, [C.POINTER(TailDesc), _vp]),
     "hmmr_pair_stream_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "hmmr_b1_unit_stream_bytes": (C.c_size_t, [C.c_int]),
     "hmmr_conv3x3_stream_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "hmmr_mfma_rate_probe": (C.c_int, [C.c_int, C.c_int, _fp, _vp]),
     "hmmr_render_handoff": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, _fp, C.c_int64, _fp, C.c_int, C.c_int, C.c_int,
@@ -184,6 +192,13 @@ def load():
         raise HmmrError("libhmmr_hip.so ABI version mismatch")
     _lib = lib
     return lib
+
+
+def launch_counts(clear=False):
+    """{kernel family: launches since the last clear} (hmmr_launch_counts)."""
+    c = LaunchCounts()
+    load().hmmr_launch_counts(C.byref(c), int(bool(clear)))
+    return {k: int(getattr(c, k)) for k, _ in LaunchCounts._fields_}
 
 
 def check(rc, what=""):

@@ -2,6 +2,10 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <atomic>
+
+#include <hip/hip_runtime.h>
+
 #include "hmmr_hip.h"
 
 static thread_local char g_err[512] = "";
@@ -20,6 +24,15 @@ const hmmr_debug_t* hmmr_debug_state() { return &g_debug; }
 extern "C" void hmmr_set_debug(const hmmr_debug_t* d) { g_debug = d ? *d : hmmr_debug_t{}; }
 extern "C" void hmmr_get_debug(hmmr_debug_t* d) { if (d) *d = g_debug; }
 
+// ---- launch counters (include/hmmr_hip.h: hmmr_launch_counts); `which` indexes hmmr_launch_counts_t's fields
+static std::atomic<unsigned long long> g_launches[4];
+void hmmr_count_launch(int which) { if (which >= 0 && which < 4) g_launches[which].fetch_add(1ull, std::memory_order_relaxed); }
+extern "C" void hmmr_launch_counts(hmmr_launch_counts_t* out, int clear) {
+    unsigned long long v[4];
+    for (int i = 0; i < 4; ++i) v[i] = clear ? g_launches[i].exchange(0ull, std::memory_order_relaxed) : g_launches[i].load(std::memory_order_relaxed);
+    if (out) { out->unit_pair = v[0]; out->b1_unit = v[1]; out->tail_split = v[2]; out->conv3x3_stream = v[3]; }
+}
+
 extern "C" int hmmr_abi_version(void) { return HMMR_ABI_VERSION; }
 extern "C" const char* hmmr_last_error(void) { return g_err; }
 
@@ -32,6 +45,8 @@ void hmmr_register_flag_reader(hmmr_flag_reader_t fn) {
 }
 extern "C" int hmmr_run_flags(unsigned* flags, int clear) {
     if (!flags) { hmmr_set_error("hmmr_run_flags: null argument"); return -1; }
+    // the readers copy with the null stream, which does not wait for non-blocking streams: drain the device first
+    if (hipDeviceSynchronize() != hipSuccess) { hmmr_set_error("hmmr_run_flags: hipDeviceSynchronize failed"); return -2; }
     unsigned all = 0;
     for (int i = 0; i < g_n_flag_readers; ++i) {
         unsigned v = 0;

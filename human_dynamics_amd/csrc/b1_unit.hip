@@ -1,0 +1,489 @@
+// A whole stride-1 bottleneck unit of block 1 (64 -> 256 -> 64 channels, 56 x 56 pixels) for gfx950, f16x3 ("split") operands:
+//
+//     h2     = relu(bn2(conv2_3x3(h1)))                                (bottleneck_v2 `conv2`, SAME, stride 1)
+//     trunk' = conv3({h2 [, xp]}) * scale3 + shift3 [+ shortcut]       (`conv3` + add; with xp the unit's conv shortcut is folded in)
+//     h1'    = relu(bn1'(conv1'(relu(bn_pre'(trunk')))))               (the NEXT unit's `preact` + `conv1`)
+//
+// in ONE kernel (slim resnet_v2.bottleneck as invoked at src/models.py:65-75).  Round 5's replacement of the
+// CONV2 form of bottleneck_split.hip (8 x 8 pixel tiles, 24 barriers per 64 pixels, filters as per-wave fragments from L2:
+// 0.59-0.61 ms per unit at 2.4-3.6 TB/s, neither HBM- nor MFMA-bound).  What bounds block 1 is the trunk: 2.5 KB of HBM
+// traffic per pixel (shortcut in, trunk out, h1 in, h1' out) against 408-504 MFMAs per 32 pixels, i.e. 0.41 / 0.29 ms of
+// HBM time against 0.17 / 0.21 ms of matrix time per unit -- so the kernel is built to keep HBM requests in flight while
+// some wave of the CU computes:
+//   * TWO workgroups per CU (4 waves each, 256 registers per lane, 79 KB of LDS): while one runs its conv2 (matrix work,
+//     no HBM traffic to speak of) the other streams its trunk chunks; inside a workgroup the code is plain (compiler-
+//     scheduled) -- the second wave of every SIMD is what fills its stalls;
+//   * a workgroup owns 128 consecutive pixels of the flattened [img][y][x] order, a WAVE owns 32 of them for the whole
+//     unit.  conv2: K is chunk-major in 16-channel chunks (K step kt = chunk kt / 9, tap kt % 9 -- the order of
+//     conv3x3_stream.hip, so the results equal its launches bit for bit); the chunk of every pixel the tile can touch
+//     (128 + 2 W + 2 rows of 64 bytes, slots XOR-swizzled by (row >> 2) & 3) is DMA'd into one of two patch buffers, a
+//     tap is a row shift, out-of-image taps read a zero row of the same bank;
+//   * the wave's conv2 result (32 px x 64 channels) gets its BN + ReLU, is split and turned from the MFMA's D layout
+//     into B-operand fragments IN REGISTERS (one v_permlane32_swap per register pair, as unit_pair.hip): h2 never exists
+//     in LDS or HBM.  With a folded shortcut the unit's pre-activated input xp is a second register panel;
+//   * ALL filters of the unit -- conv2 (144 KB), conv3 (64 / 128 KB), conv1' (64 KB) -- are ONE stream of 2 KB MFMA
+//     A-operand fragments in the order the kernel consumes them (packing.pack_b1_unit_stream), DMA'd through a 5-slab
+//     LDS ring (8 KB slabs, four in flight) that every wave reads: 272 / 336 KB of L2 -> LDS traffic per 128 pixels
+//     (the old form: 4 KB per PIXEL of per-wave fragment reads);
+//   * conv3's output channels are walked 32 at a time (= one K step of conv1').  The shortcut chunk is DMA'd two chunks
+//     ahead into a wave-private staging tile (which aliases the patch buffers: chunk 0 is requested while conv2 still
+//     runs on the other buffer), the trunk chunk is written over it in place, leaves as coalesced 16-byte row stores
+//     and is pre-activated in registers for conv1';
+//   * every wave issues the same vector-memory instructions (rows beyond M read row 0 and store to a dump page), so the
+//     waits on the ring / patch / shortcut are COUNTED s_waitcnt vmcnt(N), N from a compile-time table of the schedule.
+// Rounding points, product order (w.hi x.lo, w.lo x.hi, w.hi x.hi) and K order are those of the launches it replaces
+// (conv3x3_stream tiles 19 / 20, then gemm_conv.hip's conv3 and conv1): bit-identical, tested per kernel and through the ResNet.
+#include <type_traits>
+#include <utility>
+
+#include "common.h"
+#include "hmmr_hip.h"
+
+namespace {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+__device__ u32x4 g_b1_dump[64];             // 1 KB: where the stores of rows beyond M go
+
+struct B1Args {
+    const char* h1;                         // [M][64] split rows (256 B): conv2's input
+    const char* stream;                     // packing.pack_b1_unit_stream
+    const float* scale2; const float* shift2;        // [64]: conv2's folded BN
+    const bsplit_t* xp;                     // KC3B: [M][64], the folded shortcut's operand
+    const float* scale3; const float* shift3; const float* pre_scale; const float* pre_shift;     // [256]
+    const bsplit_t* res; int ldr;           // RES: the shortcut, rows of ldr elements
+    bsplit_t* out;                          // [M][256]
+    const float* scale1; const float* shift1; int relu1;     // [64]
+    bsplit_t* out_h1;                       // [M][64]
+    int M, H, W, n_tiles;
+};
+
+constexpr int B1_BM = 128, B1_DEPTH = 256, B1_NCH = B1_DEPTH / 32;
+constexpr int B1_NS = 5, B1_SLAB = 8192, B1_RING = B1_NS * B1_SLAB;
+constexpr int B1_NPP = 4;                                   // 64-row pieces of a patch: 128 + 2 * 56 + 2 = 242 rows
+constexpr int B1_PROWS = B1_NPP * 64 + 16;                   // + the zero rows
+constexpr int B1_PBUF = B1_PROWS * 64;
+constexpr int B1_OFF_P = B1_RING;                            // two patch buffers; later the staging tiles: wave w, tile b at b * PBUF + w * 4096
+constexpr int B1_OFF_C = B1_OFF_P + 2 * B1_PBUF;             // scale3, shift3, pre_scale, pre_shift [256]; scale2, shift2, scale1, shift1 [64]
+constexpr int B1_LDS = B1_OFF_C + 4 * B1_DEPTH * 4 + 4 * 64 * 4;
+static_assert(2 * B1_LDS <= 160 * 1024, "two workgroups per CU");
+constexpr int B1_CONV2_SLABS = 18;                           // 36 K steps of 4 KB
+
+// ---- the schedule of vector-memory instructions per wave, by slab step t (the step that READS slab t): first the ring's DMA of
+// slab t + 4 (2 instructions), then the step's other requests.  KC3: conv3's 16-wide K chunks (4, or 8 with a folded shortcut);
+// a chunk of conv3's output is SPC slabs: KC3 / 4 of conv3 fragments, one of conv1' fragments.
+constexpr int b1_total(int kc3) { return B1_CONV2_SLABS + B1_NCH * (kc3 / 4 + 1); }
+constexpr int b1_ring_ops(int t, int kc3) { return t + (B1_NS - 1) < b1_total(kc3) ? 2 : 0; }
+// requests of step t behind its ring DMA: the patch of chunk 2 / 3 (steps 5 / 9), shortcut chunk 0 (step 14), shortcut chunk 1
+// (first thing of step 18), and at the end of a chunk's last conv3 slab its 4 trunk stores + the shortcut chunk two ahead
+constexpr int b1_extra_ops(int t, int kc3, bool res) {
+    if (t == 5 || t == 9) return 4;
+    if (t == 14) return res ? 4 : 0;
+    if (t < B1_CONV2_SLABS) return 0;
+    const int spc = kc3 / 4 + 1, c = (t - B1_CONV2_SLABS) / spc, i = (t - B1_CONV2_SLABS) % spc;
+    int n = 0;
+    if (t == B1_CONV2_SLABS && res) n += 4;                 // shortcut chunk 1
+    if (i == spc - 2) n += 4 + ((res && c + 2 < B1_NCH) ? 4 : 0);
+    return n;
+}
+// what may stay in flight at the wait of step s: everything issued after step s - 4 (whose ring DMA is slab s, and whose other
+// requests -- a patch, a shortcut chunk -- are first read in step s).  One exception: shortcut chunk 1, requested at the top of
+// step 18, is read in step 20
+constexpr int b1_wait_n(int s, int kc3, bool res) {
+    int n = 0;
+    for (int t = s - 3; t < s; ++t) n += b1_ring_ops(t, kc3) + b1_extra_ops(t, kc3, res);
+    if (res && s == B1_CONV2_SLABS + 2)
+        n = (b1_extra_ops(B1_CONV2_SLABS, kc3, res) - 4) + b1_ring_ops(B1_CONV2_SLABS + 1, kc3) + b1_extra_ops(B1_CONV2_SLABS + 1, kc3, res);
+    return n;
+}
+
+// s_waitcnt vmcnt(N) lgkmcnt(0) (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14])
+template <int N> __device__ __forceinline__ void b1_wait() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (0 << 8) | ((N >> 4) << 14));
+}
+
+template <int V> using b1_ic = std::integral_constant<int, V>;
+// f(b1_ic<0>{}), f(b1_ic<1>{}), ... in order
+template <class F, int... I> __device__ __forceinline__ void b1_for(F&& f, std::integer_sequence<int, I...>) { (f(b1_ic<I>{}), ...); }
+
+struct xfrag { shalf8 hi, lo; };            // MFMA B-operand fragment: 32 pixels x 16 channels
+
+// D layout of a 32-channel block (nh / nl[g][i]: the packed hi / lo halves of channels 8 g + 4 lh + 2 i, + 1 of pixel lr) -> the two
+// B-operand fragments of its 16-wide K chunks (lane (lr, lh): channels 16 k + 8 lh .. + 7): one v_permlane32_swap per register pair
+__device__ __forceinline__ void b1_d_to_b(const shalf2 (&nh)[4][2], const shalf2 (&nl)[4][2], xfrag (&th)[2]) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        unsigned fh[4], fl[4];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const u32x2 sh = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, nh[2 * k][d]),
+                                                              __builtin_bit_cast(unsigned, nh[2 * k + 1][d]), false, false);
+            const u32x2 sl = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, nl[2 * k][d]),
+                                                              __builtin_bit_cast(unsigned, nl[2 * k + 1][d]), false, false);
+            fh[d] = sh[0]; fh[2 + d] = sh[1];
+            fl[d] = sl[0]; fl[2 + d] = sl[1];
+        }
+        th[k].hi = __builtin_bit_cast(shalf8, u32x4{fh[0], fh[1], fh[2], fh[3]});
+        th[k].lo = __builtin_bit_cast(shalf8, u32x4{fl[0], fl[1], fl[2], fl[3]});
+    }
+}
+// four fp32 values that are already inside the fp16 range's lower bound (ReLU'd) -> packed hi / lo halves (the bits of split4)
+__device__ __forceinline__ void b1_split_pairs(const float (&y)[4], shalf2 (&h)[2], shalf2 (&l)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const shalf_t a = (shalf_t)y[2 * i], b = (shalf_t)y[2 * i + 1];
+        h[i] = shalf2{a, b};
+        l[i] = shalf2{(shalf_t)(y[2 * i] - (float)a), (shalf_t)(y[2 * i + 1] - (float)b)};
+    }
+}
+
+// KC3B: 16-wide K chunks of conv3 that come from xp (0, or 4: the folded shortcut); RES: a shortcut tensor is added
+template <int KC3B, bool RES>
+__global__ __launch_bounds__(256, 2) void b1_unit_kernel(const B1Args a) {
+    constexpr int KC3 = 4 + KC3B, SPC = KC3 / 4 + 1, TOTAL = b1_total(KC3);
+    constexpr int NS = B1_NS, SLAB = B1_SLAB, NCH = B1_NCH, DEPTH = B1_DEPTH;
+    static_assert(!(RES && KC3B), "either a shortcut tensor or a folded one");
+
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int m0 = xcd_remap(blockIdx.x, a.n_tiles) * B1_BM;
+    const int W = a.W, HW = a.H * a.W;
+    const int mbase = m0 + wave * 32;                           // this wave's first pixel
+    const int lane16 = lane * 16;
+
+    // ---- the filter stream: slab -> ring slot slab % 5; each wave moves a quarter (2 x 1 KB)
+    const char* gstream = a.stream + wave * 2048 + lane16;
+    auto ring_dma = [&](int slab) {                             // slab is a constant after unrolling
+        const char* src = gstream + (long long)slab * SLAB;
+        char* dst = smem + (slab % NS) * SLAB + wave * 2048;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);       // (the instruction offset moves both addresses)
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 1024, 0);
+    };
+    // ---- patch DMA: piece q of this wave = rows 64 q + 16 wave .. + 15 of the patch (row r = input pixel m0 - W - 1 + r), four
+    // lanes per row (one coalesced 64-byte chunk), source slot swizzled.  Rows outside the tensor read its first / last pixel: only
+    // out-of-image taps (which read a zero row instead) and pixels >= M see them
+    const char* pptr[B1_NPP];
+#pragma unroll
+    for (int q = 0; q < B1_NPP; ++q) {
+        const int r = 64 * q + 16 * wave + (lane >> 2);
+        int px = m0 - W - 1 + r;
+        px = px < 0 ? 0 : (px >= a.M ? a.M - 1 : px);
+        pptr[q] = a.h1 + (long long)px * 256 + (((lane & 3) ^ ((r >> 2) & 3)) << 4);
+    }
+    auto patch_dma = [&](int c, int buf) {
+        char* dst = smem + B1_OFF_P + buf * B1_PBUF + wave * 1024;
+#pragma unroll
+        for (int q = 0; q < B1_NPP; ++q)
+            __builtin_amdgcn_global_load_lds((gptr_t)(pptr[q] + c * 64), (lptr_t)(dst + q * 4096), 16, 0, 0);
+    };
+    // ---- staging tiles of this wave (rows = pixels, 128 B = 8 slots of 16 B: hi / lo of 4 groups interleaved, slot XOR-swizzled by
+    // (row >> 1) & 7).  A row piece q covers rows 8 q .. 8 q + 7: lane L = (row 8 q + (L >> 3), physical slot L & 7)
+    const int rsub = lane >> 3, pslot = lane & 7;
+    auto stg_of = [&](int b) -> char* { return smem + B1_OFF_P + b * B1_PBUF + wave * 4096; };
+    const bsplit_t* rrow[4];
+    bsplit_t* orow[4];
+    bsplit_t* hrow[4];
+    int ostep[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = 8 * q + rsub, m = mbase + r;
+        const int ls = pslot ^ ((r >> 1) & 7);
+        const bool ok = m < a.M;
+        orow[q] = ok ? a.out + (long long)m * DEPTH + ls * 4 : (bsplit_t*)g_b1_dump + lane * 4;
+        hrow[q] = ok ? a.out_h1 + (long long)m * 64 + ls * 4 : (bsplit_t*)g_b1_dump + lane * 4;
+        ostep[q] = ok ? 32 : 0;
+        rrow[q] = RES ? a.res + (long long)(ok ? m : 0) * a.ldr + ls * 4 : nullptr;
+    }
+    auto res_dma = [&](int chunk, int b) {
+        if constexpr (RES) {
+            char* dst = stg_of(b);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                __builtin_amdgcn_global_load_lds((gptr_t)(rrow[q] + chunk * 32), (lptr_t)(dst + q * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- prologue: the constants (one value of each array per thread, requested up front: a load under a branch would cost its own
+    // round trip), four slabs, the first two patch chunks, the zero rows
+    const float c_s3 = (a.scale3 ? a.scale3 : a.pre_scale)[tid], c_b3 = (a.shift3 ? a.shift3 : a.pre_shift)[tid];
+    const float c_ps = a.pre_scale[tid], c_pb = a.pre_shift[tid];
+    const float c_64 = (tid < 128 ? (tid < 64 ? a.scale2 : a.shift2) : (tid < 192 ? a.scale1 : a.shift1))[tid & 63];
+#pragma unroll
+    for (int s_ = 0; s_ < NS - 1; ++s_) ring_dma(s_);
+    patch_dma(0, 0);
+    patch_dma(1, 1);
+    float* sS3 = (float*)(smem + B1_OFF_C);
+    float* sB3 = sS3 + DEPTH;
+    float* sPS = sB3 + DEPTH;
+    float* sPB = sPS + DEPTH;
+    float* sS2 = sPB + DEPTH;                                   // scale2, shift2, scale1, shift1: 64 floats each, contiguous
+    float* sB2 = sS2 + 64;
+    float* sS1 = sB2 + 64;
+    float* sB1 = sS1 + 64;
+    {
+        sS3[tid] = a.scale3 ? c_s3 : 1.0f;
+        sB3[tid] = a.shift3 ? c_b3 : 0.0f;
+        sPS[tid] = c_ps;
+        sPB[tid] = c_pb;
+        sS2[tid] = c_64;
+        if (tid < 128) {                                        // 16 zero rows behind the data rows of either patch buffer
+            const int pl = tid >> 6, o = tid & 63;
+            *(u32x4*)(smem + B1_OFF_P + pl * B1_PBUF + B1_NPP * 64 * 64 + o * 16) = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    // the folded shortcut's operand: this wave's 32 pixels x 64 channels as B-operand fragments (lane (lr, lh): channels 16 kc + 8 lh ..)
+    xfrag xh[KC3];
+    if constexpr (KC3B > 0) {
+        const int m = mbase + lr;
+        const long long row = m < a.M ? m : 0;
+#pragma unroll
+        for (int kc = 0; kc < KC3B; ++kc) {
+            const bsplit_t* p = a.xp + row * 64 + (2 * kc + lh) * 8;
+            xh[4 + kc].hi = *(const shalf8*)p;
+            xh[4 + kc].lo = *((const shalf8*)p + 1);
+        }
+    }
+    // border flags of this lane's pixel (SAME padding: a tap that leaves the image reads a zero row)
+    bool top, bot, lef, rig;
+    {
+        const int m = mbase + lr;
+        const int rem = m % HW, y = rem / W, x = rem - y * W;
+        top = y == 0; bot = y == a.H - 1; lef = x == 0; rig = x == W - 1;
+    }
+    const int rb0 = wave * 32 + lr;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0);                              // everything landed (vmcnt(0) lgkmcnt(0) expcnt(0))
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- the start of slab step S: slab S has landed for every wave, slab S - 1 is free
+    auto slab_step = [&](auto s_c) {
+        constexpr int S = decltype(s_c)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (S >= NS - 1) b1_wait<b1_wait_n(S, KC3, RES)>();
+        else b1_wait<63>();                                     // (lgkmcnt(0) alone: slabs 0 .. 3 landed in the prologue)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (S + NS - 1 < TOTAL) ring_dma(S + NS - 1);
+        if constexpr (S == 5) patch_dma(2, 0);                  // (buffer 0: chunk 0, last read in K step 8 = slab 4)
+        if constexpr (S == 9) patch_dma(3, 1);                  // (buffer 1: chunk 1, last read in K step 17 = slab 8)
+        if constexpr (S == 14) res_dma(0, 0);                   // (buffer 0: chunk 2, last read in K step 26 = slab 13)
+        if constexpr (S == B1_CONV2_SLABS) res_dma(1, 1);       // (buffer 1: chunk 3, last read in K step 35 = slab 17)
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // fragment f (0 .. 3) of slab S: hi plane, lo plane
+    auto ring_frag = [&](int slab, int f) -> wfrag {
+        const char* p = smem + (slab % NS) * SLAB + f * 2048 + lane16;
+        wfrag w;
+        w.hi = *(const shalf8*)p;
+        w.lo = *(const shalf8*)(p + 1024);
+        return w;
+    };
+
+    // ---- conv2: 36 K steps (chunk KT / 9 of 16 channels, tap KT % 9), two per slab
+    auto kstep = [&](auto kt_c) {
+        constexpr int KT = decltype(kt_c)::value, TAP = KT % 9, KY = TAP / 3, KX = TAP % 3, BUF = (KT / 9) & 1;
+        if constexpr ((KT & 1) == 0) slab_step(b1_ic<KT / 2>{});
+        const unsigned rowp = (unsigned)(rb0 + KY * W + KX);
+        const unsigned ph = ((2u * lh) ^ ((rowp >> 2) & 3u)) << 4;
+        unsigned ad = B1_OFF_P + BUF * B1_PBUF + rowp * 64 + ph;
+        if constexpr (TAP != 4) {
+            const bool outside = (KY == 0 && top) || (KY == 2 && bot) || (KX == 0 && lef) || (KX == 2 && rig);
+            const unsigned zb = B1_OFF_P + BUF * B1_PBUF + B1_NPP * 64 * 64 + (rowp & 3u) * 64 + ph;      // the zero row of the same bank
+            ad = outside ? zb : ad;
+        }
+        const shalf8 xhi = *(const shalf8*)(smem + ad), xlo = *(const shalf8*)(smem + (ad ^ 16u));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const wfrag w = ring_frag(KT / 2, (KT & 1) * 2 + j);
+            acc[j] = mma3(w, xhi, xlo, acc[j]);
+        }
+    };
+    b1_for(kstep, std::make_integer_sequence<int, 36>{});
+
+    // ---- conv2's epilogue: folded BN + ReLU, split, D layout -> the h2 panel as B-operand fragments
+    float satm = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        shalf2 nh[4][2], nl[4][2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = 32 * j + 8 * g + 4 * lh;
+            const f32x4 s4 = *(const f32x4*)(sS2 + n), b4 = *(const f32x4*)(sB2 + n);
+            float y[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = fmaf(acc[j][4 * g + e], s4[e], b4[e]);
+                satm = __builtin_fmaxf(satm, __builtin_fabsf(v));
+                y[e] = split_relu(v);
+            }
+            b1_split_pairs(y, nh[g], nl[g]);
+        }
+        xfrag t2[2];
+        b1_d_to_b(nh, nl, t2);
+        xh[2 * j] = t2[0]; xh[2 * j + 1] = t2[1];
+    }
+
+    // ---- the tail: conv3's output channels 32 at a time
+    f32x16 acc2[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
+    const int sw = (lr >> 1) & 7;
+    auto chunk = [&](auto c_c) {
+        constexpr int C = decltype(c_c)::value, S0 = B1_CONV2_SLABS + SPC * C, B = C & 1;
+        f32x16 acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+        // conv3 chunk C: K chunks in order over {h2, xp}
+        slab_step(b1_ic<S0>{});
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) acc1 = mma3(ring_frag(S0, kc), xh[kc].hi, xh[kc].lo, acc1);
+        if constexpr (KC3B > 0) {
+            slab_step(b1_ic<S0 + 1>{});
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) acc1 = mma3(ring_frag(S0 + 1, kc), xh[4 + kc].hi, xh[4 + kc].lo, acc1);
+        }
+        // * scale3 + shift3 (+ shortcut), split, IN PLACE into the staging tile; the pre-activation of the STORED value
+        char* stg = stg_of(B);
+        shalf2 nh[4][2], nl[4][2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ch = C * 32 + 8 * g + 4 * lh;
+            const f32x4 s4 = *(const f32x4*)(sS3 + ch), b4 = *(const f32x4*)(sB3 + ch);
+            char* ph = stg + lr * 128 + (((2 * g) ^ sw) << 4) + 8 * lh;
+            char* pl = stg + lr * 128 + (((2 * g + 1) ^ sw) << 4) + 8 * lh;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(acc1[4 * g + e], s4[e], b4[e]);
+            if constexpr (RES) {
+                const unsigned long long h = *(const unsigned long long*)ph, l = *(const unsigned long long*)pl;
+                v[0] += shalf_lo((unsigned)h) + shalf_lo((unsigned)l);
+                v[1] += shalf_hi((unsigned)h) + shalf_hi((unsigned)l);
+                v[2] += shalf_lo((unsigned)(h >> 32)) + shalf_lo((unsigned)(l >> 32));
+                v[3] += shalf_hi((unsigned)(h >> 32)) + shalf_hi((unsigned)(l >> 32));
+            }
+            unsigned long long oh, ol;
+            split4(v, oh, ol, satm);
+            *(unsigned long long*)ph = oh;
+            *(unsigned long long*)pl = ol;
+            const f32x4 ps = *(const f32x4*)(sPS + ch), pb = *(const f32x4*)(sPB + ch);
+            float y[4];
+            y[0] = split_relu(fmaf(shalf_lo((unsigned)oh) + shalf_lo((unsigned)ol), ps[0], pb[0]));
+            y[1] = split_relu(fmaf(shalf_hi((unsigned)oh) + shalf_hi((unsigned)ol), ps[1], pb[1]));
+            y[2] = split_relu(fmaf(shalf_lo((unsigned)(oh >> 32)) + shalf_lo((unsigned)(ol >> 32)), ps[2], pb[2]));
+            y[3] = split_relu(fmaf(shalf_hi((unsigned)(oh >> 32)) + shalf_hi((unsigned)(ol >> 32)), ps[3], pb[3]));
+            b1_split_pairs(y, nh[g], nl[g]);
+        }
+        xfrag th[2];
+        b1_d_to_b(nh, nl, th);
+        // the trunk chunk leaves as 16-byte row pieces; the shortcut chunk two ahead is requested into the tile it leaves
+        {
+            u32x4 xr[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xr[q] = *(const u32x4*)(stg + q * 1024 + lane16);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { *(u32x4*)orow[q] = xr[q]; orow[q] += ostep[q]; }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (C + 2 < NCH) res_dma(C + 2, B);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // conv1' K step C: K chunks 2 C, 2 C + 1 against both row blocks
+        slab_step(b1_ic<S0 + SPC - 1>{});
+#pragma unroll
+        for (int kcl = 0; kcl < 2; ++kcl)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc2[j] = mma3(ring_frag(S0 + SPC - 1, kcl * 2 + j), th[kcl].hi, th[kcl].lo, acc2[j]);
+    };
+    b1_for(chunk, std::make_integer_sequence<int, NCH>{});
+
+    // ---- conv1' epilogue: BN (+ ReLU), split, through this wave's staging tiles, coalesced stores
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        char* stg = stg_of(j);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n2 = j * 32 + 8 * g + 4 * lh;
+            const f32x4 s4 = *(const f32x4*)(sS1 + n2), b4 = *(const f32x4*)(sB1 + n2);
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = fmaf(acc2[j][4 * g + e], s4[e], b4[e]);
+                if (a.relu1) v[e] = fmaxf(v[e], 0.f);
+            }
+            unsigned long long oh, ol;
+            split4(v, oh, ol, satm);
+            *(unsigned long long*)(stg + lr * 128 + (((2 * g) ^ sw) << 4) + 8 * lh) = oh;
+            *(unsigned long long*)(stg + lr * 128 + (((2 * g + 1) ^ sw) << 4) + 8 * lh) = ol;
+        }
+        u32x4 xr[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xr[q] = *(const u32x4*)(stg + q * 1024 + lane16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *(u32x4*)(hrow[q] + (ostep[q] ? j * 32 : 0)) = xr[q];
+    }
+    split_flag(satm > HMMR_SPLIT_MAX);
+}
+
+template <int KC3B, bool RES>
+int launch_b1(const B1Args& base, hipStream_t stream) {
+    B1Args a = base;
+    a.n_tiles = (a.M + B1_BM - 1) / B1_BM;
+    auto kern = b1_unit_kernel<KC3B, RES>;
+    static DeviceOnce once;
+    if (const unsigned long long bit = once.due()) {
+        HMMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, B1_LDS));
+        once.mark(bit);
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)a.n_tiles), dim3(256), B1_LDS, stream, a);
+    HMMR_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+// bytes of the filter stream of a block-1 unit (packing.pack_b1_unit_stream): conv2's 36 K steps of 4 KB, then per 32 channels of
+// conv3's output kc3 = (64 + c_xp) / 16 fragments of conv3 and 4 of conv1', 2 KB each
+extern "C" size_t hmmr_b1_unit_stream_bytes(int c_xp) {
+    return (size_t)B1_CONV2_SLABS * B1_SLAB + (size_t)B1_NCH * (size_t)((64 + c_xp) / 16 + 4) * 2048;
+}
+
+// hmmr_bottleneck_tail with unit_stream set (called from bottleneck_split.hip)
+int hmmr_b1_unit_split(const hmmr_tail_desc_t* d, hipStream_t stream) {
+    HMMR_REQUIRE(d->h1 && !d->h2 && d->unit_stream && d->out && d->out_h1 && d->pre_scale && d->pre_shift && d->scale1 && d->shift1 &&
+                 d->scale2 && d->shift2 && !d->out_pre && !d->res_strided && d->m > 0 && d->conv2_stride <= 1,
+                 "hmmr_bottleneck_tail (f16x3, unit_stream): needs h1, the unit's filter stream, conv2's and the next conv1's constants, "
+                 "the next unit's preact, out, out_h1 and a dense shortcut");
+    HMMR_REQUIRE(d->c_mid == 64 && d->depth == 256 && d->n2 == 64 && d->hin > 0 && d->win > 0 && d->win <= 56 && d->m % (d->hin * d->win) == 0,
+                 "hmmr_bottleneck_tail (f16x3, unit_stream): the 64 -> 256 -> 64 shape on whole images at most 56 pixels wide (got %d, %d, %d, %d x %d)",
+                 d->c_mid, d->depth, d->n2, d->hin, d->win);
+    const bool folded = d->xp != nullptr;
+    HMMR_REQUIRE(folded != (d->res != nullptr), "hmmr_bottleneck_tail (f16x3, unit_stream): either a shortcut tensor (res) or a folded one (xp)");
+    HMMR_REQUIRE(!folded || d->c_xp == 64, "hmmr_bottleneck_tail (f16x3, unit_stream): a folded shortcut has 64 input channels (got %d)", d->c_xp);
+    HMMR_REQUIRE(folded || d->ldr >= d->depth, "hmmr_bottleneck_tail: residual row stride < depth");
+    B1Args a = {};
+    a.h1 = (const char*)d->h1; a.stream = (const char*)d->unit_stream; a.scale2 = d->scale2; a.shift2 = d->shift2;
+    a.xp = (const bsplit_t*)d->xp;
+    a.scale3 = d->scale3; a.shift3 = d->shift3; a.pre_scale = d->pre_scale; a.pre_shift = d->pre_shift;
+    a.res = (const bsplit_t*)d->res; a.ldr = d->ldr; a.out = (bsplit_t*)d->out;
+    a.scale1 = d->scale1; a.shift1 = d->shift1; a.relu1 = d->relu1; a.out_h1 = (bsplit_t*)d->out_h1;
+    a.M = d->m; a.H = d->hin; a.W = d->win;
+    return folded ? launch_b1<4, false>(a, stream) : launch_b1<0, true>(a, stream);
+}

@@ -434,7 +434,7 @@ int launch_tail(const TailArgs& a, hipStream_t stream) {
 int hmmr_bottleneck_tail_split(const hmmr_tail_desc_t* d, hipStream_t stream);      // bottleneck_split.hip
 
 extern "C" int hmmr_bottleneck_tail(const hmmr_tail_desc_t* d, void* stream) {
-    HMMR_REQUIRE(d && (d->h2 || d->h1) && (d->w3 || d->pair_stream) && (d->res || d->xp), "hmmr_bottleneck_tail: null argument");
+    HMMR_REQUIRE(d && (d->h2 || d->h1) && (d->w3 || d->pair_stream || d->unit_stream) && (d->res || d->xp), "hmmr_bottleneck_tail: null argument");
     if (d->dtype == HMMR_F16X3) return hmmr_bottleneck_tail_split(d, (hipStream_t)stream);
     const bool ph2 = d->w1 != nullptr;
     HMMR_REQUIRE(!ph2 || (d->out && d->pre_scale && d->pre_shift && d->scale1 && d->shift1 && d->out_h1 && !d->out_pre),

@@ -367,10 +367,13 @@ int launch_split_tail(const SplitTailArgs& a, hipStream_t stream) {
 }  // namespace
 
 int hmmr_unit_pair_split(const hmmr_tail_desc_t* d, hipStream_t stream);       // unit_pair.hip
+int hmmr_b1_unit_split(const hmmr_tail_desc_t* d, hipStream_t stream);         // b1_unit.hip
 
 // hmmr_bottleneck_tail for HMMR_F16X3 (called from bottleneck.hip).  w3 / w1 are FRAGMENT-MAJOR here (hmmr_hip.h).
 int hmmr_bottleneck_tail_split(const hmmr_tail_desc_t* d, hipStream_t stream) {
-    if (d->pair_stream) return hmmr_unit_pair_split(d, stream);
+    if (d->pair_stream) { hmmr_count_launch(HMMR_COUNT_UNIT_PAIR); return hmmr_unit_pair_split(d, stream); }
+    if (d->unit_stream) { hmmr_count_launch(HMMR_COUNT_B1_UNIT); return hmmr_b1_unit_split(d, stream); }
+    hmmr_count_launch(HMMR_COUNT_TAIL_SPLIT);
     HMMR_REQUIRE((d->h2 != nullptr) != (d->h1 != nullptr) && d->w1 && d->out && d->out_h1 && d->pre_scale && d->pre_shift && d->scale1 &&
                  d->shift1 && !d->out_pre && !d->res_strided,
                  "hmmr_bottleneck_tail (f16x3): needs h2 or h1 (conv2 in front), the next conv1, out, out_h1 and a dense shortcut");

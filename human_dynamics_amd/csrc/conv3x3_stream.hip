@@ -437,6 +437,7 @@ int hmmr_conv3x3_stream(const hmmr_conv_desc_t* d, hipStream_t stream) {
     HMMR_REQUIRE(split || d->cin % 64 == 0, "hmmr_conv_gemm: k_order 2 with bf16 tensors needs cin %% 64 == 0 (K steps of 32 channels, taken in pairs)");
     HMMR_REQUIRE(d->cin % 32 == 0 && (d->cout % 128 == 0 || d->cout == 64) && d->win <= 56 && d->scale && d->shift,
                  "hmmr_conv_gemm: k_order 2 needs cin %% 32 == 0, cout %% 128 == 0 (or cout = 64), an image at most 56 pixels wide and scale + shift");
+    hmmr_count_launch(HMMR_COUNT_CONV3X3_STREAM);
     S3Args a = {};
     a.in = (const char*)d->in; a.wstream = (const char*)d->w; a.scale = d->scale; a.shift = d->shift;
     a.out = d->out; a.ldo = d->ldo;

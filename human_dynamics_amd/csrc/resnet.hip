@@ -291,7 +291,9 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
         // a register-resident unit pair (csrc/unit_pair.hip) is one round of 128-pixel workgroups with a ~20 k-cycle prologue however few
         // pixels there are: below ~12 k pixels (61 frames in block 3) the two launches it replaces are faster (profiles/r04_unit_pair_check.log:
         // 0.064 against 0.096 ms at 33 frames), and they produce the same bits, so a short batch simply takes them
-        const bool pair_off = w->dtype == HMMR_F16X3 && U.pair_stream && U.fuse_tail == 1 && (long long)n * Ho * Ho < 12000;
+        // (hmmr_debug_t.pair_min_pixels moves the switch: tests run one batch on either side of it)
+        const long long pair_min = dbg->pair_min_pixels > 0 ? dbg->pair_min_pixels : 12000;
+        const bool pair_off = w->dtype == HMMR_F16X3 && U.pair_stream && U.fuse_tail == 1 && (long long)n * Ho * Ho < pair_min;
         const int fuse_tail = pair_off ? 0 : U.fuse_tail;
         const bool sc_in_tail = fuse_tail == 3;          // the conv shortcut is computed inside the fused tail
         // the conv shortcut is folded into conv3: ONE GEMM over {h2, preact} with [W3 | Wsc] (hmmr_conv_desc_t.in2);
@@ -383,7 +385,7 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
             if (hmmr_bottleneck_tail(&t, s)) return -2;
         } else if (fuse_tail) {       // conv3 + add + the next unit's preact + conv1 in one launch (csrc/bottleneck.hip)
             const bool pair = w->dtype == HMMR_F16X3 && U.pair_stream && fuse_tail == 1;        // csrc/unit_pair.hip
-            HMMR_REQUIRE(!last && (w->dtype == HMMR_BF16 || pair || (w->dtype == HMMR_F16X3 && U.w3_frag && U.w1n_frag && fuse_tail <= 2)) &&
+            HMMR_REQUIRE(!last && (w->dtype == HMMR_BF16 || pair || (w->dtype == HMMR_F16X3 && ((U.w3_frag && U.w1n_frag) || U.unit_stream) && fuse_tail <= 2)) &&
                          U.stride == 1 && write_raw && !write_pre && next_fused &&
                          next_identity && w->unit[u + 1].base == U.base && w->unit[u + 1].c_in == U.depth &&
                          ((U.base == 64 && U.depth == 256) || (U.base == 128 && U.depth == 512) || (pair && U.base == 256 && U.depth == 1024)),
@@ -394,7 +396,10 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
             if (conv2_in_tail) {      // h2 never exists in HBM; the conv1' output goes to T2 (T1 is still being read
                                       // by neighbouring tiles' halos), and the two buffers swap roles afterwards
                 HMMR_REQUIRE(U.conv2.scale && U.conv2.shift, "resnet: unit %d cannot fuse its conv2", u);
+                HMMR_REQUIRE((U.conv2.k_order == 2) == (w->dtype == HMMR_F16X3 && U.unit_stream != nullptr),
+                             "resnet: unit %d: a k_order 2 conv2 runs inside the unit only as part of its unit_stream (csrc/b1_unit.hip)", u);
                 t.h1 = T1; t.hin = H; t.win = H; t.w2 = U.conv2.w; t.scale2 = U.conv2.scale; t.shift2 = U.conv2.shift;
+                if (w->dtype == HMMR_F16X3) t.unit_stream = U.unit_stream;
             } else {
                 t.h2 = T2;
             }

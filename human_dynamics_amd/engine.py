@@ -26,11 +26,12 @@ DEFAULT_DTYPE = "f16x3"
 TILE_TABLES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tile_tables.json")
 
 
-def set_debug(stem_route=0, stem_no_conv1=0, gemm_probe=0, smpl_blend_mfma=0, ief_no_group=0):
-    """Development switches of libhmmr_hip.so (hmmr_debug_t; process-wide, zeros = product defaults)."""
+def set_debug(stem_route=0, stem_no_conv1=0, gemm_probe=0, smpl_blend_mfma=0, ief_no_group=0, pair_min_pixels=0):
+    """Development switches of libhmmr_hip.so (hmmr_debug_t; process-wide, zeros = product defaults).
+    pair_min_pixels: the unit-pair switch of hmmr_resnet50_fwd (0 = 12000 pixels, 1 = always the pair kernel, 2**31 - 1 = never)."""
     d = L.Debug()
     d.stem_route, d.stem_no_conv1, d.gemm_probe = int(stem_route), int(stem_no_conv1), int(gemm_probe)
-    d.smpl_blend_mfma, d.ief_no_group = int(smpl_blend_mfma), int(ief_no_group)
+    d.smpl_blend_mfma, d.ief_no_group, d.pair_min_pixels = int(smpl_blend_mfma), int(ief_no_group), int(pair_min_pixels)
     L.load().hmmr_set_debug(C.byref(d))
 
 
@@ -81,7 +82,7 @@ class HmmrEngine(object):
     def __init__(self, weights, smpl, dtype=DEFAULT_DTYPE, device="cuda:0", num_conv_layers=3,
                  delta_t_values=(-5, 5), joint_type="cocoplus", resnet_chunk=0,
                  temporal_dtype=None, ief_dtype=None, autotune=True, fold_sc=None, fuse_tail=None, patch_3x3=None,
-                 unit_pair=None, b1_stream=None):
+                 unit_pair=None, b1_stream=None, b1_unit=None):
         self.lib = L.load()
         _debug_from_env()
         if not torch.cuda.is_available():
@@ -111,7 +112,8 @@ class HmmrEngine(object):
                                        patch_3x3=int(devflags.get("PATCH_3X3")) if patch_3x3 is None else patch_3x3,
                                        unit_pair=({"0": False, "1": True}.get(devflags.get("UNIT_PAIR"), devflags.get("UNIT_PAIR"))
                                                   if unit_pair is None else unit_pair),
-                                       b1_stream=(devflags.get("B1_STREAM") == "1") if b1_stream is None else b1_stream)
+                                       b1_stream=(devflags.get("B1_STREAM") == "1") if b1_stream is None else b1_stream,
+                                       b1_unit=(devflags.get("B1_UNIT") == "1") if b1_unit is None else b1_unit)
                    if "resnet_v2_50/conv1/weights" in w else None)
         self.tw = (packing.pack_temporal(w, self.temporal_dtype, self.store, num_conv_layers)
                    if assets.temporal_scopes(0)[1] + "/weights" in w else None)
@@ -664,3 +666,50 @@ def bottleneck_tail_single(h1, conv2, stride, w3_hwio, bias3, res, pre, want_raw
     L.check(lib.hmmr_bottleneck_tail(C.byref(d), torch.cuda.current_stream(dev).cuda_stream), "hmmr_bottleneck_tail")
     torch.cuda.synchronize(dev)
     return (out.float().cpu().numpy() if want_raw else None), (outp.float().cpu().numpy() if want_pre else None)
+
+
+def b1_unit(h1, conv2, w3_hwio, bias3, pre, w1_hwio, bn1, res=None, shortcut=None, device="cuda:0"):
+    """Test/utility entry for the whole-unit kernel of block 1 (hmmr_tail_desc_t.unit_stream, csrc/b1_unit.hip; f16x3):
+    h1 [n,h,w,64] (a split device tensor or a float array), conv2 = (w2 [3,3,64,64], scale2, shift2), w3 [1,1,64,256], bias3 [256],
+    pre = (scale, shift) [256], w1 [1,1,256,64], bn1 = (scale, shift) [64]; either res [n,h,w,256] (a float array: the identity
+    shortcut) or shortcut = (xp [n,h,w,64], wsc [1,1,64,256], bias [256]) folded into conv3.  Returns the split device tensors
+    (trunk [n,h,w,256], h1' [n,h,w,64])."""
+    lib = L.load()
+    dev = torch.device(device)
+    store = packing.DeviceStore(dev)
+    X3 = L.HMMR_F16X3
+    x = h1.contiguous() if isinstance(h1, torch.Tensor) and h1.is_cuda else store.put(np.asarray(h1, np.float32), packing.SPLIT)
+    n, h, w_, cm = x.shape
+    w2 = np.asarray(conv2[0], np.float32)
+    k2 = packing.row_pow2(packing.pack_conv_weight(w2)[:64])
+    w3 = np.asarray(w3_hwio, np.float32)[0, 0]                                   # [K][256]
+    b3 = np.asarray(bias3, np.float64)
+    d = L.TailDesc()
+    if shortcut is not None:
+        xp = store.put(np.asarray(shortcut[0], np.float32), packing.SPLIT)
+        w3 = np.concatenate([w3, np.asarray(shortcut[1], np.float32)[0, 0]], axis=0)
+        b3 = b3 + np.asarray(shortcut[2], np.float64)
+        d.xp, d.c_xp = xp.data_ptr(), 64
+    else:
+        rt = store.put(np.asarray(res, np.float32), packing.SPLIT)
+        d.res, d.ldr = rt.data_ptr(), 256
+    w1 = np.asarray(w1_hwio, np.float32)[0, 0]                                   # [256][64]
+    stream = store.put_tensor(packing.pack_b1_unit_stream(w2, k2, w3.T, w1.T))
+    assert stream.numel() * 2 == lib.hmmr_b1_unit_stream_bytes(0 if shortcut is None else 64)
+    k3, k1 = packing.row_pow2(w3.T), packing.row_pow2(w1.T)
+    out = packing.empty_act((n, h, w_, 256), X3, dev, zero=True)
+    h1n = packing.empty_act((n, h, w_, 64), X3, dev, zero=True)
+    d.dtype, d.m, d.c_mid, d.depth, d.n2 = X3, n * h * w_, cm, 256, 64
+    d.h1, d.hin, d.win, d.ho, d.wo = x.data_ptr(), h, w_, h, w_
+    d.unit_stream = stream.data_ptr()
+    d.scale2 = store.vec((np.asarray(conv2[1], np.float64) * np.exp2(-k2.astype(np.float64))).astype(np.float32)).data_ptr()
+    d.shift2 = store.vec(conv2[2]).data_ptr()
+    d.scale3 = store.vec(np.exp2(-k3.astype(np.float64)).astype(np.float32)).data_ptr()
+    d.shift3 = store.vec(b3.astype(np.float32)).data_ptr()
+    d.pre_scale, d.pre_shift = store.vec(pre[0]).data_ptr(), store.vec(pre[1]).data_ptr()
+    d.scale1 = store.vec((np.asarray(bn1[0], np.float64) * np.exp2(-k1.astype(np.float64))).astype(np.float32)).data_ptr()
+    d.shift1, d.relu1 = store.vec(bn1[1]).data_ptr(), 1
+    d.out, d.out_h1 = out.data_ptr(), h1n.data_ptr()
+    L.check(lib.hmmr_bottleneck_tail(C.byref(d), torch.cuda.current_stream(dev).cuda_stream), "hmmr_bottleneck_tail")
+    torch.cuda.synchronize(dev)
+    return out, h1n

@@ -194,6 +194,41 @@ def pack_pair_stream(w3_nk, w1_nk):
     return out.contiguous()
 
 
+def pack_b1_unit_stream(w2_hwio, k2, w3_nk, w1_nk):
+    """The filter stream of a whole block-1 unit (hmmr_tail_desc_t.unit_stream, csrc/b1_unit.hip): w2_hwio [3,3,64,64] = conv2 with its row
+    exponents k2 (as _layer_stream3x3 scales them), w3_nk [256][K3] = conv3's rows ([W3 | Wsc] along K with a folded shortcut, K3 = 64 or
+    128), w1_nk [64][256] = the next unit's conv1 rows -> fp16 [fragments][2 (hi, lo plane)][64 lanes][8], 2 KB per fragment:
+    conv2's stream exactly as pack_conv3x3_stream lays it out for cout = 64 (36 K steps x two row blocks), then for every 32 channels c
+    of conv3's output the K3 / 16 fragments of conv3 row block c (K chunks in order) and the four fragments of conv1' K chunks 2 c and
+    2 c + 1 (row blocks 0, 1 of each).  Rows of w3 / w1 carry row_pow2() like every split filter bank."""
+    w2 = np.asarray(w2_hwio, np.float32)
+    assert w2.shape == (3, 3, 64, 64), w2.shape
+    w3_nk = np.ascontiguousarray(w3_nk, dtype=np.float32)
+    w1_nk = np.ascontiguousarray(w1_nk, dtype=np.float32)
+    depth, K3 = w3_nk.shape
+    assert depth == 256 and K3 in (64, 128) and w1_nk.shape == (64, 256), (w3_nk.shape, w1_nk.shape)
+    parts = [pack_conv3x3_stream(w2, k2).reshape(-1, 2, 64, 8)]          # [36 x 2 fragments][plane][lane][8]
+
+    def planar(w_nk):
+        t = torch.from_numpy(scale_rows(w_nk, row_pow2(w_nk)))
+        n, K = t.shape
+        hi = t.to(SPLIT_HALF)
+        lo = (t - hi.to(torch.float32)).to(SPLIT_HALF)
+
+        def frag(x):
+            x = x.reshape(n // 32, 32, K // 16, 2, 8)                # rb, row, kc, half, e
+            return x.permute(0, 2, 3, 1, 4).reshape(n // 32, K // 16, 64, 8)
+        return torch.stack([frag(hi), frag(lo)], dim=2)              # [rb, kc, plane, lane, 8]
+
+    f3, f1 = planar(w3_nk), planar(w1_nk)
+    for c in range(depth // 32):
+        parts.append(f3[c])                                          # conv3 row block c: K3 / 16 fragments
+        parts.append(torch.stack([f1[j, 2 * c + kcl] for kcl in range(2) for j in range(2)]))
+    out = torch.cat(parts).contiguous()
+    assert out.numel() * 2 == 18 * 8192 + (depth // 32) * (K3 // 16 + 4) * 2048
+    return out
+
+
 def pack_stem_weight(w_hwio):
     """[7,7,3,64] -> [128][8*32]: k = ky*32 + kx*4 + c (kx = 7, c = 3 and ky = 7 are zero)."""
     out = np.zeros((64, 8, 8, 4), np.float32)
@@ -263,7 +298,7 @@ def _layer_stream3x3(store, w_hwio, scale, shift, bf16=False):
 
 
 def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3", "block4"), fuse_tail=True,
-                fuse_sc=True, fuse_preact_first=False, fold_sc=None, patch_3x3=2, unit_pair=True, b1_stream=False):
+                fuse_sc=True, fuse_preact_first=False, fold_sc=None, patch_3x3=2, unit_pair=True, b1_stream=False, b1_unit=True):
     """fuse_preact_blocks: blocks whose units apply their `preact` BN+ReLU inside the operand
     staging of conv1/shortcut instead of reading a materialised preact tensor (csrc/resnet.hip;
     measured at batch 256: -4.5 % ResNet time with blocks 1-2 fused, neutral for blocks 3-4).
@@ -276,6 +311,10 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
     56-pixel images) and their fused tails start at conv3 (hmmr_resnet_unit_t.fuse_tail = 1); False: conv2 runs inside those tails,
     tap-major.  Measured equal (profiles/r04c: 0.188 + 0.434 ms against 0.632 ms per unit), so the form with 0.4 GB less HBM traffic stays.
     The stride-2 units keep the im2col gather.
+    b1_unit (with patch_3x3 = 2, f16x3; default on, round 5): block1/unit_1 and unit_2 run as the whole-unit kernel of csrc/b1_unit.hip
+    (hmmr_resnet_unit_t.unit_stream, fuse_tail = 2): their conv2 is packed k_order 2 as with b1_stream, so the layer-per-launch schedule
+    (fuse_tail=False) of the same configuration runs it through the 3x3 stream kernel and produces the same bits.  False (and b1_stream
+    False): the round-3 tails of csrc/bottleneck_split.hip with conv2 inside, tap-major.
     unit_pair (f16x3 only; True | "block2" | "block3" | False): the stride-1 units of blocks 2-3 run conv3 + add + the next
     unit's preact + conv1 as the register-resident unit pair of csrc/unit_pair.hip (one filter stream per unit); block3/unit_1
     then keeps its conv shortcut as a launch (shortcut + conv1 as one column-split GEMM) instead of folding it into conv3."""
@@ -311,7 +350,7 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
         # (bf16: the conv2 of blocks 1-2 runs inside the fused bf16 units, which read the tap-major order -- unless fuse_tail="conv2b1"
         #  keeps block 2's outside, as launches of the stream kernel)
         b16_min = 128 if (stream and fuse_tail == "conv2b1") else 256
-        kord = int(bool(patch_3x3) and stride == 1 and ((dtype == L.HMMR_F16X3 and (base >= 128 or (stream and b1_stream))) or
+        kord = int(bool(patch_3x3) and stride == 1 and ((dtype == L.HMMR_F16X3 and (base >= 128 or (stream and (b1_stream or b1_unit)))) or
                                                          (dtype == L.HMMR_BF16 and base >= b16_min)))
         # (a chunk-major layer cannot fall back to the im2col gather: its 128-pixel patch -- tile + halo of W + 1 on either side --
         #  must fit the 4 x 64 rows the 128x256 tile keeps in LDS.  ResNet-50 on 224 x 224 crops: W <= 28)
@@ -369,6 +408,13 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
             if pair:
                 u.pair_stream = store.put_tensor(pack_pair_stream(w3.T, w1n.T)).data_ptr()
                 u.fuse_tail = 1
+                continue
+            if base == 64 and b1_unit and not b1_stream and fuse_tail != "noconv2" and u.conv2.k_order == 2:
+                # the whole unit as one launch (csrc/b1_unit.hip): conv2 (chunk-major, the stream kernel's order) + conv3 + add + next conv1
+                w2 = np.asarray(w[scope + "/conv2/weights"], np.float32)
+                k2 = row_pow2(pack_conv_weight(w2)[:w2.shape[3]])
+                u.unit_stream = store.put_tensor(pack_b1_unit_stream(w2, k2, w3.T, w1n.T)).data_ptr()
+                u.fuse_tail = 2
                 continue
             u.w3_frag = store.put_tensor(pack_frag_major(w3.T)).data_ptr()
             u.w1n_frag = store.put_tensor(pack_frag_major(w1n.T)).data_ptr()

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HMMR_ABI_VERSION 15      /* 15: k_order = 2 (the one-wave-per-SIMD 3x3 stream kernel, tiles 12 .. 18), hmmr_conv3x3_stream_bytes; 14: hmmr_tail_desc_t.pair_stream / c_xp, hmmr_resnet_unit_t.pair_stream (the register-resident unit pair of blocks 2-3), hmmr_run_flags; 13: hmmr_conv_desc_t.batch (grouped launches); 12: k_order = 1, 3x3 SAME convolutions out of an LDS-resident input patch (tiles 9, 10, 11) */
+#define HMMR_ABI_VERSION 16      /* 16: hmmr_tail_desc_t.unit_stream, hmmr_resnet_unit_t.unit_stream (the whole-unit kernel of block 1, csrc/b1_unit.hip), hmmr_b1_unit_stream_bytes, hmmr_debug_t.pair_min_pixels / launch counters; 15: k_order = 2 (the one-wave-per-SIMD 3x3 stream kernel, tiles 12 .. 18), hmmr_conv3x3_stream_bytes; 14: hmmr_tail_desc_t.pair_stream / c_xp, hmmr_resnet_unit_t.pair_stream (the register-resident unit pair of blocks 2-3), hmmr_run_flags; 13: hmmr_conv_desc_t.batch (grouped launches); 12: k_order = 1, 3x3 SAME convolutions out of an LDS-resident input patch (tiles 9, 10, 11) */
 
 /* HMMR_F16X3: "split" tensors -- every group of 8 consecutive channels is 32 bytes, [hi x8][lo x8] with
  * hi = fp16(x), lo = fp16(x - hi), x clamped to +-65504 (4 bytes per element, 22 mantissa bits while lo is a normal
@@ -48,7 +48,11 @@ const char* hmmr_last_error(void);
 /* Sticky run flags of the CURRENT device, OR-ed over everything launched on it since the last clear.  HMMR_FLAG_SATURATED: a value
  * beyond the fp16 range (+-65504, or +-inf) reached a split (HMMR_F16X3) store and was clamped -- the results of that call are not
  * the network's; run it with fp32 operands instead (the Python mirror does: Tester.precision["saturated"]).  Synchronises with the
- * device (a 4-byte copy per translation unit): call it where the results are read, not per launch.  clear != 0 resets the flags. */
+ * device (hipDeviceSynchronize, then a 4-byte copy per translation unit): call it where the results are read, not per launch.
+ * clear != 0 resets the flags.  NaN: the checks compare |v| against the range with fp32 max / compare instructions, which drop NaN --
+ * but a NaN cannot be the FIRST non-finite value of a split pipeline: fp16 operands bound every product by 4.3e9 and every fp32
+ * accumulation over K <= 4608 by 2e13, so an accumulator is finite, and an epilogue that overflows stores +-inf, which is flagged
+ * (and clamped) at that store before anything downstream can turn it into inf - inf. */
 #define HMMR_FLAG_SATURATED 1u
 int hmmr_run_flags(unsigned* flags, int clear);
 
@@ -68,9 +72,23 @@ typedef struct hmmr_debug_s {
                               them to ~1e-7 m */
     int ief_no_group;      /* 1: hmmr_ief_fwd runs the delta regressors one after the other instead of as grouped launches (same bits) */
     int reserved[3];
+    int pair_min_pixels;   /* hmmr_resnet50_fwd runs a register-resident unit pair (csrc/unit_pair.hip) as the two launches it replaces when
+                              the unit has fewer pixels than this (same bits, faster for short batches): 0 = the default (12000),
+                              1 = always the pair kernel, INT_MAX = never */
 } hmmr_debug_t;
 void hmmr_set_debug(const hmmr_debug_t* d);     /* NULL = defaults */
 void hmmr_get_debug(hmmr_debug_t* d);
+
+/* Launch counters of the fused-unit kernels, process-wide, since the last clear: how often hmmr_bottleneck_tail / hmmr_conv_gemm ended in
+ * each of them.  For tests that must know WHICH kernel a schedule ran (a bit-identity test of two schedules that silently take the same
+ * kernels proves nothing). */
+typedef struct {
+    unsigned long long unit_pair;       /* csrc/unit_pair.hip */
+    unsigned long long b1_unit;         /* csrc/b1_unit.hip */
+    unsigned long long tail_split;      /* csrc/bottleneck_split.hip (LDS-panel tails) */
+    unsigned long long conv3x3_stream;  /* csrc/conv3x3_stream.hip */
+} hmmr_launch_counts_t;
+void hmmr_launch_counts(hmmr_launch_counts_t* out, int clear);
 
 /* ------------------------------------------------------------------------- *
  * Generic implicit-GEMM convolution / fully-connected building block.
@@ -200,6 +218,8 @@ typedef struct {
     const void* w1n_frag;      /* ... and the NEXT unit's conv1 filters, both FRAGMENT-MAJOR (hmmr_tail_desc_t); else NULL */
     const void* pair_stream;   /* f16x3 fused tail of blocks 2-3 (fuse_tail == 1): this unit's conv3 filters ([W3 | Wsc] when c3sc is
                                   set) and the NEXT unit's conv1 filters as ONE fragment stream (hmmr_tail_desc_t.pair_stream); else NULL */
+    const void* unit_stream;   /* f16x3 whole-unit kernel of block 1 (fuse_tail == 2, conv2.k_order == 2): conv2's, conv3's ([W3 | Wsc]) and
+                                  the NEXT unit's conv1 filters as ONE fragment stream (hmmr_tail_desc_t.unit_stream); else NULL */
     const float* pre_scale;    /* this unit's folded `preact` BN, [c_in] */
     const float* pre_shift;
     int c_in, base, depth, stride;
@@ -274,8 +294,18 @@ typedef struct {
      * the launches it replaces. */
     const void* pair_stream;
     int c_xp;
+    /* HMMR_F16X3, (c_mid, depth, n2) = (64, 256, 64) [block1] with conv2 in front (h1; hin x win whole images, win <= 56): the whole-unit
+     * kernel of csrc/b1_unit.hip.  w2 / w3 / w1 are not read; `unit_stream` holds ALL filters of the unit as the flat sequence of 2 KB
+     * MFMA A-operand fragments ([hi plane: 64 lanes x 16 B][lo plane], lane = 32 * (k half) + row, rows scaled like every split filter
+     * bank) the kernel consumes (hmmr_b1_unit_stream_bytes; packing.pack_b1_unit_stream): conv2's stream exactly as k_order = 2 packs it
+     * for cout = 64 (36 K steps kt = (ci / 16) * 9 + tap of two row blocks), then for each 32 channels c of conv3's output the
+     * kc3 = (64 + c_xp) / 16 fragments of conv3 row block c (K chunks in order) and the four fragments of conv1' K chunks 2 c, 2 c + 1
+     * (row blocks 0, 1 of each).  scale2 / shift2: conv2's folded BN as the k_order 2 layer carries it.  With xp (c_xp = 64; res == NULL)
+     * conv3's K is {h2, xp}.  Bit-identical to hmmr_conv_gemm(k_order 2) + conv3 + conv1 as three launches. */
+    const void* unit_stream;
 } hmmr_tail_desc_t;
 size_t hmmr_pair_stream_bytes(int kc3, int depth, int n2);
+size_t hmmr_b1_unit_stream_bytes(int c_xp);
 /* measurement aid (bench.py's `roofline.mfma_sustained`): one launch of `workgroups` x 4 waves, one wave per SIMD, each issuing 8 * n8
  * v_mfma_f32_32x32x16_f16 (32768 FLOP each) on four independent accumulators and nothing else.  out: NULL or workgroups * 256 floats. */
 int hmmr_mfma_rate_probe(int workgroups, int n8, float* out, void* stream);

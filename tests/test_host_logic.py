@@ -121,7 +121,8 @@ def test_window_plan_matches_oracle():
 def test_ctypes_struct_sizes_are_plausible():
     # catches accidental field drift between include/hmmr_hip.h and _lib.py
     assert C.sizeof(_lib.Layer) == 32
-    assert C.sizeof(_lib.ResnetUnit) == 6 * 32 + 24 + 16 + 16 + 8
+    assert C.sizeof(_lib.ResnetUnit) == 6 * 32 + 32 + 16 + 16 + 8
+    assert C.sizeof(_lib.Debug) == 9 * 4 and C.sizeof(_lib.LaunchCounts) == 32
     assert C.sizeof(_lib.ConvDesc) % 8 == 0
 
 
@@ -145,7 +146,13 @@ def test_packer_marks_the_fused_launches(weights):
     # (b1_stream: block 1's conv2 as a launch of the 3x3 stream kernel, csrc/conv3x3_stream.hip, the tails start at conv3)
     b1s = packing.pack_resnet(weights, _lib.HMMR_F16X3, packing.DeviceStore("cpu"), b1_stream=True)
     assert [b1s.unit[i].fuse_tail for i in range(3)] == [1, 1, 0] and [b1s.unit[i].conv2.k_order for i in range(3)] == [2, 2, 0]
-    assert [bool(rwx.unit[i].w3_frag) for i in range(16)] == [True, True] + [False] * 14              # block 1: LDS-panel tails, fragment-major filters
+    # round 5: block1/unit_1 and unit_2 are whole-unit launches (csrc/b1_unit.hip): one filter stream each, conv2 chunk-major (k_order 2)
+    assert [bool(rwx.unit[i].unit_stream) for i in range(16)] == [True, True] + [False] * 14 and not any(rwx.unit[i].w3_frag for i in range(16))
+    assert [rwx.unit[i].conv2.k_order for i in range(3)] == [2, 2, 0] and not any(b1s.unit[i].unit_stream for i in range(16))
+    r3 = packing.pack_resnet(weights, _lib.HMMR_F16X3, packing.DeviceStore("cpu"), b1_unit=False)       # the round-3 / 4 block 1
+    assert [bool(r3.unit[i].w3_frag) for i in range(16)] == [True, True] + [False] * 14              # LDS-panel tails, fragment-major filters
+    assert [r3.unit[i].fuse_tail for i in range(3)] == [2, 2, 0] and [r3.unit[i].conv2.k_order for i in range(3)] == [0, 0, 0]
+    assert not any(r3.unit[i].unit_stream for i in range(16))
     assert [bool(rwx.unit[i].pair_stream) for i in range(16)] == [False] * 3 + [True] * 3 + [False] + [True] * 5 + [False] * 4
     old = packing.pack_resnet(weights, _lib.HMMR_F16X3, packing.DeviceStore("cpu"), unit_pair=False)      # the round-3 schedule
     assert [i for i in range(16) if old.unit[i].c3sc.w] == [0, 3, 7, 13] and not any(old.unit[i].sc_c1.w for i in range(16))
@@ -196,7 +203,7 @@ def test_chunk_major_filter_pack():
     assert [on.unit[i].conv2.k_order for i in range(16)] == [0, 0, 0, 1, 1, 1, 0, 1, 1, 1, 1, 1, 0, 1, 1, 1]
     # the default: the same layers as the filter stream of the one-wave-per-SIMD kernel (k_order 2, csrc/conv3x3_stream.hip)
     st = packing.pack_resnet(ws, _lib.HMMR_F16X3, packing.DeviceStore("cpu"))
-    assert [st.unit[i].conv2.k_order for i in range(16)] == [0, 0, 0, 2, 2, 2, 0, 2, 2, 2, 2, 2, 0, 2, 2, 2]
+    assert [st.unit[i].conv2.k_order for i in range(16)] == [2, 2, 0, 2, 2, 2, 0, 2, 2, 2, 2, 2, 0, 2, 2, 2]
     off = packing.pack_resnet(ws, _lib.HMMR_F16X3, packing.DeviceStore("cpu"), patch_3x3=False)
     assert not any(off.unit[i].conv2.k_order for i in range(16))
     # bf16 (round 4): blocks 3-4 only -- the conv2 of blocks 1-2 runs inside the fused bf16 units, which read the tap-major order
@@ -236,6 +243,35 @@ def test_conv3x3_stream_pack():
         tile, rb, row = co // 128, (co % 128) // 32, co % 32
         kt, plane, half, e = (ci // 32) * 9 + ky * 3 + kx, (ci % 32) // 16, (ci % 16) // 8, ci % 8
         assert float(sb[tile, kt, rb, plane, 32 * half + row, e]) == float(torch.tensor(w[ky, kx, ci, co]).to(torch.bfloat16))
+
+
+def test_b1_unit_stream_pack():
+    """packing.pack_b1_unit_stream (hmmr_tail_desc_t.unit_stream, csrc/b1_unit.hip): conv2's k_order 2 stream, then per 32 channels c of
+    conv3's output its K3 / 16 conv3 fragments and the four conv1' fragments of K chunks 2 c, 2 c + 1; a fragment = [hi | lo plane][lane =
+    32 * (k half) + row][8]; hi + lo reproduce the scaled filter rows."""
+    rng = np.random.default_rng(5)
+    w2 = rng.normal(size=(3, 3, 64, 64)).astype(np.float32)
+    k2 = packing.row_pow2(packing.pack_conv_weight(w2)[:64])
+    lib = _lib.load()
+    for K3 in (64, 128):
+        w3 = rng.normal(size=(256, K3)).astype(np.float32)
+        w1 = rng.normal(size=(64, 256)).astype(np.float32)
+        st = packing.pack_b1_unit_stream(w2, k2, w3, w1)
+        nf = K3 // 16 + 4
+        assert tuple(st.shape) == (72 + 8 * nf, 2, 64, 8) and st.dtype == torch.float16
+        assert st.numel() * 2 == lib.hmmr_b1_unit_stream_bytes(K3 - 64)
+        assert torch.equal(st[:72].reshape(-1), packing.pack_conv3x3_stream(w2, k2).reshape(-1))
+        k3, k1 = packing.row_pow2(w3), packing.row_pow2(w1)
+        val = lambda f, lane, e: float(st[f, 0, lane, e]) + float(st[f, 1, lane, e])
+        for co, ci in ((0, 0), (37, 5), (255, K3 - 1), (130, 17)):              # conv3: W3[co][ci]
+            f = 72 + (co // 32) * nf + ci // 16
+            want = float(w3[co, ci]) * 2.0 ** int(k3[co])
+            assert abs(val(f, 32 * ((ci % 16) // 8) + co % 32, ci % 8) - want) <= abs(want) * 2.0 ** -21
+        for n2, ci in ((0, 0), (33, 47), (63, 255), (5, 144)):                  # conv1': W1[n2][ci], K chunk ci // 16 = 2 c + kcl
+            c, kcl = ci // 32, (ci // 16) % 2
+            f = 72 + c * nf + K3 // 16 + kcl * 2 + n2 // 32
+            want = float(w1[n2, ci]) * 2.0 ** int(k1[n2])
+            assert abs(val(f, 32 * ((ci % 16) // 8) + n2 % 32, ci % 8) - want) <= abs(want) * 2.0 ** -21
 
 
 def test_tuner_candidates_map_onto_the_stream_kernels_tiles():
