@@ -60,6 +60,14 @@ struct B1Args {
     int M, H, W, n_tiles;
 };
 
+// Development build only (tools/b1_probe_build.sh, -DB1_PROBE_BITS=n): drop the MFMAs (1), the HBM traffic (2: every tile reads tile 0's
+// pixels and stores to the dump page), the waits and barriers of the slab steps (4) or the epilogue arithmetic (8) at COMPILE time, to
+// see what bounds the kernel.  Results are garbage in those modes; the product build compiles the switches away.
+#ifndef B1_PROBE_BITS
+#define B1_PROBE_BITS 0
+#endif
+#define B1_PROBE(bit) (((B1_PROBE_BITS) & (bit)) != 0)
+
 constexpr int B1_BM = 128, B1_DEPTH = 256, B1_NCH = B1_DEPTH / 32;
 constexpr int B1_NS = 5, B1_SLAB = 8192, B1_RING = B1_NS * B1_SLAB;
 constexpr int B1_NPP = 4;                                   // 64-row pieces of a patch: 128 + 2 * 56 + 2 = 242 rows
@@ -140,6 +148,12 @@ __device__ __forceinline__ void b1_split_pairs(const float (&y)[4], shalf2 (&h)[
     }
 }
 
+// mma3 (common.h), or under probe bit 1 something that only keeps its operands alive
+__device__ __forceinline__ f32x16 b1_mma3(const wfrag& w, const shalf8& xh, const shalf8& xl, f32x16 c) {
+    if constexpr (B1_PROBE(1)) { c[0] += (float)w.hi[0] + (float)w.lo[0] + (float)xh[0] + (float)xl[0]; return c; }
+    else return mma3(w, xh, xl, c);
+}
+
 // KC3B: 16-wide K chunks of conv3 that come from xp (0, or 4: the folded shortcut); RES: a shortcut tensor is added
 template <int KC3B, bool RES>
 __global__ __launch_bounds__(256, 2) void b1_unit_kernel(const B1Args a) {
@@ -151,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void b1_unit_kernel(const B1Args a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, lh = lane >> 5;
-    const int m0 = xcd_remap(blockIdx.x, a.n_tiles) * B1_BM;
+    const int m0 = B1_PROBE(2) ? 0 : xcd_remap(blockIdx.x, a.n_tiles) * B1_BM;
     const int W = a.W, HW = a.H * a.W;
     const int mbase = m0 + wave * 32;                           // this wave's first pixel
     const int lane16 = lane * 16;
@@ -193,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void b1_unit_kernel(const B1Args a) {
     for (int q = 0; q < 4; ++q) {
         const int r = 8 * q + rsub, m = mbase + r;
         const int ls = pslot ^ ((r >> 1) & 7);
-        const bool ok = m < a.M;
+        const bool ok = m < a.M && !B1_PROBE(2);
         orow[q] = ok ? a.out + (long long)m * DEPTH + ls * 4 : (bsplit_t*)g_b1_dump + lane * 4;
         hrow[q] = ok ? a.out_h1 + (long long)m * 64 + ls * 4 : (bsplit_t*)g_b1_dump + lane * 4;
         ostep[q] = ok ? 32 : 0;
@@ -273,9 +287,10 @@ __global__ __launch_bounds__(256, 2) void b1_unit_kernel(const B1Args a) {
     auto slab_step = [&](auto s_c) {
         constexpr int S = decltype(s_c)::value;
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (S >= NS - 1) b1_wait<b1_wait_n(S, KC3, RES)>();
+        if constexpr (B1_PROBE(4)) b1_wait<63>();
+        else if constexpr (S >= NS - 1) b1_wait<b1_wait_n(S, KC3, RES)>();
         else b1_wait<63>();                                     // (lgkmcnt(0) alone: slabs 0 .. 3 landed in the prologue)
-        __builtin_amdgcn_s_barrier();
+        if (!B1_PROBE(4)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (S + NS - 1 < TOTAL) ring_dma(S + NS - 1);
@@ -310,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void b1_unit_kernel(const B1Args a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const wfrag w = ring_frag(KT / 2, (KT & 1) * 2 + j);
-            acc[j] = mma3(w, xhi, xlo, acc[j]);
+            acc[j] = b1_mma3(w, xhi, xlo, acc[j]);
         }
     };
     b1_for(kstep, std::make_integer_sequence<int, 36>{});
@@ -353,11 +368,11 @@ __global__ __launch_bounds__(256, 2) void b1_unit_kernel(const B1Args a) {
         // conv3 chunk C: K chunks in order over {h2, xp}
         slab_step(b1_ic<S0>{});
 #pragma unroll
-        for (int kc = 0; kc < 4; ++kc) acc1 = mma3(ring_frag(S0, kc), xh[kc].hi, xh[kc].lo, acc1);
+        for (int kc = 0; kc < 4; ++kc) acc1 = b1_mma3(ring_frag(S0, kc), xh[kc].hi, xh[kc].lo, acc1);
         if constexpr (KC3B > 0) {
             slab_step(b1_ic<S0 + 1>{});
 #pragma unroll
-            for (int kc = 0; kc < 4; ++kc) acc1 = mma3(ring_frag(S0 + 1, kc), xh[4 + kc].hi, xh[4 + kc].lo, acc1);
+            for (int kc = 0; kc < 4; ++kc) acc1 = b1_mma3(ring_frag(S0 + 1, kc), xh[4 + kc].hi, xh[4 + kc].lo, acc1);
         }
         // * scale3 + shift3 (+ shortcut), split, IN PLACE into the staging tile; the pre-activation of the STORED value
         char* stg = stg_of(B);
@@ -379,9 +394,17 @@ __global__ __launch_bounds__(256, 2) void b1_unit_kernel(const B1Args a) {
                 v[3] += shalf_hi((unsigned)(h >> 32)) + shalf_hi((unsigned)(l >> 32));
             }
             unsigned long long oh, ol;
-            split4(v, oh, ol, satm);
+            if constexpr (B1_PROBE(8)) {
+                oh = (unsigned long long)__float_as_uint(v[0]) | ((unsigned long long)__float_as_uint(v[1]) << 32);
+                ol = (unsigned long long)__float_as_uint(v[2]) | ((unsigned long long)__float_as_uint(v[3]) << 32);
+            } else split4(v, oh, ol, satm);
             *(unsigned long long*)ph = oh;
             *(unsigned long long*)pl = ol;
+            if constexpr (B1_PROBE(8)) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { nh[g][i] = __builtin_bit_cast(shalf2, (unsigned)(oh >> (32 * i))); nl[g][i] = __builtin_bit_cast(shalf2, (unsigned)(ol >> (32 * i))); }
+                continue;
+            }
             const f32x4 ps = *(const f32x4*)(sPS + ch), pb = *(const f32x4*)(sPB + ch);
             float y[4];
             y[0] = split_relu(fmaf(shalf_lo((unsigned)oh) + shalf_lo((unsigned)ol), ps[0], pb[0]));
@@ -409,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void b1_unit_kernel(const B1Args a) {
 #pragma unroll
         for (int kcl = 0; kcl < 2; ++kcl)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc2[j] = mma3(ring_frag(S0 + SPC - 1, kcl * 2 + j), th[kcl].hi, th[kcl].lo, acc2[j]);
+            for (int j = 0; j < 2; ++j) acc2[j] = b1_mma3(ring_frag(S0 + SPC - 1, kcl * 2 + j), th[kcl].hi, th[kcl].lo, acc2[j]);
     };
     b1_for(chunk, std::make_integer_sequence<int, NCH>{});
 

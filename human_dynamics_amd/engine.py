@@ -122,7 +122,10 @@ class HmmrEngine(object):
             self.iw, self.reg_keys = packing.pack_ief(w, self.ief_dtype, self.store, self.delta_keys)
         else:
             self.iw, self.reg_keys = None, [0]
-        self.sc = packing.pack_smpl(smpl, self.store, joint_type) if smpl is not None else None
+        # an all-fp32 engine is the exact-arithmetic reference (the probe's last rung, the saturation fallback): its SMPL blend product
+        # stays on fp32 operands too, so nothing in it can clamp
+        all_f32 = (self.dtype, self.temporal_dtype, self.ief_dtype) == (L.HMMR_F32,) * 3
+        self.sc = packing.pack_smpl(smpl, self.store, joint_type, split=not all_f32) if smpl is not None else None
         self.num_kps = self.sc.num_kps if self.sc is not None else assets.NUM_KPS
         self.num_verts = self.sc.num_verts if self.sc is not None else assets.NUM_VERTS
         self._ws = {k: _Workspace(self.device) for k in ("resnet", "temporal", "ief", "smpl", "hal")}   # + "resnet<i>" per side stream
@@ -165,14 +168,32 @@ class HmmrEngine(object):
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    # flags that a scoped reader (flag_scope: Tester's saturation guard, the operand-mode probe) found raised BEFORE its own work and
+    # took out of the device word so that it would not mistake them for its own: run_flags() keeps reporting them, per device
+    _carried_flags = {}
+
     def run_flags(self, clear=False):
         """Sticky run flags of this engine's device (hmmr_run_flags; _lib.FLAG_SATURATED: a split store clamped a value to the
         fp16 range since the last clear).  Synchronises with the device."""
+        key = (self.device.type, self.device.index)
+        v = self._device_flags(clear) | HmmrEngine._carried_flags.get(key, 0)
+        if clear:
+            HmmrEngine._carried_flags.pop(key, None)
+        return v
+
+    def _device_flags(self, clear):
         torch.cuda.synchronize(self.device)
         with torch.cuda.device(self.device):
             v = C.c_uint(0)
             L.check(self.lib.hmmr_run_flags(C.byref(v), int(bool(clear))), "hmmr_run_flags")
         return int(v.value)
+
+    def flag_scope(self):
+        """Context manager around a piece of work whose OWN flags are wanted: on entry whatever the (device-wide, sticky) word already
+        holds is moved aside -- it stays visible to run_flags() -- and `.flags` after the block holds what was raised inside it (the word
+        is left clear).  The flags are per device, not per engine: earlier work of any engine (the operand-mode probe's rejected rungs,
+        raw engine calls, another Tester) must neither demote this caller nor be erased by it."""
+        return _FlagScope(self)
 
     def to_device(self, a, dtype=torch.float32):
         if isinstance(a, torch.Tensor):
@@ -493,6 +514,23 @@ class HmmrEngine(object):
         L.check(self.lib.hmmr_groupnorm_relu(x.data_ptr(), g.data_ptr(), be.data_ptr(), b, t, c, groups,
                                              out.data_ptr(), out_dtype, self._stream()), "hmmr_groupnorm_relu")
         return out
+
+
+class _FlagScope(object):
+    def __init__(self, engine):
+        self.engine, self.flags = engine, 0
+
+    def __enter__(self):
+        e = self.engine
+        stale = e._device_flags(True)
+        if stale:
+            key = (e.device.type, e.device.index)
+            HmmrEngine._carried_flags[key] = HmmrEngine._carried_flags.get(key, 0) | stale
+        return self
+
+    def __exit__(self, *exc):
+        self.flags = self.engine._device_flags(True)
+        return False
 
 
 def conv_gemm(x, w_hwio, stride=1, pad=0, scale=None, shift=None, res=None, relu=False,

@@ -292,7 +292,7 @@ class Tester(object):
     # ------------------------------------------------------------------------
     def _uses_split_operands(self):
         e = self.engine
-        return L.HMMR_F16X3 in (e.dtype, e.temporal_dtype, e.ief_dtype)
+        return L.HMMR_F16X3 in (e.dtype, e.temporal_dtype, e.ief_dtype) or bool(e.sc is not None and e.sc.dirs_split)
 
     def _guard_saturation(self, run):
         """Run a host-facing call; if any split (f16x3) store clamped a value to the fp16 range while it ran (libhmmr_hip.so's
@@ -302,8 +302,9 @@ class Tester(object):
         synthetic frames only; this is the check on the caller's own data."""
         if not self._uses_split_operands():
             return run()
-        out = run()
-        if not (self.engine.run_flags(clear=True) & L.FLAG_SATURATED):
+        with self.engine.flag_scope() as scope:      # only what THIS call raises counts (the word is device-wide and sticky)
+            out = run()
+        if not (scope.flags & L.FLAG_SATURATED):
             return out
         import warnings
         warnings.warn("human_dynamics_amd: an activation left the fp16 range of the f16x3 operand mode (clamped to +-65504) -- "

@@ -504,8 +504,11 @@ def pack_ief(w, dtype, store, delta_t_values=(-5, 5), num_stages=3):
     return iw, keys
 
 
-def pack_smpl(smpl, store, joint_type="cocoplus"):
-    """tf_smpl-layout constants (src/tf_smpl/batch_smpl.py:35-80) -> SmplConsts."""
+def pack_smpl(smpl, store, joint_type="cocoplus", split=True):
+    """tf_smpl-layout constants (src/tf_smpl/batch_smpl.py:35-80) -> SmplConsts.
+    split: also pack the blend basis as split-fp16 MFMA fragments (hmmr_smpl_consts_t.dirs_split: the default blend form of
+    hmmr_smpl_fwd).  False -- what an all-fp32 engine passes -- or a basis whose entries x 2^13 leave the fp16 range: dirs_split = NULL,
+    the library then takes the exact-fp32 vector form."""
     nv = smpl["v_template"].shape[0]
     vpad = (nv + 255) // 256 * 256
     v_t = smpl["v_template"].astype(np.float64)
@@ -543,11 +546,13 @@ def pack_smpl(smpl, store, joint_type="cocoplus"):
     sc.num_verts, sc.num_kps, sc.lbs_nnz, sc.vpad = nv, nk, nnz, vpad
     sc.dirs = store.put(dirs).data_ptr()
     # the same basis as split-fp16 MFMA B-operand fragments (hmmr_smpl_consts_t.dirs_split): [K / 16][3][hi, lo][k half][vpad][8]
-    ds = torch.from_numpy(dirs.astype(np.float64) * 8192.0).to(torch.float32)            # exact: a power of two
-    hi = ds.to(SPLIT_HALF)
-    lo = (ds - hi.to(torch.float32)).to(SPLIT_HALF)
-    frag = lambda x: x.reshape(14, 2, 8, 3, vpad).permute(0, 3, 1, 4, 2)                # kc, c, h, v, e
-    sc.dirs_split = store.put_tensor(torch.stack([frag(hi), frag(lo)], dim=2).contiguous()).data_ptr()      # kc, c, plane, h, v, e
+    # (an entry beyond 65504 / 2^13 = 7.99 m would become inf in torch's fp16 cast: no such body model, but then the vector form it is)
+    if split and float(np.abs(dirs).max()) * 8192.0 < 65504.0:
+        ds = torch.from_numpy(dirs.astype(np.float64) * 8192.0).to(torch.float32)            # exact: a power of two
+        hi = ds.to(SPLIT_HALF)
+        lo = (ds - hi.to(torch.float32)).to(SPLIT_HALF)
+        frag = lambda x: x.reshape(14, 2, 8, 3, vpad).permute(0, 3, 1, 4, 2)                # kc, c, h, v, e
+        sc.dirs_split = store.put_tensor(torch.stack([frag(hi), frag(lo)], dim=2).contiguous()).data_ptr()      # kc, c, plane, h, v, e
     sc.j_template = store.put(j_template.astype(np.float32)).data_ptr()
     sc.j_shapedirs = store.put(j_shapedirs.astype(np.float32)).data_ptr()
     sc.parents = store.put(np.asarray(smpl["parents"]).astype(np.int32), torch.int32).data_ptr()

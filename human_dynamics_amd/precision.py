@@ -61,14 +61,29 @@ def probe_outputs(engine, frames, T=20, pred_mode="pred"):
 _DECISIONS = {}          # weights fingerprint -> (rung index, report): one probe per weight set and process
 
 
-def weights_fingerprint(weights, pred_mode):
-    """A cheap identity of a weight set: names, shapes and two moments of every array (float64 sums)."""
+def weights_fingerprint(weights, pred_mode, smpl=None, engine_kw=None):
+    """A cheap identity of what a decision was probed on: names, shapes and two moments of every weight array (float64 sums), the same
+    of the SMPL model's arrays, and the engine's configuration (the probe measures vertices: another body model or another
+    kernel schedule is another measurement)."""
     import hashlib
     h = hashlib.sha1(pred_mode.encode())
-    for k in sorted(weights):
-        a = np.asarray(weights[k])
-        h.update(k.encode()); h.update(str(a.shape).encode())
-        h.update(np.array([a.sum(dtype=np.float64), np.abs(a).sum(dtype=np.float64)]).tobytes())
+
+    def arrays(d):
+        for k in sorted(d):
+            try:
+                a = np.asarray(d[k])
+                if a.dtype == object or a.dtype.kind not in "fiub":
+                    raise TypeError
+            except (TypeError, ValueError):
+                h.update(("%s=%r" % (k, d[k])).encode())
+                continue
+            h.update(str(k).encode()); h.update(str(a.shape).encode())
+            h.update(np.array([a.sum(dtype=np.float64), np.abs(a).sum(dtype=np.float64)]).tobytes())
+    arrays(weights)
+    if smpl is not None:
+        h.update(b"|smpl|")
+        arrays(smpl if isinstance(smpl, dict) else getattr(smpl, "__dict__", {"smpl": repr(smpl)}))
+    h.update(repr(sorted((engine_kw or {}).items())).encode())
     return h.hexdigest()
 
 
@@ -82,19 +97,31 @@ def choose_engine(weights, smpl, device, pred_mode="pred", **engine_kw):
 
     def make(rung):
         return HmmrEngine(weights, smpl, dtype=rung[0], temporal_dtype=rung[1], ief_dtype=rung[2], device=device, **engine_kw)
-    key = weights_fingerprint(weights, pred_mode)
+    key = weights_fingerprint(weights, pred_mode, smpl, engine_kw)
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-    if key not in _DECISIONS and multi and dist.get_rank() != 0:
-        box = [None]
-        dist.broadcast_object_list(box, src=0)               # rank 0's decision (below)
+    if multi:
+        # EVERY rank takes part in ONE broadcast per call, whatever its own cache holds (the per-process caches may differ -- a
+        # Tester built on rank 0 before init_process_group -- and a rank that skipped the collective would leave the others hanging):
+        # rank 0 decides (from its cache or by probing) and sends; the others adopt its decision
+        chosen = None
+        if dist.get_rank() == 0:
+            if key not in _DECISIONS:
+                chosen, report, idx = _probe(weights, smpl, device, pred_mode, make)
+                _DECISIONS[key] = (idx, copy.deepcopy(report))
+            box = [_DECISIONS[key]]
+        else:
+            box = [None]
+        dist.broadcast_object_list(box, src=0)
         _DECISIONS[key] = box[0]
+        if chosen is not None:
+            return chosen, report
+        idx, report = _DECISIONS[key]
+        return make(LADDER[idx]), dict(copy.deepcopy(report), cached=True)
     if key in _DECISIONS:
         idx, report = _DECISIONS[key]
         return make(LADDER[idx]), dict(copy.deepcopy(report), cached=True)
     chosen, report, idx = _probe(weights, smpl, device, pred_mode, make)
     _DECISIONS[key] = (idx, copy.deepcopy(report))
-    if multi:
-        dist.broadcast_object_list([_DECISIONS[key]], src=0)
     return chosen, report
 
 
@@ -106,6 +133,13 @@ def _probe(weights, smpl, device, pred_mode, make):
     tol = PROBE_FRACTION * TOLERANCE
 
     ref_engine = make(LADDER[-1])
+    # (the probe's own work -- a rejected f16x3 rung on noise frames may well saturate -- must not leave the device's sticky run
+    #  flags raised for whoever reads them next: the scope takes earlier flags aside and clears what the probe raises)
+    with ref_engine.flag_scope():
+        return _probe_ladder(make, ref_engine, frames, tol, pred_mode)
+
+
+def _probe_ladder(make, ref_engine, frames, tol, pred_mode):
     ref = probe_outputs(ref_engine, frames, pred_mode=pred_mode)
     rungs, chosen, idx = [], None, len(LADDER) - 1
     for ri, rung in enumerate(LADDER[:-1]):

@@ -224,3 +224,50 @@ def test_bench_self_launch_and_default_workload(tmp_path):
     assert bench.resolve_workload(ns(), 8) == (True, 4096)
     assert bench.resolve_workload(ns(weak=True), 8) == (False, 2048)
     assert bench.resolve_workload(ns(video_frames=1024), 2) == (True, 1024)
+
+
+def _choose_worker(rank, world, port, results):
+    """precision.choose_engine's collective with DIFFERENT per-process caches: rank 0 already holds a decision for the weight set (a
+    Tester built before init_process_group), rank 1 does not -- every rank must still take part in the one broadcast, and all end on
+    rank 0's rung.  The engine and the probe are stand-ins (no device here): what is under test is who calls the collective."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    from human_dynamics_amd import precision as P
+    built = []
+    P.HmmrEngine = lambda w, s, dtype, temporal_dtype, ief_dtype, device, **kw: built.append((dtype, temporal_dtype, ief_dtype)) or built[-1]
+    probes = []
+
+    def fake_probe(weights, smpl, device, pred_mode, make):
+        probes.append(rank)
+        idx = 1 if rank == 0 else 0                      # a borderline weight set: the ranks would decide differently on their own
+        return make(P.LADDER[idx]), {"operands": "x", "rungs": []}, idx
+    P._probe = fake_probe
+    w = {"a": np.arange(6, dtype=np.float32).reshape(2, 3)}
+    smpl_a, smpl_b = {"v_template": np.ones((4, 3), np.float32)}, {"v_template": np.full((4, 3), 2.0, np.float32)}
+    if rank == 0:
+        P.choose_engine(w, smpl_a, "cpu")                # before the process group exists: rank 0's cache is filled, rank 1's is not
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        e1, r1 = P.choose_engine(w, smpl_a, "cpu")       # rank 0: cached; rank 1: nothing cached -- one broadcast either way
+        e2, r2 = P.choose_engine(w, smpl_b, "cpu")       # another body model is another decision: rank 0 probes, rank 1 adopts
+        e3, r3 = P.choose_engine(w, smpl_a, "cpu", unit_pair=False)      # ... and so is another engine configuration
+        results[rank] = dict(rungs=[e1, e2, e3], probes=list(probes), cached=[bool(r.get("cached")) for r in (r1, r2, r3)])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_choose_engine_collective_with_different_caches():
+    from human_dynamics_amd import precision as P
+    assert (P.weights_fingerprint({"a": np.ones(3)}, "pred", {"v": np.ones(2)}) !=
+            P.weights_fingerprint({"a": np.ones(3)}, "pred", {"v": np.zeros(2)}))
+    assert P.weights_fingerprint({"a": np.ones(3)}, "pred", None, {"unit_pair": False}) != P.weights_fingerprint({"a": np.ones(3)}, "pred")
+    world, port = 2, _free_port()
+    with mp.Manager() as man:
+        results = man.dict()
+        mp.spawn(_choose_worker, args=(world, port, results), nprocs=world, join=True)
+        r0, r1 = results[0], results[1]
+    f16, mixed = ("f16x3",) * 3, ("f32", "f16x3", "f16x3")
+    assert r0["rungs"] == r1["rungs"] == [mixed, mixed, mixed], (r0, r1)        # everybody runs rank 0's rung (index 1)
+    assert r0["probes"] == [0, 0, 0] and r1["probes"] == []                     # only rank 0 ever probes
+    assert r1["cached"] == [True, True, True] and r0["cached"] == [True, False, False]
+    assert f16 != mixed

@@ -79,10 +79,6 @@ def test_b1_unit_kernel_equals_its_three_launches(shape, folded, gpu_device):
 
 def test_b1_unit_refuses_what_it_is_not_built_for(gpu_device):
     from human_dynamics_amd import engine as E
-    d = _unit_inputs(1, 8, 8, 3, False)
-    with pytest.raises(L.HmmrError, match="either a shortcut tensor"):
-        E.b1_unit(d["h1"], (d["w2"],) + d["bn2"], d["w3"], d["b3"], d["pre"], d["w1"], d["bn1"], res=d["res"],
-                  shortcut=(d["h1"], d["w3"], d["b3"]), device=gpu_device)
     wide = _unit_inputs(1, 4, 64, 3, False)
     with pytest.raises(L.HmmrError, match="at most 56 pixels wide"):
         E.b1_unit(wide["h1"], (wide["w2"],) + wide["bn2"], wide["w3"], wide["b3"], wide["pre"], wide["w1"], wide["bn1"], res=wide["res"],
