@@ -58,15 +58,23 @@ struct B1Args {
     const float* scale1; const float* shift1; int relu1;     // [64]
     bsplit_t* out_h1;                       // [M][64]
     int M, H, W, n_tiles;
+    unsigned long long* ts;                 // probe build (bit 64): [tiles][4 waves][16] s_memtime stamps, or NULL
 };
 
 // Development build only (tools/b1_probe_build.sh, -DB1_PROBE_BITS=n): drop the MFMAs (1), the HBM traffic (2: every tile reads tile 0's
 // pixels and stores to the dump page), the waits and barriers of the slab steps (4) or the epilogue arithmetic (8) at COMPILE time, to
-// see what bounds the kernel.  Results are garbage in those modes; the product build compiles the switches away.
+// see what bounds the kernel; 16: no filter stream (the ring keeps whatever it holds).  Results are garbage in those modes; the product build compiles the switches away.
+#ifndef B1_NT_RES
+#define B1_NT_RES 0         /* A/B: the shortcut chunks (read exactly once) as non-temporal requests */
+#endif
+#ifndef B1_NT_ST
+#define B1_NT_ST 0          /* A/B: the trunk stores as non-temporal stores */
+#endif
 #ifndef B1_PROBE_BITS
 #define B1_PROBE_BITS 0
 #endif
 #define B1_PROBE(bit) (((B1_PROBE_BITS) & (bit)) != 0)
+#define B1_STAMP(k) do { if (B1_PROBE(64) && a.ts) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) a.ts[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (k)] = t_; } } while (0)
 
 constexpr int B1_BM = 128, B1_DEPTH = 256, B1_NCH = B1_DEPTH / 32;
 constexpr int B1_NS = 5, B1_SLAB = 8192, B1_RING = B1_NS * B1_SLAB;
@@ -83,27 +91,26 @@ constexpr int B1_CONV2_SLABS = 18;                           // 36 K steps of 4 
 // slab t + 4 (2 instructions), then the step's other requests.  KC3: conv3's 16-wide K chunks (4, or 8 with a folded shortcut);
 // a chunk of conv3's output is SPC slabs: KC3 / 4 of conv3 fragments, one of conv1' fragments.
 constexpr int b1_total(int kc3) { return B1_CONV2_SLABS + B1_NCH * (kc3 / 4 + 1); }
-constexpr int b1_ring_ops(int t, int kc3) { return t + (B1_NS - 1) < b1_total(kc3) ? 2 : 0; }
+constexpr int b1_ring_ops(int t, int kc3) { return (t + (B1_NS - 1) < b1_total(kc3) && !B1_PROBE(16)) ? 2 : 0; }
 // requests of step t behind its ring DMA: the patch of chunk 2 / 3 (steps 5 / 9), shortcut chunk 0 (step 14), shortcut chunk 1
-// (first thing of step 18), and at the end of a chunk's last conv3 slab its 4 trunk stores + the shortcut chunk two ahead
+// (step 18), and in a chunk's conv1' slab step (its last) the 4 trunk stores + the shortcut chunk two ahead
 constexpr int b1_extra_ops(int t, int kc3, bool res) {
     if (t == 5 || t == 9) return 4;
-    if (t == 14) return res ? 4 : 0;
+    if (t == 14 || t == B1_CONV2_SLABS) return res ? 4 : 0;
     if (t < B1_CONV2_SLABS) return 0;
     const int spc = kc3 / 4 + 1, c = (t - B1_CONV2_SLABS) / spc, i = (t - B1_CONV2_SLABS) % spc;
-    int n = 0;
-    if (t == B1_CONV2_SLABS && res) n += 4;                 // shortcut chunk 1
-    if (i == spc - 2) n += 4 + ((res && c + 2 < B1_NCH) ? 4 : 0);
-    return n;
+    return i == spc - 1 ? 4 + ((res && c + 2 < B1_NCH) ? 4 : 0) : 0;
 }
 // what may stay in flight at the wait of step s: everything issued after step s - 4 (whose ring DMA is slab s, and whose other
-// requests -- a patch, a shortcut chunk -- are first read in step s).  One exception: shortcut chunk 1, requested at the top of
-// step 18, is read in step 20
+// requests -- a patch, a shortcut chunk -- are first read in step s or later).  One exception: shortcut chunk 1, requested in
+// step 18 (RES: 2 steps per chunk), is read behind the wait of step 21
 constexpr int b1_wait_n(int s, int kc3, bool res) {
     int n = 0;
     for (int t = s - 3; t < s; ++t) n += b1_ring_ops(t, kc3) + b1_extra_ops(t, kc3, res);
-    if (res && s == B1_CONV2_SLABS + 2)
-        n = (b1_extra_ops(B1_CONV2_SLABS, kc3, res) - 4) + b1_ring_ops(B1_CONV2_SLABS + 1, kc3) + b1_extra_ops(B1_CONV2_SLABS + 1, kc3, res);
+    if (res && s == B1_CONV2_SLABS + 3) {
+        n = 0;
+        for (int t = B1_CONV2_SLABS + 1; t < s; ++t) n += b1_ring_ops(t, kc3) + b1_extra_ops(t, kc3, res);
+    }
     return n;
 }
 
@@ -138,13 +145,30 @@ __device__ __forceinline__ void b1_d_to_b(const shalf2 (&nh)[4][2], const shalf2
         th[k].lo = __builtin_bit_cast(shalf8, u32x4{fl[0], fl[1], fl[2], fl[3]});
     }
 }
-// four fp32 values that are already inside the fp16 range's lower bound (ReLU'd) -> packed hi / lo halves (the bits of split4)
-__device__ __forceinline__ void b1_split_pairs(const float (&y)[4], shalf2 (&h)[2], shalf2 (&l)[2]) {
+// ---- the epilogues' arithmetic.  Two waves per SIMD share one vector issue port, and the unit does ~18 values per lane and 32 output
+// channels: the instruction COUNT is what the kernel's skeleton costs (the first version, written with split4 and float conversions,
+// spent 22 vector instructions per value: 0.32 ms of a 0.6 ms launch with the MFMAs and the HBM traffic taken out, profiles/r05b).
+// Two values already clamped to the fp16 range -> their packed hi halves (one v_cvt_pk_f16_f32) and packed lo halves: lo = fp16(c - hi),
+// c - hi is exact in fp32, so the mixed-precision fma rounds once, like the cast of split4 (common.h) -- the idiom of conv3x3_stream.hip
+__device__ __forceinline__ void b1_split2(float c0, float c1, unsigned& h, unsigned& l) {
+    h = __builtin_bit_cast(unsigned, shalf2{(shalf_t)c0, (shalf_t)c1});
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(c0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(c1));
+}
+// the value a packed (hi, lo) pair holds: hi + lo, exact before its one rounding to fp32 (= (float)hi + (float)lo); low / high half of the dwords
+__device__ __forceinline__ float b1_sum_lo(unsigned h, unsigned l) {
+    float v; asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(v) : "v"(h), "v"(l)); return v;
+}
+__device__ __forceinline__ float b1_sum_hi(unsigned h, unsigned l) {
+    float v; asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(v) : "v"(h), "v"(l)); return v;
+}
+// four values of one lane (4 consecutive channels): clamp to [lo_clamp, 65504], split -> oh / ol (the 8-byte hi and lo pieces the lane
+// writes) ; satm: running maximum of |v| (one v_max3_f32 per two values)
+__device__ __forceinline__ void b1_split4(const float (&v)[4], float lo_clamp, unsigned (&h)[2], unsigned (&l)[2], float& satm) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const shalf_t a = (shalf_t)y[2 * i], b = (shalf_t)y[2 * i + 1];
-        h[i] = shalf2{a, b};
-        l[i] = shalf2{(shalf_t)(y[2 * i] - (float)a), (shalf_t)(y[2 * i + 1] - (float)b)};
+        satm = __builtin_fmaxf(__builtin_fmaxf(satm, __builtin_fabsf(v[2 * i])), __builtin_fabsf(v[2 * i + 1]));
+        b1_split2(__builtin_amdgcn_fmed3f(v[2 * i], lo_clamp, HMMR_SPLIT_MAX), __builtin_amdgcn_fmed3f(v[2 * i + 1], lo_clamp, HMMR_SPLIT_MAX), h[i], l[i]);
     }
 }
 
@@ -162,6 +186,7 @@ __global__ __launch_bounds__(256, 2) void b1_unit_kernel(const B1Args a) {
     static_assert(!(RES && KC3B), "either a shortcut tensor or a folded one");
 
     extern __shared__ __attribute__((aligned(256))) char smem[];
+    B1_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, lh = lane >> 5;
@@ -173,6 +198,7 @@ __global__ __launch_bounds__(256, 2) void b1_unit_kernel(const B1Args a) {
     // ---- the filter stream: slab -> ring slot slab % 5; each wave moves a quarter (2 x 1 KB)
     const char* gstream = a.stream + wave * 2048 + lane16;
     auto ring_dma = [&](int slab) {                             // slab is a constant after unrolling
+        if (B1_PROBE(16)) return;                               // (probe: nothing enters the ring after the prologue... nor in it)
         const char* src = gstream + (long long)slab * SLAB;
         char* dst = smem + (slab % NS) * SLAB + wave * 2048;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);       // (the instruction offset moves both addresses)
@@ -218,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void b1_unit_kernel(const B1Args a) {
             char* dst = stg_of(b);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                __builtin_amdgcn_global_load_lds((gptr_t)(rrow[q] + chunk * 32), (lptr_t)(dst + q * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(rrow[q] + chunk * 32), (lptr_t)(dst + q * 1024), 16, 0, B1_NT_RES ? 2 : 0);
         }
     };
 
@@ -283,6 +309,7 @@ __global__ __launch_bounds__(256, 2) void b1_unit_kernel(const B1Args a) {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 
+    B1_STAMP(1);
     // ---- the start of slab step S: slab S has landed for every wave, slab S - 1 is free
     auto slab_step = [&](auto s_c) {
         constexpr int S = decltype(s_c)::value;
@@ -309,27 +336,59 @@ __global__ __launch_bounds__(256, 2) void b1_unit_kernel(const B1Args a) {
         return w;
     };
 
-    // ---- conv2: 36 K steps (chunk KT / 9 of 16 channels, tap KT % 9), two per slab
-    auto kstep = [&](auto kt_c) {
-        constexpr int KT = decltype(kt_c)::value, TAP = KT % 9, KY = TAP / 3, KX = TAP % 3, BUF = (KT / 9) & 1;
-        if constexpr ((KT & 1) == 0) slab_step(b1_ic<KT / 2>{});
-        const unsigned rowp = (unsigned)(rb0 + KY * W + KX);
-        const unsigned ph = ((2u * lh) ^ ((rowp >> 2) & 3u)) << 4;
-        unsigned ad = B1_OFF_P + BUF * B1_PBUF + rowp * 64 + ph;
-        if constexpr (TAP != 4) {
-            const bool outside = (KY == 0 && top) || (KY == 2 && bot) || (KX == 0 && lef) || (KX == 2 && rig);
-            const unsigned zb = B1_OFF_P + BUF * B1_PBUF + B1_NPP * 64 * 64 + (rowp & 3u) * 64 + ph;      // the zero row of the same bank
-            ad = outside ? zb : ad;
-        }
-        const shalf8 xhi = *(const shalf8*)(smem + ad), xlo = *(const shalf8*)(smem + (ad ^ 16u));
+    // ---- conv2: 36 K steps (chunk KT / 9 of 16 channels, tap KT % 9), two per slab.  Software pipeline over slabs: the fragments of
+    // slab s + 1 (filters out of the ring, pixels out of the patch) are requested BEFORE the MFMAs of slab s issue, so LDS latency, the
+    // wait on the ring and the barrier sit behind matrix work instead of in front of it
+    struct Slab2 { wfrag w[4]; shalf8 xh[2], xl[2]; };         // two K steps: filters (K step, row block), pixels (K step)
+    auto read_slab2 = [&](auto s_c, Slab2& f) {
+        constexpr int S = decltype(s_c)::value;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const wfrag w = ring_frag(KT / 2, (KT & 1) * 2 + j);
-            acc[j] = b1_mma3(w, xhi, xlo, acc[j]);
+        for (int h = 0; h < 2; ++h) {
+            const int kt = 2 * S + h, tap = kt % 9, ky = tap / 3, kx = tap % 3, buf = (kt / 9) & 1;      // (constants after unrolling)
+            const unsigned rowp = (unsigned)(rb0 + ky * W + kx);
+            const unsigned ph = ((2u * lh) ^ ((rowp >> 2) & 3u)) << 4;
+            unsigned ad = B1_OFF_P + buf * B1_PBUF + rowp * 64 + ph;
+            if (tap != 4) {
+                const bool outside = (ky == 0 && top) || (ky == 2 && bot) || (kx == 0 && lef) || (kx == 2 && rig);
+                const unsigned zb = B1_OFF_P + buf * B1_PBUF + B1_NPP * 64 * 64 + (rowp & 3u) * 64 + ph;     // the zero row of the same bank
+                ad = outside ? zb : ad;
+            }
+            f.xh[h] = *(const shalf8*)(smem + ad);
+            f.xl[h] = *(const shalf8*)(smem + (ad ^ 16u));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) f.w[2 * h + j] = ring_frag(S, 2 * h + j);
         }
+        __builtin_amdgcn_sched_barrier(0);                      // (the requests stay in front of the MFMAs that follow)
     };
-    b1_for(kstep, std::make_integer_sequence<int, 36>{});
+    auto mma_slab2 = [&](const Slab2& f) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[j] = b1_mma3(f.w[2 * h + j], f.xh[h], f.xl[h], acc[j]);
+    };
+    struct Slab1 { wfrag w[4]; };                               // four fragments of a tail slab
+    auto read_slab1 = [&](int slab, Slab1& f) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) f.w[k] = ring_frag(slab, k);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    Slab2 fa, fb;
+    Slab1 fA;                                                   // conv3 fragments of the chunk about to start
+    slab_step(b1_ic<0>{});
+    read_slab2(b1_ic<0>{}, fa);
+    auto slab_pair = [&](auto s_c) {                            // slabs S (in fa) and S + 1 (in fb), S even
+        constexpr int S = decltype(s_c)::value;
+        slab_step(b1_ic<S + 1>{});
+        read_slab2(b1_ic<S + 1>{}, fb);
+        mma_slab2(fa);
+        slab_step(b1_ic<S + 2>{});                              // (S + 2 = 18: the first slab of the tail, conv3 chunk 0)
+        if constexpr (S + 2 < B1_CONV2_SLABS) read_slab2(b1_ic<S + 2>{}, fa);
+        else read_slab1(S + 2, fA);
+        mma_slab2(fb);
+    };
+    b1_for([&](auto i_c) { slab_pair(b1_ic<2 * decltype(i_c)::value>{}); }, std::make_integer_sequence<int, B1_CONV2_SLABS / 2>{});
 
+    B1_STAMP(2);
     // ---- conv2's epilogue: folded BN + ReLU, split, D layout -> the h2 panel as B-operand fragments
     float satm = 0.f;
 #pragma unroll
@@ -339,20 +398,20 @@ __global__ __launch_bounds__(256, 2) void b1_unit_kernel(const B1Args a) {
         for (int g = 0; g < 4; ++g) {
             const int n = 32 * j + 8 * g + 4 * lh;
             const f32x4 s4 = *(const f32x4*)(sS2 + n), b4 = *(const f32x4*)(sB2 + n);
-            float y[4];
+            float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float v = fmaf(acc[j][4 * g + e], s4[e], b4[e]);
-                satm = __builtin_fmaxf(satm, __builtin_fabsf(v));
-                y[e] = split_relu(v);
-            }
-            b1_split_pairs(y, nh[g], nl[g]);
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(acc[j][4 * g + e], s4[e], b4[e]);
+            unsigned h[2], l[2];
+            b1_split4(v, 0.f, h, l, satm);                      // (ReLU and the clamp to the fp16 range are one v_med3_f32)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { nh[g][i] = __builtin_bit_cast(shalf2, h[i]); nl[g][i] = __builtin_bit_cast(shalf2, l[i]); }
         }
         xfrag t2[2];
         b1_d_to_b(nh, nl, t2);
         xh[2 * j] = t2[0]; xh[2 * j + 1] = t2[1];
     }
 
+    B1_STAMP(3);
     // ---- the tail: conv3's output channels 32 at a time
     f32x16 acc2[2];
 #pragma unroll
@@ -365,15 +424,20 @@ __global__ __launch_bounds__(256, 2) void b1_unit_kernel(const B1Args a) {
         f32x16 acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
-        // conv3 chunk C: K chunks in order over {h2, xp}
-        slab_step(b1_ic<S0>{});
+        // conv3 chunk C: K chunks in order over {h2, xp}; its first four fragments were requested a phase ago
 #pragma unroll
-        for (int kc = 0; kc < 4; ++kc) acc1 = b1_mma3(ring_frag(S0, kc), xh[kc].hi, xh[kc].lo, acc1);
+        for (int kc = 0; kc < 4; ++kc) acc1 = b1_mma3(fA.w[kc], xh[kc].hi, xh[kc].lo, acc1);
         if constexpr (KC3B > 0) {
             slab_step(b1_ic<S0 + 1>{});
+            Slab1 fA2;
+            read_slab1(S0 + 1, fA2);
 #pragma unroll
-            for (int kc = 0; kc < 4; ++kc) acc1 = b1_mma3(ring_frag(S0 + 1, kc), xh[4 + kc].hi, xh[4 + kc].lo, acc1);
+            for (int kc = 0; kc < 4; ++kc) acc1 = b1_mma3(fA2.w[kc], xh[4 + kc].hi, xh[4 + kc].lo, acc1);
         }
+        // the conv1' fragments of this chunk are requested in front of the epilogue
+        slab_step(b1_ic<S0 + SPC - 1>{});
+        Slab1 fB;
+        read_slab1(S0 + SPC - 1, fB);
         // * scale3 + shift3 (+ shortcut), split, IN PLACE into the staging tile; the pre-activation of the STORED value
         char* stg = stg_of(B);
         shalf2 nh[4][2], nl[4][2];
@@ -388,30 +452,35 @@ __global__ __launch_bounds__(256, 2) void b1_unit_kernel(const B1Args a) {
             for (int e = 0; e < 4; ++e) v[e] = fmaf(acc1[4 * g + e], s4[e], b4[e]);
             if constexpr (RES) {
                 const unsigned long long h = *(const unsigned long long*)ph, l = *(const unsigned long long*)pl;
-                v[0] += shalf_lo((unsigned)h) + shalf_lo((unsigned)l);
-                v[1] += shalf_hi((unsigned)h) + shalf_hi((unsigned)l);
-                v[2] += shalf_lo((unsigned)(h >> 32)) + shalf_lo((unsigned)(l >> 32));
-                v[3] += shalf_hi((unsigned)(h >> 32)) + shalf_hi((unsigned)(l >> 32));
+                v[0] += b1_sum_lo((unsigned)h, (unsigned)l);
+                v[1] += b1_sum_hi((unsigned)h, (unsigned)l);
+                v[2] += b1_sum_lo((unsigned)(h >> 32), (unsigned)(l >> 32));
+                v[3] += b1_sum_hi((unsigned)(h >> 32), (unsigned)(l >> 32));
             }
-            unsigned long long oh, ol;
+            unsigned oh[2], ol[2];
             if constexpr (B1_PROBE(8)) {
-                oh = (unsigned long long)__float_as_uint(v[0]) | ((unsigned long long)__float_as_uint(v[1]) << 32);
-                ol = (unsigned long long)__float_as_uint(v[2]) | ((unsigned long long)__float_as_uint(v[3]) << 32);
-            } else split4(v, oh, ol, satm);
-            *(unsigned long long*)ph = oh;
-            *(unsigned long long*)pl = ol;
+                oh[0] = __float_as_uint(v[0]); oh[1] = __float_as_uint(v[1]); ol[0] = __float_as_uint(v[2]); ol[1] = __float_as_uint(v[3]);
+            } else b1_split4(v, -HMMR_SPLIT_MAX, oh, ol, satm);
+            *(unsigned long long*)ph = (unsigned long long)oh[0] | ((unsigned long long)oh[1] << 32);
+            *(unsigned long long*)pl = (unsigned long long)ol[0] | ((unsigned long long)ol[1] << 32);
             if constexpr (B1_PROBE(8)) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) { nh[g][i] = __builtin_bit_cast(shalf2, (unsigned)(oh >> (32 * i))); nl[g][i] = __builtin_bit_cast(shalf2, (unsigned)(ol >> (32 * i))); }
+                for (int i = 0; i < 2; ++i) { nh[g][i] = __builtin_bit_cast(shalf2, oh[i]); nl[g][i] = __builtin_bit_cast(shalf2, ol[i]); }
                 continue;
             }
+            // the next unit's pre-activation of the value AS STORED (hi + lo), ReLU'd, clamped and split again
             const f32x4 ps = *(const f32x4*)(sPS + ch), pb = *(const f32x4*)(sPB + ch);
             float y[4];
-            y[0] = split_relu(fmaf(shalf_lo((unsigned)oh) + shalf_lo((unsigned)ol), ps[0], pb[0]));
-            y[1] = split_relu(fmaf(shalf_hi((unsigned)oh) + shalf_hi((unsigned)ol), ps[1], pb[1]));
-            y[2] = split_relu(fmaf(shalf_lo((unsigned)(oh >> 32)) + shalf_lo((unsigned)(ol >> 32)), ps[2], pb[2]));
-            y[3] = split_relu(fmaf(shalf_hi((unsigned)(oh >> 32)) + shalf_hi((unsigned)(ol >> 32)), ps[3], pb[3]));
-            b1_split_pairs(y, nh[g], nl[g]);
+            y[0] = fmaf(b1_sum_lo(oh[0], ol[0]), ps[0], pb[0]);
+            y[1] = fmaf(b1_sum_hi(oh[0], ol[0]), ps[1], pb[1]);
+            y[2] = fmaf(b1_sum_lo(oh[1], ol[1]), ps[2], pb[2]);
+            y[3] = fmaf(b1_sum_hi(oh[1], ol[1]), ps[3], pb[3]);
+            unsigned qh[2], ql[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                b1_split2(split_relu(y[2 * i]), split_relu(y[2 * i + 1]), qh[i], ql[i]);
+                nh[g][i] = __builtin_bit_cast(shalf2, qh[i]); nl[g][i] = __builtin_bit_cast(shalf2, ql[i]);
+            }
         }
         xfrag th[2];
         b1_d_to_b(nh, nl, th);
@@ -422,22 +491,31 @@ __global__ __launch_bounds__(256, 2) void b1_unit_kernel(const B1Args a) {
             for (int q = 0; q < 4; ++q) xr[q] = *(const u32x4*)(stg + q * 1024 + lane16);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { *(u32x4*)orow[q] = xr[q]; orow[q] += ostep[q]; }
+            for (int q = 0; q < 4; ++q) {
+                if (B1_NT_ST) __builtin_nontemporal_store(xr[q], (u32x4*)orow[q]); else *(u32x4*)orow[q] = xr[q];
+                orow[q] += ostep[q];
+            }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (C + 2 < NCH) res_dma(C + 2, B);
             __builtin_amdgcn_sched_barrier(0);
         }
+        // the next chunk's conv3 fragments are requested in front of this chunk's conv1' MFMAs
+        if constexpr (C + 1 < NCH) {
+            slab_step(b1_ic<S0 + SPC>{});
+            read_slab1(S0 + SPC, fA);
+        }
         // conv1' K step C: K chunks 2 C, 2 C + 1 against both row blocks
-        slab_step(b1_ic<S0 + SPC - 1>{});
 #pragma unroll
         for (int kcl = 0; kcl < 2; ++kcl)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc2[j] = b1_mma3(ring_frag(S0 + SPC - 1, kcl * 2 + j), th[kcl].hi, th[kcl].lo, acc2[j]);
+            for (int j = 0; j < 2; ++j) acc2[j] = b1_mma3(fB.w[kcl * 2 + j], th[kcl].hi, th[kcl].lo, acc2[j]);
+        B1_STAMP(4 + C);
     };
     b1_for(chunk, std::make_integer_sequence<int, NCH>{});
 
     // ---- conv1' epilogue: BN (+ ReLU), split, through this wave's staging tiles, coalesced stores
     __builtin_amdgcn_sched_barrier(0);
+    const float lo1 = a.relu1 ? 0.f : -HMMR_SPLIT_MAX;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         char* stg = stg_of(j);
@@ -447,14 +525,11 @@ __global__ __launch_bounds__(256, 2) void b1_unit_kernel(const B1Args a) {
             const f32x4 s4 = *(const f32x4*)(sS1 + n2), b4 = *(const f32x4*)(sB1 + n2);
             float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[e] = fmaf(acc2[j][4 * g + e], s4[e], b4[e]);
-                if (a.relu1) v[e] = fmaxf(v[e], 0.f);
-            }
-            unsigned long long oh, ol;
-            split4(v, oh, ol, satm);
-            *(unsigned long long*)(stg + lr * 128 + (((2 * g) ^ sw) << 4) + 8 * lh) = oh;
-            *(unsigned long long*)(stg + lr * 128 + (((2 * g + 1) ^ sw) << 4) + 8 * lh) = ol;
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(acc2[j][4 * g + e], s4[e], b4[e]);
+            unsigned oh[2], ol[2];
+            b1_split4(v, lo1, oh, ol, satm);
+            *(unsigned long long*)(stg + lr * 128 + (((2 * g) ^ sw) << 4) + 8 * lh) = (unsigned long long)oh[0] | ((unsigned long long)oh[1] << 32);
+            *(unsigned long long*)(stg + lr * 128 + (((2 * g + 1) ^ sw) << 4) + 8 * lh) = (unsigned long long)ol[0] | ((unsigned long long)ol[1] << 32);
         }
         u32x4 xr[4];
 #pragma unroll
@@ -463,6 +538,7 @@ __global__ __launch_bounds__(256, 2) void b1_unit_kernel(const B1Args a) {
         for (int q = 0; q < 4; ++q) *(u32x4*)(hrow[q] + (ostep[q] ? j * 32 : 0)) = xr[q];
     }
     split_flag(satm > HMMR_SPLIT_MAX);
+    B1_STAMP(12);
 }
 
 template <int KC3B, bool RES>
@@ -508,5 +584,7 @@ int hmmr_b1_unit_split(const hmmr_tail_desc_t* d, hipStream_t stream) {
     a.res = (const bsplit_t*)d->res; a.ldr = d->ldr; a.out = (bsplit_t*)d->out;
     a.scale1 = d->scale1; a.shift1 = d->shift1; a.relu1 = d->relu1; a.out_h1 = (bsplit_t*)d->out_h1;
     a.M = d->m; a.H = d->hin; a.W = d->win;
+    if (B1_PROBE(64))       // (development build: the stamp buffer's address travels in the reserved debug words, like the other probe builds')
+        a.ts = (unsigned long long*)(((unsigned long long)(unsigned)hmmr_debug_state()->reserved[1] << 32) | (unsigned)hmmr_debug_state()->reserved[0]);
     return folded ? launch_b1<4, false>(a, stream) : launch_b1<0, true>(a, stream);
 }

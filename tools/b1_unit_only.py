@@ -24,6 +24,12 @@ s2, b2 = vec(np.exp2(-k2.astype(np.float64))), vec(rng.normal(size=64) * 0.1)
 ps, pb = vec(rng.uniform(0.5, 1.5, 256)), vec(rng.normal(size=256) * 0.1)
 b3 = vec(rng.normal(size=256) * 0.1)
 b1 = vec(rng.normal(size=64) * 0.1)
+ts = None
+if "b1p64" in L.LIB_PATH or "b1p66" in L.LIB_PATH:              # stamp build: [tiles][4 waves][16] s_memtime values (100 MHz)
+    ts = torch.zeros(((m + 127) // 128, 4, 16), dtype=torch.int64, device=dev)
+    d_ = L.Debug()
+    d_.reserved[0], d_.reserved[1] = ts.data_ptr() & 0xffffffff, ts.data_ptr() >> 32
+    lib.hmmr_set_debug(C.byref(d_))
 st = torch.cuda.current_stream().cuda_stream
 for folded in (True, False):
     K3 = 128 if folded else 64
@@ -53,4 +59,12 @@ for folded in (True, False):
     ms = e0.elapsed_time(e1) / 10
     gb = (h1.numel() + (xp.numel() if folded else res.numel()) + out.numel() + h1n.numel()) * 4 / 1e9
     fl = 2.0 * m * (9 * 64 * 64 + K3 * 256 + 256 * 64)
+    if ts is not None:
+        t = ts.cpu().numpy().astype(np.float64)                  # s_memtime ticks of the LAST launch
+        t = t[:, :, :13]
+        d0 = (t - t[:, :, :1]) * 10.0                            # ns since the workgroup's start (100 MHz counter)
+        names = ["prologue", "conv2", "c2 epi"] + ["chunk %d" % c for c in range(8)] + ["h1' epi"]
+        med = np.median(np.diff(d0, axis=2).reshape(-1, 12), axis=0)
+        print("   per phase, median ns per wave: " + ", ".join("%s %.0f" % (nm, v) for nm, v in zip(names, med)))
+        print("   workgroup lifetime: median %.1f us, launch span %.1f us" % (np.median(d0[:, :, 12]) / 1e3, (t[:, :, 12].max() - t[:, :, 0].min()) * 10.0 / 1e3))
     print("b1 unit %s: %.4f ms per launch, %.2f GB -> %.2f TB/s, %.0f TFLOP/s" % ("folded  " if folded else "identity", ms, gb, gb / ms, fl / ms / 1e9))
