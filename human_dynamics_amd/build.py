@@ -18,13 +18,18 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libhmmr_hip.so")
 SOURCES = ["api.cpp", "gemm_conv.hip", "conv3x3_stream.hip", "stem.hip", "bottleneck.hip", "bottleneck_split.hip", "unit_pair.hip", "b1_unit.hip", "resnet.hip", "temporal.hip", "ief.hip", "smpl.hip", "eval_metrics.hip", "preprocess.hip", "handoff.hip", "probe.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC,
+# -fno-slp-vectorize (every file, round 5): under plain -O3 the SLP vectoriser packs adjacent scalar fp32 operations into v_pk_*_f32 with
+# op_sel shuffles.  In smpl_pose_kernel's kinematic chain that code produced WRONG translations for the last quarter of a wave (lanes
+# 48-55: joints 16-23 of every odd instance) in 20-60 % of the launches that ran beside ResNet kernels of another stream, and in none that
+# ran alone -- a rare wrong frame in Tester.predict_all_images' streamed path (profiles/r05_smpl_pose_packed_fp32.log; tests/
+# test_gpu_stress.py::test_tail_beside_the_resnet_is_deterministic).  Without the flag-made packing: 0 of 600.  The flag changes no
+# arithmetic (the same IEEE operations, unpacked); the one-wave-per-SIMD kernels had it already because the packing costs them issue slots.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-I", INCLUDE, "-I", CSRC,
          "-Wall", "-Wno-unused-function"]
 
 
-# per-file flags.  unit_pair.hip: a single wave per SIMD issues one vector instruction per ~8 cycles, so the instruction COUNT of its
-# epilogue is what bounds it; the SLP vectoriser packs pairs of its fp32 FMAs into v_pk_fma_f32 at the price of a v_mov per operand
-EXTRA_FLAGS = {"unit_pair.hip": ["-fno-slp-vectorize"], "conv3x3_stream.hip": ["-fno-slp-vectorize"]}
+# per-file flags (none at present)
+EXTRA_FLAGS = {}
 
 
 def _newer(src, dst):

@@ -58,6 +58,8 @@ class HostStreamer(object):
         self.s_tail = torch.cuda.Stream(device=self.dev)       # the ~150 small launches of a chunk's tail run under the next ResNet
         self._pin, self._dev_in, self._geom, self._dev_f32 = {}, {}, None, None
         self._phi_zero = None
+        from .. import devflags
+        self._poison = devflags.get("STREAM_POISON") == "1"
         self.layout, self.rec_len = tester.record_layout()
         # staging copies (pageable user array -> pinned buffer) run on a small private pool of plain memcpy workers
         # (NumPy releases the GIL): torch's intra-op pool would wake one spinning thread per core for every chunk,
@@ -107,8 +109,15 @@ class HostStreamer(object):
         return out
 
     def run(self, all_images, want=None):
+        return self.run_many([all_images], want)[0]
+
+    def run_many(self, videos, want=None):
+        """Several videos back to back as ONE pipeline (demo_video.py:172 calls predict_all_images once per person track): the chunks of
+        all videos form one sequence, so the upload of video v+1's first chunk runs under the ResNet of video v's last one and its tail
+        under the next video's ResNet -- what `run` does between the chunks of one long video, across call boundaries.  Every video
+        keeps its own padding, windows and output arrays: each result is byte-identical to its own `run` (tested).  Returns a list of
+        dicts, one per video."""
         t, eng, dev = self.t, self.eng, self.dev
-        N = len(all_images)
         keys = [k for k, _, _, _ in self.layout]        # a Tester without delta_t_values has no *_delta fields
         if want is not None:
             unknown = [k for k in want if k not in keys]
@@ -116,21 +125,37 @@ class HostStreamer(object):
                 raise KeyError("unknown output keys %s" % unknown)
             keys = [k for k in keys if k in want]
         fields = {k: (shp, off, size) for k, shp, off, size in self.layout if k in keys}
-        if N == 0:
-            return {k: np.zeros((0,) + fields[k][0], np.float32) for k in keys}
-        src = all_images if isinstance(all_images, np.ndarray) else np.asarray(all_images)
-        if src.dtype != np.uint8:
-            src = src if src.dtype == np.float32 else src.astype(np.float32)
-        assert src.shape[1:] == (224, 224, 3), src.shape
-        tdt = torch.uint8 if src.dtype == np.uint8 else torch.float32
-        if not src.flags.c_contiguous:
-            src = np.ascontiguousarray(src)
-        pin, dev_in = self._staging(tdt)
         C, g, margin, T = self.chunk, self.g, self.margin, t.sequence_length
-        n_chunks = (N + C - 1) // C
+        results = [None] * len(videos)
+        V, G = [], []                   # per-video state; the global chunk sequence [(video, chunk)]
+        tdt = None
+        for vi, all_images in enumerate(videos):
+            N = len(all_images)
+            if N == 0:
+                results[vi] = {k: np.zeros((0,) + fields[k][0], np.float32) for k in keys}
+                V.append(None)
+                continue
+            src = all_images if isinstance(all_images, np.ndarray) else np.asarray(all_images)
+            if src.dtype != np.uint8:
+                src = src if src.dtype == np.float32 else src.astype(np.float32)
+            assert src.shape[1:] == (224, 224, 3), src.shape
+            vdt = torch.uint8 if src.dtype == np.uint8 else torch.float32
+            if tdt is not None and vdt != tdt:                 # one pipeline stages one element type: mixed input runs call by call
+                return [self.run(v, want) for v in videos]
+            tdt = vdt
+            if not src.flags.c_contiguous:
+                src = np.ascontiguousarray(src)
+            n_chunks = (N + C - 1) // C
+            V.append(dict(N=N, src=src, n_chunks=n_chunks, first=len(G)))
+            G.extend((vi, k) for k in range(n_chunks))
+        if not G:
+            return results
+        pin, dev_in = self._staging(tdt)
         cur = torch.cuda.current_stream(dev)
-        phi = torch.empty((N + 1, 2048), dtype=torch.float32, device=dev)      # row N: the zero padding image
-        host = {k: torch.empty((N,) + fields[k][0], dtype=torch.float32, pin_memory=True) for k in keys}
+        for v in V:
+            if v is not None:
+                v["phi"] = torch.empty((v["N"] + 1, 2048), dtype=torch.float32, device=dev)      # row N: the zero padding image
+                v["host"] = {k: torch.empty((v["N"],) + fields[k][0], dtype=torch.float32, pin_memory=True) for k in keys}
         recs = [torch.empty((C, self.rec_len), dtype=torch.float32, device=dev) for _ in range(2)]
         in_free = [None, None]          # compute finished reading dev_in[slot]
         out_free = [None, None]         # copy-out finished reading recs[slot]
@@ -144,7 +169,9 @@ class HostStreamer(object):
         if self._phi_zero is None:
             self._phi_zero = torch.empty((1, 2048), dtype=torch.float32, device=dev)
             eng.resnet(torch.empty((0, 224, 224, 3), dtype=torch.float32, device=dev), n_zero=1, out=self._phi_zero)
-        phi[N:N + 1].copy_(self._phi_zero)
+        for v in V:
+            if v is not None:
+                v["phi"][v["N"]:v["N"] + 1].copy_(self._phi_zero)
         tr = (lambda tag: trace.append((tag, _time.perf_counter()))) if trace is not None else (lambda tag: None)
         gpu_marks = [] if trace is not None else None          # (tag, event): device-side timeline of the same call
 
@@ -155,28 +182,34 @@ class HostStreamer(object):
                 gpu_marks.append((tag, e))
         self._mark = mark
         mark("start", cur)
-        is_staged = lambda k_: (k_ > 0) if self.staged == "auto" else bool(self.staged)
+        is_staged = lambda j_: (j_ > 0) if self.staged == "auto" else bool(self.staged)
+        n_glob = len(G)
 
-        def stage_ahead(k_):
-            if k_ >= n_chunks or not is_staged(k_):
+        def span(j_):
+            v = V[G[j_][0]]
+            lo_ = G[j_][1] * C
+            return v, lo_, min(v["N"], lo_ + C)
+
+        def stage_ahead(j_):
+            if j_ >= n_glob or not is_staged(j_):
                 return None
-            lo_, hi_ = k_ * C, min(N, (k_ + 1) * C)
-            return self._stager.submit(self._stage_when_free, pin[k_ % 2], src[lo_:hi_], in_free[k_ % 2])
+            v, lo_, hi_ = span(j_)
+            return self._stager.submit(self._stage_when_free, pin[j_ % 2], v["src"][lo_:hi_], in_free[j_ % 2])
 
-        enc = [None] * n_chunks          # enc[k]: chunk k is encoded (recorded on the caller's stream)
+        enc = [None] * n_glob            # enc[j]: global chunk j is encoded (recorded on the caller's stream)
 
-        def encode(k_, ahead_):
-            """Chunk k_: upload (+ conversion) and ResNet, part by part -- the engine's split of a chunk into contiguous
+        def encode(j_, ahead_):
+            """Global chunk j_: upload (+ conversion) and ResNet, part by part -- the engine's split of a chunk into contiguous
             parts on concurrent streams, fed here so that part i starts when ITS frames have landed, under the upload of
-            part i+1.  Blocks the host until the buffer pair of the slot is free, i.e. until chunk k_-2 is encoded."""
-            lo_, hi_ = k_ * C, min(N, (k_ + 1) * C)
-            n_, slot_ = hi_ - lo_, k_ % 2
-            staged = is_staged(k_)
+            part i+1.  Blocks the host until the buffer pair of the slot is free, i.e. until chunk j_-2 is encoded."""
+            v, lo_, hi_ = span(j_)
+            n_, slot_ = hi_ - lo_, j_ % 2
+            staged = is_staged(j_)
             if staged:
                 ahead_.result()                                      # pageable -> pinned, done one chunk ahead
-                tr(" staged %d" % k_)
+                tr(" staged %d" % j_)
             elif in_free[slot_] is not None:
-                in_free[slot_].synchronize()                         # the device-side pair is free again (chunk k_-2 is encoded)
+                in_free[slot_].synchronize()                         # the device-side pair is free again (chunk j_-2 is encoded)
             cuts = eng.resnet_cuts(n_)
             one = len(cuts) == 2
             frames = dev_in[slot_][:n_]
@@ -188,7 +221,7 @@ class HostStreamer(object):
                         frames[a_:b_].copy_(pin[slot_][a_:b_], non_blocking=True)
                     else:
                         # straight from the caller's array; the call returns when the bytes have left it
-                        frames[a_:b_].copy_(torch.from_numpy(src[lo_ + a_:lo_ + b_]), non_blocking=True)
+                        frames[a_:b_].copy_(torch.from_numpy(v["src"][lo_ + a_:lo_ + b_]), non_blocking=True)
                     landed = torch.cuda.Event()
                     landed.record(self.s_in)
                 sc = cur if one else eng.side_stream(i_)
@@ -198,37 +231,41 @@ class HostStreamer(object):
                     sc.wait_event(landed)
                     if tdt == torch.uint8:                           # a kernel: on the stream of its consumer
                         self._to_float(frames[a_:b_], b_ - a_, fl[a_:b_])
-                    mark("upload %d.%d landed" % (k_, i_), sc)
-                    eng.resnet(fl[a_:b_], out=phi[lo_ + a_:lo_ + b_], parts=1, ws_key="resnet" if one else "resnet%d" % i_)
+                    mark("upload %d.%d landed" % (j_, i_), sc)
+                    eng.resnet(fl[a_:b_], out=v["phi"][lo_ + a_:lo_ + b_], parts=1, ws_key="resnet" if one else "resnet%d" % i_)
                 streams.append(sc)
             for sc in streams:
                 if sc is not cur:
                     cur.wait_stream(sc)
-            tr(" chunk %d queued" % k_)
-            mark("resnet %d done" % k_, cur)
-            enc[k_] = in_free[slot_] = torch.cuda.Event()
-            enc[k_].record(cur)
+            tr(" chunk %d queued" % j_)
+            mark("resnet %d done" % j_, cur)
+            enc[j_] = in_free[slot_] = torch.cuda.Event()
+            enc[j_].record(cur)
 
-        # staging runs ONE CHUNK AHEAD of its use: chunk k+2's memcpy is handed to the stager thread as soon as chunk k+1 is
-        # queued (it first waits, on its own thread, for the slot's previous user -- chunk k -- to be encoded), so the Python
-        # thread finds chunk k+1 already staged when it comes to encode it
+        # staging runs ONE CHUNK AHEAD of its use: chunk j+2's memcpy is handed to the stager thread as soon as chunk j+1 is
+        # queued (it first waits, on its own thread, for the slot's previous user -- chunk j -- to be encoded), so the Python
+        # thread finds chunk j+1 already staged when it comes to encode it
         ahead = {0: stage_ahead(0)}
         encode(0, ahead.pop(0))
         ahead[1] = stage_ahead(1)
-        for k in range(n_chunks + 1):
-            tr("chunk %d" % k)
-            if k + 1 < n_chunks:
-                # chunk k+1 goes into the queues before the tail (and the downloads) of chunk k-1 do: queued behind them,
-                # the copy of chunk k+1 was seen to wait for those downloads, and its ResNet with it
-                encode(k + 1, ahead.pop(k + 1))
-                ahead[k + 2] = stage_ahead(k + 2)
-            if k >= 1:
-                # tail of output frames [o0, o1): their windows reach margin frames into chunk k, encoded just above
+        for j in range(n_glob + 1):
+            tr("chunk %d" % j)
+            if j + 1 < n_glob:
+                # chunk j+1 goes into the queues before the tail (and the downloads) of chunk j-1 do: queued behind them,
+                # the copy of chunk j+1 was seen to wait for those downloads, and its ResNet with it
+                encode(j + 1, ahead.pop(j + 1))
+                ahead[j + 2] = stage_ahead(j + 2)
+            if j >= 1:
+                # tail of the output frames of global chunk j-1: their windows reach margin frames into the NEXT chunk of the same
+                # video (global chunk j, encoded just above) -- or, for a video's last chunk, into its padding
+                vi, k = G[j - 1]
+                v = V[vi]
+                last = k == v["n_chunks"] - 1
                 with torch.cuda.stream(self.s_tail):
-                    self.s_tail.wait_event(enc[min(k, n_chunks - 1)])
+                    self.s_tail.wait_event(enc[j - 1 if last else j])
                     # (a one-chunk video's tail as two halves, the first half's download under the second: measured SLOWER, 0.88 ms per
                     #  half against 1.0 ms for the whole -- the tail is ~60 short launches -- profiles/r04e_host_surface.log)
-                    self._tail((k - 1) % 2, (k - 1) * C, min(N, k * C), N, phi, recs, out_free, host, fields, keys, ar_T)
+                    self._tail((j - 1) % 2, k * C, min(v["N"], (k + 1) * C), v["N"], v["phi"], recs, out_free, v["host"], fields, keys, ar_T)
                 tr(" tail queued")
         self.s_tail.synchronize()
         for f in out_free:
@@ -242,7 +279,10 @@ class HostStreamer(object):
             t0 = trace[0][1]
             print("\n".join("%8.2f ms %s" % ((t - t0) * 1e3, tag) for tag, t in trace))
             print("\n".join("%8.2f ms (device) %s" % (gpu_marks[0][1].elapsed_time(e), tag) for tag, e in gpu_marks[1:]))
-        return {k: host[k].numpy() for k in keys}
+        for vi, v in enumerate(V):
+            if v is not None:
+                results[vi] = {k: v["host"][k].numpy() for k in keys}
+        return results
 
     def _tail(self, slot, o0, o1, N, phi, recs, out_free, host, fields, keys, ar_T):
         """output frames [o0, o1) (o0 a multiple of g): windows -> records in recs[slot] -> the downloader thread"""
@@ -256,6 +296,8 @@ class HostStreamer(object):
         if out_free[slot] is not None:
             cur.wait_event(out_free[slot].result())                 # the previous copy-out of this buffer is done
         rec = recs[slot]
+        if self._poison:                                            # development switch: a record row nobody wrote shows up as NaN on the host
+            rec.fill_(float("nan"))
         t.predict_strips_records(phi[idx], o1 - o0, out=rec)
         ready = torch.cuda.Event(blocking=True)
         ready.record(cur)

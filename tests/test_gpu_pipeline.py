@@ -349,6 +349,33 @@ def test_streamed_host_path_is_byte_identical_to_one_shot(weights, smpl_consts, 
     assert np.array_equal(sub["joints"], ref["joints"]) and np.array_equal(sub["omegas_delta"], ref["omegas_delta"])
 
 
+def test_predict_videos_is_byte_identical_to_one_call_per_video(weights, smpl_consts, gpu_device):
+    """Tester.predict_videos: several person tracks as ONE pipeline (track k+1 uploads under track k's ResNet; the reference calls
+    predict_all_images once per track, demo_video.py:172, tester.py:229-312).  Every track's result equals its own one-shot call byte for
+    byte: a track shorter than a chunk, one that ends in a partial chunk, an empty one, a two-chunk one; float32 and uint8 input."""
+    from human_dynamics_amd.evaluation.tester import Tester
+    t = Tester(Config(), weights=weights, smpl=smpl_consts, dtype="f16x3", device=gpu_device)
+    t._streamer = None
+    from human_dynamics_amd.evaluation.streaming import HostStreamer
+    t._streamer = HostStreamer(t, chunk=64)
+    lens = [37, 64, 0, 100, 8]
+    vids = [assets.make_synthetic_frames(n, seed=40 + i) if n else np.zeros((0, 224, 224, 3), np.float32) for i, n in enumerate(lens)]
+    got = t.predict_videos(vids)
+    assert len(got) == len(vids)
+    for v, g in zip(vids, got):
+        ref = t.predict_all_images(v, stream=False) if len(v) else None
+        for k in g:
+            assert g[k].shape[0] == len(v)
+            if len(v):
+                assert np.array_equal(g[k], ref[k]), k
+    sub = t.predict_videos(vids[:2], want=("joints", "omegas"))
+    assert sorted(sub[0]) == ["joints", "omegas"] and np.array_equal(sub[1]["joints"], got[1]["joints"])
+    u8 = [np.clip(np.rint((v + 1.0) * 127.5), 0, 255).astype(np.uint8) for v in vids[:2]]
+    a = t.predict_videos(u8, want=("omegas",))
+    for v, g in zip(u8, a):
+        assert np.array_equal(g["omegas"], t.predict_all_images(v, want=("omegas",))["omegas"])
+
+
 def test_streamed_host_path_without_delta_regressors(weights, smpl_consts, gpu_device):
     """config.delta_t_values = []: the record has no *_delta fields (tester.py:245-255 adds them per delta); the
     streamed path derives its keys from the record layout and equals the one-shot path, 640 frames = 3 chunks."""

@@ -120,7 +120,16 @@ def test_saturating_frames_raise_the_flag_and_fall_back_to_f32(gpu_device):
     big = frames * 3.0e4                                          # stem activations of ~1e5: beyond fp16
     eng16 = t.engine
     eng16.resnet(big[0])
+    # the flag word is device-wide and sticky: a flag raised by EARLIER work (this raw engine call; the operand-mode probe's rejected
+    # rungs; another Tester) is not this call's -- the guard must not demote the Tester for it, and must not erase it either
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        again0 = t.predict(frames)
+    assert t.precision["saturated"] is False and t.engine.dtype == L.HMMR_F16X3
+    assert np.array_equal(again0["verts"], ok["verts"])
+    assert eng16.run_flags() & L.FLAG_SATURATED                   # ... still there for whoever raised it
     assert eng16.run_flags(clear=True) & L.FLAG_SATURATED         # the raw engine call raises the flag ...
+    assert eng16.run_flags() == 0
     with pytest.warns(RuntimeWarning, match="fp16 range"):
         got = t.predict(big)                                      # ... and the Tester acts on it
     assert t.precision["saturated"] is True and t.precision["operands"] == "f32" and t.engine.dtype == L.HMMR_F32
@@ -131,3 +140,44 @@ def test_saturating_frames_raise_the_flag_and_fall_back_to_f32(gpu_device):
         warnings.simplefilter("error")
         again = t.predict(frames)                                 # sticky: later calls run on f32 operands without further ado
     assert np.abs(again["verts"] - ok["verts"]).max() < 1e-4
+
+
+@pytest.mark.parametrize("dt", ["f16x3", "bf16"])
+def test_tail_beside_the_resnet_is_deterministic(gpu_device, dt):
+    """The per-window tail (f_movie -> IEF -> SMPL records) gives the same records whether it runs alone or beside the ResNet passes of the
+    engine's two priority streams -- the overlap every streamed / sharded call runs with (evaluation/streaming.py, dist.ShardedPredictor).
+    Round 5: with the SLP vectoriser's packed fp32 (v_pk_*_f32) in smpl_pose_kernel, 20-60 % of such launches returned a wrong bone
+    translation for joints 16-23 of odd instances (lanes 48-55 of a wave) -- vertices off by centimetres in ~1 % of the streamed calls, none
+    of it visible to a test that runs a call twice.  The library is now built with -fno-slp-vectorize (human_dynamics_amd/build.py); this
+    test repeats the overlap 80 times and compares every record word."""
+    from conftest import Config
+    from human_dynamics_amd import dist as hd
+    from human_dynamics_amd.evaluation.tester import Tester
+    w, s = assets.make_synthetic_weights(0), assets.make_synthetic_smpl(2)
+    t = Tester(Config(batch_size=8), weights=w, smpl=s, dtype=dt, device=gpu_device)
+    eng, dev, n = t.engine, t.engine.device, 128
+    windows = torch.randn((16, 20, 2048), generator=torch.Generator().manual_seed(1)).to(dev)
+    _, rec_len = hd.record_layout(2)
+    ref = torch.zeros((n, rec_len), device=dev)
+    t.predict_strips_records(windows, n, out=ref)
+    torch.cuda.synchronize()
+    frames = torch.rand((128, 224, 224, 3), device=dev) * 2 - 1
+    phi = torch.empty((128, 2048), device=dev)
+    s_tail = torch.cuda.Stream()
+    bad = []
+    for rep in range(80):
+        rec = torch.full((n, rec_len), float("nan"), device=dev)
+        torch.cuda.synchronize()
+        cur = torch.cuda.current_stream()
+        for i, (a, b) in enumerate(((0, 64), (64, 128))):
+            sc = eng.side_stream(i)
+            sc.wait_stream(cur)
+            with torch.cuda.stream(sc):
+                eng.resnet(frames[a:b], out=phi[a:b], parts=1, ws_key="resnet%d" % i)
+        with torch.cuda.stream(s_tail):
+            s_tail.wait_stream(cur)
+            t.predict_strips_records(windows, n, out=rec)
+        torch.cuda.synchronize()
+        if not torch.equal(rec, ref):
+            bad.append((rep, (rec != ref).any(1).nonzero().flatten().tolist()[:8]))
+    assert not bad, "records differ beside the ResNet in %d of 80 runs: %s" % (len(bad), bad[:4])

@@ -1,0 +1,70 @@
+"""The per-window tail (f_movie, IEF, SMPL records) beside a two-part ResNet on the engine's priority streams, 300 times, against the tail run
+alone: every record must come out the same.  Round 5 found smpl_pose_kernel compiled with SLP-packed fp32 (v_pk_*_f32) failing this in 20-60 %
+of the launches (wrong A[j][1][3] for joints 16-23 of odd instances: the last quarter of a wave); the build now passes -fno-slp-vectorize.
+    [DBG_DT=bf16|f16x3|f32] python tools/tail_race_check.py"""
+import sys, numpy as np, torch
+sys.path.insert(0, ".")
+sys.path.insert(0, "tests")
+from conftest import Config
+from human_dynamics_amd import assets, _lib as L
+from human_dynamics_amd.evaluation.tester import Tester, OUTPUT_KEYS
+from human_dynamics_amd import dist as hd
+w, s = assets.make_synthetic_weights(0), assets.make_synthetic_smpl(2)
+import os
+t = Tester(Config(batch_size=8), weights=w, smpl=s, dtype=os.environ.get("DBG_DT", "bf16"), device="cuda:0")
+eng = t.engine
+dev = eng.device
+n = 128
+g = torch.Generator().manual_seed(1)
+windows = torch.randn((16, 20, 2048), generator=g).to(dev)
+layout, rec_len = hd.record_layout(2)
+ref = torch.zeros((n, rec_len), device=dev)
+t.predict_strips_records(windows, n, out=ref)
+om_ref = t.predict_strips_omegas(windows, n).clone()
+torch.cuda.synchronize()
+ws_ref = eng._ws["smpl"].buf.clone()
+LDF, LDA = 224, 288
+mp = 384
+featA = lambda b: (b[:mp * LDF * 4].view(torch.float32).reshape(mp, LDF), b[mp * LDF * 4:mp * LDF * 4 + mp * LDA * 4].view(torch.float32).reshape(mp, LDA))
+frames = torch.rand((128, 224, 224, 3), device=dev) * 2 - 1
+phi = torch.empty((128, 2048), device=dev)
+s_tail = torch.cuda.Stream()
+off = {k: (o, sz) for k, shp, o, sz in layout}
+for mode in ("with 2-part resnet on priority streams",):
+    bad = 0
+    for rep in range(300):
+        rec = torch.full((n, rec_len), float("nan"), device=dev)
+        torch.cuda.synchronize()
+        cur = torch.cuda.current_stream()
+        if mode != "alone":
+            for i, (a, b) in enumerate(((0, 64), (64, 128))):
+                sc = eng.side_stream(i)
+                sc.wait_stream(cur)
+                with torch.cuda.stream(sc):
+                    eng.resnet(frames[a:b], out=phi[a:b], parts=1, ws_key="resnet%d" % i)
+        with torch.cuda.stream(s_tail):
+            s_tail.wait_stream(cur)
+            if mode.startswith("smpl only"):
+                t.records_from_omegas(om_ref, rec)
+            else:
+                om = t.predict_strips_omegas(windows, n)
+                om_at_launch = om.clone()                       # (a copy kernel on s_tail between the IEF and the SMPL kernels)
+                t.records_from_omegas(om, rec)
+        torch.cuda.synchronize()
+        if not mode.startswith("smpl only") and (not torch.equal(om, om_ref) or not torch.equal(om_at_launch, om_ref)):
+            dd = (om_at_launch != om_ref)
+            print("   om differs: final", int((om != om_ref).sum()), "at-launch copy", int(dd.sum()), "rows", dd.any(2).nonzero().tolist()[:6], "cols", dd.any(0).any(0).nonzero().flatten().tolist()[:12])
+        if not torch.equal(rec, ref):
+            bad += 1
+            d = (rec != ref)
+            fr = d.any(1).nonzero().flatten().tolist()
+            ks = [k for k, (o, sz) in off.items() if bool(d[:, o:o + sz].any())]
+            f_r, a_r = featA(ws_ref)
+            f_g, a_g = featA(eng._ws["smpl"].buf)
+            df, da = (f_g != f_r), (a_g != a_r)
+            if bad <= 8:
+                print("  frames", fr[:6], "| feat rows differing", df.any(1).nonzero().flatten().tolist()[:6], "cols", df.any(0).nonzero().flatten().tolist()[:8],
+                      "| A rows differing", da.any(1).nonzero().flatten().tolist()[:6], "cols", da.any(0).nonzero().flatten().tolist()[:16])
+            if bad <= 0:
+                print(mode, "rep", rep, "frames", fr[:10], "fields", ks, "nan", int(torch.isnan(rec).sum()))
+    print(os.environ.get("DBG_DT", "bf16"), {k: v for k, v in os.environ.items() if k.startswith("HMMR_")}, mode, ": bad", bad, "of 300")
