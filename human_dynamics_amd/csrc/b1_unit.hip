@@ -148,13 +148,8 @@ __device__ __forceinline__ void b1_d_to_b(const shalf2 (&nh)[4][2], const shalf2
 // ---- the epilogues' arithmetic.  Two waves per SIMD share one vector issue port, and the unit does ~18 values per lane and 32 output
 // channels: the instruction COUNT is what the kernel's skeleton costs (the first version, written with split4 and float conversions,
 // spent 22 vector instructions per value: 0.32 ms of a 0.6 ms launch with the MFMAs and the HBM traffic taken out, profiles/r05b).
-// Two values already clamped to the fp16 range -> their packed hi halves (one v_cvt_pk_f16_f32) and packed lo halves: lo = fp16(c - hi),
-// c - hi is exact in fp32, so the mixed-precision fma rounds once, like the cast of split4 (common.h) -- the idiom of conv3x3_stream.hip
-__device__ __forceinline__ void b1_split2(float c0, float c1, unsigned& h, unsigned& l) {
-    h = __builtin_bit_cast(unsigned, shalf2{(shalf_t)c0, (shalf_t)c1});
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(c0));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(c1));
-}
+// split2_mix / split4_mix (common.h): the split in that form.
+__device__ __forceinline__ void b1_split2(float c0, float c1, unsigned& h, unsigned& l) { split2_mix(c0, c1, h, l); }
 // the value a packed (hi, lo) pair holds: hi + lo, exact before its one rounding to fp32 (= (float)hi + (float)lo); low / high half of the dwords
 __device__ __forceinline__ float b1_sum_lo(unsigned h, unsigned l) {
     float v; asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(v) : "v"(h), "v"(l)); return v;
@@ -162,15 +157,7 @@ __device__ __forceinline__ float b1_sum_lo(unsigned h, unsigned l) {
 __device__ __forceinline__ float b1_sum_hi(unsigned h, unsigned l) {
     float v; asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(v) : "v"(h), "v"(l)); return v;
 }
-// four values of one lane (4 consecutive channels): clamp to [lo_clamp, 65504], split -> oh / ol (the 8-byte hi and lo pieces the lane
-// writes) ; satm: running maximum of |v| (one v_max3_f32 per two values)
-__device__ __forceinline__ void b1_split4(const float (&v)[4], float lo_clamp, unsigned (&h)[2], unsigned (&l)[2], float& satm) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        satm = __builtin_fmaxf(__builtin_fmaxf(satm, __builtin_fabsf(v[2 * i])), __builtin_fabsf(v[2 * i + 1]));
-        b1_split2(__builtin_amdgcn_fmed3f(v[2 * i], lo_clamp, HMMR_SPLIT_MAX), __builtin_amdgcn_fmed3f(v[2 * i + 1], lo_clamp, HMMR_SPLIT_MAX), h[i], l[i]);
-    }
-}
+__device__ __forceinline__ void b1_split4(const float (&v)[4], float lo_clamp, unsigned (&h)[2], unsigned (&l)[2], float& satm) { split4_mix(v, lo_clamp, h, l, satm); }
 
 // mma3 (common.h), or under probe bit 1 something that only keeps its operands alive
 __device__ __forceinline__ f32x16 b1_mma3(const wfrag& w, const shalf8& xh, const shalf8& xl, f32x16 c) {

@@ -296,6 +296,23 @@ __device__ __forceinline__ void split4(const float (&v)[4], unsigned long long& 
     lo = (unsigned long long)l[0] | ((unsigned long long)l[1] << 32);
 }
 
+// ---- the same split in mixed-precision FMA form (round 5: csrc/b1_unit.hip, the unit pair's last epilogue): two values already clamped
+// to the fp16 range -> their packed hi halves (one v_cvt_pk_f16_f32) and packed lo halves, lo = fp16(c - hi): c - hi is exact in fp32,
+// so v_fma_mixlo/hi_f16 rounds once, like the cast above -- the same bits in half the instructions
+__device__ __forceinline__ void split2_mix(float c0, float c1, unsigned& h, unsigned& l) {
+    h = __builtin_bit_cast(unsigned, shalf2{(shalf_t)c0, (shalf_t)c1});
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(c0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(c1));
+}
+// four values of one lane: clamp to [lo_clamp, 65504] (lo_clamp = 0: a ReLU in the same v_med3_f32), split; satmax as in split4
+__device__ __forceinline__ void split4_mix(const float (&v)[4], float lo_clamp, unsigned (&h)[2], unsigned (&l)[2], float& satmax) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        satmax = __builtin_fmaxf(__builtin_fmaxf(satmax, __builtin_fabsf(v[2 * i])), __builtin_fabsf(v[2 * i + 1]));
+        split2_mix(__builtin_amdgcn_fmed3f(v[2 * i], lo_clamp, HMMR_SPLIT_MAX), __builtin_amdgcn_fmed3f(v[2 * i + 1], lo_clamp, HMMR_SPLIT_MAX), h[i], l[i]);
+    }
+}
+
 __device__ __forceinline__ void split4(const float (&v)[4], unsigned long long& hi, unsigned long long& lo, unsigned long long& satmask) {
     const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])), __builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
     satmask |= __builtin_amdgcn_ballot_w64(m > HMMR_SPLIT_MAX);

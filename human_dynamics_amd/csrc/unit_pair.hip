@@ -589,6 +589,7 @@ __global__ __launch_bounds__(256, 1) void unit_pair_kernel(const PairArgs a) {
     __syncthreads();
     char* stg = stg_of(0);
     float satmax = 0.f;
+    const float lo1 = a.relu1 ? 0.f : -HMMR_SPLIT_MAX;
     bsplit_t* hrow[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -604,14 +605,13 @@ __global__ __launch_bounds__(256, 1) void unit_pair_kernel(const PairArgs a) {
             const f32x4 s4 = *(const f32x4*)(sS1 + n2), b4 = *(const f32x4*)(sB1 + n2);
             float v[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v[j] = fmaf(acc2[of][4 * g + j], s4[j], b4[j]);
-                if (a.relu1) v[j] = fmaxf(v[j], 0.f);
-            }
-            unsigned long long oh, ol;
-            split4(v, oh, ol, satmax);
-            *(unsigned long long*)(stg + (of & 1) * 4096 + lr * 128 + (((2 * g) ^ sw) << 4) + 8 * lh) = oh;
-            *(unsigned long long*)(stg + (of & 1) * 4096 + lr * 128 + (((2 * g + 1) ^ sw) << 4) + 8 * lh) = ol;
+            for (int j = 0; j < 4; ++j) v[j] = fmaf(acc2[of][4 * g + j], s4[j], b4[j]);
+            // (ReLU and the clamp to the fp16 range as one v_med3_f32, the halves in mixed-precision FMA form: split4's bits at half its
+            //  instruction count -- this epilogue is 128 values per lane in block 3 with nothing to hide behind)
+            unsigned h2[2], l2[2];
+            split4_mix(v, lo1, h2, l2, satmax);
+            *(unsigned long long*)(stg + (of & 1) * 4096 + lr * 128 + (((2 * g) ^ sw) << 4) + 8 * lh) = (unsigned long long)h2[0] | ((unsigned long long)h2[1] << 32);
+            *(unsigned long long*)(stg + (of & 1) * 4096 + lr * 128 + (((2 * g + 1) ^ sw) << 4) + 8 * lh) = (unsigned long long)l2[0] | ((unsigned long long)l2[1] << 32);
         }
         // (the two staging tiles alternate: the row reads of block `of` do not hold up the writes of block of + 1)
         u32x4 xr[4];
