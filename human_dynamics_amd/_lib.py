@@ -66,7 +66,7 @@ class TailDesc(C.Structure):
 class Debug(C.Structure):
     """hmmr_debug_t: development switches, all zero = product defaults."""
     _fields_ = [("stem_route", C.c_int), ("stem_no_conv1", C.c_int), ("gemm_probe", C.c_int), ("smpl_blend_mfma", C.c_int), ("ief_no_group", C.c_int), ("reserved", C.c_int * 3),
-                ("pair_min_pixels", C.c_int)]
+                ("pair_min_pixels", C.c_int), ("pair_two_tile_min", C.c_int)]
 
 
 class LaunchCounts(C.Structure):

@@ -28,6 +28,10 @@
 //     ALTERNATELY (the dependent accumulator chains of either never run back to back) while the vector unit does the
 //     epilogue of chunk it-1.  Rounding points, product order (x.lo*w.hi, x.hi*w.lo, x.hi*w.hi) and K order are those of
 //     gemm_conv.hip: the results are bit-identical to the two launches (tested through the whole ResNet).
+// Round 5: PERSISTENT WORKGROUPS for the block-2 shapes once a launch is at least two rounds of workgroups (one workgroup per CU, tiles
+// b, b + grid, b + 2 grid ...: a.tpw of them): the ring is left streaming across the tile boundary (the stream is periodic and the loop already requests NS - 1 slabs past
+// the end), the constants stay in LDS, so the second tile's prologue is its panel + first shortcut chunk instead of 96 KB of ring + both
+// (the prologue was 20 k of a block-2 tile's ~75 k cycles).  The conv1' constants then live behind the other constants, not in the ring.
 // Every wave executes the same sequence of vector-memory instructions (invalid rows read row 0 and store to a dump page),
 // so the waits on the ring are COUNTED s_waitcnt vmcnt(N) with N a compile-time function of the position in the
 // iteration.
@@ -54,6 +58,7 @@ struct PairArgs {
     const float* scale1; const float* shift1; int relu1;
     bsplit_t* out_h1;                       // [M][N2]
     int M;
+    int tpw;                                // tiles (of 128 pixels) per workgroup (tiles b, b + grid, ...): 1, or more for the shapes with TWO (see the kernel)
     float one;                              // 1.0f (a run-time value: see the epilogue)
     int probe;                              // always 0 in the product build (HMMR_GEMM_PROBE below)
     unsigned long long* ts;                 // probe build: [blocks][4 waves][8] s_memtime stamps, or NULL
@@ -167,6 +172,8 @@ __global__ __launch_bounds__(256, 1) void unit_pair_kernel(const PairArgs a) {
     constexpr int TOTAL = (NCH + 2) * CL;                      // slabs of the stream
     constexpr int OFF_STG = NS * SLAB;                         // [4 waves][2][4 KB]: 32 px x 32 channels x 4 B
     constexpr int OFF_C = OFF_STG + 4 * 2 * 4096;              // scale3, shift3, pre_scale, pre_shift: [DEPTH] floats each
+    constexpr bool TWO = DEPTH <= 512;                         // room for conv1's constants behind them: the ring may stay busy across tiles
+    constexpr int OFF_C1 = OFF_C + 4 * DEPTH * 4;              // TWO: scale1, shift1 [N2]
     constexpr int EOPS = RES ? 8 : 4;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -174,7 +181,8 @@ __global__ __launch_bounds__(256, 1) void unit_pair_kernel(const PairArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, lh = lane >> 5;
-    const int mbase = blockIdx.x * 128 + wave * 32;            // this wave's first pixel
+    const int tpw = TWO ? a.tpw : 1;
+    int mbase = blockIdx.x * 128 + wave * 32;                  // this wave's first pixel (of the workgroup's first tile: tiles b, b + grid, ...)
 
     float* sS3 = (float*)(smem + OFF_C);
     float* sB3 = sS3 + DEPTH;
@@ -223,16 +231,23 @@ __global__ __launch_bounds__(256, 1) void unit_pair_kernel(const PairArgs a) {
 
 #pragma unroll
     for (int s_ = 0; s_ < NS - 1; ++s_) dma_slab(s_, s_);
-    dma_res(0, 0);
-    if constexpr (RES) {                                       // the pipeline's fill iteration reads tile 1 before any shortcut chunk landed in it: finite values
-#pragma unroll
-        for (int q = 0; q < 4; ++q) *(u32x4*)(stg_of(1) + q * 1024 + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+    if constexpr (TWO) {
+        // the constants go to LDS ONCE, in front of the tile loop (inside it their registers would stay live across its back edge:
+        // the folded form then spilled); their requests have been out since the top of the kernel
+        if (!a.scale3) c_s3 = f32x4{1.f, 1.f, 1.f, 1.f};
+        if (!a.shift3) c_b3 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ci4 < DEPTH) {
+            *(f32x4*)(sS3 + ci4) = c_s3; *(f32x4*)(sB3 + ci4) = c_b3; *(f32x4*)(sPS + ci4) = c_ps; *(f32x4*)(sPB + ci4) = c_pb;
+        }
+        if (tid < N2) { ((float*)(smem + OFF_C1))[tid] = c_s1; ((float*)(smem + OFF_C1))[N2 + tid] = c_b1; }
     }
-
-    // ---- this wave's h2 panel as B-operand fragments: lane (lr, lh) = pixel lr, channels 16 kc + 8 lh .. + 7
+    float satm = 0.f;                                          // largest |trunk value| of this thread: the flag is raised once per tile
+    int slot = 0, dslab = NS - 1;                              // ring state: persists across the tiles of a workgroup
+    // ---- a wave's h2 panel as B-operand fragments: lane (lr, lh) = pixel lr, channels 16 kc + 8 lh .. + 7.  Requested for the first
+    // tile here, for every further tile of a persistent workgroup in front of the previous tile's h1' epilogue (13 k cycles of cover)
     xfrag xh[KC3];
-    {
-        const int m = mbase + lr;
+    auto load_panel = [&](int mb) {
+        const int m = mb + lr;
         const long long row = m < a.M ? m : 0;
 #pragma unroll
         for (int kc = 0; kc < KC3; ++kc) {
@@ -241,10 +256,24 @@ __global__ __launch_bounds__(256, 1) void unit_pair_kernel(const PairArgs a) {
             xh[kc].hi = *(const shalf8*)p;
             xh[kc].lo = *((const shalf8*)p + 1);
         }
-        if (!a.scale3) c_s3 = f32x4{1.f, 1.f, 1.f, 1.f};
-        if (!a.shift3) c_b3 = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (ci4 < DEPTH) {
-            *(f32x4*)(sS3 + ci4) = c_s3; *(f32x4*)(sB3 + ci4) = c_b3; *(f32x4*)(sPS + ci4) = c_ps; *(f32x4*)(sPB + ci4) = c_pb;
+    };
+    load_panel(mbase);
+#pragma unroll 1
+    for (int t = 0; t < tpw; ++t, mbase += gridDim.x * 128) {
+    if (t > 0 && (blockIdx.x + t * gridDim.x) * 128 >= a.M) break;          // (the last round of tiles is a partial one)
+    dma_res(0, 0);
+    if constexpr (RES) {                                       // the pipeline's fill iteration reads tile 1 before any shortcut chunk landed in it: finite values
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *(u32x4*)(stg_of(1) + q * 1024 + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+    }
+
+    {
+        if constexpr (!TWO) {
+            if (!a.scale3) c_s3 = f32x4{1.f, 1.f, 1.f, 1.f};
+            if (!a.shift3) c_b3 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ci4 < DEPTH) {
+                *(f32x4*)(sS3 + ci4) = c_s3; *(f32x4*)(sB3 + ci4) = c_b3; *(f32x4*)(sPS + ci4) = c_ps; *(f32x4*)(sPB + ci4) = c_pb;
+            }
         }
         // the panel is read by MFMAs only (B operand): keep it in the AGPR half of the register file, where the conv1' accumulators
         // already are -- left to itself the allocator parks part of it there anyway and copies it back before every use
@@ -345,11 +374,9 @@ __global__ __launch_bounds__(256, 1) void unit_pair_kernel(const PairArgs a) {
         return n;
     };
 
-    float satm = 0.f;                                          // largest |trunk value| of this thread: the flag is raised once, at the end
-    int slot = 0, dslab = NS - 1;
     wfrag wq[4][2];                                            // fragments of the units u, u+1, u+2 (slot u & 3): requested TWO units ahead
 #pragma unroll
-    for (int u = 0; u < 2; ++u) { wq[u][0] = lds_frag(fbase0, 2 * u); wq[u][1] = lds_frag(fbase0, 2 * u + 1); }
+    for (int u = 0; u < 2; ++u) { wq[u][0] = lds_frag(fbase0 + slot * SLAB, 2 * u); wq[u][1] = lds_frag(fbase0 + slot * SLAB, 2 * u + 1); }
     group_loads(-1, std::integral_constant<int, 1>{}, 0);
     wait_lgkm(0);
     __builtin_amdgcn_sched_barrier(0);
@@ -580,13 +607,19 @@ __global__ __launch_bounds__(256, 1) void unit_pair_kernel(const PairArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(0);                             // (the last shortcut request must not land in the tile any more)
     PAIR_STAMP(4);
+    if constexpr (TWO) {                                       // the next tile's panel: its registers are free since conv3's last chunk
+        if (t + 1 < tpw) load_panel(mbase + (int)gridDim.x * 128);          // (past the last tile: rows clamp to row 0, never used)
+    }
     // conv1's folded BN constants: through the (now idle) ring, one global round trip for the workgroup instead of one per row block
-    __syncthreads();                                           // every wave has left the loop: the ring is free
-    float* sS1 = (float*)smem;
+    // (TWO: behind the other constants since the prologue -- the ring is busy with the next tile's slabs)
+    float* sS1 = (float*)(smem + (TWO ? OFF_C1 : 0));
     float* sB1 = sS1 + N2;
-    asm volatile("" : "+v"(c_s1), "+v"(c_b1));                 // (requested in the prologue)
-    if (tid < N2) { sS1[tid] = c_s1; sB1[tid] = c_b1; }
-    __syncthreads();
+    if constexpr (!TWO) {
+        __syncthreads();                                       // every wave has left the loop: the ring is free
+        asm volatile("" : "+v"(c_s1), "+v"(c_b1));             // (requested in the prologue)
+        if (tid < N2) { sS1[tid] = c_s1; sB1[tid] = c_b1; }
+        __syncthreads();
+    }
     char* stg = stg_of(0);
     float satmax = 0.f;
     const float lo1 = a.relu1 ? 0.f : -HMMR_SPLIT_MAX;
@@ -625,11 +658,13 @@ __global__ __launch_bounds__(256, 1) void unit_pair_kernel(const PairArgs a) {
     }
     split_flag(satmax > HMMR_SPLIT_MAX);
     PAIR_STAMP(5);
+    satm = 0.f;
+    }   // tiles of this workgroup
 }
 
 template <int KC3A, int KC3B, int DEPTH, int N2, bool RES>
 int launch_pair(const PairArgs& a, hipStream_t stream) {
-    constexpr int lds = PAIR_NS * PAIR_SLAB + 4 * 2 * 4096 + 4 * DEPTH * (int)sizeof(float);
+    constexpr int lds = PAIR_NS * PAIR_SLAB + 4 * 2 * 4096 + 4 * DEPTH * (int)sizeof(float) + (DEPTH <= 512 ? 2 * N2 * (int)sizeof(float) : 0);
     static_assert(lds <= 160 * 1024, "LDS");
     auto kern = unit_pair_kernel<KC3A, KC3B, DEPTH, N2, RES>;
     static DeviceOnce once;
@@ -637,7 +672,21 @@ int launch_pair(const PairArgs& a, hipStream_t stream) {
         HMMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         once.mark(bit);
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)((a.M + 127) / 128)), dim3(256), lds, stream, a);
+    // persistent workgroups (block-2 shapes) once the launch is at least two rounds of one workgroup per CU: below that a second tile only
+    // lengthens the launch (hmmr_debug_t.pair_two_tile_min moves the switch: tests run both forms on one batch)
+    PairArgs b = a;
+    const int n_tiles = (a.M + 127) / 128;
+    const int two_min = hmmr_debug_state()->pair_two_tile_min > 0 ? hmmr_debug_state()->pair_two_tile_min : 512;
+    int grid = n_tiles;
+    b.tpw = 1;
+    if (DEPTH <= 512 && n_tiles >= two_min) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (cus < 1) cus = 256;
+        grid = n_tiles < cus ? (n_tiles + 1) / 2 : cus;          // (forced on for a short launch: two tiles per workgroup)
+        b.tpw = (n_tiles + grid - 1) / grid;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, b);
     HMMR_CHECK_HIP(hipGetLastError());
     return 0;
 }

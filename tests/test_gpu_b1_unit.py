@@ -133,6 +133,18 @@ def test_unit_pair_on_equals_unit_pair_off_on_one_batch(weights, gpu_device, n):
         off = eng.resnet(frames, n_zero=1, parts=1)
         torch.cuda.synchronize()
         assert L.launch_counts(clear=True)["unit_pair"] == 0
+        # the block-2 pairs with TWO tiles per workgroup (the ring left streaming across the tile boundary; the default from 512 tiles of
+        # 128 pixels = 84 frames): forced on here at 122.5 / 410.4 tiles -- an odd tile count leaves the last workgroup one tile
+        E.set_debug(pair_min_pixels=1, pair_two_tile_min=1)
+        two = eng.resnet(frames, n_zero=1, parts=1)
+        torch.cuda.synchronize()
+        assert L.launch_counts(clear=True)["unit_pair"] == 8
+        assert torch.equal(two, on), float((two - on).abs().max())
+        E.set_debug(pair_min_pixels=1, pair_two_tile_min=2 ** 31 - 1)
+        one = eng.resnet(frames, n_zero=1, parts=1)
+        torch.cuda.synchronize()
+        L.launch_counts(clear=True)
+        assert torch.equal(one, on)
     finally:
         E.set_debug()
     dflt = eng.resnet(frames, n_zero=1, parts=1)
