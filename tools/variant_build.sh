@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/.."
 NAME=$1; shift
 C=human_dynamics_amd/csrc
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I include -I $C -Wall -Wno-unused-function "$@" -x hip -c $C/gemm_conv.hip -o /tmp/gemm_conv_$NAME.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I include -I $C -Wall -Wno-unused-function -fno-slp-vectorize "$@" -x hip -c $C/gemm_conv.hip -o /tmp/gemm_conv_$NAME.o
 objs=$(ls $C/*.o | grep -v gemm_conv.o)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o human_dynamics_amd/libhmmr_hip_$NAME.so /tmp/gemm_conv_$NAME.o $objs
 ls -la human_dynamics_amd/libhmmr_hip_$NAME.so
