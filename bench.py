@@ -309,7 +309,7 @@ def roofline_leg(tester, plan, span, dtype, frames):
     skipped = {0: 0, 1: 1, 2: 2, 3: 3, 4: 1}       # launches a fused unit saves, by hmmr_resnet_unit_t.fuse_tail
     n_tails = sum(int(eng.rw.unit[i].fuse_tail > 0) for i in range(16))
     n_conv = 53 - sum(skipped[int(eng.rw.unit[i].fuse_tail)] + int(bool(eng.rw.unit[i].sc_c1.w)) + int(bool(eng.rw.unit[i].c3sc.w)) for i in range(16))
-    if dtype == "bf16" and os.environ.get("HMMR_STEM_C1", "1") != "0":
+    if dtype in ("bf16", "f16x3") and os.environ.get("HMMR_STEM_C1", "1") != "0":
         n_conv -= 1                                   # block1/unit_1's conv1 runs inside the fused stem launch
     flops_per_launch = RESNET_FLOPS_PER_FRAME * n_enc / n_conv
     avg_launch_s = conv_ms * 1e-3 / n_conv

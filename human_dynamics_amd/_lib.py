@@ -80,7 +80,7 @@ class Layer(C.Structure):
 
 class ResnetUnit(C.Structure):
     _fields_ = [("conv1", Layer), ("conv2", Layer), ("conv3", Layer), ("shortcut", Layer), ("c3sc", Layer), ("sc_c1", Layer),
-                ("w3_frag", _vp), ("w1n_frag", _vp), ("pair_stream", _vp), ("unit_stream", _vp), ("pre_scale", _fp), ("pre_shift", _fp),
+                ("w3_frag", _vp), ("w1n_frag", _vp), ("pair_stream", _vp), ("conv1_frag", _vp), ("unit_stream", _vp), ("pre_scale", _fp), ("pre_shift", _fp),
                 ("c_in", C.c_int), ("base", C.c_int), ("depth", C.c_int), ("stride", C.c_int),
                 ("fuse_preact", C.c_int), ("fuse_tail", C.c_int)]
 

@@ -223,10 +223,12 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
     if (!unfused) {
         // bf16: block1/unit_1's conv1 is computed on each pooled tile inside the same launch (-> T1)
         const hmmr_resnet_unit_t& U0 = w->unit[0];
-        stem_c1 = !dbg->stem_no_conv1 && w->dtype == HMMR_BF16 && !U0.sc_c1.w && U0.c_in == 64 && U0.base == 64 &&
-                  U0.conv1.scale && U0.conv1.shift;
+        // (f16x3, round 5: with the fragment-major copy of the conv1 filters, hmmr_resnet_unit_t.conv1_frag)
+        stem_c1 = !dbg->stem_no_conv1 && (w->dtype == HMMR_BF16 || (w->dtype == HMMR_F16X3 && U0.conv1_frag)) && !U0.sc_c1.w && U0.c_in == 64 &&
+                  U0.base == 64 && U0.conv1.scale && U0.conv1.shift;
         if (hmmr_stem_fused(images, n_real, n, w->stem.w, w->stem.scale, w->stem.shift, U0.pre_scale, U0.pre_shift, P[0], w->dtype, s,
-                            stem_c1 ? U0.conv1.w : nullptr, U0.conv1.scale, U0.conv1.shift, stem_c1 ? T1 : nullptr))
+                            stem_c1 ? (w->dtype == HMMR_F16X3 ? U0.conv1_frag : U0.conv1.w) : nullptr, U0.conv1.scale, U0.conv1.shift,
+                            stem_c1 ? T1 : nullptr))
             return -2;
         if (prof_mark(pf)) return -2;
         if (prof_mark(pf)) return -2;     // (keeps the profile slot numbering of the 3-kernel route)

@@ -258,13 +258,17 @@ constexpr int X3_PLANE = IP * IPW * 8;                       // one 16-bit RGBX 
 constexpr int X3_WROW = 7 * TAPK * 2 + 16;                   // padded filter row of one plane (464 B: conflict-free b128 reads)
 constexpr int X3_WPLANE = X3_CO * X3_WROW;
 constexpr int X3_STAGE = MT * 32 * X3_CO * 4;                // conv + bias as fp32 [pixel][32] (overlaps the filters)
-constexpr int X3_LDS = 2 * X3_PLANE + (2 * X3_WPLANE > X3_STAGE ? 2 * X3_WPLANE : X3_STAGE);
+constexpr int X3_PTILE = PT * PT * 128;                      // the pooled, pre-activated tile of one channel half as split rows: 64 pixels x 128 B
+constexpr int X3_LDS0 = 2 * X3_PLANE + (2 * X3_WPLANE > X3_STAGE ? 2 * X3_WPLANE : X3_STAGE);
+constexpr int X3_LDS = X3_LDS0 + X3_PTILE;                   // (the second half's tile goes over the patch planes, dead by then)
+static_assert(2 * X3_PTILE <= 2 * X3_PLANE + X3_PTILE && 2 * X3_LDS <= 160 * 1024, "two workgroups per CU");
 
 __global__ __launch_bounds__(X3_NT) void stem_fused_split_kernel(const float* __restrict__ img, const bsplit_t* __restrict__ wts,
                                                                  const float* __restrict__ wscale,
                                                                  const float* __restrict__ bias, const float* __restrict__ pscale,
                                                                  const float* __restrict__ pshift, bsplit_t* __restrict__ out,
-                                                                 int n_real) {
+                                                                 int n_real, const char* __restrict__ w1f, const float* __restrict__ s1,
+                                                                 const float* __restrict__ b1, bsplit_t* __restrict__ out_h1) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_ph = smem;                            // patch, hi plane
     char* s_pl = smem + X3_PLANE;                 // patch, lo plane
@@ -431,8 +435,63 @@ __global__ __launch_bounds__(X3_NT) void stem_fused_split_kernel(const float* __
         load8(pscale + ch0 + v8 * 8, sc); load8(pshift + ch0 + v8 * 8, sh);
 #pragma unroll
         for (int j = 0; j < 8; ++j) m[j] = fmaxf(fmaf(m[j], sc[j], sh[j]), 0.f);   // one explicit fma: = maxpool_bn_relu_kernel
-        store8(out + (((long long)n * POOL + PT * ty + py) * POOL + PT * tx + px) * CO + ch0 + v8 * 8, m);
+        bsplit_t* o = out + (((long long)n * POOL + PT * ty + py) * POOL + PT * tx + px) * CO + ch0 + v8 * 8;
+        store8(o, m);
+        if (w1f) {
+            // block1/unit_1's conv1 reads this tile as STORED: the same 32 bytes (hi 8 | lo 8) go into the pooled tile of this half,
+            // the 32-byte group index XOR-swizzled with the pixel (rows are 128 B: the fragment reads below would hit two banks' worth)
+            shalf8 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float cv = split_clamp(m[j]);
+                hi[j] = (shalf_t)cv;
+                lo[j] = (shalf_t)(cv - (float)hi[j]);
+            }
+            char* pt = (ch0 ? smem : smem + X3_LDS0) + pp * 128 + ((v8 ^ (pp & 3)) << 5);
+            *(shalf8*)pt = hi;
+            *(shalf8*)(pt + 16) = lo;
+        }
     }
+    }
+    // ---- 5. (round 5) block1/unit_1's conv1 (1x1, 64 -> 64, folded BN + ReLU) on the pooled tile before it leaves the CU: the launch of
+    // that layer and its 0.2 GB read of this kernel's own output are gone.  Weights = the MFMA A operand as fragment-major copies straight
+    // from L2 (packing.pack_frag_major), the tile's pixels = B out of the two pooled half tiles; products and K order are those of
+    // hmmr_conv_gemm on the stored tensor (w.hi x.lo, w.lo x.hi, w.hi x.hi per 16-wide chunk, chunks in order): the same bits.
+    if (!w1f) return;
+    __syncthreads();
+    if (wave < 4) {
+        const int lr = lane & 31, lh = lane >> 5;
+        const int wn = wave >> 1, wm = wave & 1;
+        const int p = wm * 32 + lr;                                // this lane's pixel of the 8 x 8 tile
+        f32x16 acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            const shalf8* wp = (const shalf8*)(w1f + ((long long)((wn * 4 + kc) * 64 + lane)) * 32);
+            wfrag wf; wf.hi = wp[0]; wf.lo = wp[1];
+            const int g = (2 * kc + lh) & 3;                       // 8-channel group inside its half (kc >= 2: the second half)
+            const char* pt = (kc >= 2 ? smem : smem + X3_LDS0) + p * 128 + ((g ^ (p & 3)) << 5);
+            acc1 = mma3(wf, *(const shalf8*)pt, *(const shalf8*)(pt + 16), acc1);
+        }
+        const int py = p >> 3, px = p & 7;
+        bsplit_t* o = out_h1 + (((long long)n * POOL + PT * ty + py) * POOL + PT * tx + px) * CO;
+        float satmax = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ch = wn * 32 + 8 * g + 4 * lh;
+            const f32x4 s4 = *(const f32x4*)(s1 + ch), b4 = *(const f32x4*)(b1 + ch);
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(acc1[4 * g + e], s4[e], b4[e]);
+            unsigned h2[2], l2[2];
+            split4_mix(v, 0.f, h2, l2, satmax);                    // (ReLU + clamp in one v_med3_f32)
+            // lane (pixel, half lh) holds channels 8 g + 4 lh .. + 3 of its row block: 8 bytes of the hi and of the lo half of group g
+            char* og = (char*)o + (wn * 4 + g) * 32 + 8 * lh;
+            *(unsigned long long*)og = (unsigned long long)h2[0] | ((unsigned long long)h2[1] << 32);
+            *(unsigned long long*)(og + 16) = (unsigned long long)l2[0] | ((unsigned long long)l2[1] << 32);
+        }
+        split_flag(satmax > HMMR_SPLIT_MAX);
     }
 }
 }  // namespace
@@ -451,7 +510,8 @@ int hmmr_stem_fused(const float* images, int n_real, int n, const void* wts, con
             oncex3.mark(bit);
         }
         hipLaunchKernelGGL(kern, dim3((POOL / PT) * (POOL / PT), n), dim3(X3_NT), X3_LDS, s, images,
-                           (const bsplit_t*)wts, wscale, bias, pscale, pshift, (bsplit_t*)out, n_real);
+                           (const bsplit_t*)wts, wscale, bias, pscale, pshift, (bsplit_t*)out, n_real, (const char*)w1, s1, b1,
+                           (bsplit_t*)out_h1);
     } else if (dtype == HMMR_BF16) {
         auto kern = stem_fused_kernel<bf16_t>;
         static DeviceOnce once16;

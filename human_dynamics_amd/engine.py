@@ -84,7 +84,7 @@ class HmmrEngine(object):
     def __init__(self, weights, smpl, dtype=DEFAULT_DTYPE, device="cuda:0", num_conv_layers=3,
                  delta_t_values=(-5, 5), joint_type="cocoplus", resnet_chunk=0,
                  temporal_dtype=None, ief_dtype=None, autotune=True, fold_sc=None, fuse_tail=None, patch_3x3=None,
-                 unit_pair=None, b1_stream=None, b1_unit=None):
+                 unit_pair=None, b1_stream=None, b1_unit=None, stem_conv1=True):
         self.lib = L.load()
         _debug_from_env()
         if not torch.cuda.is_available():
@@ -115,7 +115,8 @@ class HmmrEngine(object):
                                        unit_pair=({"0": False, "1": True}.get(devflags.get("UNIT_PAIR"), devflags.get("UNIT_PAIR"))
                                                   if unit_pair is None else unit_pair),
                                        b1_stream=(devflags.get("B1_STREAM") == "1") if b1_stream is None else b1_stream,
-                                       b1_unit=(devflags.get("B1_UNIT") == "1") if b1_unit is None else b1_unit)
+                                       b1_unit=(devflags.get("B1_UNIT") == "1") if b1_unit is None else b1_unit,
+                                       stem_conv1=stem_conv1)
                    if "resnet_v2_50/conv1/weights" in w else None)
         self.tw = (packing.pack_temporal(w, self.temporal_dtype, self.store, num_conv_layers)
                    if assets.temporal_scopes(0)[1] + "/weights" in w else None)

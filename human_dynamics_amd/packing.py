@@ -298,7 +298,8 @@ def _layer_stream3x3(store, w_hwio, scale, shift, bf16=False):
 
 
 def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3", "block4"), fuse_tail=True,
-                fuse_sc=True, fuse_preact_first=False, fold_sc=None, patch_3x3=2, unit_pair=True, b1_stream=False, b1_unit=True):
+                fuse_sc=True, fuse_preact_first=False, fold_sc=None, patch_3x3=2, unit_pair=True, b1_stream=False, b1_unit=True,
+                stem_conv1=True):
     """fuse_preact_blocks: blocks whose units apply their `preact` BN+ReLU inside the operand
     staging of conv1/shortcut instead of reading a materialised preact tensor (csrc/resnet.hip;
     measured at batch 256: -4.5 % ResNet time with blocks 1-2 fused, neutral for blocks 3-4).
@@ -315,6 +316,8 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
     (hmmr_resnet_unit_t.unit_stream, fuse_tail = 2): their conv2 is packed k_order 2 as with b1_stream, so the layer-per-launch schedule
     (fuse_tail=False) of the same configuration runs it through the 3x3 stream kernel and produces the same bits.  False (and b1_stream
     False): the round-3 tails of csrc/bottleneck_split.hip with conv2 inside, tap-major.
+    stem_conv1 (f16x3; default on, round 5): block1/unit_1's conv1 is computed by the fused stem kernel on its pooled tile (hmmr_resnet_unit_t.
+    conv1_frag); bf16 does that since round 1 (hmmr_debug_t.stem_no_conv1 switches either off at run time).  Same bits as the launch.
     unit_pair (f16x3 only; True | "block2" | "block3" | False): the stride-1 units of blocks 2-3 run conv3 + add + the next
     unit's preact + conv1 as the register-resident unit pair of csrc/unit_pair.hip (one filter stream per unit); block3/unit_1
     then keeps its conv shortcut as a launch (shortcut + conv1 as one column-split GEMM) instead of folding it into conv3."""
@@ -344,6 +347,10 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
             u.fuse_preact = 0
         s, b = fold_bn(w, scope + "/conv1/BatchNorm")
         u.conv1 = _layer(store, pack_conv_weight(w[scope + "/conv1/weights"]), dtype, s, b)
+        if i == 0 and dtype == L.HMMR_F16X3 and stem_conv1:
+            # block1/unit_1's conv1 runs inside the fused stem (csrc/stem.hip): its filters as MFMA A-operand fragments (the same rows and
+            # row scaling as the layer above, so the layer's scale / shift apply)
+            u.conv1_frag = store.put_tensor(pack_frag_major(np.asarray(w[scope + "/conv1/weights"], np.float32)[0, 0].T)).data_ptr()
         s, b = fold_bn(w, scope + "/conv2/BatchNorm")
         # (bf16, round 4: blocks 3-4 only -- the conv2 of blocks 1-2 runs inside the fused bf16 units, which read the tap-major order)
         stream = dtype in (L.HMMR_F16X3, L.HMMR_BF16) and patch_3x3 == 2 and patch_3x3 is not True

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HMMR_ABI_VERSION 16      /* 16: hmmr_tail_desc_t.unit_stream, hmmr_resnet_unit_t.unit_stream (the whole-unit kernel of block 1, csrc/b1_unit.hip), hmmr_b1_unit_stream_bytes, hmmr_debug_t.pair_min_pixels / launch counters; 15: k_order = 2 (the one-wave-per-SIMD 3x3 stream kernel, tiles 12 .. 18), hmmr_conv3x3_stream_bytes; 14: hmmr_tail_desc_t.pair_stream / c_xp, hmmr_resnet_unit_t.pair_stream (the register-resident unit pair of blocks 2-3), hmmr_run_flags; 13: hmmr_conv_desc_t.batch (grouped launches); 12: k_order = 1, 3x3 SAME convolutions out of an LDS-resident input patch (tiles 9, 10, 11) */
+#define HMMR_ABI_VERSION 16      /* 16: hmmr_tail_desc_t.unit_stream, hmmr_resnet_unit_t.unit_stream (the whole-unit kernel of block 1, csrc/b1_unit.hip), hmmr_b1_unit_stream_bytes, hmmr_debug_t.pair_min_pixels / pair_two_tile_min / launch counters, hmmr_resnet_unit_t.conv1_frag (block1/unit_1's conv1 inside the split stem); 15: k_order = 2 (the one-wave-per-SIMD 3x3 stream kernel, tiles 12 .. 18), hmmr_conv3x3_stream_bytes; 14: hmmr_tail_desc_t.pair_stream / c_xp, hmmr_resnet_unit_t.pair_stream (the register-resident unit pair of blocks 2-3), hmmr_run_flags; 13: hmmr_conv_desc_t.batch (grouped launches); 12: k_order = 1, 3x3 SAME convolutions out of an LDS-resident input patch (tiles 9, 10, 11) */
 
 /* HMMR_F16X3: "split" tensors -- every group of 8 consecutive channels is 32 bytes, [hi x8][lo x8] with
  * hi = fp16(x), lo = fp16(x - hi), x clamped to +-65504 (4 bytes per element, 22 mantissa bits while lo is a normal
@@ -220,6 +220,8 @@ typedef struct {
     const void* w1n_frag;      /* ... and the NEXT unit's conv1 filters, both FRAGMENT-MAJOR (hmmr_tail_desc_t); else NULL */
     const void* pair_stream;   /* f16x3 fused tail of blocks 2-3 (fuse_tail == 1): this unit's conv3 filters ([W3 | Wsc] when c3sc is
                                   set) and the NEXT unit's conv1 filters as ONE fragment stream (hmmr_tail_desc_t.pair_stream); else NULL */
+    const void* conv1_frag;    /* f16x3, unit 0 only (optional): this unit's conv1 filters [base][c_in] FRAGMENT-MAJOR (as w3_frag): the fused stem
+                                  computes block1/unit_1's conv1 on its pooled tile in the same launch (csrc/stem.hip); else NULL */
     const void* unit_stream;   /* f16x3 whole-unit kernel of block 1 (fuse_tail == 2, conv2.k_order == 2): conv2's, conv3's ([W3 | Wsc]) and
                                   the NEXT unit's conv1 filters as ONE fragment stream (hmmr_tail_desc_t.unit_stream); else NULL */
     const float* pre_scale;    /* this unit's folded `preact` BN, [c_in] */

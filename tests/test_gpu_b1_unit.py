@@ -154,3 +154,20 @@ def test_unit_pair_on_equals_unit_pair_off_on_one_batch(weights, gpu_device, n):
     assert float(on.abs().max()) > 0.1
     assert torch.equal(on, off), float((on - off).abs().max())
     assert torch.equal(on, dflt)
+
+
+def test_stem_with_unit1_conv1_inside_equals_the_separate_launch(weights, gpu_device):
+    """f16x3, round 5: the fused stem kernel computes block1/unit_1's conv1 on its pooled tile (hmmr_resnet_unit_t.conv1_frag) -- the same
+    products in the same order on the tile as stored, so the features equal those of the schedule that launches the layer
+    (stem_conv1=False), bit for bit; 7 images: 343 stem tiles, the zero padding image among them."""
+    from human_dynamics_amd.engine import HmmrEngine
+    frames = assets.make_synthetic_frames(6, seed=41)
+    a = HmmrEngine(weights, None, dtype="f16x3", device=gpu_device, autotune=False)
+    b = HmmrEngine(weights, None, dtype="f16x3", device=gpu_device, autotune=False, stem_conv1=False)
+    assert a.rw.unit[0].conv1_frag and not b.rw.unit[0].conv1_frag
+    fa, fb = a.resnet(frames, n_zero=1), b.resnet(frames, n_zero=1)
+    assert float(fb.abs().max()) > 0.1
+    assert torch.equal(fa, fb), float((fa - fb).abs().max())
+    _, pa = a.resnet(frames, n_zero=1, prof=True)
+    _, pb = b.resnet(frames, n_zero=1, prof=True)
+    assert pa[4] < 0.5 * pb[4]            # profile slot 4 = block1/unit_1 conv1 (slot 3: its folded shortcut): no launch there any more
