@@ -25,7 +25,8 @@
 //     A-operand fragments in the order the kernel consumes them (packing.pack_b1_unit_stream), DMA'd through a 5-slab
 //     LDS ring (8 KB slabs, four in flight) that every wave reads: 272 / 336 KB of L2 -> LDS traffic per 128 pixels
 //     (the old form: 4 KB per PIXEL of per-wave fragment reads);
-//   * conv3's output channels are walked 32 at a time (= one K step of conv1').  The shortcut chunk is DMA'd two chunks
+//   * conv3's output channels are walked 32 at a time (= one K step of conv1'), software-pipelined: the MFMAs of conv3 chunk c + 1 are
+//     issued in front of the epilogue of chunk c (the stream holds the slabs in that order: A(0) | A(1) B(0) | A(2) B(1) | ...).  The shortcut chunk is DMA'd two chunks
 //     ahead into a wave-private staging tile (which aliases the patch buffers: chunk 0 is requested while conv2 still
 //     runs on the other buffer), the trunk chunk is written over it in place, leaves as coalesced 16-byte row stores
 //     and is pre-activated in registers for conv1';
@@ -88,30 +89,48 @@ static_assert(2 * B1_LDS <= 160 * 1024, "two workgroups per CU");
 constexpr int B1_CONV2_SLABS = 18;                           // 36 K steps of 4 KB
 
 // ---- the schedule of vector-memory instructions per wave, by slab step t (the step that READS slab t): first the ring's DMA of
-// slab t + 4 (2 instructions), then the step's other requests.  KC3: conv3's 16-wide K chunks (4, or 8 with a folded shortcut);
-// a chunk of conv3's output is SPC slabs: KC3 / 4 of conv3 fragments, one of conv1' fragments.
+// slab t + 4 (2 instructions), then the step's other requests.  KC3: conv3's 16-wide K chunks (4, or 8 with a folded shortcut); NA = KC3 / 4
+// slabs hold the conv3 fragments A(c) of one 32-channel chunk c of conv3's output, one slab its conv1' fragments B(c).  The tail's slabs
+// come in the order the software pipeline consumes them -- conv3 of chunk c + 1 is issued BEFORE the epilogue of chunk c:
+//     A(0) | A(1) B(0) | A(2) B(1) | ... | A(7) B(6) | B(7)
 constexpr int b1_total(int kc3) { return B1_CONV2_SLABS + B1_NCH * (kc3 / 4 + 1); }
-constexpr int b1_ring_ops(int t, int kc3) { return (t + (B1_NS - 1) < b1_total(kc3) && !B1_PROBE(16)) ? 2 : 0; }
-// requests of step t behind its ring DMA: the patch of chunk 2 / 3 (steps 5 / 9), shortcut chunk 0 (step 14), shortcut chunk 1
-// (step 18), and in a chunk's conv1' slab step (its last) the 4 trunk stores + the shortcut chunk two ahead
-constexpr int b1_extra_ops(int t, int kc3, bool res) {
-    if (t == 5 || t == 9) return 4;
-    if (t == 14 || t == B1_CONV2_SLABS) return res ? 4 : 0;
-    if (t < B1_CONV2_SLABS) return 0;
-    const int spc = kc3 / 4 + 1, c = (t - B1_CONV2_SLABS) / spc, i = (t - B1_CONV2_SLABS) % spc;
-    return i == spc - 1 ? 4 + ((res && c + 2 < B1_NCH) ? 4 : 0) : 0;
+constexpr int b1_step_a(int c, int kc3) { return c == 0 ? B1_CONV2_SLABS : B1_CONV2_SLABS + kc3 / 4 + (c - 1) * (kc3 / 4 + 1); }   // first slab of A(c)
+constexpr int b1_step_b(int c, int kc3) {                    // the slab of B(c)
+    return c + 1 < B1_NCH ? B1_CONV2_SLABS + 2 * (kc3 / 4) + c * (kc3 / 4 + 1) : b1_total(kc3) - 1;
 }
-// what may stay in flight at the wait of step s: everything issued after step s - 4 (whose ring DMA is slab s, and whose other
-// requests -- a patch, a shortcut chunk -- are first read in step s or later).  One exception: shortcut chunk 1, requested in
-// step 18 (RES: 2 steps per chunk), is read behind the wait of step 21
-constexpr int b1_wait_n(int s, int kc3, bool res) {
+constexpr int b1_chunk_of_b(int t, int kc3) {                // c if step t is B(c), else -1
+    for (int c = 0; c < B1_NCH; ++c) if (b1_step_b(c, kc3) == t) return c;
+    return -1;
+}
+constexpr int b1_ring_ops(int t, int kc3) { return (t + (B1_NS - 1) < b1_total(kc3) && !B1_PROBE(16)) ? 2 : 0; }
+// requests of step t behind its ring DMA -- first group: shortcut chunk 1 (step 18); second group: the patch of chunk 2 / 3 (steps 5 / 9),
+// shortcut chunk 0 (step 14), and in a chunk's B step its 4 trunk stores + the shortcut chunk two ahead
+constexpr int b1_extra_first(int t, int kc3, bool res) { return (t == B1_CONV2_SLABS && res) ? 4 : 0; }
+constexpr int b1_extra_last(int t, int kc3, bool res) {
+    if (t == 5 || t == 9) return 4;
+    if (t == 14) return res ? 4 : 0;
+    const int c = b1_chunk_of_b(t, kc3);
+    return c < 0 ? 0 : 4 + ((res && c + 2 < B1_NCH) ? 4 : 0);
+}
+// instructions issued from the start of step 0 through step t's ring DMA (phase 0), first group (1), last group (2)
+constexpr int b1_cum(int t, int phase, int kc3, bool res) {
     int n = 0;
-    for (int t = s - 3; t < s; ++t) n += b1_ring_ops(t, kc3) + b1_extra_ops(t, kc3, res);
-    if (res && s == B1_CONV2_SLABS + 3) {
-        n = 0;
-        for (int t = B1_CONV2_SLABS + 1; t < s; ++t) n += b1_ring_ops(t, kc3) + b1_extra_ops(t, kc3, res);
+    for (int u = 0; u <= t; ++u) {
+        n += b1_ring_ops(u, kc3);
+        if (u < t || phase >= 1) n += b1_extra_first(u, kc3, res);
+        if (u < t || phase >= 2) n += b1_extra_last(u, kc3, res);
     }
     return n;
+}
+// what may stay in flight at the wait of step s: everything issued after the youngest request step s depends on -- all of step s - 4
+// (its ring DMA is slab s; a patch or shortcut chunk 0 requested there is first read in step s or later) and, in a B step, the
+// shortcut chunk its epilogue adds (chunk 1: the first group of step 18; chunk c >= 2: the last group of B(c - 2))
+constexpr int b1_wait_n(int s, int kc3, bool res) {
+    int cover = b1_cum(s - 4, 2, kc3, res);
+    const int c = b1_chunk_of_b(s, kc3);
+    if (res && c == 1) { const int v = b1_cum(B1_CONV2_SLABS, 1, kc3, res); cover = v > cover ? v : cover; }
+    if (res && c >= 2) { const int v = b1_cum(b1_step_b(c - 2, kc3), 2, kc3, res); cover = v > cover ? v : cover; }
+    return b1_cum(s - 1, 2, kc3, res) - cover;
 }
 
 // s_waitcnt vmcnt(N) lgkmcnt(0) (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14])
@@ -168,7 +187,7 @@ __device__ __forceinline__ f32x16 b1_mma3(const wfrag& w, const shalf8& xh, cons
 // KC3B: 16-wide K chunks of conv3 that come from xp (0, or 4: the folded shortcut); RES: a shortcut tensor is added
 template <int KC3B, bool RES>
 __global__ __launch_bounds__(256, 2) void b1_unit_kernel(const B1Args a) {
-    constexpr int KC3 = 4 + KC3B, SPC = KC3 / 4 + 1, TOTAL = b1_total(KC3);
+    constexpr int KC3 = 4 + KC3B, TOTAL = b1_total(KC3);
     constexpr int NS = B1_NS, SLAB = B1_SLAB, NCH = B1_NCH, DEPTH = B1_DEPTH;
     static_assert(!(RES && KC3B), "either a shortcut tensor or a folded one");
 
@@ -406,25 +425,36 @@ __global__ __launch_bounds__(256, 2) void b1_unit_kernel(const B1Args a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
     const int sw = (lr >> 1) & 7;
-    auto chunk = [&](auto c_c) {
-        constexpr int C = decltype(c_c)::value, S0 = B1_CONV2_SLABS + SPC * C, B = C & 1;
-        f32x16 acc1;
+    // conv3 of chunk C into `dst` (zeroed here): K chunks in order over {h2, xp}.  Its first slab's fragments are in fA already
+    auto conv3 = [&](auto c_c, f32x16& dst) {
+        constexpr int C = decltype(c_c)::value, SA = b1_step_a(C, KC3);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
-        // conv3 chunk C: K chunks in order over {h2, xp}; its first four fragments were requested a phase ago
+        for (int r = 0; r < 16; ++r) dst[r] = 0.f;
 #pragma unroll
-        for (int kc = 0; kc < 4; ++kc) acc1 = b1_mma3(fA.w[kc], xh[kc].hi, xh[kc].lo, acc1);
+        for (int kc = 0; kc < 4; ++kc) dst = b1_mma3(fA.w[kc], xh[kc].hi, xh[kc].lo, dst);
         if constexpr (KC3B > 0) {
-            slab_step(b1_ic<S0 + 1>{});
+            slab_step(b1_ic<SA + 1>{});
             Slab1 fA2;
-            read_slab1(S0 + 1, fA2);
+            read_slab1(SA + 1, fA2);
 #pragma unroll
-            for (int kc = 0; kc < 4; ++kc) acc1 = b1_mma3(fA2.w[kc], xh[4 + kc].hi, xh[4 + kc].lo, acc1);
+            for (int kc = 0; kc < 4; ++kc) dst = b1_mma3(fA2.w[kc], xh[4 + kc].hi, xh[4 + kc].lo, dst);
+        }
+    };
+    f32x16 accP, accQ;                                         // conv3 accumulators of even / odd chunks
+    conv3(b1_ic<0>{}, accP);
+    auto chunk = [&](auto c_c) {
+        constexpr int C = decltype(c_c)::value, SB = b1_step_b(C, KC3), B = C & 1;
+        f32x16& acc1 = (C & 1) ? accQ : accP;
+        // software pipeline: the MFMAs of conv3 chunk C + 1 are issued in front of the epilogue of chunk C, which then runs beside them
+        if constexpr (C + 1 < NCH) {
+            slab_step(b1_ic<b1_step_a(C + 1, KC3)>{});
+            read_slab1(b1_step_a(C + 1, KC3), fA);
+            conv3(b1_ic<C + 1>{}, (C & 1) ? accP : accQ);
         }
         // the conv1' fragments of this chunk are requested in front of the epilogue
-        slab_step(b1_ic<S0 + SPC - 1>{});
+        slab_step(b1_ic<SB>{});
         Slab1 fB;
-        read_slab1(S0 + SPC - 1, fB);
+        read_slab1(SB, fB);
         // * scale3 + shift3 (+ shortcut), split, IN PLACE into the staging tile; the pre-activation of the STORED value
         char* stg = stg_of(B);
         shalf2 nh[4][2], nl[4][2];
@@ -485,11 +515,6 @@ __global__ __launch_bounds__(256, 2) void b1_unit_kernel(const B1Args a) {
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (C + 2 < NCH) res_dma(C + 2, B);
             __builtin_amdgcn_sched_barrier(0);
-        }
-        // the next chunk's conv3 fragments are requested in front of this chunk's conv1' MFMAs
-        if constexpr (C + 1 < NCH) {
-            slab_step(b1_ic<S0 + SPC>{});
-            read_slab1(S0 + SPC, fA);
         }
         // conv1' K step C: K chunks 2 C, 2 C + 1 against both row blocks
 #pragma unroll

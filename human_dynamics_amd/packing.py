@@ -198,9 +198,9 @@ def pack_b1_unit_stream(w2_hwio, k2, w3_nk, w1_nk):
     """The filter stream of a whole block-1 unit (hmmr_tail_desc_t.unit_stream, csrc/b1_unit.hip): w2_hwio [3,3,64,64] = conv2 with its row
     exponents k2 (as _layer_stream3x3 scales them), w3_nk [256][K3] = conv3's rows ([W3 | Wsc] along K with a folded shortcut, K3 = 64 or
     128), w1_nk [64][256] = the next unit's conv1 rows -> fp16 [fragments][2 (hi, lo plane)][64 lanes][8], 2 KB per fragment:
-    conv2's stream exactly as pack_conv3x3_stream lays it out for cout = 64 (36 K steps x two row blocks), then for every 32 channels c
-    of conv3's output the K3 / 16 fragments of conv3 row block c (K chunks in order) and the four fragments of conv1' K chunks 2 c and
-    2 c + 1 (row blocks 0, 1 of each).  Rows of w3 / w1 carry row_pow2() like every split filter bank."""
+    conv2's stream exactly as pack_conv3x3_stream lays it out for cout = 64 (36 K steps x two row blocks), then the tail in the order the
+    kernel's software pipeline consumes it, A(0) | A(1) B(0) | A(2) B(1) | ... | A(7) B(6) | B(7): A(c) = the K3 / 16 fragments of conv3 row
+    block c (K chunks in order), B(c) = the four fragments of conv1' K chunks 2 c and 2 c + 1 (row blocks 0, 1 of each).  Rows of w3 / w1 carry row_pow2() like every split filter bank."""
     w2 = np.asarray(w2_hwio, np.float32)
     assert w2.shape == (3, 3, 64, 64), w2.shape
     w3_nk = np.ascontiguousarray(w3_nk, dtype=np.float32)
@@ -221,9 +221,12 @@ def pack_b1_unit_stream(w2_hwio, k2, w3_nk, w1_nk):
         return torch.stack([frag(hi), frag(lo)], dim=2)              # [rb, kc, plane, lane, 8]
 
     f3, f1 = planar(w3_nk), planar(w1_nk)
-    for c in range(depth // 32):
-        parts.append(f3[c])                                          # conv3 row block c: K3 / 16 fragments
-        parts.append(torch.stack([f1[j, 2 * c + kcl] for kcl in range(2) for j in range(2)]))
+    nch = depth // 32
+    parts.append(f3[0])                                              # A(0): conv3 row block 0, K3 / 16 fragments
+    for c in range(nch):
+        if c + 1 < nch:
+            parts.append(f3[c + 1])                                  # A(c + 1): issued in front of chunk c's epilogue
+        parts.append(torch.stack([f1[j, 2 * c + kcl] for kcl in range(2) for j in range(2)]))     # B(c)
     out = torch.cat(parts).contiguous()
     assert out.numel() * 2 == 18 * 8192 + (depth // 32) * (K3 // 16 + 4) * 2048
     return out

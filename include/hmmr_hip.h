@@ -302,9 +302,9 @@ typedef struct {
      * kernel of csrc/b1_unit.hip.  w2 / w3 / w1 are not read; `unit_stream` holds ALL filters of the unit as the flat sequence of 2 KB
      * MFMA A-operand fragments ([hi plane: 64 lanes x 16 B][lo plane], lane = 32 * (k half) + row, rows scaled like every split filter
      * bank) the kernel consumes (hmmr_b1_unit_stream_bytes; packing.pack_b1_unit_stream): conv2's stream exactly as k_order = 2 packs it
-     * for cout = 64 (36 K steps kt = (ci / 16) * 9 + tap of two row blocks), then for each 32 channels c of conv3's output the
-     * kc3 = (64 + c_xp) / 16 fragments of conv3 row block c (K chunks in order) and the four fragments of conv1' K chunks 2 c, 2 c + 1
-     * (row blocks 0, 1 of each).  scale2 / shift2: conv2's folded BN as the k_order 2 layer carries it.  With xp (c_xp = 64; res == NULL)
+     * for cout = 64 (36 K steps kt = (ci / 16) * 9 + tap of two row blocks), then, with A(c) = the kc3 = (64 + c_xp) / 16 fragments of
+     * conv3 row block c (32 output channels; K chunks in order) and B(c) = the four fragments of conv1' K chunks 2 c, 2 c + 1 (row blocks
+     * 0, 1 of each): A(0) | A(1) B(0) | A(2) B(1) | ... | A(7) B(6) | B(7) (the order of the kernel's software pipeline).  scale2 / shift2: conv2's folded BN as the k_order 2 layer carries it.  With xp (c_xp = 64; res == NULL)
      * conv3's K is {h2, xp}.  Bit-identical to hmmr_conv_gemm(k_order 2) + conv3 + conv1 as three launches. */
     const void* unit_stream;
 } hmmr_tail_desc_t;

@@ -246,8 +246,8 @@ def test_conv3x3_stream_pack():
 
 
 def test_b1_unit_stream_pack():
-    """packing.pack_b1_unit_stream (hmmr_tail_desc_t.unit_stream, csrc/b1_unit.hip): conv2's k_order 2 stream, then per 32 channels c of
-    conv3's output its K3 / 16 conv3 fragments and the four conv1' fragments of K chunks 2 c, 2 c + 1; a fragment = [hi | lo plane][lane =
+    """packing.pack_b1_unit_stream (hmmr_tail_desc_t.unit_stream, csrc/b1_unit.hip): conv2's k_order 2 stream, then the tail as
+    A(0) | A(1) B(0) | ... | A(7) B(6) | B(7) (A(c): the K3 / 16 conv3 fragments of output chunk c, B(c): the four conv1' fragments of K chunks 2 c, 2 c + 1); a fragment = [hi | lo plane][lane =
     32 * (k half) + row][8]; hi + lo reproduce the scaled filter rows."""
     rng = np.random.default_rng(5)
     w2 = rng.normal(size=(3, 3, 64, 64)).astype(np.float32)
@@ -263,13 +263,16 @@ def test_b1_unit_stream_pack():
         assert torch.equal(st[:72].reshape(-1), packing.pack_conv3x3_stream(w2, k2).reshape(-1))
         k3, k1 = packing.row_pow2(w3), packing.row_pow2(w1)
         val = lambda f, lane, e: float(st[f, 0, lane, e]) + float(st[f, 1, lane, e])
+        na = K3 // 16
+        pos_a = lambda c: 72 if c == 0 else 72 + na + (c - 1) * nf              # first fragment of A(c) / B(c) in the pipelined order
+        pos_b = lambda c: 72 + 2 * na + c * nf if c < 7 else 72 + 8 * nf - 4
         for co, ci in ((0, 0), (37, 5), (255, K3 - 1), (130, 17)):              # conv3: W3[co][ci]
-            f = 72 + (co // 32) * nf + ci // 16
+            f = pos_a(co // 32) + ci // 16
             want = float(w3[co, ci]) * 2.0 ** int(k3[co])
             assert abs(val(f, 32 * ((ci % 16) // 8) + co % 32, ci % 8) - want) <= abs(want) * 2.0 ** -21
         for n2, ci in ((0, 0), (33, 47), (63, 255), (5, 144)):                  # conv1': W1[n2][ci], K chunk ci // 16 = 2 c + kcl
             c, kcl = ci // 32, (ci // 16) % 2
-            f = 72 + c * nf + K3 // 16 + kcl * 2 + n2 // 32
+            f = pos_b(c) + kcl * 2 + n2 // 32
             want = float(w1[n2, ci]) * 2.0 ** int(k1[n2])
             assert abs(val(f, 32 * ((ci % 16) // 8) + n2 % 32, ci % 8) - want) <= abs(want) * 2.0 ** -21
 
