@@ -64,7 +64,7 @@ struct B1Args {
 
 // Development build only (tools/b1_probe_build.sh, -DB1_PROBE_BITS=n): drop the MFMAs (1), the HBM traffic (2: every tile reads tile 0's
 // pixels and stores to the dump page), the waits and barriers of the slab steps (4) or the epilogue arithmetic (8) at COMPILE time, to
-// see what bounds the kernel; 16: no filter stream (the ring keeps whatever it holds).  Results are garbage in those modes; the product build compiles the switches away.
+// see what bounds the kernel; 16: no filter stream (the ring keeps whatever it holds); 32: no fragment reads out of the ring.  Results are garbage in those modes; the product build compiles the switches away.
 #ifndef B1_NT_RES
 #define B1_NT_RES 0         /* A/B: the shortcut chunks (read exactly once) as non-temporal requests */
 #endif
@@ -337,6 +337,7 @@ __global__ __launch_bounds__(256, 2) void b1_unit_kernel(const B1Args a) {
     auto ring_frag = [&](int slab, int f) -> wfrag {
         const char* p = smem + (slab % NS) * SLAB + f * 2048 + lane16;
         wfrag w;
+        if constexpr (B1_PROBE(32)) { w.hi = shalf8{}; w.lo = shalf8{}; w.hi[0] = (shalf_t)(float)slab; return w; }     // (probe: no fragment reads)
         w.hi = *(const shalf8*)p;
         w.lo = *(const shalf8*)(p + 1024);
         return w;
