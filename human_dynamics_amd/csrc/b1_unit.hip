@@ -170,12 +170,8 @@ __device__ __forceinline__ void b1_d_to_b(const shalf2 (&nh)[4][2], const shalf2
 // split2_mix / split4_mix (common.h): the split in that form.
 __device__ __forceinline__ void b1_split2(float c0, float c1, unsigned& h, unsigned& l) { split2_mix(c0, c1, h, l); }
 // the value a packed (hi, lo) pair holds: hi + lo, exact before its one rounding to fp32 (= (float)hi + (float)lo); low / high half of the dwords
-__device__ __forceinline__ float b1_sum_lo(unsigned h, unsigned l) {
-    float v; asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(v) : "v"(h), "v"(l)); return v;
-}
-__device__ __forceinline__ float b1_sum_hi(unsigned h, unsigned l) {
-    float v; asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(v) : "v"(h), "v"(l)); return v;
-}
+__device__ __forceinline__ float b1_sum_lo(unsigned h, unsigned l) { return split_sum_lo(h, l); }
+__device__ __forceinline__ float b1_sum_hi(unsigned h, unsigned l) { return split_sum_hi(h, l); }
 __device__ __forceinline__ void b1_split4(const float (&v)[4], float lo_clamp, unsigned (&h)[2], unsigned (&l)[2], float& satm) { split4_mix(v, lo_clamp, h, l, satm); }
 
 // mma3 (common.h), or under probe bit 1 something that only keeps its operands alive

@@ -143,6 +143,23 @@ __device__ __forceinline__ float shalf_lo(unsigned v) { return (float)__builtin_
 __device__ __forceinline__ float shalf_hi(unsigned v) { return (float)__builtin_bit_cast(shalf2, v)[1]; }
 __device__ __forceinline__ unsigned shalf_pack(shalf_t a, shalf_t b) { return __builtin_bit_cast(unsigned, shalf2{a, b}); }
 
+
+// ---- mixed-precision FMA forms of the split arithmetic (round 5).  hi + lo of a packed pair as ONE v_fma_mix_f32 (exact before its
+// single rounding to fp32: the value of (float)hi + (float)lo); two clamped values -> packed hi halves (one v_cvt_pk_f16_f32) and packed lo
+// halves, lo = fp16(c - hi): c - hi is exact in fp32, so v_fma_mixlo/hi_f16 rounds once, like the casts they replace -- the same bits in
+// half the instructions
+__device__ __forceinline__ float split_sum_lo(unsigned h, unsigned l) {
+    float v; asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(v) : "v"(h), "v"(l)); return v;
+}
+__device__ __forceinline__ float split_sum_hi(unsigned h, unsigned l) {
+    float v; asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(v) : "v"(h), "v"(l)); return v;
+}
+__device__ __forceinline__ void split2_mix(float c0, float c1, unsigned& h, unsigned& l) {
+    h = __builtin_bit_cast(unsigned, shalf2{(shalf_t)c0, (shalf_t)c1});
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(c0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(c1));
+}
+
 // the value an output element has after being stored in type T and read back
 template <typename T> __device__ __forceinline__ float stored_value(float v);
 template <> __device__ __forceinline__ float stored_value<float>(float v) { return v; }
@@ -190,15 +207,11 @@ template <> __device__ __forceinline__ void store8<bsplit_t>(bsplit_t* p, const 
     satmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(satmax, __builtin_fabsf(v[0])), __builtin_fmaxf(__builtin_fabsf(v[1]), __builtin_fabsf(v[2]))),
                              __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[3]), __builtin_fabsf(v[4])),
                                              __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[5]), __builtin_fabsf(v[6])), __builtin_fabsf(v[7]))));
-    shalf8 hi, lo;
+    unsigned h[4], l[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float c = split_clamp(v[i]);
-        hi[i] = (shalf_t)c;
-        lo[i] = (shalf_t)(c - (float)hi[i]);
-    }
-    *(shalf8*)p = hi;
-    *((shalf8*)p + 1) = lo;
+    for (int i = 0; i < 4; ++i) split2_mix(split_clamp(v[2 * i]), split_clamp(v[2 * i + 1]), h[i], l[i]);
+    *(u32x4*)p = u32x4{h[0], h[1], h[2], h[3]};
+    *((u32x4*)p + 1) = u32x4{l[0], l[1], l[2], l[3]};
 }
 __device__ __forceinline__ void store8(bsplit_t* p, const float (&v)[8]) {
     split_flag(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])), __builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3]))),
@@ -250,17 +263,13 @@ __device__ __forceinline__ u32x4 preact_slot_split(const u32x4& v, const f32x4& 
     const unsigned h0 = is_lo ? r0 : v[0], h1 = is_lo ? r1 : v[1];       // hi halves of this lane's four channels
     const unsigned l0 = is_lo ? v[2] : r0, l1 = is_lo ? v[3] : r1;       // lo halves
     float y[4];       // relu and the clamp to the fp16 range are one v_med3_f32 (= store8's split_clamp of a ReLU'd value)
-    y[0] = split_relu(fmaf(shalf_lo(h0) + shalf_lo(l0), sc[0], sh[0]));
-    y[1] = split_relu(fmaf(shalf_hi(h0) + shalf_hi(l0), sc[1], sh[1]));
-    y[2] = split_relu(fmaf(shalf_lo(h1) + shalf_lo(l1), sc[2], sh[2]));
-    y[3] = split_relu(fmaf(shalf_hi(h1) + shalf_hi(l1), sc[3], sh[3]));
+    y[0] = split_relu(fmaf(split_sum_lo(h0, l0), sc[0], sh[0]));      // (hi + lo as one v_fma_mix_f32: round 5)
+    y[1] = split_relu(fmaf(split_sum_hi(h0, l0), sc[1], sh[1]));
+    y[2] = split_relu(fmaf(split_sum_lo(h1, l1), sc[2], sh[2]));
+    y[3] = split_relu(fmaf(split_sum_hi(h1, l1), sc[3], sh[3]));
     unsigned ph[2], pl[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const shalf_t a = (shalf_t)y[2 * i], b = (shalf_t)y[2 * i + 1];
-        ph[i] = shalf_pack(a, b);
-        pl[i] = shalf_pack((shalf_t)(y[2 * i] - (float)a), (shalf_t)(y[2 * i + 1] - (float)b));
-    }
+    for (int i = 0; i < 2; ++i) split2_mix(y[2 * i], y[2 * i + 1], ph[i], pl[i]);
     // the partner's slot needs this lane's OTHER half: hi lane sends its lo[0..3], lo lane sends its hi[4..7]
     const unsigned s0 = dpp_swap(is_lo ? ph[0] : pl[0]), s1 = dpp_swap(is_lo ? ph[1] : pl[1]);
     return is_lo ? u32x4{s0, s1, pl[0], pl[1]} : u32x4{ph[0], ph[1], s0, s1};
@@ -296,14 +305,6 @@ __device__ __forceinline__ void split4(const float (&v)[4], unsigned long long& 
     lo = (unsigned long long)l[0] | ((unsigned long long)l[1] << 32);
 }
 
-// ---- the same split in mixed-precision FMA form (round 5: csrc/b1_unit.hip, the unit pair's last epilogue): two values already clamped
-// to the fp16 range -> their packed hi halves (one v_cvt_pk_f16_f32) and packed lo halves, lo = fp16(c - hi): c - hi is exact in fp32,
-// so v_fma_mixlo/hi_f16 rounds once, like the cast above -- the same bits in half the instructions
-__device__ __forceinline__ void split2_mix(float c0, float c1, unsigned& h, unsigned& l) {
-    h = __builtin_bit_cast(unsigned, shalf2{(shalf_t)c0, (shalf_t)c1});
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(c0));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(c1));
-}
 // four values of one lane: clamp to [lo_clamp, 65504] (lo_clamp = 0: a ReLU in the same v_med3_f32), split; satmax as in split4
 __device__ __forceinline__ void split4_mix(const float (&v)[4], float lo_clamp, unsigned (&h)[2], unsigned (&l)[2], float& satmax) {
 #pragma unroll

@@ -168,6 +168,3 @@ def test_stem_with_unit1_conv1_inside_equals_the_separate_launch(weights, gpu_de
     fa, fb = a.resnet(frames, n_zero=1), b.resnet(frames, n_zero=1)
     assert float(fb.abs().max()) > 0.1
     assert torch.equal(fa, fb), float((fa - fb).abs().max())
-    _, pa = a.resnet(frames, n_zero=1, prof=True)
-    _, pb = b.resnet(frames, n_zero=1, prof=True)
-    assert pa[4] < 0.5 * pb[4]            # profile slot 4 = block1/unit_1 conv1 (slot 3: its folded shortcut): no launch there any more
