@@ -318,3 +318,101 @@ def test_shipped_tile_tables_fit_their_layers():
                 ok = {0: (0, 1, 2, 3, 5, 6, 7, 8), 1: (0, 9, 10, 11), 2: (0, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21)}[lay.k_order]
                 assert tile in ok, (key, lk, tile)
     assert {40, 64, 65, 128, 129, 256, 257, 512, 513, 1024} <= sizes
+
+
+def test_b1_unit_instruction_stream_matches_its_wait_table():
+    """csrc/b1_unit.hip waits on its filter ring / patch / shortcut chunks with COUNTED s_waitcnt vmcnt(N): N comes from a constexpr table
+    of the vector-memory instructions each wave issues per slab step, so the table and the instruction stream hipcc emits have to agree --
+    a reordered store or a request the table does not know would make a wave read a slab before it has landed.  This test cross-compiles
+    the file (no GPU needed), walks both kernels' ISA and checks, step by step, the global_load_lds / global_store counts between the
+    barriers and every vmcnt against a Python restatement of the table."""
+    import os
+    import subprocess
+    import tempfile
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(here, "human_dynamics_amd", "csrc")
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "b1.s")
+        from human_dynamics_amd import build as B
+        cmd = [B.HIPCC] + [f for f in B.FLAGS if f != "-fPIC"] + ["-x", "hip", "--cuda-device-only", "-S", os.path.join(csrc, "b1_unit.hip"), "-o", out]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout[-2000:]
+        asm = open(out).read()
+    NCH, CONV2, NS = 8, 18, 5
+
+    def table(kc3, res):
+        na = kc3 // 4
+        total = CONV2 + NCH * (na + 1)
+        step_b = lambda c: CONV2 + 2 * na + c * (na + 1) if c + 1 < NCH else total - 1
+        chunk_of_b = {step_b(c): c for c in range(NCH)}
+        ring = lambda t: 2 if t + NS - 1 < total else 0
+        first = lambda t: 4 if (t == CONV2 and res) else 0
+
+        def last(t):
+            if t in (5, 9):
+                return 4
+            if t == 14:
+                return 4 if res else 0
+            c = chunk_of_b.get(t)
+            return 0 if c is None else 4 + (4 if (res and c + 2 < NCH) else 0)
+
+        def cum(t, phase):
+            n = 0
+            for u in range(t + 1):
+                n += ring(u)
+                if u < t or phase >= 1:
+                    n += first(u)
+                if u < t or phase >= 2:
+                    n += last(u)
+            return n
+
+        def wait_n(s):
+            cover = cum(s - 4, 2)
+            c = chunk_of_b.get(s)
+            if res and c == 1:
+                cover = max(cover, cum(CONV2, 1))
+            if res and c is not None and c >= 2:
+                cover = max(cover, cum(step_b(c - 2), 2))
+            return cum(s - 1, 2) - cover
+        return total, ring, first, last, wait_n
+
+    for sym, kc3, res in (("ILi0ELb1EEE", 4, True), ("ILi4ELb0EEE", 8, False)):
+        start = asm.index("_ZN12_GLOBAL__N_114b1_unit_kernel%svNS_6B1ArgsE:" % sym)
+        body = asm[start:asm.index("s_endpgm", start)]
+        ev = []
+        for line in body.splitlines():
+            t = line.strip().split()
+            if not t:
+                continue
+            if t[0].startswith("global_load_lds"):
+                ev.append("D")
+            elif t[0].startswith("global_store"):
+                ev.append("S")
+            elif t[0] == "s_barrier":
+                ev.append("|")
+            elif t[0] == "s_waitcnt" and "vmcnt" in line:
+                ev.append(int(line.split("vmcnt(")[1].split(")")[0]))
+        total, ring, first, last, wait_n = table(kc3, res)
+        # skip the prologue: everything up to and including its barrier (the first one)
+        i = ev.index("|") + 1
+        for s in range(total):
+            waits = []
+            while ev[i] != "|":                                  # what sits in front of step s's barrier: its counted wait (from step 4 on)
+                assert isinstance(ev[i], int) or s == 0, (sym, s, ev[i])
+                if isinstance(ev[i], int):
+                    waits.append(ev[i])
+                i += 1
+            i += 1
+            if s >= NS - 1:
+                assert waits and waits[-1] == wait_n(s), (sym, "step", s, "vmcnt", waits, "table", wait_n(s))
+            j, ops = i, []
+            while j < len(ev) and ev[j] in ("D", "S"):
+                ops.append(ev[j])
+                j += 1
+            want_d_first = ring(s) + first(s)
+            if s == total - 1:
+                ops = ops[:last(s)]                              # (the last step's stores are followed by the eight h1' stores)
+            lst = last(s)
+            stores = 4 if (lst >= 4 and s not in (5, 9, 14)) else 0
+            assert ops == ["D"] * want_d_first + ["S"] * stores + ["D"] * (lst - stores), (sym, "step", s, "".join(ops), want_d_first, stores, lst)
+            i = j if s < total - 1 else i
