@@ -17,7 +17,7 @@ LIB_PATH = devflags.get("LIB_PATH") or os.path.join(HERE, "libhmmr_hip.so")
 
 HMMR_F32, HMMR_BF16, HMMR_F16X3 = 0, 1, 2
 FLAG_SATURATED = 1
-ABI_VERSION = 16
+ABI_VERSION = 17
 RESNET_UNITS = 16
 RESNET_PROF_SLOTS = 64
 MAX_TEMPORAL_BLOCKS = 8
@@ -149,6 +149,7 @@ SIGNATURES = {
     "hmmr_pair_stream_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "hmmr_b1_unit_stream_bytes": (C.c_size_t, [C.c_int]),
     "hmmr_conv3x3_stream_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "hmmr_conv1x1_stream_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "hmmr_mfma_rate_probe": (C.c_int, [C.c_int, C.c_int, _fp, _vp]),
     "hmmr_render_handoff": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, _fp, C.c_int64, _fp, C.c_int, C.c_int, C.c_int,
                                       _fp, _fp, _fp, _vp]),

@@ -1225,6 +1225,7 @@ static int ilog2_exact(int v) {
 }
 
 int hmmr_conv3x3_stream(const hmmr_conv_desc_t* d, hipStream_t stream);     // conv3x3_stream.hip
+int hmmr_conv1x1_stream(const hmmr_conv_desc_t* d, hipStream_t stream);     // conv1x1_stream.hip
 
 extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
     HMMR_REQUIRE(d && d->in && d->w && (d->out || d->out2), "hmmr_conv_gemm: null operand");
@@ -1290,6 +1291,7 @@ extern "C" int hmmr_conv_gemm(const hmmr_conv_desc_t* d, void* stream) {
 #endif
     if (a.M <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
+    if (d->k_order == 2 && d->kh == 1 && d->kw == 1) return hmmr_conv1x1_stream(d, s);      // (checks its own geometry)
     if (d->k_order) {
         HMMR_REQUIRE((d->k_order == 1 || d->k_order == 2) && d->kh == 3 && d->kw == 3 && d->sy == 1 && d->sx == 1 && d->py == 1 && d->px == 1 &&
                      d->ho == d->hin && d->wo == d->win && d->in_px_stride == d->cin && d->in_row_stride == d->win * d->cin &&

@@ -318,7 +318,7 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
             d.in_img_stride = (int64_t)H * H * U.c_in; d.in_row_stride = H * U.c_in; d.in_px_stride = U.c_in;
             d.kh = d.kw = 1; d.sy = d.sx = U.stride; d.ho = d.wo = Ho; d.cout = U.depth; d.ldo = U.depth;
             if (sc_c1) {              // ... and conv1 over the same operand as extra output columns (-> T1, BN + ReLU)
-                d.w = U.sc_c1.w; d.scale = U.sc_c1.scale; d.shift = U.sc_c1.shift;
+                d.w = U.sc_c1.w; d.scale = U.sc_c1.scale; d.shift = U.sc_c1.shift; d.k_order = U.sc_c1.k_order;
                 d.cout = U.depth + U.base; d.out_b = T1; d.ldo_b = U.base; d.n_split = U.depth; d.relu_b = 1;
             }
             if (hmmr_conv_gemm(&d, s)) return -2;
@@ -330,6 +330,7 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
             d = hmmr_conv_desc_t{};
             d.in = xin; d.pro_scale = ps; d.pro_shift = pb;
             d.w = U.conv1.w; d.scale = U.conv1.scale; d.shift = U.conv1.shift; d.relu = 1; d.tile = U.conv1.tile;
+            d.k_order = U.conv1.k_order;      // (2: the two-ring stream kernel of csrc/conv1x1_stream.hip; it takes the pre-activated tensor)
             d.out = T1; d.in_dtype = d.out_dtype = w->dtype;
             d.n_img = n; d.hin = H; d.win = H; d.cin = U.c_in;
             d.in_img_stride = (int64_t)H * H * U.c_in; d.in_row_stride = H * U.c_in; d.in_px_stride = U.c_in;

@@ -26,6 +26,7 @@ FLAGS = {
     "PATCH_3X3": ("2", "the stride-1 3x3 layers of blocks 2-4 (f16x3): 2 = the one-wave-per-SIMD stream kernel (k_order 2), 1 = the 8-wave patch kernels (k_order 1), 0 = tap-major K order and the im2col gather; the three differ by fp32 accumulation rounding"),
     "B1_STREAM": ("0", "1: the conv2 of block1/unit_1 and unit_2 as a launch of the 3x3 stream kernel (64-channel tiles) instead of inside their fused tails (f16x3; measured equal)"),
     "B1_UNIT": ("1", "0: block1/unit_1 and unit_2 as the round-3 LDS-panel tails with conv2 inside (tap-major conv2) instead of the whole-unit kernel of csrc/b1_unit.hip (f16x3; conv2 chunk-major: the two differ by fp32 accumulation rounding)"),
+    "STREAM_1X1": ("1", "0: the conv1 of block 4 and of block2/unit_1 and block3/unit_1's shortcut + conv1 as launches of the 8-wave tiles (csrc/gemm_conv.hip) instead of the two-ring stream kernel of csrc/conv1x1_stream.hip (f16x3; the two differ by fp32 accumulation rounding)"),
     "UNIT_PAIR": ("1", "0 | 1 | block2 | block3: the stride-1 units of blocks 2-3 as register-resident unit pairs (csrc/unit_pair.hip; f16x3)"),
     "AUTOTUNE": ("1", "0: no per-layer tile tuning pass (shipped table / library heuristic only)"),
     "TILE_TABLE": ("1", "0: ignore the shipped tile tables (tile_tables.json), tune or fall back to the heuristic"),

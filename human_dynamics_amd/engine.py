@@ -84,7 +84,7 @@ class HmmrEngine(object):
     def __init__(self, weights, smpl, dtype=DEFAULT_DTYPE, device="cuda:0", num_conv_layers=3,
                  delta_t_values=(-5, 5), joint_type="cocoplus", resnet_chunk=0,
                  temporal_dtype=None, ief_dtype=None, autotune=True, fold_sc=None, fuse_tail=None, patch_3x3=None,
-                 unit_pair=None, b1_stream=None, b1_unit=None, stem_conv1=True):
+                 unit_pair=None, b1_stream=None, b1_unit=None, stem_conv1=True, stream_1x1=None):
         self.lib = L.load()
         _debug_from_env()
         if not torch.cuda.is_available():
@@ -116,7 +116,8 @@ class HmmrEngine(object):
                                                   if unit_pair is None else unit_pair),
                                        b1_stream=(devflags.get("B1_STREAM") == "1") if b1_stream is None else b1_stream,
                                        b1_unit=(devflags.get("B1_UNIT") == "1") if b1_unit is None else b1_unit,
-                                       stem_conv1=stem_conv1)
+                                       stem_conv1=stem_conv1,
+                                       stream_1x1=(devflags.get("STREAM_1X1") == "1") if stream_1x1 is None else stream_1x1)
                    if "resnet_v2_50/conv1/weights" in w else None)
         self.tw = (packing.pack_temporal(w, self.temporal_dtype, self.store, num_conv_layers)
                    if assets.temporal_scopes(0)[1] + "/weights" in w else None)
@@ -226,11 +227,13 @@ class HmmrEngine(object):
         return getattr(U, nm)
 
     @staticmethod
-    def _tile_for(lay, cand, cout, dtype=None):
+    def _tile_for(lay, cand, cout, dtype=None, one=False):
         """hmmr_layer_t.tile for candidate `cand` on a layer with `cout` output columns: 0 (the library's choice) where
         the tile does not fit; a layer packed chunk-major (k_order 1, the 3x3 patch kernels) runs tiles 9 / 10, the patch
         forms of 7 / 8, or 11, the 256x128 tile without a load segment; a k_order 2 layer (csrc/conv3x3_stream.hip) takes the
-        tuner's candidates as its own tile shapes 13 .. 18."""
+        tuner's candidates as its own tile shapes 13 .. 18; a k_order 2 layer with a 1x1 filter (`one`; csrc/conv1x1_stream.hip) tiles 22 .. 25."""
+        if lay.k_order == 2 and one:
+            return {5: 22, 6: 23, 3: 24, 1: 25}.get(cand, cand if 22 <= cand <= 25 else 0)
         if lay.k_order == 2:                                 # the stream kernel's tiles: 12 .. 18 and 21 (128-channel tiles), 19 / 20 (64 channels)
             if cout == 64:
                 return {5: 19, 6: 20}.get(cand, cand if cand in (19, 20) else 0)
@@ -253,7 +256,7 @@ class HmmrEngine(object):
 
     def _set_tiles(self, table):
         for (u, nm), t in table.items():
-            self._layer_of(u, nm).tile = self._tile_for(self._layer_of(u, nm), int(t), self._layer_cout(u, nm), self.dtype)
+            self._layer_of(u, nm).tile = self._tile_for(self._layer_of(u, nm), int(t), self._layer_cout(u, nm), self.dtype, nm != "conv2")
 
     def _needs_tuning(self, nt):
         """A tuning pass is due for batch size nt: tuning is on, the size is worth it, it has no table of its own and (unless
@@ -283,7 +286,7 @@ class HmmrEngine(object):
         for cand in (0,) + self._TUNE_TILES:
             for slot, u, nm in layers:
                 lay = self._layer_of(u, nm)
-                lay.tile = self._tile_for(lay, cand, self._layer_cout(u, nm), self.dtype)
+                lay.tile = self._tile_for(lay, cand, self._layer_cout(u, nm), self.dtype, nm != "conv2")
             t = None
             for rep in range(reps):
                 pm = (C.c_float * L.RESNET_PROF_SLOTS)()
@@ -538,10 +541,11 @@ class _FlagScope(object):
 
 def conv_gemm(x, w_hwio, stride=1, pad=0, scale=None, shift=None, res=None, relu=False,
               scale2=None, shift2=None, in_dtype=L.HMMR_F32, out_dtype=L.HMMR_F32, tile=0,
-              device="cuda:0", res_stride=1, split_k=0, pro=None, raw=False, second=None, k_order=0):
+              device="cuda:0", res_stride=1, split_k=0, pro=None, raw=False, second=None, k_order=0, n_split=0, relu_b=False):
     """Test/utility entry: run one NHWC convolution through hmmr_conv_gemm.
     x [n,h,w,cin] (numpy/torch), w_hwio [kh,kw,cin,cout].  Returns (out, out2) as float32 arrays, or with
-    raw=True the device tensors in their storage type; x may itself be such a device tensor."""
+    raw=True the device tensors in their storage type; x may itself be such a device tensor.  n_split > 0: the column split
+    (hmmr_conv_desc_t.out_b) -- returns (out [.., n_split], out_b [.., cout - n_split]) with ReLU flags relu / relu_b."""
     lib = L.load()
     dev = torch.device(device)
     store = packing.DeviceStore(dev)
@@ -568,7 +572,7 @@ def conv_gemm(x, w_hwio, stride=1, pad=0, scale=None, shift=None, res=None, relu
         sc = np.ones(cout, np.float64) if scale is None else np.asarray(scale, np.float64)
         scale = (sc * np.exp2(-k.astype(np.float64))).astype(np.float32)
         shift = np.zeros(cout, np.float32) if shift is None else shift
-        wt = store.put_tensor(packing.pack_conv3x3_stream(np.asarray(w_hwio, np.float32), k))
+        wt = store.put_tensor(packing.pack_conv3x3_stream(np.asarray(w_hwio, np.float32), k))      # (a 1x1 filter: pack_conv1x1_stream, the same layout)
     elif packing.TORCH_DT[in_dtype] is packing.SPLIT:   # as packing._layer: rows scaled by a power of two, undone by `scale`
         k = packing.row_pow2(wp)
         wp = packing.scale_rows(wp, k)
@@ -607,6 +611,10 @@ def conv_gemm(x, w_hwio, stride=1, pad=0, scale=None, shift=None, res=None, relu
     d.kh, d.kw, d.sy, d.sx, d.py, d.px = kh, kw, stride, stride, py, px
     d.ho, d.wo, d.cout, d.ldo = ho, wo, cout, ldo
     d.relu, d.tile, d.k_order = int(relu), tile, k_order
+    out_b = None
+    if n_split:
+        out_b = packing.empty_act((n, ho, wo, cout - n_split), out_dtype, dev, zero=True)
+        d.out_b, d.ldo_b, d.n_split, d.relu_b = out_b.data_ptr(), cout - n_split, n_split, int(relu_b)
     if pro is not None:
         d.pro_scale, d.pro_shift = store.put(pro[0]).data_ptr(), store.put(pro[1]).data_ptr()
     if split_k > 1:
@@ -616,7 +624,9 @@ def conv_gemm(x, w_hwio, stride=1, pad=0, scale=None, shift=None, res=None, relu
     L.check(lib.hmmr_conv_gemm(C.byref(d), torch.cuda.current_stream(dev).cuda_stream), "hmmr_conv_gemm")
     torch.cuda.synchronize(dev)
     if raw:
-        return out, out2
+        return out, (out_b if n_split else out2)
+    if n_split:
+        return (packing.act_to_f32(out, out_dtype)[..., :n_split].cpu().numpy(), packing.act_to_f32(out_b, out_dtype).cpu().numpy())
     o = packing.act_to_f32(out, out_dtype)[..., :cout].cpu().numpy()
     o2 = packing.act_to_f32(out2, out_dtype)[..., :cout].cpu().numpy() if out2 is not None else None
     return o, o2

@@ -130,23 +130,33 @@ def pack_conv3x3_stream(w_hwio, k=None, bf16=False):
     two 16-wide MFMA chunks of those 32 channels (8 values = W[.., 32 (ci // 32) + 16 plane + 8 half .. + 7, ..]); no row scaling."""
     w = np.asarray(w_hwio, np.float64)
     kh, kw, cin, cout = w.shape
-    assert (kh, kw) == (3, 3) and cin % 16 == 0 and (cout % 128 == 0 or cout == 64), w.shape
+    assert (kh, kw) in ((3, 3), (1, 1)) and cin % 16 == 0 and (cout % 128 == 0 or cout == 64), w.shape      # ((1, 1): pack_conv1x1_stream)
+    T = kh * kw
     tw = 128 if cout % 128 == 0 else 64
     if bf16:
-        assert cin % 32 == 0, w.shape
+        assert cin % 32 == 0 and T == 9, w.shape
         t = torch.from_numpy(w.astype(np.float32)).to(torch.bfloat16)
         x = t.reshape(9, cin // 32, 2, 2, 8, cout // tw, tw // 32, 32)       # tap, c32, plane, half, e, tile, rb, row
         return x.permute(5, 1, 0, 6, 2, 3, 7, 4).reshape(cout // tw, 9 * (cin // 32), tw // 32, 2, 64, 8).contiguous()
     if k is None:
-        k = row_pow2(w.reshape(9 * cin, cout).T)
+        k = row_pow2(w.reshape(T * cin, cout).T)
     t = torch.from_numpy((w * np.exp2(np.asarray(k, np.float64))).astype(np.float32))
     hi = t.to(SPLIT_HALF)
     lo = (t - hi.to(torch.float32)).to(SPLIT_HALF)
 
     def frag(x):
-        x = x.reshape(9, cin // 16, 2, 8, cout // tw, tw // 32, 32)      # tap, c16, half, e, tile, rb, row
-        return x.permute(4, 1, 0, 5, 2, 6, 3).reshape(cout // tw, 9 * (cin // 16), tw // 32, 64, 8)
+        x = x.reshape(T, cin // 16, 2, 8, cout // tw, tw // 32, 32)      # tap, c16, half, e, tile, rb, row
+        return x.permute(4, 1, 0, 5, 2, 6, 3).reshape(cout // tw, T * (cin // 16), tw // 32, 64, 8)
     return torch.stack([frag(hi), frag(lo)], dim=3).contiguous()          # [tile, kt, rb, plane, lane, 8]
+
+
+def pack_conv1x1_stream(w_hwio, k=None):
+    """[1,1,cin,cout] -> fp16 [cout / 128][cin / 16][4][2 (hi, lo plane)][64 lanes][8]: the filter stream of a 1x1 layer with k_order 2
+    (csrc/conv1x1_stream.hip): K step kt = 16 input channels, the same 8 KB of MFMA A-operand fragments per 128 output channels as one tap
+    of pack_conv3x3_stream; rows scaled by 2^k (row_pow2 of the rows)."""
+    w = np.asarray(w_hwio)
+    assert w.shape[:2] == (1, 1) and w.shape[3] % 128 == 0, w.shape
+    return pack_conv3x3_stream(w, k)
 
 
 def pair_is_a(i, na, ft):
@@ -300,9 +310,23 @@ def _layer_stream3x3(store, w_hwio, scale, shift, bf16=False):
     return lay
 
 
+def _layer_stream1x1(store, w_hwio, scale, shift):
+    """hmmr_layer_t of a k_order 2 1x1 layer (f16x3): the filter stream instead of a matrix, the same row scaling as _layer."""
+    lay = L.Layer()
+    w_hwio = np.asarray(w_hwio, np.float32)
+    cout = w_hwio.shape[3]
+    k = row_pow2(pack_conv_weight(w_hwio)[:cout])
+    lay.w = store.put_tensor(pack_conv1x1_stream(w_hwio, k)).data_ptr()
+    sc = np.ones(cout, np.float64) if scale is None else np.asarray(scale, np.float64)
+    lay.scale = store.vec((sc * np.exp2(-k.astype(np.float64))).astype(np.float32)).data_ptr()
+    lay.shift = store.vec(shift).data_ptr()
+    lay.k_order = 2
+    return lay
+
+
 def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3", "block4"), fuse_tail=True,
                 fuse_sc=True, fuse_preact_first=False, fold_sc=None, patch_3x3=2, unit_pair=True, b1_stream=False, b1_unit=True,
-                stem_conv1=True):
+                stem_conv1=True, stream_1x1=True):
     """fuse_preact_blocks: blocks whose units apply their `preact` BN+ReLU inside the operand
     staging of conv1/shortcut instead of reading a materialised preact tensor (csrc/resnet.hip;
     measured at batch 256: -4.5 % ResNet time with blocks 1-2 fused, neutral for blocks 3-4).
@@ -321,6 +345,9 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
     False): the round-3 tails of csrc/bottleneck_split.hip with conv2 inside, tap-major.
     stem_conv1 (f16x3; default on, round 5): block1/unit_1's conv1 is computed by the fused stem kernel on its pooled tile (hmmr_resnet_unit_t.
     conv1_frag); bf16 does that since round 1 (hmmr_debug_t.stem_no_conv1 switches either off at run time).  Same bits as the launch.
+    stream_1x1 (f16x3; default on, round 5): the conv1 of block 4's units and of block2/unit_1, and block3/unit_1's shortcut + conv1 launch run the two-ring
+    stream kernel of csrc/conv1x1_stream.hip (hmmr_layer_t.k_order = 2 on a 1x1 layer); the kernel takes the pre-activated tensor, so
+    block4/unit_2 and unit_3 read the one their predecessor's conv3 writes (fuse_preact = 0) instead of applying it while staging.
     unit_pair (f16x3 only; True | "block2" | "block3" | False): the stride-1 units of blocks 2-3 run conv3 + add + the next
     unit's preact + conv1 as the register-resident unit pair of csrc/unit_pair.hip (one filter stream per unit); block3/unit_1
     then keeps its conv shortcut as a launch (shortcut + conv1 as one column-split GEMM) instead of folding it into conv3."""
@@ -349,7 +376,13 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
             # down-sampled) preact tensor once and both consumers take the plain LDS-DMA operand path
             u.fuse_preact = 0
         s, b = fold_bn(w, scope + "/conv1/BatchNorm")
-        u.conv1 = _layer(store, pack_conv_weight(w[scope + "/conv1/weights"]), dtype, s, b)
+        s1x1 = bool(stream_1x1) and dtype == L.HMMR_F16X3 and stride == 1
+        if s1x1 and i > 0 and base % 128 == 0 and (base == 512 or not u.fuse_preact):
+            # block 4's three units, and the first unit of blocks 2-4 (which reads a materialised preact tensor anyway)
+            u.fuse_preact = 0
+            u.conv1 = _layer_stream1x1(store, w[scope + "/conv1/weights"], s, b)
+        else:
+            u.conv1 = _layer(store, pack_conv_weight(w[scope + "/conv1/weights"]), dtype, s, b)
         if i == 0 and dtype == L.HMMR_F16X3 and stem_conv1:
             # block1/unit_1's conv1 runs inside the fused stem (csrc/stem.hip): its filters as MFMA A-operand fragments (the same rows and
             # row scaling as the layer above, so the layer's scale / shift apply)
@@ -391,9 +424,13 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
                 # after the shortcut's; scale 1 on the shortcut columns (fma(v, 1, b) == v + b exactly)
                 both = np.concatenate([w[scope + "/shortcut/weights"], w[scope + "/conv1/weights"]], axis=3)
                 s1, b1 = fold_bn(w, scope + "/conv1/BatchNorm")
-                u.sc_c1 = _layer(store, pack_conv_weight(both), dtype,
-                                 np.concatenate([np.ones(depth, np.float32), s1]),
-                                 np.concatenate([np.asarray(w[scope + "/shortcut/biases"], np.float32), b1]))
+                sc_s = np.concatenate([np.ones(depth, np.float32), s1])
+                sc_b = np.concatenate([np.asarray(w[scope + "/shortcut/biases"], np.float32), b1])
+                if s1x1 and not u.fuse_preact and depth % 128 == 0 and base % 128 == 0:
+                    u.sc_c1 = _layer_stream1x1(store, both, sc_s, sc_b)
+                    u.shortcut.k_order = 2          # (the launch reads its tile from `shortcut`: HmmrEngine._tile_for)
+                else:
+                    u.sc_c1 = _layer(store, pack_conv_weight(both), dtype, sc_s, sc_b)
         s, b = fold_bn(w, scope + "/preact")
         u.pre_scale, u.pre_shift = store.vec(s).data_ptr(), store.vec(b).data_ptr()
     if dtype == L.HMMR_F16X3 and fuse_tail:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HMMR_ABI_VERSION 16      /* 16: hmmr_tail_desc_t.unit_stream, hmmr_resnet_unit_t.unit_stream (the whole-unit kernel of block 1, csrc/b1_unit.hip), hmmr_b1_unit_stream_bytes, hmmr_debug_t.pair_min_pixels / pair_two_tile_min / launch counters, hmmr_resnet_unit_t.conv1_frag (block1/unit_1's conv1 inside the split stem); 15: k_order = 2 (the one-wave-per-SIMD 3x3 stream kernel, tiles 12 .. 18), hmmr_conv3x3_stream_bytes; 14: hmmr_tail_desc_t.pair_stream / c_xp, hmmr_resnet_unit_t.pair_stream (the register-resident unit pair of blocks 2-3), hmmr_run_flags; 13: hmmr_conv_desc_t.batch (grouped launches); 12: k_order = 1, 3x3 SAME convolutions out of an LDS-resident input patch (tiles 9, 10, 11) */
+#define HMMR_ABI_VERSION 17      /* 17: k_order = 2 on a 1x1 filter (the two-ring stream kernel of csrc/conv1x1_stream.hip, tiles 22 .. 25), hmmr_conv1x1_stream_bytes; 16: hmmr_tail_desc_t.unit_stream, hmmr_resnet_unit_t.unit_stream (the whole-unit kernel of block 1, csrc/b1_unit.hip), hmmr_b1_unit_stream_bytes, hmmr_debug_t.pair_min_pixels / pair_two_tile_min / launch counters, hmmr_resnet_unit_t.conv1_frag (block1/unit_1's conv1 inside the split stem); 15: k_order = 2 (the one-wave-per-SIMD 3x3 stream kernel, tiles 12 .. 18), hmmr_conv3x3_stream_bytes; 14: hmmr_tail_desc_t.pair_stream / c_xp, hmmr_resnet_unit_t.pair_stream (the register-resident unit pair of blocks 2-3), hmmr_run_flags; 13: hmmr_conv_desc_t.batch (grouped launches); 12: k_order = 1, 3x3 SAME convolutions out of an LDS-resident input patch (tiles 9, 10, 11) */
 
 /* HMMR_F16X3: "split" tensors -- every group of 8 consecutive channels is 32 bytes, [hi x8][lo x8] with
  * hi = fp16(x), lo = fp16(x - hi), x clamped to +-65504 (4 bytes per element, 22 mantissa bits while lo is a normal
@@ -138,7 +138,10 @@ typedef struct {
                               k_order 2 only (csrc/conv3x3_stream.hip; 4 waves, one per SIMD, 128 output channels per tile): 12 = 448 pixels
                               (wave tile 7 x 2 accumulators of 32 x 32), 13 = 256 (4 x 2), 14 = 512 (8 x 2), 15 = 384 (6 x 2), 16 = 320 (5 x 2);
                               17 = 512, 18 = 384 pixels with the waves splitting the pixels (4 x 4 / 3 x 4); 19 = 640, 20 = 512 pixels x 64 channels
-                              (cout = 64, images up to 56 pixels wide); 21 = 224 pixels, every wave all of them and 32 channels (7 x 1; split only) */
+                              (cout = 64, images up to 56 pixels wide); 21 = 224 pixels, every wave all of them and 32 channels (7 x 1; split only);
+                              k_order 2 with a 1x1 filter only (csrc/conv1x1_stream.hip; 4 waves, one per SIMD, 128 output channels per tile, both
+                              operands through LDS rings): 22 = 224 pixels (7 x 1 accumulators per wave, every wave 32 of the channels),
+                              23 = 256 pixels (8 x 1), 24 = 448 pixels (7 x 2, waves 2 x 2), 25 = 256 pixels (4 x 2, waves 2 x 2) */
     /* split-K (for GEMMs with few output tiles and a long K): split_k > 1 slices K into that many
      * contiguous ranges, each range leaves an fp32 partial plane in `ws`, and a second launch adds the
      * planes IN SLICE ORDER and applies the epilogue.  The caller fixes split_k per layer (never from
@@ -178,7 +181,13 @@ typedef struct {
      * A-operand fragments (lane = 32 * (k half) + row; 8 halves = W[row][16 (ci / 16) + 8 half .. + 7] of that tap), rows scaled
      * like every split filter bank.  Same convolutions and epilogue as k_order 1; split (f16x3) tensors, cin % 32 == 0 -- or bf16 tensors (K steps of 32
      * channels `(ci / 32) * 9 + tap`, the two planes = the two 16-wide MFMA chunks, no row scaling), cin % 64 == 0 --,
-     * cout % 128 == 0 and win <= 28 (tiles 12 .. 18, 21) or cout = 64 and win <= 56 (tiles 19 / 20) (csrc/conv3x3_stream.hip).  Every tile produces the same bits. */
+     * cout % 128 == 0 and win <= 28 (tiles 12 .. 18, 21) or cout = 64 and win <= 56 (tiles 19 / 20) (csrc/conv3x3_stream.hip).  Every tile produces the same bits.
+     * 2 with kh = kw = 1 (round 5; csrc/conv1x1_stream.hip, tiles 22 .. 25): `w` is the stream of packing.pack_conv1x1_stream
+     * (hmmr_conv1x1_stream_bytes(cin, cout) bytes: K steps of 16 input channels, the same 8 KB per 128 output channels as one tap above).  A
+     * stride-1 1x1 convolution over a dense [M][cin] split tensor (below 4 GB), cin % 16 == 0 (>= 96), cout % 128 == 0, scale and shift
+     * given; epilogue scale / shift / relu with the out_b column split (n_split % 128 == 0); no res, out2, pro_scale, in2, split_k, batch.
+     * Both operands go through LDS rings 4-6 K steps deep (one wave per SIMD), for layers whose K loop is bound by the round trip of
+     * a two-stage ring (block 4, block3/unit_1's shortcut + conv1).  Differs from k_order 0 by fp32 rounding of the accumulation only. */
     int k_order;
     /* grouped launch: `batch` > 1 runs that many problems of this one shape as ONE launch (grid z); problem z reads and
      * writes at these BYTE offsets (multiples of 16, negative allowed) from problem 0: `in`, `w`, `out` / `out2`, `res`,
@@ -205,7 +214,8 @@ typedef struct {
     int tile;              /* hmmr_conv_desc_t.tile for this layer's launch; 0 = library heuristic.
                               Results do not depend on it (same K order per output element);
                               the host may tune it per layer and batch size. */
-    int k_order;           /* hmmr_conv_desc_t.k_order the filter rows of `w` were packed in (read for the 3x3 conv2 layers) */
+    int k_order;           /* hmmr_conv_desc_t.k_order the filter rows of `w` were packed in (read for the 3x3 conv2 layers, and -- 2: the filter stream of
+                              csrc/conv1x1_stream.hip -- for conv1 and the shortcut + conv1 bank sc_c1; such a unit has fuse_preact = 0) */
 } hmmr_layer_t;
 
 typedef struct {
@@ -316,6 +326,8 @@ int hmmr_mfma_rate_probe(int workgroups, int n8, float* out, void* stream);
 /* bytes of the filter stream of a k_order 2 layer of split tensors: (cout / 128) x 9 (cin / 16) K steps of 8 KB (bf16 tensors: half of it,
  * 9 (cin / 32) K steps) */
 size_t hmmr_conv3x3_stream_bytes(int cin, int cout);
+/* bytes of the filter stream of a 1x1 layer with k_order 2 (split tensors): (cout / 128) x (cin / 16) K steps of 8 KB */
+size_t hmmr_conv1x1_stream_bytes(int cin, int cout);
 int hmmr_bottleneck_tail(const hmmr_tail_desc_t* d, void* stream);
 
 size_t hmmr_resnet50_workspace_bytes(int n, int dtype);

@@ -1,0 +1,95 @@
+"""csrc/conv1x1_stream.hip on the GPU: the 1x1 layers of the late ResNet blocks (slim resnet_v2.bottleneck conv1 / shortcut, src/models.py:65-75)
+as one MFMA stream per SIMD with both operands in LDS rings (hmmr_conv_desc_t.k_order = 2 with a 1x1 filter, tiles 22 .. 25)."""
+import zlib
+
+import numpy as np
+import pytest
+
+from human_dynamics_amd import _lib as L
+from test_gpu_f16x3 import _split_round, _split_round_w
+from test_gpu_kernels import _ref_conv
+
+pytestmark = pytest.mark.gpu
+X3 = L.HMMR_F16X3
+
+CASES = [
+    # name, n, h, w, cin, cout, n_split
+    ("b4_conv1_1024", 3, 7, 7, 1024, 512, 0),          # 147 pixels: one ragged tile
+    ("b4_conv1_2048", 11, 7, 7, 2048, 512, 0),         # 539 pixels: 3 tiles of 224, K = 128 steps
+    ("b31_sc_c1", 2, 14, 14, 512, 1280, 1024),         # shortcut + conv1 of block3/unit_1 as one launch: 10 N tiles, split after 8
+    ("short_k", 1, 5, 7, 128, 128, 0),                 # 8 K steps (cin is a power of two: 6 + 2 for the 6-deep rings), 35 pixels
+    ("k_not_a_group", 5, 14, 14, 256, 256, 128),       # 16 K steps: 6 + 6 + 4, the last group of the unrolled loop is cut short
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv1x1_stream_kernel(case, gpu_device):
+    """Against a float64 convolution of the same 16-bit operands (2e-5 of the largest value, the bound of every split kernel's test) and
+    against hmmr_conv_gemm's 8-wave tiles (another accumulation order); the four tile shapes agree bit for bit, with and without ReLU, and
+    the column split writes each range with its own ReLU flag."""
+    from human_dynamics_amd.engine import conv_gemm
+    name, n, h, w_, cin, cout, n_split = case
+    rng = np.random.default_rng(zlib.crc32(name.encode()) % 1000)
+    x = rng.normal(size=(n, h, w_, cin)).astype(np.float32)
+    w = (rng.normal(size=(1, 1, cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.normal(size=cout).astype(np.float32)
+    for relu in (True, False):
+        kw = dict(stride=1, pad=0, scale=scale, shift=shift, relu=relu, in_dtype=X3, out_dtype=X3, device=gpu_device)
+        if n_split:
+            kw.update(n_split=n_split, relu_b=not relu)
+        outs = {tile: conv_gemm(x, w, tile=tile, k_order=2, **kw) for tile in ((0, 22, 23, 24, 25) if relu else (0, 24))}
+        ref, _ = _ref_conv(_split_round(x), _split_round_w(w), 1, 0, scale, shift, None, False, None, None, 1)
+        mag = max(1.0, np.abs(ref).max())
+        if n_split:
+            refs = (np.maximum(ref[..., :n_split], 0) if relu else ref[..., :n_split],
+                    np.maximum(ref[..., n_split:], 0) if not relu else ref[..., n_split:])
+        else:
+            refs = (np.maximum(ref, 0) if relu else ref,)
+        for tile, out in outs.items():
+            for part, (o, r) in enumerate(zip(out, refs)):
+                assert o.shape == r.shape
+                assert np.abs(o - r).max() < 2e-5 * mag, "%s tile %d part %d" % (name, tile, part)
+                assert np.array_equal(o, outs[0][part]), "%s: tile %d differs from the library's choice" % (name, tile)
+        other = conv_gemm(x, w, tile=0, k_order=0, **kw)
+        for o, r in zip(outs[0], other):
+            if r is not None:
+                assert np.abs(o - r).max() < 2e-5 * mag
+
+
+def test_conv1x1_stream_kernel_saturation_flag(gpu_device):
+    """Values beyond the fp16 range are clamped where they are split and raise the sticky run flag, as in every split kernel."""
+    from human_dynamics_amd.engine import conv_gemm
+    lib = L.load()
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=(1, 7, 7, 128)).astype(np.float32)
+    w = (rng.normal(size=(1, 1, 128, 128)) / np.sqrt(128)).astype(np.float32)
+    import ctypes as C
+    fl = C.c_uint(0)
+    L.check(lib.hmmr_run_flags(C.byref(fl), 1), "hmmr_run_flags")
+    kw = dict(stride=1, pad=0, shift=np.zeros(128, np.float32), in_dtype=X3, out_dtype=X3, device=gpu_device, k_order=2)
+    out, _ = conv_gemm(x, w, scale=np.ones(128, np.float32), **kw)
+    L.check(lib.hmmr_run_flags(C.byref(fl), 1), "hmmr_run_flags")
+    assert fl.value == 0 and np.abs(out).max() < 100
+    out, _ = conv_gemm(x, w, scale=np.full(128, 1e6, np.float32), **kw)
+    L.check(lib.hmmr_run_flags(C.byref(fl), 1), "hmmr_run_flags")
+    assert fl.value & 1 and np.abs(out).max() == 65504.0
+
+
+def test_conv1x1_stream_kernel_refuses_what_it_is_not_built_for(gpu_device):
+    from human_dynamics_amd.engine import conv_gemm
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(2, 7, 7, 256)).astype(np.float32)
+    w = rng.normal(size=(1, 1, 256, 256)).astype(np.float32)
+    ok = dict(stride=1, pad=0, shift=np.zeros(256, np.float32), in_dtype=X3, out_dtype=X3, device=gpu_device, k_order=2)
+    conv_gemm(x, w, **ok)
+    for bad in (dict(stride=2), dict(res=np.zeros((2, 7, 7, 256), np.float32)), dict(tile=5), dict(tile=12),
+                dict(scale2=np.ones(256, np.float32), shift2=np.zeros(256, np.float32)),
+                dict(pro=(np.ones(256, np.float32), np.zeros(256, np.float32))), dict(n_split=64)):
+        with pytest.raises(L.HmmrError):
+            conv_gemm(x, w, **dict(ok, **bad))
+    conv_gemm(x[..., :64], w[:, :, :64], **ok)                   # 4 K steps: the library's choice is the tile with rings 4 deep
+    with pytest.raises(L.HmmrError, match="at least"):          # ... which a tile with 6-deep rings refuses
+        conv_gemm(x[..., :64], w[:, :, :64], **dict(ok, tile=22))
+    with pytest.raises(L.HmmrError, match="at least"):          # fewer K steps than any ring is deep
+        conv_gemm(x[..., :32], w[:, :, :32], **ok)
