@@ -41,7 +41,12 @@ struct S1Args {
     void* out; int ldo, relu;               // N tiles [0, split_tiles)
     void* out_b; int ldo_b, relu_b;         // N tiles [split_tiles, tiles_n): channel n - 128 split_tiles
     int split_tiles;
-    int M, C, nk;                           // nk = C / 16 K steps
+    // the conv3 form (EPI = 1): a second operand source along K (K steps nk1 .. nk - 1 are in2's rows of C2 channels), a shortcut added
+    // before the split (rows of ldo elements, like out), and the next unit's pre-activation of the stored value as a second output
+    const char* in2; int C2, nk1;
+    const char* res;
+    void* out2; const float* scale2; const float* shift2;
+    int M, C, nk;                           // nk = (C + C2) / 16 K steps
     int tiles_n, n_tiles;
     long long nt_stride;                    // bytes of one 128-channel tile of the stream: nk x 8 KB
 };
@@ -74,8 +79,12 @@ template <typename F, int... S> __device__ __forceinline__ void s1_group(F&& f, 
     ((kt0 + S < nk ? f(s1_ic<S>{}, kt0 + S) : (void)0), ...);
 }
 
+template <typename F, int... Bs> __device__ __forceinline__ void s1_blocks(F&& f, std::integer_sequence<int, Bs...>) { (f(s1_ic<Bs>{}), ...); }
+
 // FM x FN accumulators per wave, WGM x WGN waves: the tile is 32 WGM FM pixels x 128 channels; D: ring depth of both operands
-template <int FM, int FN, int WGM, int WGN, int D>
+// EPI 0: scale / shift / relu, column split.  EPI 1: conv3 of a bottleneck unit -- IN2: the folded shortcut's operand, RES: the shortcut tensor,
+// OUT2: the next unit's pre-activation
+template <int FM, int FN, int WGM, int WGN, int D, int EPI = 0, bool IN2 = false, bool RES = false, bool OUT2 = false>
 __global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const S1Args a) {
     constexpr int NB = WGN * FN;                                // row blocks of 32 output channels per tile
     static_assert(WGM * WGN == 4 && NB == 4 && FM * FN <= 16 && D >= 4 && D <= 6 && D % 2 == 0, "4 waves, 128 channels, at most 16 accumulators");
@@ -85,9 +94,10 @@ __global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const S1Args a) 
     constexpr int SLAB = NB * 2048, RING = D * SLAB;
     constexpr int RW = NB / 2;                                  // 1 KB pieces of a filter slab each wave moves
     constexpr int P = RW + NPX;                                 // requests per wave and stage
-    constexpr int CST = RING + D * XSLAB;                       // this tile's folded BN constants
+    constexpr int CST = RING + D * XSLAB;                       // this tile's folded BN constants (EPI 1: 2 KB, scale2 / shift2 behind them)
+    static_assert(EPI == 0 || (FN == 2 && !(IN2 && RES)), "the conv3 form is built for the 2 x 2 wave arrangements");
     constexpr int NR = 2 * (FM + FN), NG = 3 * FM * FN;         // fragment reads and MFMAs (= gaps) of a step
-    static_assert(RING + D * XSLAB + 1024 <= 160 * 1024, "LDS");
+    static_assert(RING + D * XSLAB + 2048 <= 160 * 1024, "LDS");
     static_assert(D * P < 64, "vmcnt");
     static_assert(2048 * (FM - 1) + 16 < 65536 && (D - 1) * SLAB + 3 * 2048 + 1024 < 65536, "instruction offsets");
     static_assert(NR <= NG - 4 && NPX + 2 <= NG, "one fragment read and one request per gap");
@@ -105,9 +115,11 @@ __global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const S1Args a) 
 
     // ---- this tile's folded BN constants (128 scales, 128 shifts): loaded before any DMA request is in flight, stored behind the rings
     const float cv = tid < 128 ? a.scale[nt * 128 + tid] : a.shift[nt * 128 + tid - 128];
+    float cv2 = 0.f;
+    if constexpr (OUT2) cv2 = tid < 128 ? a.scale2[nt * 128 + tid] : a.shift2[nt * 128 + tid - 128];
 
     // ---- pixel DMA: piece q of this wave = rows 64 q + 16 wave .. + 15 of the slab, four lanes per row; rows beyond M read the last pixel
-    unsigned poff[NPX];
+    unsigned poff[NPX], poff2[IN2 ? NPX : 1];
 #pragma unroll
     for (int q = 0; q < NPX; ++q) {
         const int r = 64 * q + 16 * wave + (lane >> 2);
@@ -115,15 +127,19 @@ __global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const S1Args a) 
         px = px >= a.M ? a.M - 1 : px;
         poff[q] = (unsigned)px * (unsigned)(a.C * 4) + ((((unsigned)lane & 3u) ^ (((unsigned)r >> 2) & 3u)) << 4);
         if (S1_PROBE(32)) poff[q] = (unsigned)(m0 + 64 * q + 16 * wave) * (unsigned)(a.C * 4) + lane * 16;       // (probe: a coalesced KB of the wrong bytes)
+        if constexpr (IN2) poff2[q] = (unsigned)px * (unsigned)(a.C2 * 4) + ((((unsigned)lane & 3u) ^ (((unsigned)r >> 2) & 3u)) << 4);
     }
     auto x_base = [&](int s) {                                  // K step s of pixel 0: a uniform address the compiler keeps in scalar registers
         unsigned long long ub = (unsigned long long)a.in + (unsigned long long)(s * 64);      // (so that a piece is base + 32-bit lane offset)
+        if constexpr (IN2) { if (s >= a.nk1) ub = (unsigned long long)a.in2 + (unsigned long long)((s - a.nk1) * 64); }
         asm volatile("" : "+s"(ub));
         return (const char*)ub;
     };
-    auto x_piece = [&](int q, const char* xb, int slot) {       // q, slot are constants after unrolling
+    auto x_piece = [&](int q, const char* xb, int slot, bool first) {      // q, slot are constants after unrolling; first: the step reads `in`
         char* dst = smem + RING + slot * XSLAB + q * 4096 + wave * 1024;
-        __builtin_amdgcn_global_load_lds((gptr_t)(xb + poff[q]), (lptr_t)dst, 16, 0, 0);
+        unsigned off = poff[q];
+        if constexpr (IN2) off = first ? poff[q] : poff2[q];
+        __builtin_amdgcn_global_load_lds((gptr_t)(xb + off), (lptr_t)dst, 16, 0, 0);
     };
     // ---- filter stream: K step s -> ring slot s % D; each wave moves a quarter (one row block, hi and lo plane)
     const char* gw = a.wstream + (long long)nt * a.nt_stride + wave * (RW * 1024) + lane * 16;
@@ -139,10 +155,11 @@ __global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const S1Args a) 
         ring_dma(s_, s_);
         const char* xb = x_base(s_);
 #pragma unroll
-        for (int q = 0; q < NPX; ++q) x_piece(q, xb, s_);
+        for (int q = 0; q < NPX; ++q) x_piece(q, xb, s_, !IN2 || s_ < a.nk1);
     }
     __builtin_amdgcn_sched_barrier(0);
     ((float*)(smem + CST))[tid] = cv;
+    if constexpr (OUT2) ((float*)(smem + CST))[256 + tid] = cv2;
 
     f32x16 acc[FM][FN];
 #pragma unroll
@@ -207,6 +224,7 @@ __global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const S1Args a) 
         constexpr int S = decltype(s_c)::value, CUR = S & 1, NXT = CUR ^ 1, SNEXT = (S + 1) % D;
         const int sn = kt + D < nk ? kt + D : nk - 1;
         const char* xsrc = x_base(sn);
+        const bool xfirst = !IN2 || sn < a.nk1;
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -219,7 +237,7 @@ __global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const S1Args a) 
                     const int g = (3 * i + p) * FN + j;
                     if (g == 0 && !S1_PROBE(4)) ring_dma(sn, S);
                     if (g == 1) slot_setup(SNEXT);
-                    if (g >= 2 && g < 2 + NPX && !S1_PROBE(4) && !S1_PROBE(8)) x_piece(g - 2 < NPX ? g - 2 : 0, xsrc, S);
+                    if (g >= 2 && g < 2 + NPX && !S1_PROBE(4) && !S1_PROBE(8)) x_piece(g - 2 < NPX ? g - 2 : 0, xsrc, S, xfirst);
 #pragma unroll
                     for (int r = 0; r < NR; ++r)
                         if (2 + (r * (NG - 4)) / NR == g && !S1_PROBE(2)) read_one(NXT, r, SNEXT);
@@ -239,6 +257,129 @@ __global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const S1Args a) 
     s1_wait<0>();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+
+
+    if constexpr (EPI == 1) {
+        // ---- the conv3 epilogue: bias (folded row scale), + the shortcut (its 32 x 32 blocks DMA'd two blocks ahead into wave-private LDS tiles
+        // with the staging tiles' swizzle, read back in the D layout), split -> out; the next unit's pre-activation of the STORED value
+        // (hi + lo as the consumer would read it: gemm_conv.hip's out2), ReLU, split -> out2.  Per wave: out staging 2 x 4 KB | out2
+        // staging 2 x 4 KB | shortcut tiles 5 x 4 KB, requested PD = 4 blocks ahead (one wave per SIMD: a block's arithmetic is 0.5 us, a
+        // request's round trip 2 us, and nothing else runs meanwhile).  Vector-memory order per block b: [shortcut b + PD] wait(b) ... [stores of b]
+        constexpr int B = FM * FN, NST = OUT2 ? 8 : 4, PD = 4, RT = PD + 1;
+        char* wv = smem + wave * 36864;
+        static_assert(4 * 36864 <= RING + D * XSLAB, "the epilogue's tiles live in the idle rings");
+        const int rsub = lane >> 3, pslot = lane & 7, sw = (lr >> 1) & 7;
+        const int nb = nt * 128 + wn * FN * 32;
+        const float lo_clamp = a.relu ? 0.f : -HMMR_SPLIT_MAX;
+        // byte offset of this lane's 16-byte slot of row 8 q + rsub of row block i (out, out2 and the shortcut share the row stride); rows
+        // beyond M: the last row for loads, the dump for stores
+        auto row_off = [&](int i, int q, bool& valid) {
+            const int r = 8 * q + rsub;
+            int m = m0 + (wm * FM + i) * 32 + r;
+            valid = m < a.M;
+            m = valid ? m : a.M - 1;
+            return ((unsigned)m * (unsigned)a.ldo + (unsigned)(nb + (pslot ^ ((r >> 1) & 7)) * 4)) * 4u;
+        };
+        auto res_dma = [&](int b) {                             // b is a constant after unrolling
+            const int i = b / FN, j = b % FN;
+            char* dst = wv + 16384 + (b % RT) * 4096;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                bool valid;
+                const unsigned off = row_off(i, q, valid);
+                __builtin_amdgcn_global_load_lds((gptr_t)(a.res + off + j * 128), (lptr_t)(dst + q * 1024), 16, 0, 0);
+            }
+        };
+        f32x4 s4[FN][4], b4[FN][4], s2[OUT2 ? FN : 1][4], b2[OUT2 ? FN : 1][4];
+        {
+            const float* cst = (const float*)(smem + CST) + wn * FN * 32 + 4 * lh;
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    s4[j][g] = *(const f32x4*)(cst + j * 32 + 8 * g);
+                    b4[j][g] = *(const f32x4*)(cst + 128 + j * 32 + 8 * g);
+                    if constexpr (OUT2) {
+                        s2[j][g] = *(const f32x4*)(cst + 256 + j * 32 + 8 * g);
+                        b2[j][g] = *(const f32x4*)(cst + 384 + j * 32 + 8 * g);
+                    }
+                }
+        }
+        asm volatile("" ::: "memory");
+        if constexpr (RES) s1_blocks([&](auto b_c) { res_dma(decltype(b_c)::value); }, std::make_integer_sequence<int, (PD < B ? PD : B)>{});
+        float satmax = 0.f;
+        auto block = [&](auto b_c) {
+            constexpr int b = decltype(b_c)::value, i = b / FN, j = b % FN;
+            if constexpr (RES) {
+                asm volatile("" ::: "memory");
+                if constexpr (b + PD < B) res_dma(b + PD);
+                // younger than shortcut block b: the shortcut blocks b + 1 .. b + PD and the stores of blocks b - PD .. b - 1
+                constexpr int ahead = (B - 1 - b) < PD ? (B - 1 - b) : PD, behind = b < PD ? b : PD;
+                s1_wait<4 * ahead + NST * behind>();
+                asm volatile("" ::: "memory");
+            }
+            char* to = wv + (b & 1) * 4096;
+            char* t2 = wv + 8192 + (b & 1) * 4096;
+            const char* rt = wv + 16384 + (b % RT) * 4096;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const unsigned oh_ = lr * 128 + (((2 * g) ^ sw) << 4) + 8 * lh, ol_ = lr * 128 + (((2 * g + 1) ^ sw) << 4) + 8 * lh;
+                float c[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) c[e] = fmaf(acc[i][j][4 * g + e], s4[j][g][e], b4[j][g][e]);
+                if constexpr (RES) {
+                    const unsigned long long rh = *(const unsigned long long*)(rt + oh_), rl = *(const unsigned long long*)(rt + ol_);
+                    c[0] += split_sum_lo((unsigned)rh, (unsigned)rl);
+                    c[1] += split_sum_hi((unsigned)rh, (unsigned)rl);
+                    c[2] += split_sum_lo((unsigned)(rh >> 32), (unsigned)(rl >> 32));
+                    c[3] += split_sum_hi((unsigned)(rh >> 32), (unsigned)(rl >> 32));
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    satmax = __builtin_fmaxf(satmax, __builtin_fabsf(c[e]));
+                    c[e] = __builtin_amdgcn_fmed3f(c[e], lo_clamp, HMMR_SPLIT_MAX);
+                }
+                unsigned h01, l01, h23, l23;
+                split2_mix(c[0], c[1], h01, l01);
+                split2_mix(c[2], c[3], h23, l23);
+                *(unsigned long long*)(to + oh_) = (unsigned long long)h01 | ((unsigned long long)h23 << 32);
+                *(unsigned long long*)(to + ol_) = (unsigned long long)l01 | ((unsigned long long)l23 << 32);
+                if constexpr (OUT2) {
+                    float u[4];
+                    u[0] = fmaf(split_sum_lo(h01, l01), s2[j][g][0], b2[j][g][0]);
+                    u[1] = fmaf(split_sum_hi(h01, l01), s2[j][g][1], b2[j][g][1]);
+                    u[2] = fmaf(split_sum_lo(h23, l23), s2[j][g][2], b2[j][g][2]);
+                    u[3] = fmaf(split_sum_hi(h23, l23), s2[j][g][3], b2[j][g][3]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        satmax = __builtin_fmaxf(satmax, u[e]);
+                        u[e] = __builtin_amdgcn_fmed3f(u[e], 0.f, HMMR_SPLIT_MAX);
+                    }
+                    unsigned p01, q01, p23, q23;
+                    split2_mix(u[0], u[1], p01, q01);
+                    split2_mix(u[2], u[3], p23, q23);
+                    *(unsigned long long*)(t2 + oh_) = (unsigned long long)p01 | ((unsigned long long)p23 << 32);
+                    *(unsigned long long*)(t2 + ol_) = (unsigned long long)q01 | ((unsigned long long)q23 << 32);
+                }
+            }
+            u32x4 xr[4], x2[OUT2 ? 4 : 1];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                xr[q] = *(const u32x4*)(to + q * 1024 + lane * 16);
+                if constexpr (OUT2) x2[q] = *(const u32x4*)(t2 + q * 1024 + lane * 16);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                bool valid;
+                const unsigned off = row_off(i, q, valid);
+                *(u32x4*)(valid ? (char*)a.out + off + j * 128 : (char*)g_s1_dump + lane * 16) = xr[q];
+                if constexpr (OUT2) *(u32x4*)(valid ? (char*)a.out2 + off + j * 128 : (char*)g_s1_dump + lane * 16) = x2[q];
+            }
+        };
+        s1_blocks(block, std::make_integer_sequence<int, B>{});
+        split_flag(satmax > HMMR_SPLIT_MAX);
+        return;
+    }
 
     // ---- epilogue: D layout (lane = pixel, 4 consecutive channels per register group) -> folded BN, ReLU, split -> this wave's
     // staging tiles (rows of 128 B, slot XOR-swizzled by (row >> 1) & 7; the rings are idle) -> 16-byte row stores
@@ -303,14 +444,14 @@ __global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const S1Args a) 
     split_flag(satmax > HMMR_SPLIT_MAX);
 }
 
-template <int FM, int FN, int WGM, int WGN, int D>
+template <int FM, int FN, int WGM, int WGN, int D, int EPI = 0, bool IN2 = false, bool RES = false, bool OUT2 = false>
 int launch_s1(const S1Args& base, hipStream_t stream) {
     S1Args a = base;
     constexpr int BM = 32 * WGM * FM, NPX = (BM + 63) / 64;
-    constexpr int lds = D * 8192 + D * NPX * 4096 + 1024;
+    constexpr int lds = D * 8192 + D * NPX * 4096 + 2048;
     HMMR_REQUIRE(a.nk >= D, "hmmr_conv_gemm: k_order 2 (1x1): cin must be at least %d channels for this tile", 16 * D);
     a.n_tiles = ((a.M + BM - 1) / BM) * a.tiles_n;
-    auto kern = conv1x1_stream_kernel<FM, FN, WGM, WGN, D>;
+    auto kern = conv1x1_stream_kernel<FM, FN, WGM, WGN, D, EPI, IN2, RES, OUT2>;
     static DeviceOnce once;
     if (const unsigned long long bit = once.due()) {
         HMMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -319,6 +460,14 @@ int launch_s1(const S1Args& base, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3((unsigned)a.n_tiles), dim3(256), lds, stream, a);
     HMMR_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+// the conv3 form of a tile shape: which of in2 / res / out2 the launch has picks the instantiation
+template <int FM, int FN, int WGM, int WGN, int D>
+int launch_s1_c3(const S1Args& a, hipStream_t stream) {
+    if (a.in2) return a.out2 ? launch_s1<FM, FN, WGM, WGN, D, 1, true, false, true>(a, stream) : launch_s1<FM, FN, WGM, WGN, D, 1, true, false, false>(a, stream);
+    if (a.res) return a.out2 ? launch_s1<FM, FN, WGM, WGN, D, 1, false, true, true>(a, stream) : launch_s1<FM, FN, WGM, WGN, D, 1, false, true, false>(a, stream);
+    return a.out2 ? launch_s1<FM, FN, WGM, WGN, D, 1, false, false, true>(a, stream) : launch_s1<FM, FN, WGM, WGN, D, 0>(a, stream);
 }
 
 }  // namespace
@@ -334,12 +483,17 @@ int hmmr_conv1x1_stream(const hmmr_conv_desc_t* d, hipStream_t stream) {
     HMMR_REQUIRE(d->in_dtype == HMMR_F16X3 && d->out_dtype == HMMR_F16X3, "hmmr_conv_gemm: k_order 2 with a 1x1 filter is built for split (f16x3) tensors");
     HMMR_REQUIRE(d->kh == 1 && d->kw == 1 && d->sy == 1 && d->sx == 1 && d->py == 0 && d->px == 0 && d->ho == d->hin && d->wo == d->win &&
                  d->in_px_stride == d->cin && d->in_row_stride == d->win * d->cin && d->in_img_stride == (int64_t)d->hin * d->win * d->cin &&
-                 d->cin % 16 == 0 && d->cout % 128 == 0 && d->scale && d->shift && d->out &&
-                 !d->res && !d->out2 && !d->pro_scale && !d->in2 && d->split_k <= 1 && d->batch <= 1,
+                 d->cin % 16 == 0 && d->cout % 128 == 0 && d->scale && d->shift && d->out && !d->pro_scale && d->split_k <= 1 && d->batch <= 1,
                  "hmmr_conv_gemm: k_order 2 (1x1) is for stride-1 1x1 convolutions over a dense [M][cin] tensor, cin %% 16 == 0, cout %% 128 == 0, "
-                 "with a scale / shift / relu epilogue (and the out_b column split): no res, out2, pro_scale, in2, split_k, batch");
+                 "scale, shift and out given: no pro_scale, split_k, batch");
+    const bool c3 = d->res || d->out2 || d->in2;               // the conv3 form
+    HMMR_REQUIRE(!c3 || (!d->out_b && !(d->res && d->in2) && (!d->res || (!d->res_strided && d->ldr == d->ldo)) && (!d->in2 || (d->cin2 > 0 && d->cin2 % 16 == 0)) &&
+                         (!d->out2 || (d->scale2 && d->shift2)) && d->ldo % 32 == 0),
+                 "hmmr_conv_gemm: k_order 2 (1x1) with res / out2 / in2 (the conv3 form): no out_b, not res and in2 together, res dense with ldr == ldo, "
+                 "cin2 %% 16 == 0, scale2 + shift2 with out2");
     HMMR_REQUIRE(!d->out_b || (d->n_split % 128 == 0 && d->n_split > 0 && d->n_split < d->cout), "hmmr_conv_gemm: k_order 2 (1x1): n_split must be a multiple of 128 inside (0, cout)");
-    HMMR_REQUIRE(M * d->cin * 4 < (1ll << 32), "hmmr_conv_gemm: k_order 2 (1x1): the input tensor must stay below 4 GB (32-bit row offsets)");
+    HMMR_REQUIRE(M * d->cin * 4 < (1ll << 32) && M * (d->in2 ? d->cin2 : 0) * 4 < (1ll << 32) && (!c3 || M * d->ldo * 4 < (1ll << 32)),
+                 "hmmr_conv_gemm: k_order 2 (1x1): the tensors must stay below 4 GB (32-bit row offsets)");
     if (M <= 0) return 0;
     S1Args a = {};
     a.in = (const char*)d->in; a.wstream = (const char*)d->w; a.scale = d->scale; a.shift = d->shift;
@@ -347,7 +501,10 @@ int hmmr_conv1x1_stream(const hmmr_conv_desc_t* d, hipStream_t stream) {
     a.tiles_n = d->cout / 128;
     a.split_tiles = d->out_b ? d->n_split / 128 : a.tiles_n;
     a.out_b = d->out_b; a.ldo_b = d->ldo_b; a.relu_b = d->relu_b;
-    a.M = (int)M; a.C = d->cin; a.nk = d->cin / 16;
+    a.M = (int)M; a.C = d->cin; a.nk1 = d->cin / 16;
+    a.in2 = (const char*)d->in2; a.C2 = d->in2 ? d->cin2 : 0;
+    a.nk = a.nk1 + a.C2 / 16;
+    a.res = (const char*)d->res; a.out2 = d->out2; a.scale2 = d->scale2; a.shift2 = d->shift2;
     a.nt_stride = (long long)a.nk * 8192;
     int tile = d->tile;
     if (!tile) {
@@ -357,13 +514,17 @@ int hmmr_conv1x1_stream(const hmmr_conv_desc_t* d, hipStream_t stream) {
         const long long rbs = (M + 31) / 32;
         double best = 0;
         for (const auto& cd : cand) {
-            if (a.nk < cd[2]) continue;
+            if (a.nk < cd[2] || (c3 && cd[0] != 24 && cd[0] != 25)) continue;
             const long long tiles = ((rbs + cd[1] - 1) / cd[1]) * a.tiles_n;
             const double cost = (double)((tiles + 255) / 256) * (cd[1] + 1.5) * (cd[0] == 22 || cd[0] == 23 ? 1.15 : 1.0);
             if (!tile || cost < best) { tile = cd[0]; best = cost; }
         }
     }
     HMMR_REQUIRE(tile, "hmmr_conv_gemm: k_order 2 (1x1): cin must be at least 64 channels (the rings are 4 K steps deep)");
+    if (c3) {
+        HMMR_REQUIRE(tile == 24 || tile == 25, "hmmr_conv_gemm: k_order 2 (1x1): the conv3 form (res / out2 / in2) runs tiles 24 / 25, not %d", tile);
+        return tile == 24 ? launch_s1_c3<7, 2, 2, 2, 4>(a, stream) : launch_s1_c3<4, 2, 2, 2, 6>(a, stream);
+    }
     switch (tile) {
     case 22: return launch_s1<7, 1, 1, 4, 6>(a, stream);       // 224 pixels, every wave all of them and 32 of the 128 channels
     case 23: return launch_s1<8, 1, 1, 4, 6>(a, stream);       // 256 pixels, likewise

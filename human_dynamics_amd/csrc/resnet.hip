@@ -359,7 +359,8 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
         d.n_img = n; d.hin = Ho; d.win = Ho; d.cin = U.base;
         d.in_img_stride = (int64_t)Ho * Ho * U.base; d.in_row_stride = Ho * U.base; d.in_px_stride = U.base;
         d.kh = d.kw = 1; d.sy = d.sx = 1; d.ho = d.wo = Ho; d.cout = U.depth; d.ldo = U.depth;
-        if (sc_in_c3) { d.w = U.c3sc.w; d.scale = U.c3sc.scale; d.shift = U.c3sc.shift; d.tile = U.c3sc.tile; d.in2 = xin; d.cin2 = U.c_in; }
+        d.k_order = U.conv3.k_order;         // (2: the conv3 form of csrc/conv1x1_stream.hip, block 4)
+        if (sc_in_c3) { d.w = U.c3sc.w; d.scale = U.c3sc.scale; d.shift = U.c3sc.shift; d.tile = U.c3sc.tile; d.k_order = U.c3sc.k_order; d.in2 = xin; d.cin2 = U.c_in; }
         else if (U.shortcut.w) { d.res = xn; d.ldr = U.depth; }
         else if (U.stride == 1) { d.res = X[cur]; d.ldr = U.depth; }
         else {                        // max_pool2d(x, [1,1], stride) = x[:, ::s, ::s] of the RAW input

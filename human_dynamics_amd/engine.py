@@ -227,13 +227,15 @@ class HmmrEngine(object):
         return getattr(U, nm)
 
     @staticmethod
-    def _tile_for(lay, cand, cout, dtype=None, one=False):
+    def _tile_for(lay, cand, cout, dtype=None, nm="conv2"):
         """hmmr_layer_t.tile for candidate `cand` on a layer with `cout` output columns: 0 (the library's choice) where
         the tile does not fit; a layer packed chunk-major (k_order 1, the 3x3 patch kernels) runs tiles 9 / 10, the patch
         forms of 7 / 8, or 11, the 256x128 tile without a load segment; a k_order 2 layer (csrc/conv3x3_stream.hip) takes the
-        tuner's candidates as its own tile shapes 13 .. 18; a k_order 2 layer with a 1x1 filter (`one`; csrc/conv1x1_stream.hip) tiles 22 .. 25."""
-        if lay.k_order == 2 and one:
-            return {5: 22, 6: 23, 3: 24, 1: 25}.get(cand, cand if 22 <= cand <= 25 else 0)
+        tuner's candidates as its own tile shapes 13 .. 18; a k_order 2 layer with a 1x1 filter (any layer name but conv2; csrc/conv1x1_stream.hip)
+        tiles 22 .. 25, its conv3 form 24 / 25."""
+        if lay.k_order == 2 and nm != "conv2":
+            t = {5: 22, 6: 23, 3: 24, 1: 25}.get(cand, cand if 22 <= cand <= 25 else 0)
+            return 0 if (nm == "conv3" and t in (22, 23)) else t
         if lay.k_order == 2:                                 # the stream kernel's tiles: 12 .. 18 and 21 (128-channel tiles), 19 / 20 (64 channels)
             if cout == 64:
                 return {5: 19, 6: 20}.get(cand, cand if cand in (19, 20) else 0)
@@ -256,7 +258,7 @@ class HmmrEngine(object):
 
     def _set_tiles(self, table):
         for (u, nm), t in table.items():
-            self._layer_of(u, nm).tile = self._tile_for(self._layer_of(u, nm), int(t), self._layer_cout(u, nm), self.dtype, nm != "conv2")
+            self._layer_of(u, nm).tile = self._tile_for(self._layer_of(u, nm), int(t), self._layer_cout(u, nm), self.dtype, nm)
 
     def _needs_tuning(self, nt):
         """A tuning pass is due for batch size nt: tuning is on, the size is worth it, it has no table of its own and (unless
@@ -286,7 +288,7 @@ class HmmrEngine(object):
         for cand in (0,) + self._TUNE_TILES:
             for slot, u, nm in layers:
                 lay = self._layer_of(u, nm)
-                lay.tile = self._tile_for(lay, cand, self._layer_cout(u, nm), self.dtype, nm != "conv2")
+                lay.tile = self._tile_for(lay, cand, self._layer_cout(u, nm), self.dtype, nm)
             t = None
             for rep in range(reps):
                 pm = (C.c_float * L.RESNET_PROF_SLOTS)()

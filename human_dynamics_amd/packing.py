@@ -346,7 +346,8 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
     stem_conv1 (f16x3; default on, round 5): block1/unit_1's conv1 is computed by the fused stem kernel on its pooled tile (hmmr_resnet_unit_t.
     conv1_frag); bf16 does that since round 1 (hmmr_debug_t.stem_no_conv1 switches either off at run time).  Same bits as the launch.
     stream_1x1 (f16x3; default on, round 5): the conv1 of block 4's units and of block2/unit_1, and block3/unit_1's shortcut + conv1 launch run the two-ring
-    stream kernel of csrc/conv1x1_stream.hip (hmmr_layer_t.k_order = 2 on a 1x1 layer); the kernel takes the pre-activated tensor, so
+    stream kernel of csrc/conv1x1_stream.hip (hmmr_layer_t.k_order = 2 on a 1x1 layer), and so does block 4's conv3 (with its shortcut add, folded
+    shortcut and second output); the kernel takes the pre-activated tensor, so
     block4/unit_2 and unit_3 read the one their predecessor's conv3 writes (fuse_preact = 0) instead of applying it while staging.
     unit_pair (f16x3 only; True | "block2" | "block3" | False): the stride-1 units of blocks 2-3 run conv3 + add + the next
     unit's preact + conv1 as the register-resident unit pair of csrc/unit_pair.hip (one filter stream per unit); block3/unit_1
@@ -404,8 +405,12 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
         else:
             u.conv2 = _layer(store, pack_conv_weight(w[scope + "/conv2/weights"], kord, chunk=bke), dtype, s, b)
             u.conv2.k_order = kord
-        u.conv3 = _layer(store, pack_conv_weight(w[scope + "/conv3/weights"]), dtype,
-                         shift=w[scope + "/conv3/biases"])
+        s3x = s1x1 and base == 512                   # block 4's conv3 in the conv3 form of the same kernel (shortcut add, the next pre-activation)
+        if s3x:
+            u.conv3 = _layer_stream1x1(store, w[scope + "/conv3/weights"], None, w[scope + "/conv3/biases"])
+        else:
+            u.conv3 = _layer(store, pack_conv_weight(w[scope + "/conv3/weights"]), dtype,
+                             shift=w[scope + "/conv3/biases"])
         if has_sc:
             u.shortcut = _layer(store, pack_conv_weight(w[scope + "/shortcut/weights"]), dtype,
                                 shift=w[scope + "/shortcut/biases"])
@@ -418,7 +423,7 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
                 both = np.concatenate([w[scope + "/conv3/weights"], w[scope + "/shortcut/weights"]], axis=2)   # along K
                 bias = (np.asarray(w[scope + "/conv3/biases"], np.float64) +
                         np.asarray(w[scope + "/shortcut/biases"], np.float64)).astype(np.float32)
-                u.c3sc = _layer(store, pack_conv_weight(both), dtype, shift=bias)
+                u.c3sc = _layer_stream1x1(store, both, None, bias) if s3x else _layer(store, pack_conv_weight(both), dtype, shift=bias)
             if not folded and fuse_sc and stride == 1 and (c_in >= 512 or fuse_sc == "all"):   # measured: pays in blocks 3-4 only
                 # shortcut and conv1 read the same operand: one [depth + base][c_in] filter bank, conv1's columns
                 # after the shortcut's; scale 1 on the shortcut columns (fma(v, 1, b) == v + b exactly)

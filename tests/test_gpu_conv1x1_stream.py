@@ -83,9 +83,8 @@ def test_conv1x1_stream_kernel_refuses_what_it_is_not_built_for(gpu_device):
     w = rng.normal(size=(1, 1, 256, 256)).astype(np.float32)
     ok = dict(stride=1, pad=0, shift=np.zeros(256, np.float32), in_dtype=X3, out_dtype=X3, device=gpu_device, k_order=2)
     conv_gemm(x, w, **ok)
-    for bad in (dict(stride=2), dict(res=np.zeros((2, 7, 7, 256), np.float32)), dict(tile=5), dict(tile=12),
-                dict(scale2=np.ones(256, np.float32), shift2=np.zeros(256, np.float32)),
-                dict(pro=(np.ones(256, np.float32), np.zeros(256, np.float32))), dict(n_split=64)):
+    for bad in (dict(stride=2), dict(tile=5), dict(tile=12), dict(pro=(np.ones(256, np.float32), np.zeros(256, np.float32))), dict(n_split=64),
+                dict(res=np.zeros((2, 7, 7, 256), np.float32), tile=23), dict(res=np.zeros((2, 7, 7, 256), np.float32), n_split=128)):
         with pytest.raises(L.HmmrError):
             conv_gemm(x, w, **dict(ok, **bad))
     conv_gemm(x[..., :64], w[:, :, :64], **ok)                   # 4 K steps: the library's choice is the tile with rings 4 deep
@@ -93,3 +92,58 @@ def test_conv1x1_stream_kernel_refuses_what_it_is_not_built_for(gpu_device):
         conv_gemm(x[..., :64], w[:, :, :64], **dict(ok, tile=22))
     with pytest.raises(L.HmmrError, match="at least"):          # fewer K steps than any ring is deep
         conv_gemm(x[..., :32], w[:, :, :32], **ok)
+
+
+C3_CASES = [
+    # name, n, h, w, cin, cout, cin2, res, out2
+    ("b4_conv3_res_out2", 11, 7, 7, 512, 2048, 0, True, True),       # block4/unit_2: shortcut add + the next unit's pre-activation
+    ("b4_conv3_res", 5, 7, 7, 512, 2048, 0, True, False),            # block4/unit_3 (the last unit: no second output)
+    ("b4_conv3_in2_out2", 6, 7, 7, 512, 2048, 1024, False, True),    # block4/unit_1: the shortcut folded into K ({h2, preact})
+    ("conv3_out2_only", 3, 14, 14, 256, 256, 0, False, True),
+    ("conv3_in2_only_ragged", 1, 5, 7, 128, 128, 64, False, False),
+]
+
+
+@pytest.mark.parametrize("case", C3_CASES, ids=[c[0] for c in C3_CASES])
+def test_conv1x1_stream_kernel_conv3_form(case, gpu_device):
+    """The conv3 form (hmmr_conv_desc_t.res / out2 / in2 with k_order 2 on a 1x1 filter): bias, + shortcut, split -> out; ReLU(BN(stored
+    value)) -> out2; a second operand source along K.  Against float64 on the same 16-bit operands and against the 8-wave tiles; the two
+    tile shapes agree bit for bit."""
+    from human_dynamics_amd.engine import conv_gemm
+    name, n, h, w_, cin, cout, cin2, has_res, has_out2 = case
+    rng = np.random.default_rng(zlib.crc32(name.encode()) % 1000)
+    x = rng.normal(size=(n, h, w_, cin)).astype(np.float32)
+    w = (rng.normal(size=(1, 1, cin, cout)) / np.sqrt(cin + cin2)).astype(np.float32)
+    shift = rng.normal(size=cout).astype(np.float32)
+    kw = dict(stride=1, pad=0, shift=shift, in_dtype=X3, out_dtype=X3, device=gpu_device)
+    xr, wr = _split_round(x), w
+    if cin2:
+        x2 = rng.normal(size=(n, h, w_, cin2)).astype(np.float32)
+        w2 = (rng.normal(size=(1, 1, cin2, cout)) / np.sqrt(cin + cin2)).astype(np.float32)
+        kw["second"] = (x2, w2)
+        xr, wr = np.concatenate([xr, _split_round(x2)], axis=3), np.concatenate([w, w2], axis=2)
+    res = None
+    if has_res:
+        res = (3.0 * rng.normal(size=(n, h, w_, cout))).astype(np.float32)
+        kw["res"] = res
+    s2 = b2 = None
+    if has_out2:
+        s2, b2 = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.normal(size=cout).astype(np.float32)
+        kw.update(scale2=s2, shift2=b2)
+    outs = {tile: conv_gemm(x, w, tile=tile, k_order=2, **kw) for tile in (0, 24, 25)}
+    ref, ref2 = _ref_conv(xr, _split_round_w(wr), 1, 0, None, shift, None if res is None else _split_round(res), False, s2, b2, 1)
+    mag = max(1.0, np.abs(ref).max())
+    other = conv_gemm(x, w, tile=0, k_order=0, **kw)
+    for tile, (o, o2) in outs.items():
+        assert np.abs(o - ref).max() < 2e-5 * mag, "%s tile %d" % (name, tile)
+        assert np.array_equal(o, outs[0][0])
+        assert np.abs(o - other[0]).max() < 2e-5 * mag
+        if has_out2:
+            assert np.abs(o2 - ref2).max() < 4e-5 * mag, "%s tile %d out2" % (name, tile)
+            assert np.array_equal(o2, outs[0][1])
+            assert np.abs(o2 - other[1]).max() < 4e-5 * mag
+        else:
+            assert o2 is None
+    for bad in (dict(tile=22), dict(n_split=64), dict(res_stride=2, res=np.zeros((n, 2 * h, 2 * w_, cout), np.float32))):
+        with pytest.raises(L.HmmrError):
+            conv_gemm(x, w, k_order=2, **dict(kw, **bad))

@@ -13,11 +13,14 @@ sys.path.insert(0, ".")
 from human_dynamics_amd import _lib as L
 from human_dynamics_amd import packing
 
-SHAPES = [  # name, h, cin, cout, n_split
+SHAPES = [  # name, h, cin, cout, n_split (or: "c3", cin2, res, out2 -- the conv3 form)
     ("4.1 c1", 7, 1024, 512, 0),
     ("4.2 c1", 7, 2048, 512, 0),
     ("3.1 sc+c1", 14, 512, 1280, 1024),
     ("2.1 c1", 28, 256, 128, 0),
+    ("4.1 c3", 7, 512, 2048, ("c3", 1024, False, True)),
+    ("4.2 c3", 7, 512, 2048, ("c3", 0, True, True)),
+    ("4.3 c3", 7, 512, 2048, ("c3", 0, True, False)),
 ]
 
 
@@ -29,8 +32,11 @@ def main():
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(0)
     for name, h, cin, cout, n_split in SHAPES:
+        c3 = n_split if isinstance(n_split, tuple) else None
+        n_split = 0 if c3 else n_split
+        cin2 = c3[1] if c3 else 0
         x = packing.to_split(torch.randn((n, h, h, cin), device=dev))
-        w = (rng.normal(size=(1, 1, cin, cout)) / np.sqrt(cin)).astype(np.float32)
+        w = (rng.normal(size=(1, 1, cin + cin2, cout)) / np.sqrt(cin + cin2)).astype(np.float32)
         if k_order == 2:
             wt = packing.pack_conv1x1_stream(w).to(dev)
         else:
@@ -49,7 +55,23 @@ def main():
         d.ho = d.wo = h; d.cout = cout; d.ldo = n_split or cout; d.k_order = k_order
         if n_split:
             d.out_b, d.ldo_b, d.n_split, d.relu_b = out_b.data_ptr(), cout - n_split, n_split, 1
-        flops = 2.0 * n * h * h * cin * cout
+        keep = []
+        if c3:
+            d.relu = 0
+            if cin2:
+                x2 = packing.to_split(torch.randn((n, h, h, cin2), device=dev))
+                d.in2, d.cin2 = x2.data_ptr(), cin2
+                keep.append(x2)
+            if c3[2]:
+                r = packing.to_split(torch.randn((n, h, h, cout), device=dev))
+                d.res, d.ldr = r.data_ptr(), cout
+                keep.append(r)
+            if c3[3]:
+                o2 = packing.empty_act((n, h, h, cout), L.HMMR_F16X3, dev)
+                s2 = torch.ones(cout, device=dev)
+                d.out2, d.scale2, d.shift2 = o2.data_ptr(), s2.data_ptr(), sh.data_ptr()
+                keep += [o2, s2]
+        flops = 2.0 * n * h * h * (cin + cin2) * cout
         for tile in tiles:
             d.tile = tile
             st = torch.cuda.current_stream(dev).cuda_stream
