@@ -358,7 +358,7 @@ def roofline_leg(tester, plan, span, dtype, frames):
     return {"bound": "mfma",
             "mfma_sustained": sustained,
             "kernel": "conv_gemm_kernel%s (ResNet-v2-50, %s operands: %d MFMA launches/pass, %d of them fused bottleneck units)"
-                      % ({"bf16": " / bottleneck_tail_kernel / stem_fused_kernel", "f16x3": " / conv3x3_stream_kernel / unit_pair_kernel / b1_unit_kernel / stem_fused_split_kernel"}.get(dtype, ""), dtype, n_conv, n_tails),
+                      % ({"bf16": " / bottleneck_tail_kernel / stem_fused_kernel", "f16x3": " / conv3x3_stream_kernel / conv1x1_stream_kernel / unit_pair_kernel / b1_unit_kernel / stem_fused_split_kernel"}.get(dtype, ""), dtype, n_conv, n_tails),
             "achieved": round(achieved / 1e12, 2), "peak": round(peak / 1e12, 1), "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4),
             # the other reading of the same measurement: algorithmic FLOP/s against the RAW dense bf16 / fp16 MFMA peak (2.5 PF),

@@ -44,7 +44,7 @@ def agg(root, tag, counter):
 def resnet_kernel(k, dtype):
     """The ResNet's MFMA launches of one operand mode (the IEF GEMMs of the same instantiation ride along: < 1 % of the bytes)."""
     if ("stem_fused" in k or "bottleneck_tail_kernel" in k or "tail_split_kernel" in k or "unit_pair_kernel" in k or "conv3x3_stream_kernel" in k
-            or "b1_unit_kernel" in k):
+            or "b1_unit_kernel" in k or "conv1x1_stream_kernel" in k):
         return True
     if "conv3x3_patch_kernel" in k or "conv3x3_pipe_kernel" in k:
         return ("bsplit_t" in k) == (dtype == "f16x3")
@@ -86,6 +86,7 @@ def main():
     for name, pred in (("conv_gemm_kernel", lambda k: "conv_gemm_kernel" in k and resnet_kernel(k, dtype)),
                        ("conv3x3_patch_kernel", lambda k: "conv3x3_patch_kernel" in k or "conv3x3_pipe_kernel" in k),
                        ("conv3x3_stream_kernel", lambda k: "conv3x3_stream_kernel" in k),
+                       ("conv1x1_stream_kernel", lambda k: "conv1x1_stream_kernel" in k),
                        ("fused_unit_tails", lambda k: "tail_split_kernel" in k or "bottleneck_tail_kernel" in k),
                        ("unit_pair_kernel", lambda k: "unit_pair_kernel" in k),
                        ("b1_unit_kernel", lambda k: "b1_unit_kernel" in k),
