@@ -365,19 +365,32 @@ __global__ __launch_bounds__(256, 2) void smpl_verts_mfma_kernel(
 // per coordinate as in the exact-fp32 form: a lane ends up with its vertex's blended position for 16 instances and runs the
 // (4-sparse, vector-unit) skinning sum unchanged.  Same 1-D, XCD-aware grid as smpl_verts_kernel.
 static constexpr int KCH = LDF / 16;     // 14 K chunks of 16 (rows >= 218 of the basis are zero)
+#ifndef SMPL_PROBE_BITS                  // development builds: drop the stores (1), the skinning sum (2), the matrix-core loop (4)
+#define SMPL_PROBE_BITS 0
+#endif
+#define SMPL_PROBE(bit) (((SMPL_PROBE_BITS) & (bit)) != 0)
 static constexpr float DIRS_SPLIT_SCALE = 8192.f, FEAT_SPLIT_SCALE = 256.f;
+// Round 5 (profiles/r05u: a launch without its stores / skinning sum / matrix loop is 14 / 10 / 35 us shorter, and 68 us of the 126-us call
+// remain when all three are gone): (i) a workgroup keeps its 32 instances' records and features in LDS and walks `vpw` vertex tiles, so
+// the 65-KB prologue is paid once per ~3 tiles instead of once per tile; (ii) the basis fragments are requested two K chunks ahead (three
+// register sets) -- one chunk ahead made the 14-step loop 14 L2 round trips;
+// (iii) a wave's 32 vertices x 8 instances go through a wave-private 3-KB LDS tile and leave as 16-byte stores of whole 384-byte rows
+// (one instance's 32 vertices) instead of 4-byte stores 12 bytes apart.  Same arithmetic per vertex: the same bits as before.
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));      // a record's vertex field is 4-byte aligned, no more
 __global__ __launch_bounds__(256, 2) void smpl_verts_split_kernel(
     const shalf8* __restrict__ dsplit, int vpad, const float* __restrict__ feat, const float* __restrict__ A,
-    const int* __restrict__ lbs_idx, const float* __restrict__ lbs_w, int nnz, int nv, int m,
+    const int* __restrict__ lbs_idx, const float* __restrict__ lbs_w, int nnz, int nv, int m, int vpw,
     float* __restrict__ verts, long long ld_verts, const RecMap rm) {
-    __shared__ __attribute__((aligned(16))) float smem[IBM * LDA + KCH * 2 * 2 * IBM * 4];
+    __shared__ __attribute__((aligned(16))) float smem[IBM * LDA + KCH * 2 * 2 * IBM * 4 + 4 * 768];
     float (*sA)[LDA] = (float (*)[LDA])smem;
     shalf8* sF = (shalf8*)(smem + IBM * LDA);                    // [kc][plane][k half][instance]: the A-operand fragments
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* stg = smem + IBM * LDA + KCH * 2 * 2 * IBM * 4 + wave * 768;      // this wave's [8 instances][32 vertices x 3] tile
     const int lc = lane & 31, lh = lane >> 5;
     const int nib = (m + IBM - 1) / IBM;
     const int L = xcd_remap(blockIdx.x, gridDim.x);
-    const int v = (L / nib) * VT + wave * 32 + lc;               // this lane's vertex = its column of D (v < vpad always)
+    const int vtiles = vpad / VT;
+    const int t0 = (L / nib) * vpw, t1 = t0 + vpw < vtiles ? t0 + vpw : vtiles;
     const int i0 = (L % nib) * IBM;
     for (int e = threadIdx.x; e < IBM * LDA; e += 256) {
         const int ii = e / LDA;
@@ -400,68 +413,108 @@ __global__ __launch_bounds__(256, 2) void smpl_verts_split_kernel(
         sF[((g8 >> 1) * 2 + 1) * 2 * IBM + (g8 & 1) * IBM + ii] = lo;
     }
     split_flag(sat);
-    f32x16 acc[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
-    // B fragments of chunk kc: [kc][c][plane][lh][vertex]
-    auto bptr = [&](int kc, int c, int pl) { return dsplit + ((long long)((kc * 3 + c) * 2 + pl) * 2 + lh) * vpad + v; };
-    shalf8 bh[2][3], bl[2][3];
-    auto fetch = [&](int kc, int set) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { bh[set][c] = *bptr(kc, c, 0); bl[set][c] = *bptr(kc, c, 1); }
-    };
-    fetch(0, 0);
-    __syncthreads();
-#pragma unroll
-    for (int kc = 0; kc < KCH; ++kc) {
-        if (kc + 1 < KCH) fetch(kc + 1, (kc + 1) & 1);
-        const shalf8 ah = sF[(kc * 2 + 0) * 2 * IBM + lh * IBM + lc], al = sF[(kc * 2 + 1) * 2 * IBM + lh * IBM + lc];
+    // B fragments of chunk kc: [kc][c][plane][lh][vertex]; this lane's vertex = its column of D (v < vpad always)
+    int v = t0 * VT + wave * 32 + lc;
+    constexpr int PF = 2;                                        // K chunks requested ahead (PF + 1 register sets of 24)
+    shalf8 bh[PF + 1][3], bl[PF + 1][3];
+    // (address = a uniform plane base + a 32-bit lane offset: the scalar unit walks the planes, a lane keeps ONE offset per tile)
+    const unsigned long long plane = (unsigned long long)(2 * vpad) * 16ull;
+    unsigned voff = 0;
+    auto fetch = [&](int kc, int set) {                          // kc, set are constants after unrolling
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            acc[c] = mfma_split(al, bh[kc & 1][c], acc[c]);
-            acc[c] = mfma_split(ah, bl[kc & 1][c], acc[c]);
-            acc[c] = mfma_split(ah, bh[kc & 1][c], acc[c]);
+            const char* ph = (const char*)dsplit + (unsigned long long)((kc * 3 + c) * 2 + 0) * plane;
+            const char* pl = (const char*)dsplit + (unsigned long long)((kc * 3 + c) * 2 + 1) * plane;
+            bh[set][c] = *(const shalf8*)(ph + voff);
+            bl[set][c] = *(const shalf8*)(pl + voff);
         }
-    }
-    if (v >= nv) return;
+    };
+    __syncthreads();
     constexpr float UNSCALE = 1.0f / (DIRS_SPLIT_SCALE * FEAT_SPLIT_SCALE);
-    // skinning, as in smpl_verts_kernel: the lane holds instances i0 + 8 g + 4 lh + {0..3} in accumulator rows 4 g .. 4 g + 3
-    const int* vidx = lbs_idx + (long long)v * nnz;
-    const float* vw = lbs_w + (long long)v * nnz;
+    for (int t = t0; t < t1; ++t) {
+        // (opaque per tile: as induction variables of this loop the 84 fragment addresses of a tile are 168 registers, and the feature
+        //  fragments hoisted out of it another 112)
+        asm volatile("" : "+v"(v) :: "memory");
+        voff = (unsigned)(lh * vpad + v) * 16u;
+        int lane_o = lane;                                       // (likewise: the 12 row addresses of a lane's stores are recomputed per tile, not kept)
+        asm volatile("" : "+v"(lane_o));
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int ib = 8 * g + 4 * lh;
-        if (i0 + ib >= m) continue;
-        float T[4][12];
+        for (int kc = 0; kc < PF; ++kc) fetch(kc, kc);
+        f32x16 acc[3];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int e = 0; e < 12; ++e) T[q][e] = 0.f;
-        for (int z = 0; z < nnz; ++z) {
-            const int jj = vidx[z] * 12;
-            const float wv = vw[z];
+            for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4* a4 = (const f32x4*)&sA[ib + q][jj];
-                const f32x4 r0 = a4[0], r1 = a4[1], r2 = a4[2];
+        for (int kc = 0; kc < (SMPL_PROBE(4) ? 1 : KCH); ++kc) {
+            if (kc + PF < KCH) fetch(kc + PF, (kc + PF) % (PF + 1));
+            const shalf8 ah = sF[(kc * 2 + 0) * 2 * IBM + lh * IBM + lc], al = sF[(kc * 2 + 1) * 2 * IBM + lh * IBM + lc];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    T[q][e] = fmaf(wv, r0[e], T[q][e]);
-                    T[q][4 + e] = fmaf(wv, r1[e], T[q][4 + e]);
-                    T[q][8 + e] = fmaf(wv, r2[e], T[q][8 + e]);
-                }
+            for (int c = 0; c < 3; ++c) {
+                acc[c] = mfma_split(al, bh[kc % (PF + 1)][c], acc[c]);
+                acc[c] = mfma_split(ah, bl[kc % (PF + 1)][c], acc[c]);
+                acc[c] = mfma_split(ah, bh[kc % (PF + 1)][c], acc[c]);
             }
         }
+        const int vc = v, v0 = t * VT + wave * 32;               // this tile's vertex of the lane / first vertex of the wave
+        v += VT;
+        if (v0 >= nv) continue;                                  // (the padding of the last tile: the last tile of the last group)
+        const bool whole = v0 + 32 <= nv;                        // every vertex of the wave exists: whole 384-byte rows
+        // skinning, as in smpl_verts_kernel: the lane holds instances i0 + 8 g + 4 lh + {0..3} in accumulator rows 4 g .. 4 g + 3
+        const int* vidx = lbs_idx + (long long)(vc < nv ? vc : nv - 1) * nnz;
+        const float* vw = lbs_w + (long long)(vc < nv ? vc : nv - 1) * nnz;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (i0 + ib + q < m) {
-                const float x = acc[0][4 * g + q] * UNSCALE, y = acc[1][4 * g + q] * UNSCALE, z = acc[2][4 * g + q] * UNSCALE;
-                float* o = rec_ptr(verts, i0 + ib + q, ld_verts, rm, F_VERTS) + v * 3;
-                o[0] = T[q][0] * x + T[q][1] * y + T[q][2] * z + T[q][3];
-                o[1] = T[q][4] * x + T[q][5] * y + T[q][6] * z + T[q][7];
-                o[2] = T[q][8] * x + T[q][9] * y + T[q][10] * z + T[q][11];
+        for (int g = 0; g < 4; ++g) {
+            const int ib = 8 * g + 4 * lh;
+            if (i0 + 8 * g >= m) break;
+            if (i0 + ib < m && vc < nv) {
+                float T[4][12];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 12; ++e) T[q][e] = 0.f;
+                for (int z = 0; z < (SMPL_PROBE(2) ? 1 : nnz); ++z) {
+                    const int jj = vidx[z] * 12;
+                    const float wv = vw[z];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4* a4 = (const f32x4*)&sA[ib + q][jj];
+                        const f32x4 r0 = a4[0], r1 = a4[1], r2 = a4[2];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            T[q][e] = fmaf(wv, r0[e], T[q][e]);
+                            T[q][4 + e] = fmaf(wv, r1[e], T[q][4 + e]);
+                            T[q][8 + e] = fmaf(wv, r2[e], T[q][8 + e]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (i0 + ib + q < m) {
+                        const float x = acc[0][4 * g + q] * UNSCALE, y = acc[1][4 * g + q] * UNSCALE, z = acc[2][4 * g + q] * UNSCALE;
+                        const float ox = T[q][0] * x + T[q][1] * y + T[q][2] * z + T[q][3];
+                        const float oy = T[q][4] * x + T[q][5] * y + T[q][6] * z + T[q][7];
+                        const float oz = T[q][8] * x + T[q][9] * y + T[q][10] * z + T[q][11];
+                        if (whole) {
+                            float* o = stg + (4 * lh + q) * 96 + lc * 3;
+                            o[0] = ox; o[1] = oy; o[2] = oz;
+                        } else {
+                            if (SMPL_PROBE(1) && !(ox == 1234.5f && oy == 2.f)) continue;      // (probe: the values stay live, nothing is written)
+                            float* o = rec_ptr(verts, i0 + ib + q, ld_verts, rm, F_VERTS) + vc * 3;
+                            o[0] = ox; o[1] = oy; o[2] = oz;
+                        }
+                    }
+                }
+            }
+            if (whole) {                                         // the tile's 8 rows of 384 bytes as 3 x 16 bytes per lane
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    const int o4 = (p * 64 + lane_o) * 4;        // float index inside the tile
+                    const int il = o4 / 96, inst = i0 + 8 * g + il;
+                    const f32x4 val = *(const f32x4*)(stg + o4);
+                    if (inst < m && !(SMPL_PROBE(1) && val[0] != 1234.5f))
+                        *(f32x4_u*)(rec_ptr(verts, inst, ld_verts, rm, F_VERTS) + v0 * 3 + (o4 - il * 96)) = val;
+                }
             }
         }
     }
@@ -605,9 +658,15 @@ static int smpl_launch(const hmmr_smpl_consts_t* c, const float* theta, int ld_t
     // vector form when dirs_split is NULL), 1 = the exact-fp32 MFMA form, 2 = the packed-FMA vector form.
     const int form = hmmr_debug_state()->smpl_blend_mfma;
     if (form == 0 && c->dirs_split)
-        hipLaunchKernelGGL(smpl_verts_split_kernel, dim3(vtiles * ((m + IBM - 1) / IBM)), dim3(256), 0, s, (const shalf8*)c->dirs_split,
+    {
+        // vertex tiles per workgroup: as many as it takes for the grid to be one resident round (two workgroups per CU)
+        const int nib = (m + IBM - 1) / IBM, vt = c->vpad / VT;
+        int vpw = (vt * nib + 511) / 512;
+        vpw = vpw < 1 ? 1 : (vpw > vt ? vt : vpw);
+        hipLaunchKernelGGL(smpl_verts_split_kernel, dim3(((vt + vpw - 1) / vpw) * nib), dim3(256), 0, s, (const shalf8*)c->dirs_split,
                            c->vpad, (const float*)feat, (const float*)A, c->lbs_idx, c->lbs_w, c->lbs_nnz,
-                           c->num_verts, m, verts, ld_verts, rm);
+                           c->num_verts, m, vpw, verts, ld_verts, rm);
+    }
     else if (form != 1)
         hipLaunchKernelGGL(smpl_verts_kernel, dim3(vtiles * ((m + IB - 1) / IB)), dim3(VT), 0, s, c->dirs,
                            c->vpad, (const float*)feat, (const float*)A, c->lbs_idx, c->lbs_w, c->lbs_nnz,
