@@ -71,7 +71,8 @@ class Debug(C.Structure):
 
 class LaunchCounts(C.Structure):
     """hmmr_launch_counts_t: how often each fused-unit kernel was launched since the last clear."""
-    _fields_ = [("unit_pair", C.c_ulonglong), ("b1_unit", C.c_ulonglong), ("tail_split", C.c_ulonglong), ("conv3x3_stream", C.c_ulonglong)]
+    _fields_ = [("unit_pair", C.c_ulonglong), ("b1_unit", C.c_ulonglong), ("tail_split", C.c_ulonglong), ("conv3x3_stream", C.c_ulonglong),
+                ("conv1x1_stream", C.c_ulonglong)]
 
 
 class Layer(C.Structure):

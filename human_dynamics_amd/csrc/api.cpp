@@ -25,12 +25,12 @@ extern "C" void hmmr_set_debug(const hmmr_debug_t* d) { g_debug = d ? *d : hmmr_
 extern "C" void hmmr_get_debug(hmmr_debug_t* d) { if (d) *d = g_debug; }
 
 // ---- launch counters (include/hmmr_hip.h: hmmr_launch_counts); `which` indexes hmmr_launch_counts_t's fields
-static std::atomic<unsigned long long> g_launches[4];
-void hmmr_count_launch(int which) { if (which >= 0 && which < 4) g_launches[which].fetch_add(1ull, std::memory_order_relaxed); }
+static std::atomic<unsigned long long> g_launches[5];
+void hmmr_count_launch(int which) { if (which >= 0 && which < 5) g_launches[which].fetch_add(1ull, std::memory_order_relaxed); }
 extern "C" void hmmr_launch_counts(hmmr_launch_counts_t* out, int clear) {
-    unsigned long long v[4];
-    for (int i = 0; i < 4; ++i) v[i] = clear ? g_launches[i].exchange(0ull, std::memory_order_relaxed) : g_launches[i].load(std::memory_order_relaxed);
-    if (out) { out->unit_pair = v[0]; out->b1_unit = v[1]; out->tail_split = v[2]; out->conv3x3_stream = v[3]; }
+    unsigned long long v[5];
+    for (int i = 0; i < 5; ++i) v[i] = clear ? g_launches[i].exchange(0ull, std::memory_order_relaxed) : g_launches[i].load(std::memory_order_relaxed);
+    if (out) { out->unit_pair = v[0]; out->b1_unit = v[1]; out->tail_split = v[2]; out->conv3x3_stream = v[3]; out->conv1x1_stream = v[4]; }
 }
 
 extern "C" int hmmr_abi_version(void) { return HMMR_ABI_VERSION; }

@@ -42,7 +42,7 @@ void hmmr_set_error(const char* fmt, ...);
 struct hmmr_debug_s;
 const struct hmmr_debug_s* hmmr_debug_state();
 // launch counters (include/hmmr_hip.h: hmmr_launch_counts_t, field index), owned by api.cpp
-enum { HMMR_COUNT_UNIT_PAIR = 0, HMMR_COUNT_B1_UNIT = 1, HMMR_COUNT_TAIL_SPLIT = 2, HMMR_COUNT_CONV3X3_STREAM = 3 };
+enum { HMMR_COUNT_UNIT_PAIR = 0, HMMR_COUNT_B1_UNIT = 1, HMMR_COUNT_TAIL_SPLIT = 2, HMMR_COUNT_CONV3X3_STREAM = 3, HMMR_COUNT_CONV1X1_STREAM = 4 };
 void hmmr_count_launch(int which);
 
 // "has this (kernel, device) pair had its one-time hipFuncSetAttribute?"  One bit per device; a redundant call

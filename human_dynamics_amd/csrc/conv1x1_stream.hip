@@ -124,14 +124,16 @@ __global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const S1Args a) 
     for (int q = 0; q < NPX; ++q) {
         const int r = 64 * q + 16 * wave + (lane >> 2);
         int px = m0 + r;
-        px = px >= a.M ? a.M - 1 : px;
+        px = (px >= a.M ? a.M - 1 : px) - m0;                   // relative to the tile's first pixel: a 32-bit offset whatever the tensor's size
         poff[q] = (unsigned)px * (unsigned)(a.C * 4) + ((((unsigned)lane & 3u) ^ (((unsigned)r >> 2) & 3u)) << 4);
-        if (S1_PROBE(32)) poff[q] = (unsigned)(m0 + 64 * q + 16 * wave) * (unsigned)(a.C * 4) + lane * 16;       // (probe: a coalesced KB of the wrong bytes)
+        if (S1_PROBE(32)) poff[q] = (unsigned)(px & ~15) * (unsigned)(a.C * 4) + lane * 16;       // (probe: a coalesced KB of the wrong bytes)
         if constexpr (IN2) poff2[q] = (unsigned)px * (unsigned)(a.C2 * 4) + ((((unsigned)lane & 3u) ^ (((unsigned)r >> 2) & 3u)) << 4);
     }
-    auto x_base = [&](int s) {                                  // K step s of pixel 0: a uniform address the compiler keeps in scalar registers
-        unsigned long long ub = (unsigned long long)a.in + (unsigned long long)(s * 64);      // (so that a piece is base + 32-bit lane offset)
-        if constexpr (IN2) { if (s >= a.nk1) ub = (unsigned long long)a.in2 + (unsigned long long)((s - a.nk1) * 64); }
+    const unsigned long long in_t = (unsigned long long)a.in + (unsigned long long)m0 * (unsigned long long)(a.C * 4);
+    const unsigned long long in2_t = IN2 ? (unsigned long long)a.in2 + (unsigned long long)m0 * (unsigned long long)(a.C2 * 4) : 0ull;
+    auto x_base = [&](int s) {                                  // K step s of the tile's first pixel: a uniform address the compiler keeps in scalar registers
+        unsigned long long ub = in_t + (unsigned long long)(s * 64);      // (so that a piece is base + 32-bit lane offset)
+        if constexpr (IN2) { if (s >= a.nk1) ub = in2_t + (unsigned long long)((s - a.nk1) * 64); }
         asm volatile("" : "+s"(ub));
         return (const char*)ub;
     };
@@ -273,11 +275,16 @@ __global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const S1Args a) 
         const float lo_clamp = a.relu ? 0.f : -HMMR_SPLIT_MAX;
         // byte offset of this lane's 16-byte slot of row 8 q + rsub of row block i (out, out2 and the shortcut share the row stride); rows
         // beyond M: the last row for loads, the dump for stores
+        // (relative to the tile's first row: 32 bits whatever the tensors' size)
+        const long long row0 = (long long)m0 * a.ldo * 4;
+        const char* const res_t = RES ? a.res + row0 : nullptr;
+        char* const out_t = (char*)a.out + row0;
+        char* const out2_t = OUT2 ? (char*)a.out2 + row0 : nullptr;
         auto row_off = [&](int i, int q, bool& valid) {
             const int r = 8 * q + rsub;
             int m = m0 + (wm * FM + i) * 32 + r;
             valid = m < a.M;
-            m = valid ? m : a.M - 1;
+            m = (valid ? m : a.M - 1) - m0;
             return ((unsigned)m * (unsigned)a.ldo + (unsigned)(nb + (pslot ^ ((r >> 1) & 7)) * 4)) * 4u;
         };
         auto res_dma = [&](int b) {                             // b is a constant after unrolling
@@ -287,7 +294,7 @@ __global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const S1Args a) 
             for (int q = 0; q < 4; ++q) {
                 bool valid;
                 const unsigned off = row_off(i, q, valid);
-                __builtin_amdgcn_global_load_lds((gptr_t)(a.res + off + j * 128), (lptr_t)(dst + q * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(res_t + off + j * 128), (lptr_t)(dst + q * 1024), 16, 0, 0);
             }
         };
         f32x4 s4[FN][4], b4[FN][4], s2[OUT2 ? FN : 1][4], b2[OUT2 ? FN : 1][4];
@@ -372,8 +379,8 @@ __global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const S1Args a) 
             for (int q = 0; q < 4; ++q) {
                 bool valid;
                 const unsigned off = row_off(i, q, valid);
-                *(u32x4*)(valid ? (char*)a.out + off + j * 128 : (char*)g_s1_dump + lane * 16) = xr[q];
-                if constexpr (OUT2) *(u32x4*)(valid ? (char*)a.out2 + off + j * 128 : (char*)g_s1_dump + lane * 16) = x2[q];
+                *(u32x4*)(valid ? out_t + off + j * 128 : (char*)g_s1_dump + lane * 16) = xr[q];
+                if constexpr (OUT2) *(u32x4*)(valid ? out2_t + off + j * 128 : (char*)g_s1_dump + lane * 16) = x2[q];
             }
         };
         s1_blocks(block, std::make_integer_sequence<int, B>{});
@@ -492,9 +499,9 @@ int hmmr_conv1x1_stream(const hmmr_conv_desc_t* d, hipStream_t stream) {
                  "hmmr_conv_gemm: k_order 2 (1x1) with res / out2 / in2 (the conv3 form): no out_b, not res and in2 together, res dense with ldr == ldo, "
                  "cin2 %% 16 == 0, scale2 + shift2 with out2");
     HMMR_REQUIRE(!d->out_b || (d->n_split % 128 == 0 && d->n_split > 0 && d->n_split < d->cout), "hmmr_conv_gemm: k_order 2 (1x1): n_split must be a multiple of 128 inside (0, cout)");
-    HMMR_REQUIRE(M * d->cin * 4 < (1ll << 32) && M * (d->in2 ? d->cin2 : 0) * 4 < (1ll << 32) && (!c3 || M * d->ldo * 4 < (1ll << 32)),
-                 "hmmr_conv_gemm: k_order 2 (1x1): the tensors must stay below 4 GB (32-bit row offsets)");
+    HMMR_REQUIRE(M < (1ll << 31), "hmmr_conv_gemm: k_order 2 (1x1): more than 2^31 pixels");
     if (M <= 0) return 0;
+    hmmr_count_launch(HMMR_COUNT_CONV1X1_STREAM);
     S1Args a = {};
     a.in = (const char*)d->in; a.wstream = (const char*)d->w; a.scale = d->scale; a.shift = d->shift;
     a.out = d->out; a.ldo = d->ldo; a.relu = d->relu;

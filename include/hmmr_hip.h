@@ -89,6 +89,7 @@ typedef struct {
     unsigned long long b1_unit;         /* csrc/b1_unit.hip */
     unsigned long long tail_split;      /* csrc/bottleneck_split.hip (LDS-panel tails) */
     unsigned long long conv3x3_stream;  /* csrc/conv3x3_stream.hip */
+    unsigned long long conv1x1_stream;  /* csrc/conv1x1_stream.hip (ABI 17) */
 } hmmr_launch_counts_t;
 void hmmr_launch_counts(hmmr_launch_counts_t* out, int clear);
 
@@ -183,10 +184,12 @@ typedef struct {
      * channels `(ci / 32) * 9 + tap`, the two planes = the two 16-wide MFMA chunks, no row scaling), cin % 64 == 0 --,
      * cout % 128 == 0 and win <= 28 (tiles 12 .. 18, 21) or cout = 64 and win <= 56 (tiles 19 / 20) (csrc/conv3x3_stream.hip).  Every tile produces the same bits.
      * 2 with kh = kw = 1 (round 5; csrc/conv1x1_stream.hip, tiles 22 .. 25): `w` is the stream of packing.pack_conv1x1_stream
-     * (hmmr_conv1x1_stream_bytes(cin, cout) bytes: K steps of 16 input channels, the same 8 KB per 128 output channels as one tap above).  A
-     * stride-1 1x1 convolution over a dense [M][cin] split tensor (below 4 GB), cin % 16 == 0 (>= 96), cout % 128 == 0, scale and shift
-     * given; epilogue scale / shift / relu with the out_b column split (n_split % 128 == 0); no res, out2, pro_scale, in2, split_k, batch.
-     * Both operands go through LDS rings 4-6 K steps deep (one wave per SIMD), for layers whose K loop is bound by the round trip of
+     * (hmmr_conv1x1_stream_bytes(cin + cin2, cout) bytes: K steps of 16 input channels, the same 8 KB per 128 output channels as one tap above).  A
+     * stride-1 1x1 convolution over a dense [M][cin] split tensor, cin % 16 == 0 (at least 64: the rings are 4-6 K steps deep), cout % 128 == 0,
+     * scale and shift given; no pro_scale, split_k, batch.  Two epilogues: scale / shift / relu with the out_b column split (n_split % 128 == 0), or
+     * -- with any of res / out2 / in2, tiles 24 / 25 -- the conv3 form: in2 continues K (cin2 % 16 == 0; not together with res), res is a dense
+     * shortcut tensor with ldr == ldo, out2 = relu(scale2 * stored(out) + shift2) exactly as k_order 0 defines it.
+     * Both operands go through LDS rings (one wave per SIMD), for layers whose K loop is bound by the round trip of
      * a two-stage ring (block 4, block3/unit_1's shortcut + conv1).  Differs from k_order 0 by fp32 rounding of the accumulation only. */
     int k_order;
     /* grouped launch: `batch` > 1 runs that many problems of this one shape as ONE launch (grid z); problem z reads and

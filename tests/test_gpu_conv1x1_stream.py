@@ -147,3 +147,58 @@ def test_conv1x1_stream_kernel_conv3_form(case, gpu_device):
     for bad in (dict(tile=22), dict(n_split=64), dict(res_stride=2, res=np.zeros((n, 2 * h, 2 * w_, cout), np.float32))):
         with pytest.raises(L.HmmrError):
             conv_gemm(x, w, k_order=2, **dict(kw, **bad))
+
+
+def test_conv1x1_stream_kernel_above_4_gb(gpu_device):
+    """Offsets inside the kernel are relative to a tile's first pixel: a tensor above 4 GB (540 000 pixels x 2048 channels x 4 bytes) gives
+    its last pixels the bits a launch over those pixels alone gives them (conv1 form and conv3 form)."""
+    import torch
+    from human_dynamics_amd import packing
+    from human_dynamics_amd.engine import conv_gemm
+    g = torch.Generator(device=gpu_device).manual_seed(5)
+    h, w_, cin, cout, tail = 540, 1000, 2048, 128, 700
+    x = packing.to_split(torch.randn((1, h, w_, cin), device=gpu_device, generator=g))
+    assert x.numel() * 4 > (1 << 32)
+    rng = np.random.default_rng(5)
+    w = (rng.normal(size=(1, 1, cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    shift = rng.normal(size=cout).astype(np.float32)
+    xt = x.reshape(1, 1, h * w_, cin)[:, :, -tail:].contiguous()
+    for kw in (dict(relu=True), dict(scale2=np.ones(cout, np.float32), shift2=shift)):
+        kw = dict(kw, stride=1, pad=0, shift=shift, in_dtype=X3, out_dtype=X3, device=gpu_device, k_order=2, raw=True)
+        big, big2 = conv_gemm(x, w, **kw)
+        small, small2 = conv_gemm(xt, w, **kw)
+        assert torch.equal(big.reshape(-1, cout)[-tail:], small.reshape(-1, cout))
+        if big2 is not None:
+            assert torch.equal(big2.reshape(-1, cout)[-tail:], small2.reshape(-1, cout))
+    del x
+    torch.cuda.empty_cache()
+
+
+def test_resnet_with_the_1x1_stream_kernel(gpu_device):
+    """The default f16x3 schedule runs 8 launches per pass through csrc/conv1x1_stream.hip (block 4's conv1 and conv3, block2/unit_1's conv1,
+    block3/unit_1's shortcut + conv1: counted); stream_1x1=False keeps them on the 8-wave tiles.  The two differ by fp32 accumulation
+    rounding (another K-step width) and nothing else; the fused schedule equals the layer-per-launch schedule of the same packing bit for
+    bit; batch composition does not move a frame's bits."""
+    import torch
+    from human_dynamics_amd import assets
+    from human_dynamics_amd.engine import HmmrEngine
+    weights = assets.make_synthetic_weights(0)
+    frames = assets.make_synthetic_frames(9, seed=41)
+    on = HmmrEngine(weights, None, dtype="f16x3", device=gpu_device, autotune=False)
+    off = HmmrEngine(weights, None, dtype="f16x3", device=gpu_device, autotune=False, stream_1x1=False)
+    assert [int(on.rw.unit[i].conv1.k_order) for i in (3, 13, 14, 15)] == [2, 2, 2, 2] and int(on.rw.unit[7].sc_c1.k_order) == 2
+    assert [int(on.rw.unit[i].conv3.k_order) for i in (13, 14, 15)] == [2, 2, 2] and int(on.rw.unit[13].c3sc.k_order) == 2
+    assert all(int(off.rw.unit[i].conv1.k_order) == 0 and int(off.rw.unit[i].conv3.k_order) == 0 for i in range(16))
+    L.launch_counts(clear=True)
+    a = on.resnet(frames, n_zero=1)
+    torch.cuda.synchronize()
+    assert L.launch_counts(clear=True)["conv1x1_stream"] == 8
+    b = off.resnet(frames, n_zero=1)
+    torch.cuda.synchronize()
+    assert L.launch_counts(clear=True)["conv1x1_stream"] == 0
+    assert float(a.abs().max()) > 0.1 and float((a - b).abs().max()) < 2e-4 * float(a.abs().max())
+    plain = HmmrEngine(weights, None, dtype="f16x3", device=gpu_device, autotune=False, fuse_tail=False)
+    assert torch.equal(a, plain.resnet(frames, n_zero=1))
+    # a frame's features do not depend on what else is in the batch (tiles are cut by pixel count, K order is fixed per output channel)
+    alone = on.resnet(frames[3:5])
+    assert torch.equal(a[3:5], alone)

@@ -122,7 +122,7 @@ def test_ctypes_struct_sizes_are_plausible():
     # catches accidental field drift between include/hmmr_hip.h and _lib.py
     assert C.sizeof(_lib.Layer) == 32
     assert C.sizeof(_lib.ResnetUnit) == 6 * 32 + 40 + 16 + 16 + 8
-    assert C.sizeof(_lib.Debug) == 10 * 4 and C.sizeof(_lib.LaunchCounts) == 32
+    assert C.sizeof(_lib.Debug) == 10 * 4 and C.sizeof(_lib.LaunchCounts) == 40
     assert C.sizeof(_lib.ConvDesc) % 8 == 0
 
 
