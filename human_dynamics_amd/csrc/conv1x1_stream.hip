@@ -1,5 +1,5 @@
 // 1x1 convolutions of the ResNet's late blocks for gfx950, f16x3 ("split") operands, as ONE MFMA STREAM PER SIMD with BOTH operands
-// in rings (hmmr_conv_desc_t.k_order = 2 with kh = kw = 1; tiles 22 .. 25).  slim resnet_v2.bottleneck `conv1` / `shortcut` as invoked
+// in rings (hmmr_conv_desc_t.k_order = 2 with kh = kw = 1; tiles 22 .. 26).  slim resnet_v2.bottleneck `conv1` / `shortcut` as invoked
 // at src/models.py:65-75.
 //
 // What the 8-wave tiles of gemm_conv.hip measure on these layers (block 4: 12.6 k pixels, K = 1024 / 2048; block3/unit_1's shortcut +
@@ -84,10 +84,12 @@ template <typename F, int... Bs> __device__ __forceinline__ void s1_blocks(F&& f
 // FM x FN accumulators per wave, WGM x WGN waves: the tile is 32 WGM FM pixels x 128 channels; D: ring depth of both operands
 // EPI 0: scale / shift / relu, column split.  EPI 1: conv3 of a bottleneck unit -- IN2: the folded shortcut's operand, RES: the shortcut tensor,
 // OUT2: the next unit's pre-activation
-template <int FM, int FN, int WGM, int WGN, int D, int EPI = 0, bool IN2 = false, bool RES = false, bool OUT2 = false>
-__global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const S1Args a) {
+// OCC 2: two workgroups per CU (256 registers per wave, rings 3 deep): one workgroup's prologue, epilogue and request latency under the other's loop
+template <int FM, int FN, int WGM, int WGN, int D, int EPI = 0, bool IN2 = false, bool RES = false, bool OUT2 = false, int OCC = 1>
+__global__ __launch_bounds__(256, OCC) void conv1x1_stream_kernel(const S1Args a) {
     constexpr int NB = WGN * FN;                                // row blocks of 32 output channels per tile
-    static_assert(WGM * WGN == 4 && NB == 4 && FM * FN <= 16 && D >= 4 && D <= 6 && D % 2 == 0, "4 waves, 128 channels, at most 16 accumulators");
+    static_assert(WGM * WGN == 4 && NB == 4 && FM * FN <= 16 && D >= 3 && D <= 6, "4 waves, 128 channels, at most 16 accumulators");
+    constexpr int U = D % 2 ? 2 * D : D;                        // steps per unrolled group: ring slot S % D and fragment set S & 1 are compile-time
     constexpr int R = WGM * FM, BM = 32 * R;
     constexpr int NPX = (BM + 63) / 64;                         // 64-row pieces of a pixel slab (16 rows per wave and piece)
     constexpr int XSLAB = NPX * 64 * 64;                        // rows of 64 bytes
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const S1Args a) 
     constexpr int CST = RING + D * XSLAB;                       // this tile's folded BN constants (EPI 1: 2 KB, scale2 / shift2 behind them)
     static_assert(EPI == 0 || (FN == 2 && !(IN2 && RES)), "the conv3 form is built for the 2 x 2 wave arrangements");
     constexpr int NR = 2 * (FM + FN), NG = 3 * FM * FN;         // fragment reads and MFMAs (= gaps) of a step
-    static_assert(RING + D * XSLAB + 2048 <= 160 * 1024, "LDS");
+    static_assert((RING + D * XSLAB + 2048) * OCC <= 160 * 1024, "LDS");
     static_assert(D * P < 64, "vmcnt");
     static_assert(2048 * (FM - 1) + 16 < 65536 && (D - 1) * SLAB + 3 * 2048 + 1024 < 65536, "instruction offsets");
     static_assert(NR <= NG - 4 && NPX + 2 <= NG, "one fragment read and one request per gap");
@@ -237,9 +239,9 @@ __global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const S1Args a) 
                     const shalf8& xb = p == 0 ? fx[CUR][i].lo : fx[CUR][i].hi;
                     if (!S1_PROBE(1)) acc[i][j] = mfma_split(wa, xb, acc[i][j]);
                     const int g = (3 * i + p) * FN + j;
-                    if (g == 0 && !S1_PROBE(4)) ring_dma(sn, S);
+                    if (g == 0 && !S1_PROBE(4)) ring_dma(sn, S % D);
                     if (g == 1) slot_setup(SNEXT);
-                    if (g >= 2 && g < 2 + NPX && !S1_PROBE(4) && !S1_PROBE(8)) x_piece(g - 2 < NPX ? g - 2 : 0, xsrc, S, xfirst);
+                    if (g >= 2 && g < 2 + NPX && !S1_PROBE(4) && !S1_PROBE(8)) x_piece(g - 2 < NPX ? g - 2 : 0, xsrc, S % D, xfirst);
 #pragma unroll
                     for (int r = 0; r < NR; ++r)
                         if (2 + (r * (NG - 4)) / NR == g && !S1_PROBE(2)) read_one(NXT, r, SNEXT);
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const S1Args a) 
         if (!S1_PROBE(16)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
-    for (int kt0 = 0; kt0 < nk; kt0 += D) s1_group(step, kt0, nk, std::make_integer_sequence<int, D>{});
+    for (int kt0 = 0; kt0 < nk; kt0 += U) s1_group(step, kt0, nk, std::make_integer_sequence<int, U>{});
     // (the requests of the last steps -- repeats of the last stage -- land in the rings the epilogue is about to reuse)
     __builtin_amdgcn_sched_barrier(0);
     s1_wait<0>();
@@ -267,9 +269,11 @@ __global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const S1Args a) 
         // (hi + lo as the consumer would read it: gemm_conv.hip's out2), ReLU, split -> out2.  Per wave: out staging 2 x 4 KB | out2
         // staging 2 x 4 KB | shortcut tiles 5 x 4 KB, requested PD = 4 blocks ahead (one wave per SIMD: a block's arithmetic is 0.5 us, a
         // request's round trip 2 us, and nothing else runs meanwhile).  Vector-memory order per block b: [shortcut b + PD] wait(b) ... [stores of b]
-        constexpr int B = FM * FN, NST = OUT2 ? 8 : 4, PD = 4, RT = PD + 1;
-        char* wv = smem + wave * 36864;
-        static_assert(4 * 36864 <= RING + D * XSLAB, "the epilogue's tiles live in the idle rings");
+        // (OCC 2: the other workgroup of the CU covers the round trips: one staging tile per output, shortcut blocks one ahead)
+        constexpr int B = FM * FN, NST = OUT2 ? 8 : 4, PD = OCC == 2 ? 1 : 4, RT = PD + 1, NSTG = OCC == 2 ? 1 : 2;
+        constexpr int WVB = (2 * NSTG + RT) * 4096;
+        char* wv = smem + wave * WVB;
+        static_assert(4 * WVB <= RING + D * XSLAB, "the epilogue's tiles live in the idle rings");
         const int rsub = lane >> 3, pslot = lane & 7, sw = (lr >> 1) & 7;
         const int nb = nt * 128 + wn * FN * 32;
         const float lo_clamp = a.relu ? 0.f : -HMMR_SPLIT_MAX;
@@ -289,7 +293,7 @@ __global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const S1Args a) 
         };
         auto res_dma = [&](int b) {                             // b is a constant after unrolling
             const int i = b / FN, j = b % FN;
-            char* dst = wv + 16384 + (b % RT) * 4096;
+            char* dst = wv + 2 * NSTG * 4096 + (b % RT) * 4096;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 bool valid;
@@ -297,9 +301,11 @@ __global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const S1Args a) 
                 __builtin_amdgcn_global_load_lds((gptr_t)(res_t + off + j * 128), (lptr_t)(dst + q * 1024), 16, 0, 0);
             }
         };
-        f32x4 s4[FN][4], b4[FN][4], s2[OUT2 ? FN : 1][4], b2[OUT2 ? FN : 1][4];
-        {
-            const float* cst = (const float*)(smem + CST) + wn * FN * 32 + 4 * lh;
+        // the constants of this wave's channels: in registers (OCC 1), or read per use where registers are short (OCC 2)
+        constexpr bool CREG = OCC == 1;
+        f32x4 s4[CREG ? FN : 1][4], b4[CREG ? FN : 1][4], s2[CREG && OUT2 ? FN : 1][4], b2[CREG && OUT2 ? FN : 1][4];
+        const float* const cst = (const float*)(smem + CST) + wn * FN * 32 + 4 * lh;
+        if constexpr (CREG) {
 #pragma unroll
             for (int j = 0; j < FN; ++j)
 #pragma unroll
@@ -325,15 +331,23 @@ __global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const S1Args a) 
                 s1_wait<4 * ahead + NST * behind>();
                 asm volatile("" ::: "memory");
             }
-            char* to = wv + (b & 1) * 4096;
-            char* t2 = wv + 8192 + (b & 1) * 4096;
-            const char* rt = wv + 16384 + (b % RT) * 4096;
+            char* to = wv + (b % NSTG) * 4096;
+            char* t2 = wv + NSTG * 4096 + (b % NSTG) * 4096;
+            const char* rt = wv + 2 * NSTG * 4096 + (b % RT) * 4096;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const unsigned oh_ = lr * 128 + (((2 * g) ^ sw) << 4) + 8 * lh, ol_ = lr * 128 + (((2 * g + 1) ^ sw) << 4) + 8 * lh;
                 float c[4];
+                f32x4 sv, bv, s2v = {}, b2v = {};
+                if constexpr (CREG) {
+                    sv = s4[j][g]; bv = b4[j][g];
+                    if constexpr (OUT2) { s2v = s2[j][g]; b2v = b2[j][g]; }
+                } else {
+                    sv = *(const f32x4*)(cst + j * 32 + 8 * g); bv = *(const f32x4*)(cst + 128 + j * 32 + 8 * g);
+                    if constexpr (OUT2) { s2v = *(const f32x4*)(cst + 256 + j * 32 + 8 * g); b2v = *(const f32x4*)(cst + 384 + j * 32 + 8 * g); }
+                }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) c[e] = fmaf(acc[i][j][4 * g + e], s4[j][g][e], b4[j][g][e]);
+                for (int e = 0; e < 4; ++e) c[e] = fmaf(acc[i][j][4 * g + e], sv[e], bv[e]);
                 if constexpr (RES) {
                     const unsigned long long rh = *(const unsigned long long*)(rt + oh_), rl = *(const unsigned long long*)(rt + ol_);
                     c[0] += split_sum_lo((unsigned)rh, (unsigned)rl);
@@ -353,10 +367,10 @@ __global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const S1Args a) 
                 *(unsigned long long*)(to + ol_) = (unsigned long long)l01 | ((unsigned long long)l23 << 32);
                 if constexpr (OUT2) {
                     float u[4];
-                    u[0] = fmaf(split_sum_lo(h01, l01), s2[j][g][0], b2[j][g][0]);
-                    u[1] = fmaf(split_sum_hi(h01, l01), s2[j][g][1], b2[j][g][1]);
-                    u[2] = fmaf(split_sum_lo(h23, l23), s2[j][g][2], b2[j][g][2]);
-                    u[3] = fmaf(split_sum_hi(h23, l23), s2[j][g][3], b2[j][g][3]);
+                    u[0] = fmaf(split_sum_lo(h01, l01), s2v[0], b2v[0]);
+                    u[1] = fmaf(split_sum_hi(h01, l01), s2v[1], b2v[1]);
+                    u[2] = fmaf(split_sum_lo(h23, l23), s2v[2], b2v[2]);
+                    u[3] = fmaf(split_sum_hi(h23, l23), s2v[3], b2v[3]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         satmax = __builtin_fmaxf(satmax, u[e]);
@@ -451,14 +465,14 @@ __global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const S1Args a) 
     split_flag(satmax > HMMR_SPLIT_MAX);
 }
 
-template <int FM, int FN, int WGM, int WGN, int D, int EPI = 0, bool IN2 = false, bool RES = false, bool OUT2 = false>
+template <int FM, int FN, int WGM, int WGN, int D, int EPI = 0, bool IN2 = false, bool RES = false, bool OUT2 = false, int OCC = 1>
 int launch_s1(const S1Args& base, hipStream_t stream) {
     S1Args a = base;
     constexpr int BM = 32 * WGM * FM, NPX = (BM + 63) / 64;
     constexpr int lds = D * 8192 + D * NPX * 4096 + 2048;
     HMMR_REQUIRE(a.nk >= D, "hmmr_conv_gemm: k_order 2 (1x1): cin must be at least %d channels for this tile", 16 * D);
     a.n_tiles = ((a.M + BM - 1) / BM) * a.tiles_n;
-    auto kern = conv1x1_stream_kernel<FM, FN, WGM, WGN, D, EPI, IN2, RES, OUT2>;
+    auto kern = conv1x1_stream_kernel<FM, FN, WGM, WGN, D, EPI, IN2, RES, OUT2, OCC>;
     static DeviceOnce once;
     if (const unsigned long long bit = once.due()) {
         HMMR_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -470,11 +484,11 @@ int launch_s1(const S1Args& base, hipStream_t stream) {
 }
 
 // the conv3 form of a tile shape: which of in2 / res / out2 the launch has picks the instantiation
-template <int FM, int FN, int WGM, int WGN, int D>
+template <int FM, int FN, int WGM, int WGN, int D, int OCC = 1>
 int launch_s1_c3(const S1Args& a, hipStream_t stream) {
-    if (a.in2) return a.out2 ? launch_s1<FM, FN, WGM, WGN, D, 1, true, false, true>(a, stream) : launch_s1<FM, FN, WGM, WGN, D, 1, true, false, false>(a, stream);
-    if (a.res) return a.out2 ? launch_s1<FM, FN, WGM, WGN, D, 1, false, true, true>(a, stream) : launch_s1<FM, FN, WGM, WGN, D, 1, false, true, false>(a, stream);
-    return a.out2 ? launch_s1<FM, FN, WGM, WGN, D, 1, false, false, true>(a, stream) : launch_s1<FM, FN, WGM, WGN, D, 0>(a, stream);
+    if (a.in2) return a.out2 ? launch_s1<FM, FN, WGM, WGN, D, 1, true, false, true, OCC>(a, stream) : launch_s1<FM, FN, WGM, WGN, D, 1, true, false, false, OCC>(a, stream);
+    if (a.res) return a.out2 ? launch_s1<FM, FN, WGM, WGN, D, 1, false, true, true, OCC>(a, stream) : launch_s1<FM, FN, WGM, WGN, D, 1, false, true, false, OCC>(a, stream);
+    return a.out2 ? launch_s1<FM, FN, WGM, WGN, D, 1, false, false, true, OCC>(a, stream) : launch_s1<FM, FN, WGM, WGN, D, 0, false, false, false, OCC>(a, stream);
 }
 
 }  // namespace
@@ -517,28 +531,33 @@ int hmmr_conv1x1_stream(const hmmr_conv_desc_t* d, hipStream_t stream) {
     if (!tile) {
         // the library's choice: fewest rounds of 256 workgroups x (row blocks per tile + ~1.5 for a tile's prologue and epilogue); the 7 x 1 / 8 x 1
         // wave tiles read 16-18 fragments per 21-24 MFMAs and pay ~15 % for it (profiles/r05r: LDS bandwidth)
-        static const int cand[4][3] = {{25, 8, 6}, {24, 14, 4}, {22, 7, 6}, {23, 8, 6}};      // tile, row blocks, ring depth
+        static const int cand[5][3] = {{25, 8, 6}, {24, 14, 4}, {26, 8, 3}, {22, 7, 6}, {23, 8, 6}};      // tile, row blocks, ring depth
         const long long rbs = (M + 31) / 32;
         double best = 0;
         for (const auto& cd : cand) {
-            if (a.nk < cd[2] || (c3 && cd[0] != 24 && cd[0] != 25)) continue;
+            if (a.nk < cd[2] || (c3 && cd[0] != 24 && cd[0] != 25 && cd[0] != 26)) continue;
             const long long tiles = ((rbs + cd[1] - 1) / cd[1]) * a.tiles_n;
-            const double cost = (double)((tiles + 255) / 256) * (cd[1] + 1.5) * (cd[0] == 22 || cd[0] == 23 ? 1.15 : 1.0);
+            double cost = (double)((tiles + 255) / 256) * (cd[1] + 1.5) * (cd[0] == 22 || cd[0] == 23 ? 1.15 : 1.0);
+            // tile 26 (two workgroups per CU): a round is 512 workgroups and takes two tiles' time, less what one workgroup's prologue,
+            // epilogue and round trips hide under the other's loop -- measured (profiles/r05v): 0.8 of it for the conv3 form (its epilogue is
+            // HBM time), 0.88 for a short K loop, nothing gained on a long one
+            if (cd[0] == 26) cost = (double)((tiles + 511) / 512) * 2.0 * (cd[1] + 1.5) * (c3 ? 0.8 : a.nk <= 32 ? 0.88 : 1.05);
             if (!tile || cost < best) { tile = cd[0]; best = cost; }
         }
     }
     HMMR_REQUIRE(tile, "hmmr_conv_gemm: k_order 2 (1x1): cin must be at least 64 channels (the rings are 4 K steps deep)");
     if (c3) {
-        HMMR_REQUIRE(tile == 24 || tile == 25, "hmmr_conv_gemm: k_order 2 (1x1): the conv3 form (res / out2 / in2) runs tiles 24 / 25, not %d", tile);
-        return tile == 24 ? launch_s1_c3<7, 2, 2, 2, 4>(a, stream) : launch_s1_c3<4, 2, 2, 2, 6>(a, stream);
+        HMMR_REQUIRE(tile >= 24 && tile <= 26, "hmmr_conv_gemm: k_order 2 (1x1): the conv3 form (res / out2 / in2) runs tiles 24 .. 26, not %d", tile);
+        return tile == 24 ? launch_s1_c3<7, 2, 2, 2, 4>(a, stream) : tile == 25 ? launch_s1_c3<4, 2, 2, 2, 6>(a, stream) : launch_s1_c3<4, 2, 2, 2, 3, 2>(a, stream);
     }
     switch (tile) {
     case 22: return launch_s1<7, 1, 1, 4, 6>(a, stream);       // 224 pixels, every wave all of them and 32 of the 128 channels
     case 23: return launch_s1<8, 1, 1, 4, 6>(a, stream);       // 256 pixels, likewise
     case 24: return launch_s1<7, 2, 2, 2, 4>(a, stream);       // 448 pixels, waves 2 x 2
     case 25: return launch_s1<4, 2, 2, 2, 6>(a, stream);       // 256 pixels, waves 2 x 2
+    case 26: return launch_s1<4, 2, 2, 2, 3, 0, false, false, false, 2>(a, stream);       // 256 pixels, TWO workgroups per CU (rings 3 deep)
     default: break;
     }
-    hmmr_set_error("hmmr_conv_gemm: k_order 2 (1x1) runs tiles 22 .. 25, not %d", tile);
+    hmmr_set_error("hmmr_conv_gemm: k_order 2 (1x1) runs tiles 22 .. 26, not %d", tile);
     return -1;
 }

@@ -232,9 +232,9 @@ class HmmrEngine(object):
         the tile does not fit; a layer packed chunk-major (k_order 1, the 3x3 patch kernels) runs tiles 9 / 10, the patch
         forms of 7 / 8, or 11, the 256x128 tile without a load segment; a k_order 2 layer (csrc/conv3x3_stream.hip) takes the
         tuner's candidates as its own tile shapes 13 .. 18; a k_order 2 layer with a 1x1 filter (any layer name but conv2; csrc/conv1x1_stream.hip)
-        tiles 22 .. 25, its conv3 form 24 / 25."""
+        tiles 22 .. 26, its conv3 form 24 .. 26."""
         if lay.k_order == 2 and nm != "conv2":
-            t = {5: 22, 6: 23, 3: 24, 1: 25}.get(cand, cand if 22 <= cand <= 25 else 0)
+            t = {5: 22, 6: 23, 3: 24, 1: 25, 2: 26}.get(cand, cand if 22 <= cand <= 26 else 0)
             return 0 if (nm == "conv3" and t in (22, 23)) else t
         if lay.k_order == 2:                                 # the stream kernel's tiles: 12 .. 18 and 21 (128-channel tiles), 19 / 20 (64 channels)
             if cout == 64:

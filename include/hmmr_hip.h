@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HMMR_ABI_VERSION 17      /* 17: k_order = 2 on a 1x1 filter (the two-ring stream kernel of csrc/conv1x1_stream.hip, tiles 22 .. 25), hmmr_conv1x1_stream_bytes; 16: hmmr_tail_desc_t.unit_stream, hmmr_resnet_unit_t.unit_stream (the whole-unit kernel of block 1, csrc/b1_unit.hip), hmmr_b1_unit_stream_bytes, hmmr_debug_t.pair_min_pixels / pair_two_tile_min / launch counters, hmmr_resnet_unit_t.conv1_frag (block1/unit_1's conv1 inside the split stem); 15: k_order = 2 (the one-wave-per-SIMD 3x3 stream kernel, tiles 12 .. 18), hmmr_conv3x3_stream_bytes; 14: hmmr_tail_desc_t.pair_stream / c_xp, hmmr_resnet_unit_t.pair_stream (the register-resident unit pair of blocks 2-3), hmmr_run_flags; 13: hmmr_conv_desc_t.batch (grouped launches); 12: k_order = 1, 3x3 SAME convolutions out of an LDS-resident input patch (tiles 9, 10, 11) */
+#define HMMR_ABI_VERSION 17      /* 17: k_order = 2 on a 1x1 filter (the two-ring stream kernel of csrc/conv1x1_stream.hip, tiles 22 .. 26), hmmr_conv1x1_stream_bytes; 16: hmmr_tail_desc_t.unit_stream, hmmr_resnet_unit_t.unit_stream (the whole-unit kernel of block 1, csrc/b1_unit.hip), hmmr_b1_unit_stream_bytes, hmmr_debug_t.pair_min_pixels / pair_two_tile_min / launch counters, hmmr_resnet_unit_t.conv1_frag (block1/unit_1's conv1 inside the split stem); 15: k_order = 2 (the one-wave-per-SIMD 3x3 stream kernel, tiles 12 .. 18), hmmr_conv3x3_stream_bytes; 14: hmmr_tail_desc_t.pair_stream / c_xp, hmmr_resnet_unit_t.pair_stream (the register-resident unit pair of blocks 2-3), hmmr_run_flags; 13: hmmr_conv_desc_t.batch (grouped launches); 12: k_order = 1, 3x3 SAME convolutions out of an LDS-resident input patch (tiles 9, 10, 11) */
 
 /* HMMR_F16X3: "split" tensors -- every group of 8 consecutive channels is 32 bytes, [hi x8][lo x8] with
  * hi = fp16(x), lo = fp16(x - hi), x clamped to +-65504 (4 bytes per element, 22 mantissa bits while lo is a normal
@@ -142,7 +142,8 @@ typedef struct {
                               (cout = 64, images up to 56 pixels wide); 21 = 224 pixels, every wave all of them and 32 channels (7 x 1; split only);
                               k_order 2 with a 1x1 filter only (csrc/conv1x1_stream.hip; 4 waves, one per SIMD, 128 output channels per tile, both
                               operands through LDS rings): 22 = 224 pixels (7 x 1 accumulators per wave, every wave 32 of the channels),
-                              23 = 256 pixels (8 x 1), 24 = 448 pixels (7 x 2, waves 2 x 2), 25 = 256 pixels (4 x 2, waves 2 x 2) */
+                              23 = 256 pixels (8 x 1), 24 = 448 pixels (7 x 2, waves 2 x 2), 25 = 256 pixels (4 x 2, waves 2 x 2),
+                              26 = 256 pixels (4 x 2) with TWO workgroups per CU (rings 3 deep, 256 registers per wave) */
     /* split-K (for GEMMs with few output tiles and a long K): split_k > 1 slices K into that many
      * contiguous ranges, each range leaves an fp32 partial plane in `ws`, and a second launch adds the
      * planes IN SLICE ORDER and applies the epilogue.  The caller fixes split_k per layer (never from
@@ -183,11 +184,11 @@ typedef struct {
      * like every split filter bank.  Same convolutions and epilogue as k_order 1; split (f16x3) tensors, cin % 32 == 0 -- or bf16 tensors (K steps of 32
      * channels `(ci / 32) * 9 + tap`, the two planes = the two 16-wide MFMA chunks, no row scaling), cin % 64 == 0 --,
      * cout % 128 == 0 and win <= 28 (tiles 12 .. 18, 21) or cout = 64 and win <= 56 (tiles 19 / 20) (csrc/conv3x3_stream.hip).  Every tile produces the same bits.
-     * 2 with kh = kw = 1 (round 5; csrc/conv1x1_stream.hip, tiles 22 .. 25): `w` is the stream of packing.pack_conv1x1_stream
+     * 2 with kh = kw = 1 (round 5; csrc/conv1x1_stream.hip, tiles 22 .. 26): `w` is the stream of packing.pack_conv1x1_stream
      * (hmmr_conv1x1_stream_bytes(cin + cin2, cout) bytes: K steps of 16 input channels, the same 8 KB per 128 output channels as one tap above).  A
      * stride-1 1x1 convolution over a dense [M][cin] split tensor, cin % 16 == 0 (at least 64: the rings are 4-6 K steps deep), cout % 128 == 0,
      * scale and shift given; no pro_scale, split_k, batch.  Two epilogues: scale / shift / relu with the out_b column split (n_split % 128 == 0), or
-     * -- with any of res / out2 / in2, tiles 24 / 25 -- the conv3 form: in2 continues K (cin2 % 16 == 0; not together with res), res is a dense
+     * -- with any of res / out2 / in2, tiles 24 .. 26 -- the conv3 form: in2 continues K (cin2 % 16 == 0; not together with res), res is a dense
      * shortcut tensor with ldr == ldo, out2 = relu(scale2 * stored(out) + shift2) exactly as k_order 0 defines it.
      * Both operands go through LDS rings (one wave per SIMD), for layers whose K loop is bound by the round trip of
      * a two-stage ring (block 4, block3/unit_1's shortcut + conv1).  Differs from k_order 0 by fp32 rounding of the accumulation only. */

@@ -38,7 +38,7 @@ def test_conv1x1_stream_kernel(case, gpu_device):
         kw = dict(stride=1, pad=0, scale=scale, shift=shift, relu=relu, in_dtype=X3, out_dtype=X3, device=gpu_device)
         if n_split:
             kw.update(n_split=n_split, relu_b=not relu)
-        outs = {tile: conv_gemm(x, w, tile=tile, k_order=2, **kw) for tile in ((0, 22, 23, 24, 25) if relu else (0, 24))}
+        outs = {tile: conv_gemm(x, w, tile=tile, k_order=2, **kw) for tile in ((0, 22, 23, 24, 25, 26) if relu else (0, 24, 26))}
         ref, _ = _ref_conv(_split_round(x), _split_round_w(w), 1, 0, scale, shift, None, False, None, None, 1)
         mag = max(1.0, np.abs(ref).max())
         if n_split:
@@ -130,7 +130,7 @@ def test_conv1x1_stream_kernel_conv3_form(case, gpu_device):
     if has_out2:
         s2, b2 = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.normal(size=cout).astype(np.float32)
         kw.update(scale2=s2, shift2=b2)
-    outs = {tile: conv_gemm(x, w, tile=tile, k_order=2, **kw) for tile in (0, 24, 25)}
+    outs = {tile: conv_gemm(x, w, tile=tile, k_order=2, **kw) for tile in (0, 24, 25, 26)}
     ref, ref2 = _ref_conv(xr, _split_round_w(wr), 1, 0, None, shift, None if res is None else _split_round(res), False, s2, b2, 1)
     mag = max(1.0, np.abs(ref).max())
     other = conv_gemm(x, w, tile=0, k_order=0, **kw)
