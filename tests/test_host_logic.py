@@ -418,3 +418,72 @@ def test_b1_unit_instruction_stream_matches_its_wait_table():
             stores = 4 if (lst >= 4 and s not in (5, 9, 14)) else 0
             assert ops == ["D"] * want_d_first + ["S"] * stores + ["D"] * (lst - stores), (sym, "step", s, "".join(ops), want_d_first, stores, lst)
             i = j if s < total - 1 else i
+
+
+def test_conv1x1_stream_instruction_stream_matches_its_counted_waits():
+    """csrc/conv1x1_stream.hip waits on its two operand rings with COUNTED s_waitcnt vmcnt(N): a K step issues P = 2 + BM / 64 requests per
+    wave for stage kt + D and ends on vmcnt((D - 2) P); the conv3 form's epilogue counts shortcut requests and stores.  This test
+    cross-compiles the file (no GPU needed) and walks EVERY instantiation's ISA: D P requests in the prologue, then per unrolled step exactly
+    P requests, one counted wait and one barrier (nothing the compiler added in between), the drain in front of the epilogue, and for the
+    one-workgroup-per-CU conv3 forms the epilogue's wait sequence 4 x (blocks ahead) + stores x (blocks behind)."""
+    import os
+    import re
+    import subprocess
+    import tempfile
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(here, "human_dynamics_amd", "csrc")
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "s1.s")
+        from human_dynamics_amd import build as B
+        cmd = [B.HIPCC] + [f for f in B.FLAGS if f != "-fPIC"] + ["-x", "hip", "--cuda-device-only", "-S", os.path.join(csrc, "conv1x1_stream.hip"), "-o", out]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout[-2000:]
+        asm = open(out).read()
+    syms = re.findall(r"^(_ZN12_GLOBAL__N_121conv1x1_stream_kernelI(\w+?)EEvNS_6S1ArgsE):", asm, re.M)
+    assert len(syms) >= 14
+    seen = set()
+    for sym, targs in syms:
+        vals = [int(v) for v in re.findall(r"L[ib](\d+)E", targs)]
+        FM, FN, WGM, WGN, D, EPI, IN2, RES, OUT2, OCC = vals
+        seen.add((FM, FN, D, EPI, OCC))
+        BM = 32 * WGM * FM
+        P = 2 + (BM + 63) // 64
+        U = 2 * D if D % 2 else D
+        start = asm.index(sym + ":")
+        body = asm[start:asm.index("s_endpgm", start)]
+        ev = []
+        for line in body.splitlines():
+            t = line.split(";")[0].strip().split()
+            if not t:
+                continue
+            if t[0].startswith("global_load_lds"):
+                ev.append("D")
+            elif t[0].startswith("global_store"):
+                ev.append("S")
+            elif t[0] == "s_barrier":
+                ev.append("|")
+            elif t[0] == "s_waitcnt" and "vmcnt" in line.split(";")[0]:
+                ev.append(int(line.split("vmcnt(")[1].split(")")[0]))
+        bars = [i for i, e in enumerate(ev) if e == "|"]
+        assert len(bars) == 2 + U + 1, (targs, len(bars))
+        # prologue: D stages of P requests, the counted waits for stage 0 and stage 1 in front of the first two barriers
+        assert ev[:bars[0]].count("D") == D * P and ev[bars[0] - 1] == (D - 1) * P, (targs, ev[:bars[0]])
+        assert ev[bars[0] + 1:bars[1]] == [(D - 2) * P], (targs, ev[bars[0] + 1:bars[1]])
+        # the unrolled steps: P requests, ONE wait, the barrier
+        for s in range(U):
+            seg = ev[bars[1 + s] + 1:bars[2 + s]]
+            assert seg == ["D"] * P + [(D - 2) * P], (targs, "step", s, seg)
+        # the drain in front of the epilogue (the repeats of the last stage land in rings the epilogue reuses)
+        assert ev[bars[1 + U] + 1:bars[2 + U]] == [0], (targs, ev[bars[1 + U] + 1:bars[2 + U]])
+        tail = ev[bars[2 + U] + 1:]
+        nblk = FM * FN
+        if EPI == 0:
+            assert tail.count("S") == 4 * nblk and "D" not in tail, (targs, tail)
+        else:
+            nst = 8 if OUT2 else 4
+            assert tail.count("S") == nst * nblk and tail.count("D") == (4 * nblk if RES else 0), (targs, tail.count("S"), tail.count("D"))
+            if RES and OCC == 1:
+                pd = 4
+                want = [4 * min(nblk - 1 - b, pd) + nst * min(b, pd) for b in range(nblk)]
+                assert [e for e in tail if isinstance(e, int)] == want, (targs, [e for e in tail if isinstance(e, int)], want)
+    assert {(7, 1, 6, 0, 1), (8, 1, 6, 0, 1), (7, 2, 4, 0, 1), (4, 2, 6, 0, 1), (4, 2, 3, 0, 2), (7, 2, 4, 1, 1), (4, 2, 3, 1, 2)} <= seen
