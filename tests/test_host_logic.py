@@ -487,3 +487,38 @@ def test_conv1x1_stream_instruction_stream_matches_its_counted_waits():
                 want = [4 * min(nblk - 1 - b, pd) + nst * min(b, pd) for b in range(nblk)]
                 assert [e for e in tail if isinstance(e, int)] == want, (targs, [e for e in tail if isinstance(e, int)], want)
     assert {(7, 1, 6, 0, 1), (8, 1, 6, 0, 1), (7, 2, 4, 0, 1), (4, 2, 6, 0, 1), (4, 2, 3, 0, 2), (7, 2, 4, 1, 1), (4, 2, 3, 1, 2)} <= seen
+
+
+def test_conv1x1_stream_pack_and_packer_marks():
+    """packing.pack_conv1x1_stream (hmmr_conv_desc_t.k_order = 2 on a 1x1 filter, csrc/conv1x1_stream.hip): [cout / 128][cin / 16][4 row
+    blocks][hi | lo plane][lane = 32 * (k half) + row][8]; hi + lo reproduce the scaled filter rows; the size the library expects.
+    pack_resnet marks block 4's conv1 / conv3, block2/unit_1's conv1 and block3/unit_1's shortcut + conv1 bank for it in the split mode
+    only, and those units read a materialised pre-activation (fuse_preact = 0); the tuner's candidates map onto tiles 22 .. 26."""
+    from human_dynamics_amd import engine as E
+    rng = np.random.default_rng(9)
+    lib = _lib.load()
+    for cin, cout in ((256, 128), (2048, 512), (512 + 1024, 2048)):
+        w = rng.normal(size=(1, 1, cin, cout)).astype(np.float32)
+        st = packing.pack_conv1x1_stream(w)
+        assert tuple(st.shape) == (cout // 128, cin // 16, 4, 2, 64, 8) and st.dtype == torch.float16
+        assert st.numel() * 2 == lib.hmmr_conv1x1_stream_bytes(cin, cout)
+        k = packing.row_pow2(w[0, 0].T)
+        for co, ci in ((0, 0), (cout - 1, cin - 1), (77, 130), (cout // 2 + 3, 21)):
+            t, rb, row = co // 128, (co % 128) // 32, co % 32
+            lane, e = 32 * ((ci % 16) // 8) + row, ci % 8
+            got = float(st[t, ci // 16, rb, 0, lane, e]) + float(st[t, ci // 16, rb, 1, lane, e])
+            want = float(w[0, 0, ci, co]) * 2.0 ** int(k[co])
+            assert abs(got - want) <= abs(want) * 2.0 ** -21
+    ws = assets.make_synthetic_weights(0)
+    rw = packing.pack_resnet(ws, _lib.HMMR_F16X3, packing.DeviceStore("cpu"))
+    c1 = [i for i in range(16) if rw.unit[i].conv1.k_order == 2]
+    assert c1 == [3, 7, 13, 14, 15] and [i for i in range(16) if rw.unit[i].conv3.k_order == 2] == [13, 14, 15]
+    assert rw.unit[7].sc_c1.k_order == 2 and rw.unit[7].shortcut.k_order == 2 and rw.unit[13].c3sc.k_order == 2
+    assert all(rw.unit[i].fuse_preact == 0 for i in c1) and rw.unit[12].fuse_preact == 1
+    for dt, kw in ((_lib.HMMR_BF16, {}), (_lib.HMMR_F32, {}), (_lib.HMMR_F16X3, dict(stream_1x1=False))):
+        other = packing.pack_resnet(ws, dt, packing.DeviceStore("cpu"), **kw)
+        assert all(other.unit[i].conv1.k_order == 0 and other.unit[i].conv3.k_order == 0 and other.unit[i].sc_c1.k_order == 0 for i in range(16))
+    f = E.HmmrEngine._tile_for
+    lay = rw.unit[14].conv1
+    assert [f(lay, c, 512, _lib.HMMR_F16X3, "conv1") for c in (0, 5, 6, 3, 1, 2, 7, 8, 11, 24, 26)] == [0, 22, 23, 24, 25, 26, 0, 0, 0, 24, 26]
+    assert [f(rw.unit[14].conv3, c, 2048, _lib.HMMR_F16X3, "conv3") for c in (0, 5, 6, 3, 1, 2, 22, 26)] == [0, 0, 0, 24, 25, 26, 0, 26]
