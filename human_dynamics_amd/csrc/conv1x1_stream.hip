@@ -7,7 +7,7 @@
 // 33 TB/s into LDS, but a two-stage ring with two workgroups per CU has one K step of each workgroup in flight, and a step takes an L2 /
 // fabric round trip (1.86 us per 32-channel step in block4/unit_2's conv1, 0.4 us of it matrix time).  This kernel keeps D - 1 K steps
 // of BOTH operands in flight, the way csrc/conv3x3_stream.hip does for its filters:
-//   * ONE wave per SIMD (4-wave workgroups, one per CU), FM x FN accumulators of 32 x 32 in the AGPR half, two fragment sets in the VGPR
+//   * ONE wave per SIMD (4-wave workgroups, one per CU; tile 26: two), FM x FN accumulators of 32 x 32 in the AGPR half, two fragment sets in the VGPR
 //     half; a K step is 16 channels = 3 FM FN MFMAs and one barrier, the next step's fragment reads between the MFMAs;
 //   * filters: the stream of MFMA A-operand fragments of packing.pack_conv1x1_stream ([128-channel tile][K step][4 row blocks][hi plane |
 //     lo plane] of 1 KB) through a ring of D slabs of 8 KB, D steps ahead;
@@ -17,8 +17,12 @@
 //     per-lane constants (no taps, no borders), ring slot and row block are an add and an instruction offset;
 //   * waits are COUNTED (s_waitcnt vmcnt(N)): a step issues P = 2 + BM / 64 requests per wave for stage kt + D and ends when stage
 //     kt + 2 has landed, (D - 2) P requests younger than it still in flight.
-// The epilogue is that of the 3x3 stream kernel (folded BN, ReLU, split, 16-byte row stores through wave-private staging tiles), with
+// Epilogue 0 is that of the 3x3 stream kernel (folded BN, ReLU, split, 16-byte row stores through wave-private staging tiles), with
 // hmmr_conv_desc_t's column split: N tiles from n_split on go to out_b (the conv shortcut and conv1 of a block's first unit as one launch).
+// Epilogue 1 is the conv3 form (res / out2 / in2 of the descriptor): K may continue in a second tensor, the shortcut's 32 x 32 blocks are
+// DMA'd ahead into wave-private tiles and added before the split, the next unit's pre-activation of the stored value is a second output.
+// Tile 26 runs TWO workgroups per CU (rings 3 deep, 256 registers per wave): one workgroup's prologue, epilogue and round trips under the
+// other's loop -- for short K loops and the conv3 form's HBM-heavy epilogue.  DESIGN.md section 4.1.3 has the measurements.
 // Products and their order per output element: (w.hi x.lo, w.lo x.hi, w.hi x.hi) per 16-channel K step, steps in channel order -- the
 // same for every tile of this kernel (they differ from gemm_conv.hip's 32-channel steps by fp32 rounding of the accumulation only).
 #include <type_traits>
