@@ -59,7 +59,10 @@ PEAK_BF16 = 2.5e15                       # dense MFMA peak, MI355X_MICROARCH.md
 PEAK_F32 = 157.3e12
 # f16x3 issues three fp16 MFMAs (same rate as bf16: 2.5 PF dense) per algorithmic multiply-add: its MFMA ceiling in algorithmic FLOP/s
 PEAKS = {"bf16": PEAK_BF16, "f16x3": PEAK_BF16 / 3.0, "f32": PEAK_F32}
-ERR_WINDOW_START = 96                    # output frames [96, 104) are checked end to end against the oracle
+ERR_WINDOW_START = 96                    # output frames [96, 104) are checked end to end against the oracle (every weight set of `stress`)
+# the headline's own check: four windows spread over the step's output frames -- the first (its leading frames are the reference's zero
+# padding images), two in the middle, and the last (trailing padding)
+ERR_WINDOW_STARTS = (0, 96, 176, 248)
 
 
 class Cfg(object):
@@ -124,18 +127,19 @@ def cpu_baseline(windows=16):
                       "(sched_getaffinity / cgroup cpu.max), NOT the %d cores the host shows" % (windows, dt, cores, os.cpu_count())}
 
 
-def oracle_window(span_host, f0, n_total, weights, smpl):
-    """float64 oracle on the reference's padded window that keeps output frames
-    [ERR_WINDOW_START, +8) of the bench video (tester.py:281-295)."""
+def oracle_window(span_host, f0, n_total, weights, smpl, starts=(ERR_WINDOW_START,)):
+    """float64 oracle on the reference's padded windows that keep output frames [s, s + 8) of the bench video for every s in
+    `starts` (tester.py:281-295); the kept frames of all windows, concatenated in the order of `starts`."""
     from oracle import hmmr_oracle as O
     torch.set_num_threads(usable_cores())
-    win = np.zeros((1, 20, 224, 224, 3), np.float32)
-    for j in range(20):
-        f = ERR_WINDOW_START - 6 + j
-        if 0 <= f < n_total:
-            win[0, j] = span_host[f - f0]
-    ref = O.OracleTester(weights, smpl, batch_size=1, dtype=torch.float64).predict(win)
-    return {k: ref[k][0, 6:14] for k in ("verts", "joints", "omegas")}
+    win = np.zeros((len(starts), 20, 224, 224, 3), np.float32)
+    for i, s0 in enumerate(starts):
+        for j in range(20):
+            f = s0 - 6 + j
+            if 0 <= f < n_total:
+                win[i, j] = span_host[f - f0]
+    ref = O.OracleTester(weights, smpl, batch_size=len(starts), dtype=torch.float64).predict(win)
+    return {k: np.concatenate([ref[k][i, 6:14] for i in range(len(starts))]) for k in ("verts", "joints", "omegas")}
 
 
 def free_port():
@@ -167,12 +171,76 @@ def resolve_workload(args, world):
     return strong, (args.video_frames if strong else args.frames * world)
 
 
-def run_mode(dtype, args, world, rank, device, weights, smpl, span, n_total, steps, warmup):
+def multi_gpu_fields(tester, n_total, span, world, rank, device, reps=3, pipeline=False, step_streams=True):
+    """What the N > 1 line says about the ONE collective of the path (run on every rank; works on any backend -- the CPU tests drive it
+    with gloo and a stand-in Tester):
+      rccl_ranks        dist.get_world_size(), read after an actual all-gather has completed on this group;
+      all_gather_ms     {records, theta}: the isolated cost of one gather of a step's payload (max over ranks, mean of `reps`);
+      all_gather_bytes  {records, theta}: bytes every rank ends up holding;
+      single_video_ms   {records, theta}: ONE step of the whole video -- local pass, gather and (theta) the SMPL evaluation of all
+                        frames -- launch to completion with NOTHING overlapped across steps: what one video costs, the
+                        north_star's 'reassemble the output sequence' (max over ranks, best of `reps`);
+      gather_by_measurement   the mode with the smaller single_video_ms."""
+    from human_dynamics_amd import dist as hd
+
+    def sync():
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    plan = hd.ShardPlan(n_total, tester.batch_size, tester.sequence_length, tester.fov, world, rank)
+    _, rec_len = tester.record_layout()
+    n_reg = 1 + len(tester.delta_t_values)
+    out = {"all_gather_ms": {}, "all_gather_bytes": {}, "single_video_ms": {}}
+    for mode, width in (("records", rec_len), ("theta", 85 * n_reg)):
+        loc = torch.zeros((plan.out_per_rank, width), dtype=torch.float32, device=device)
+        full = torch.empty((world * plan.out_per_rank, width), dtype=torch.float32, device=device)
+        for _ in range(2):
+            dist.all_gather_into_tensor(full, loc)
+        sync()
+        dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            dist.all_gather_into_tensor(full, loc)
+        sync()
+        out["all_gather_ms"][mode] = round(max_over_ranks((time.perf_counter() - t1) / reps * 1e3), 3)
+        out["all_gather_bytes"][mode] = int(full.numel() * 4)
+        del loc, full
+    out["rccl_ranks"] = dist.get_world_size()               # (after the gathers above have completed on this group)
+    for mode in ("records", "theta"):
+        p = hd.ShardedPredictor(tester, n_total, rank, world, overlap_gather=False, pipeline=pipeline, gather_mode=mode,
+                                step_streams=step_streams)
+        p.run(span)
+        p.finish()
+        best = None
+        for _ in range(reps):
+            sync()
+            dist.barrier()
+            t1 = time.perf_counter()
+            res = p.run(span)
+            p.finish()
+            sync()
+            ms = max_over_ranks((time.perf_counter() - t1) * 1e3)
+            best = ms if best is None else min(best, ms)
+        assert res.shape[0] == n_total
+        out["single_video_ms"][mode] = round(best, 3)
+        del p, res
+    sv = out["single_video_ms"]
+    out["gather_by_measurement"] = "theta" if sv["theta"] < sv["records"] else "records"
+    return out
+
+
+def run_mode(dtype, args, world, rank, device, weights, smpl, span, n_total, steps, warmup, sustain_s=0.0, tester=None):
     """Time `steps` passes of the hot path in operand mode `dtype`.  Returns the timing dict, the
     tester / predictor (for the roofline leg) and the last output tensor."""
     from human_dynamics_amd import dist as hd
     from human_dynamics_amd.evaluation.tester import Tester
-    tester = Tester(Cfg(), weights=weights, smpl=smpl, dtype=dtype, device=str(device))      # "auto": precision.choose_engine
+    if tester is None:
+        tester = Tester(Cfg(), weights=weights, smpl=smpl, dtype=dtype, device=str(device))  # "auto": precision.choose_engine
     eng = tester.engine
     pipeline = not (args.no_pipeline or args.graph or args.serial)
     if args.serial or args.graph:
@@ -220,13 +288,34 @@ def run_mode(dtype, args, world, rank, device, weights, smpl, span, n_total, ste
     timing = {"fps": n_total * steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "steps": steps,
               "pipeline": pipeline, "resnet_streams": eng.resnet_streams,
               "step_streams": getattr(predictor, "step_streams", None) is not None}
+    if sustain_s > 0:
+        # the same steps for at least `sustain_s` seconds of GPU time (the K-step region above is ~0.1 s: too short to say what the box
+        # does once its power management has settled): a step count from the measurement above, one timed region, same brackets
+        n2 = int(sustain_s * 1.05 / (elapsed / steps)) + 1
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n2):
+            out = predictor.run(span)
+        predictor.finish()
+        barrier()
+        el2 = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el2], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el2 = float(t.item())
+        timing.update(sustained_fps=n_total * n2 / el2, sustained_steps=n2, sustained_seconds=el2)
     return timing, tester, predictor, out
 
 
-def e2e_errors(out, tester, ref, sliced=False):
+def rows_of(out, starts):
+    """the output frames [s, s + 8) of every s in `starts`, in that order"""
+    return torch.cat([out[s0:s0 + 8] for s0 in starts])
+
+
+def e2e_errors(out, tester, ref, sliced=False, starts=(ERR_WINDOW_START,)):
     from human_dynamics_amd import dist as hd
     layout, _ = hd.record_layout(len(tester.delta_t_values))
-    rec = hd.unpack_outputs(out if sliced else out[ERR_WINDOW_START:ERR_WINDOW_START + 8], layout)
+    rec = hd.unpack_outputs(out if sliced else rows_of(out, starts), layout)
     return {"e2e_%s_max_abs_err" % k: float(np.abs(rec[k].cpu().numpy() - ref[k]).max()) for k in ("verts", "joints", "omegas")}
 
 
@@ -369,11 +458,121 @@ def roofline_leg(tester, plan, span, dtype, frames):
                           "f16x3": "dense fp16 MFMA (2.5 PF, = bf16) / 3 (three fp16 MFMAs per algorithmic multiply-add)"}[dtype],
             "traffic": traffic, "traffic_unit": "B/launch",
             "traffic_source": traffic_src, "traffic_commit": traffic_commit, "mfma_util_pmc": mfma_util,
+            # the counter figures are READ from the committed summary of separate rocprofv3 --pmc passes (the guide's procedure: counters
+            # in their own runs), taken at `traffic_commit`; nothing in THIS run measures them
+            "traffic_measured_in_this_run": False,
             "mfma_util_pmc_by_family": families,
             "avg_launch_us": round(avg_launch_s * 1e6, 2),
             "flops_per_launch": flops_per_launch,
             "measured": "one stream, no co-running kernels (the timed steps overlap streams)",
             "resnet_pass_ms": round(pass_ms, 3), "conv_ms": round(conv_ms, 3), "frames_encoded": n_enc}
+
+
+def by_config_leg(tester, weights, device, dtype, headline_frac):
+    """The hot path at the OTHER sizes the reference and BASELINE.json name (outside the headline's timed region; everything resident
+    in HBM, HIP events on the launch stream, tile tuning and workspaces warmed before each figure):
+      configs[1]  batch = 64 frames, ResNet only (FeatureExtractor's fixed batch: src/datasets/resnet_extractor.py:14,74-98) -- the
+                  ResNet pass on one stream and as the engine runs it, and the host surface compute_phis (ndarray in, ndarray out);
+      predict     the reference's default call: Tester.predict on B = 8 windows of T = 20 frames (src/config.py:43-44,
+                  tester.py:229-258), literal schedule: 160 frames through ResNet, f_movie, IEF and 3 x SMPL, all 160 frames returned;
+      configs[2]  64 windows x 20 frames = 1280 frames through ResNet + f_movie + IEF (no SMPL);
+      window      ONE 20-frame window through Tester.predict_device, launch to completion (latency, not throughput).
+    `roofline.frac` of an entry = ResNet FLOPs of its frames / its ResNet pass time (one stream) / the mode's MFMA peak, the headline's
+    definition; `frac_vs_headline` relates it to the 257-frame pass of the headline."""
+    from human_dynamics_amd.datasets.resnet_extractor import FeatureExtractor
+    eng = tester.engine
+    peak = PEAKS[dtype]
+    gen = torch.Generator(device=device)
+    gen.manual_seed(4321)
+
+    def frames(n):
+        return torch.rand((n, 224, 224, 3), generator=gen, device=device) * 2 - 1
+
+    def ev_ms(fn, reps, warm=3):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(device)
+        return e0.elapsed_time(e1) / reps
+
+    def resnet_figures(x, reps):
+        n = x.shape[0]
+        streams = eng.resnet_streams
+        eng.resnet_streams = 1
+        one = ev_ms(lambda: eng.resnet(x), reps)
+        eng.resnet_streams = streams
+        asrun = ev_ms(lambda: eng.resnet(x), reps) if len(eng.resnet_cuts(n)) > 2 else one
+        tf = RESNET_FLOPS_PER_FRAME * n / (one * 1e-3)
+        return one, asrun, {"bound": "mfma", "achieved": round(tf / 1e12, 2), "peak": round(peak / 1e12, 1), "unit": "TFLOP/s",
+                            "frac": round(tf / peak, 4), "frac_vs_headline": round(tf / peak / headline_frac, 3) if headline_frac else None}
+
+    out = {}
+    # ---- configs[1]
+    x64 = frames(64)
+    one, asrun, roof = resnet_figures(x64, 30)
+    fx = FeatureExtractor("synthetic:0", weights=weights, dtype=dtype, device=str(device))
+    x64h = x64.cpu().numpy()
+    fx.compute_phis(x64h)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        fx.compute_phis(x64h)
+    host_ms = (time.perf_counter() - t0) / 5 * 1e3
+    del fx
+    out["configs[1]: batch 64, ResNet only"] = {
+        "frames": 64, "ms": round(one, 4), "fps": round(64 / (one * 1e-3), 1), "roofline": roof,
+        "host_surface": {"call": "FeatureExtractor.compute_phis(ndarray[64,224,224,3]) -> ndarray[64,2048]", "ms": round(host_ms, 3),
+                         "fps": round(64 / (host_ms * 1e-3), 1)}}
+    # ---- the reference's default predict: B = 8, T = 20
+    cfg = Cfg(batch_size=8)
+    x160 = frames(160)
+    one, asrun, roof = resnet_figures(x160, 20)
+    img = x160.reshape(8, 20, 224, 224, 3)
+    ms = ev_ms(lambda: tester.predict_device(img), 20)
+    out["Tester.predict default: B=8, T=20 (160 frames, literal schedule, all frames returned)"] = {
+        "frames": 160, "ms": round(ms, 4), "fps": round(160 / (ms * 1e-3), 1), "resnet_ms_one_stream": round(one, 4),
+        "resnet_ms_as_run": round(asrun, 4), "roofline": roof}
+    # ---- one window: latency
+    w1 = img[:1].contiguous()
+    def one_window():
+        tester.predict_device(w1)
+        torch.cuda.synchronize(device)
+    for _ in range(3):
+        one_window()
+    lat = []
+    for _ in range(20):
+        t0 = time.perf_counter()
+        one_window()
+        lat.append((time.perf_counter() - t0) * 1e3)
+    one20, _, roof20 = resnet_figures(w1.reshape(20, 224, 224, 3), 30)
+    out["one 20-frame window, Tester.predict_device, launch to completion"] = {
+        "frames": 20, "ms": round(float(np.median(lat)), 4), "ms_min": round(float(min(lat)), 4),
+        "fps": round(20 / (float(np.median(lat)) * 1e-3), 1), "resnet_ms_one_stream": round(one20, 4), "roofline": roof20}
+    del x160, img, w1
+    # ---- configs[2]: 64 windows x 20 frames, ResNet + f_movie + IEF
+    x = frames(1280)
+    def cfg2():
+        phi = tester.features(x)
+        strips = tester._movie_strips(phi.reshape(64, 20, -1))
+        return eng.ief(strips.reshape(1280, -1))
+    ms = ev_ms(cfg2, 6, warm=2)
+    streams = eng.resnet_streams
+    eng.resnet_streams = 1
+    one = ev_ms(lambda: tester.features(x), 6, warm=1)
+    eng.resnet_streams = streams
+    tf = RESNET_FLOPS_PER_FRAME * 1280 / (one * 1e-3)
+    out["configs[2]: 64 windows x 20 frames (1280), ResNet + f_movie + IEF"] = {
+        "frames": 1280, "ms": round(ms, 4), "fps": round(1280 / (ms * 1e-3), 1), "resnet_ms_one_stream": round(one, 4),
+        "resnet_passes": "%d frames per pass (Tester.MAX_DEVICE_FRAMES)" % tester.MAX_DEVICE_FRAMES,
+        "roofline": {"bound": "mfma", "achieved": round(tf / 1e12, 2), "peak": round(peak / 1e12, 1), "unit": "TFLOP/s",
+                     "frac": round(tf / peak, 4), "frac_vs_headline": round(tf / peak / headline_frac, 3) if headline_frac else None}}
+    del x
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -389,10 +588,15 @@ def main():
                          "exact-fp32 mode, precision.py): f16x3 for well-conditioned weights")
     ap.add_argument("--no-stress", action="store_true", help="skip the tolerance stress leg (more weight seeds, hard conditioning)")
     ap.add_argument("--only-main", action="store_true", help="skip the other operand modes (`modes`)")
-    ap.add_argument("--gather", default="records", choices=["records", "theta"],
+    ap.add_argument("--gather", default="auto", choices=["auto", "records", "theta"],
                     help="N > 1: all-gather the packed per-frame records (253 KB/frame) or only the 3 x 85 omegas "
-                         "(1 KB/frame) and evaluate SMPL for the whole video on every rank")
+                         "(1 KB/frame) and evaluate SMPL for the whole video on every rank.  auto: weak scaling -> records "
+                         "(hidden under the next step); one video (--video-frames, the N > 1 default) -> whichever mode the "
+                         "measured `single_video_ms` of this run says is faster (theta, unless the fabric is very fast)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sustain", type=float, default=2.0,
+                    help="seconds of a second, longer timed leg of the same steps (`fps_sustained_2s`; 0 = skip)")
+    ap.add_argument("--no-by-config", action="store_true", help="skip the `by_config` legs (the other BASELINE sizes)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive leg (used for PMC passes)")
     ap.add_argument("--serial-gather", action="store_true",
                     help="N > 1: wait for each all-gather instead of overlapping it with the next step")
@@ -441,8 +645,20 @@ def main():
     gen.manual_seed(1234 + rank)
     span = torch.rand((plan.f1 - plan.f0, 224, 224, 3), generator=gen, device=device) * 2 - 1
 
+    # N > 1: the figures of the one collective first (outside the timed region), because the gather mode of a strong-scaling run is
+    # picked by them: ONE video is what `--video-frames` measures, and for one video the records gather (253 KB per frame) is exposed
+    # while the omegas gather (1 KB per frame + SMPL for all frames on every rank) is not
+    mg, tester0 = None, None
+    if world > 1:
+        from human_dynamics_amd.evaluation.tester import Tester
+        tester0 = Tester(Cfg(), weights=weights, smpl=smpl, dtype=args.dtype, device=str(device))
+        mg = multi_gpu_fields(tester0, n_total, span, world, rank, device,
+                              pipeline=not (args.no_pipeline or args.graph or args.serial), step_streams=not args.no_step_streams)
+    gather_requested = args.gather
+    if args.gather == "auto":
+        args.gather = mg["gather_by_measurement"] if (mg is not None and strong) else "records"
     timing, tester, predictor, out = run_mode(args.dtype, args, world, rank, device, weights, smpl, span, n_total,
-                                              args.steps, args.warmup)
+                                              args.steps, args.warmup, sustain_s=args.sustain, tester=tester0)
     value, ms_per_step = timing["fps"], timing["ms_per_step"]
     from human_dynamics_amd import precision
     from human_dynamics_amd.engine import DTYPE_NAMES
@@ -450,30 +666,15 @@ def main():
     args.dtype = DTYPE_NAMES[tester.engine.dtype]         # the ResNet's operand mode (what "auto" resolved to)
     operands_desc = precision.describe(tester.engine)
 
-    # isolated cost of the one collective of a step (outside the timed region)
-    all_gather_ms, gather_bytes = None, None
-    if world > 1:
-        width = predictor.rec_len if args.gather == "records" else 85 * (1 + len(tester.delta_t_values))
-        loc = torch.zeros((plan.out_per_rank, width), dtype=torch.float32, device=device)
-        full = torch.empty((world * plan.out_per_rank, width), dtype=torch.float32, device=device)
-        for _ in range(2):
-            dist.all_gather_into_tensor(full, loc)
-        torch.cuda.synchronize(device)
-        dist.barrier()
-        t1 = time.perf_counter()
-        for _ in range(5):
-            dist.all_gather_into_tensor(full, loc)
-        torch.cuda.synchronize(device)
-        tg = torch.tensor([(time.perf_counter() - t1) / 5 * 1e3], dtype=torch.float64, device=device)
-        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
-        all_gather_ms, gather_bytes = round(float(tg.item()), 3), int(full.numel() * 4)
-        del loc, full
+    # isolated cost of the one collective of a step (outside the timed region): multi_gpu_fields above, the mode the steps ran with
+    all_gather_ms = mg["all_gather_ms"][args.gather] if mg else None
+    gather_bytes = mg["all_gather_bytes"][args.gather] if mg else None
 
     # the same per-rank shard as a 1-GPU job (no collective), every rank at once: value / (world x this) = the scaling efficiency
     # of this run (the driver computes its own from the per-N lines)
     scaling_eff, shard_fps, rccl_ranks = None, None, None
     if world > 1:
-        rccl_ranks = dist.get_world_size()
+        rccl_ranks = mg["rccl_ranks"]
         n_loc = plan.o1 - plan.o0
         solo = hd.ShardedPredictor(tester, n_loc, 0, 1, pipeline=not (args.no_pipeline or args.graph or args.serial),
                                    step_streams=not args.no_step_streams)
@@ -503,17 +704,24 @@ def main():
         roofline["achieved_overlapped_note"] = ("ResNet FLOPs of one step / ms_per_step (the step also carries the f_movie / IEF / "
                                                 "SMPL tail on a second stream): the figure `value` corresponds to")
         single = world == 1
+        by_config = None
+        if single and not args.no_by_config:
+            try:
+                by_config = by_config_leg(tester, weights, device, args.dtype, roofline["frac"])
+            except Exception as e:                            # a reporting leg: never lose the headline over it
+                by_config = {"error": repr(e)}
         # ---- the other operand modes, same workload, same steps (extras: never the headline).  Timed BEFORE any host-side
         # work of this script (oracle, PCIe legs): under the container's CPU quota the oracle's thread pool slows the launch
         # thread down afterwards, and the 190-launch bf16 step is the first thing to become host-bound.
         others, modes = {}, {}
         all_frames_diff = None
+        err_starts = tuple(s0 for s0 in ERR_WINDOW_STARTS if s0 + 8 <= n_total) or (0,)
         if single and not args.only_main:
             for other in [m for m in ("f16x3", "bf16", "f32") if m != args.dtype]:
                 tm, t_o, pred_o, out_o = run_mode(other, args, world, rank, device, weights, smpl, span, n_total,
                                                   args.steps, args.warmup)
                 modes[other] = dict(fps=round(tm["fps"], 1), ms_per_step=round(tm["ms_per_step"], 3))
-                others[other] = (t_o, out_o[ERR_WINDOW_START:ERR_WINDOW_START + 8].clone())
+                others[other] = (t_o, rows_of(out_o, err_starts).clone())
                 if other == "f32" or args.dtype == "f32":
                     # every output frame of the step, headline mode against exact-fp32 operands: with the f32 mode's own
                     # distance from the float64 oracle (in `modes`) this bounds the error of ALL frames, not of 8
@@ -526,8 +734,8 @@ def main():
         span_host = span.cpu().numpy() if single else None
         ref = None
         if single and not args.no_cpu_baseline and n_total >= ERR_WINDOW_START + 14:
-            ref = oracle_window(span_host, plan.f0, n_total, weights, smpl)
-            modes[args.dtype] = dict(fps=round(value, 1), ms_per_step=round(ms_per_step, 3), **e2e_errors(out, tester, ref))
+            ref = oracle_window(span_host, plan.f0, n_total, weights, smpl, err_starts)
+            modes[args.dtype] = dict(fps=round(value, 1), ms_per_step=round(ms_per_step, 3), **e2e_errors(out, tester, ref, starts=err_starts))
             for other, (t_o, rows) in others.items():
                 modes[other].update(e2e_errors(rows, t_o, ref, sliced=True))
         elif modes:
@@ -611,13 +819,24 @@ def main():
                        if world > 1 else "single GPU"},
             "saturated": bool(tester.engine.run_flags() & 1),      # hmmr_run_flags: a split store clamped a value to the fp16 range
             "per_gpu_fps": round(value / world, 1),
+            # the same steps over >= 2 s of GPU time (K steps are ~0.1 s): what the box sustains once its clocks have settled
+            "fps_sustained_2s": round(timing["sustained_fps"], 1) if "sustained_fps" in timing else None,
+            "sustained_leg": ({"steps": timing["sustained_steps"], "seconds": round(timing["sustained_seconds"], 3)}
+                              if "sustained_fps" in timing else None),
             "frames_total": n_total,
             "all_gather_ms": all_gather_ms, "all_gather_bytes": gather_bytes, "rccl_ranks": rccl_ranks,
+            "gather": args.gather if world > 1 else None, "gather_requested": gather_requested if world > 1 else None,
+            # N > 1: both gather modes measured in this run -- one whole step with nothing overlapped across steps, and the bare gather
+            "single_video_ms": (mg["single_video_ms"][args.gather] if mg else None),
+            "single_video_ms_by_gather": (mg["single_video_ms"] if mg else None),
+            "all_gather_ms_by_gather": (mg["all_gather_ms"] if mg else None),
+            "all_gather_bytes_by_gather": (mg["all_gather_bytes"] if mg else None),
             # N > 1: value / (N x the fps of one rank's shard run as a 1-GPU job, all ranks at once, same run); the driver
             # computes its own from the per-N lines (tools/scale_table.py does the same)
             "scaling_efficiency": scaling_eff,
             "single_gpu_fps_same_shard": round(shard_fps, 1) if shard_fps else None,
             "roofline": roofline,
+            "by_config": by_config,
             "init_untimed": {"conv_tile_tuning_ms_by_batch": {str(n_): ms_ for n_, ms_ in tester.engine.tune_log},
                              "note": "one pass per candidate tile and batch size on the first call, before the warm-up steps"},
             "pcie_inclusive_fps": pcie_fps, "pcie_inclusive_fps_without_verts": pcie_nov,

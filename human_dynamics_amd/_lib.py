@@ -17,6 +17,7 @@ LIB_PATH = devflags.get("LIB_PATH") or os.path.join(HERE, "libhmmr_hip.so")
 
 HMMR_F32, HMMR_BF16, HMMR_F16X3 = 0, 1, 2
 FLAG_SATURATED = 1
+FLAG_NAN = 2          # with FLAG_SATURATED: the clamped value was a NaN (include/hmmr_hip.h)
 ABI_VERSION = 17
 RESNET_UNITS = 16
 RESNET_PROF_SLOTS = 64

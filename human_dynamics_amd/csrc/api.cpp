@@ -33,6 +33,21 @@ extern "C" void hmmr_launch_counts(hmmr_launch_counts_t* out, int clear) {
     if (out) { out->unit_pair = v[0]; out->b1_unit = v[1]; out->tail_split = v[2]; out->conv3x3_stream = v[3]; out->conv1x1_stream = v[4]; }
 }
 
+// compute units of the stream's device, asked once per device (csrc/common.h); 256 (an MI355X) if the runtime will not say
+int hmmr_cu_count(hipStream_t stream) {
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    if (!stream || hipStreamGetDevice(stream, &dev) != hipSuccess)
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const int slot = dev & 63;
+    int n = cus[slot].load(std::memory_order_relaxed);
+    if (n <= 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        cus[slot].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
 extern "C" int hmmr_abi_version(void) { return HMMR_ABI_VERSION; }
 extern "C" const char* hmmr_last_error(void) { return g_err; }
 

@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256, 2) void b1_unit_kernel(const B1Args a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) *(u32x4*)(hrow[q] + (ostep[q] ? j * 32 : 0)) = xr[q];
     }
-    split_flag(satm > HMMR_SPLIT_MAX);
+    split_flag_max(satm);
     B1_STAMP(12);
 }
 

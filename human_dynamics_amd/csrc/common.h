@@ -59,6 +59,9 @@ struct DeviceOnce {
     void mark(unsigned long long bit) { done.fetch_or(bit, std::memory_order_relaxed); }
 };
 
+// compute units of the device `stream` belongs to (the current device for the null stream), asked once per device (api.cpp)
+int hmmr_cu_count(hipStream_t stream);
+
 // XCD-aware, bijective remap of a 1-D block id: the hardware dispatches block
 // b to XCD b % 8; give each XCD a contiguous range of logical ids so tiles
 // that share an operand panel hit the same private L2 (speed only).
@@ -109,13 +112,37 @@ __device__ __forceinline__ float split_clamp(float v) { return __builtin_amdgcn_
 #ifndef HMMR_FLAG_SATURATED
 #define HMMR_FLAG_SATURATED 1u      /* include/hmmr_hip.h */
 #endif
+#ifndef HMMR_FLAG_NAN
+#define HMMR_FLAG_NAN 2u            /* include/hmmr_hip.h */
+#endif
 static __device__ unsigned g_split_flags __attribute__((unused));
 __device__ __forceinline__ void split_flag(bool bad) {
 #ifndef HMMR_NO_SATURATION_CHECK      // (development A/B only: what the checks cost)
     if (bad) atomicOr(&g_split_flags, HMMR_FLAG_SATURATED);
 #endif
 }
-__device__ __forceinline__ bool split_overflows(float v) { return __builtin_fabsf(v) > HMMR_SPLIT_MAX; }     // (+-inf included)
+// Round 6: a NaN must not slip through.  v_med3_f32 (the clamp) turns a NaN into a FINITE value (it returns min3 of the other two
+// operands) and v_max_f32 / v_max3_f32 (IEEE maxNum) drop a quiet NaN, so `fmaxf(...) > MAX` was false for it: a NaN activation became
+// a plausible number with hmmr_run_flags == 0.  gfx950 has the IEEE-754-2019 `maximum` as v_maximum3_f32 (NaN-propagating, |x| as a
+// source modifier): the running maximum of the hot epilogues costs the same instruction and BECOMES NaN, and the final test is
+// !(m <= MAX) -- true for NaN, +-inf and anything beyond the fp16 range.
+__device__ __forceinline__ float sat_acc(float m, float a, float b) {        // max(m, |a|, |b|), NaN-propagating
+    float r; asm("v_maximum3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(m), "v"(a), "v"(b)); return r;
+}
+__device__ __forceinline__ float sat_acc(float m, float a) {                 // max(m, |a|)
+    float r; asm("v_maximum3_f32 %0, %1, |%2|, |%2|" : "=v"(r) : "v"(m), "v"(a)); return r;
+}
+__device__ __forceinline__ float sat_acc_signed(float m, float a) {          // max(m, a): in front of a ReLU, where a large negative value is not a clamp
+    float r; asm("v_maximum3_f32 %0, %1, %2, %2" : "=v"(r) : "v"(m), "v"(a)); return r;
+}
+__device__ __forceinline__ bool sat_bad(float m) { return !(m <= HMMR_SPLIT_MAX); }
+// raise the flag(s) from a running maximum: SATURATED for anything the clamp changed, + NAN when the maximum is a NaN
+__device__ __forceinline__ void split_flag_max(float m) {
+#ifndef HMMR_NO_SATURATION_CHECK
+    if (sat_bad(m)) atomicOr(&g_split_flags, m != m ? (HMMR_FLAG_SATURATED | HMMR_FLAG_NAN) : HMMR_FLAG_SATURATED);
+#endif
+}
+__device__ __forceinline__ bool split_overflows(float v) { return !(__builtin_fabsf(v) <= HMMR_SPLIT_MAX); }     // (+-inf and NaN included)
 typedef int (*hmmr_flag_reader_t)(unsigned* flags, int clear);
 void hmmr_register_flag_reader(hmmr_flag_reader_t fn);          // api.cpp
 namespace {
@@ -204,9 +231,7 @@ template <typename T> __device__ __forceinline__ void store8(T* p, const float (
 template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8], float&) { store8(p, v); }
 template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&v)[8], float&) { store8(p, v); }
 template <> __device__ __forceinline__ void store8<bsplit_t>(bsplit_t* p, const float (&v)[8], float& satmax) {
-    satmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(satmax, __builtin_fabsf(v[0])), __builtin_fmaxf(__builtin_fabsf(v[1]), __builtin_fabsf(v[2]))),
-                             __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[3]), __builtin_fabsf(v[4])),
-                                             __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[5]), __builtin_fabsf(v[6])), __builtin_fabsf(v[7]))));
+    satmax = sat_acc(sat_acc(sat_acc(sat_acc(satmax, v[0], v[1]), v[2], v[3]), v[4], v[5]), v[6], v[7]);      // (four v_maximum3_f32)
     unsigned h[4], l[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) split2_mix(split_clamp(v[2 * i]), split_clamp(v[2 * i + 1]), h[i], l[i]);
@@ -214,8 +239,7 @@ template <> __device__ __forceinline__ void store8<bsplit_t>(bsplit_t* p, const 
     *((u32x4*)p + 1) = u32x4{l[0], l[1], l[2], l[3]};
 }
 __device__ __forceinline__ void store8(bsplit_t* p, const float (&v)[8]) {
-    split_flag(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])), __builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3]))),
-                               __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[4]), __builtin_fabsf(v[5])), __builtin_fmaxf(__builtin_fabsf(v[6]), __builtin_fabsf(v[7])))) > HMMR_SPLIT_MAX);
+    split_flag_max(sat_acc(sat_acc(sat_acc(sat_acc(0.f, v[0], v[1]), v[2], v[3]), v[4], v[5]), v[6], v[7]));
     shalf8 hi, lo;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -291,8 +315,7 @@ __device__ __forceinline__ void split4(const float (&v)[4], unsigned long long& 
 // satmax: running maximum of |v| over everything this thread has split (two v_max3_f32 per call; the caller raises the flag once,
 // with split_flag(satmax > HMMR_SPLIT_MAX), when it is done: these kernels are bound by their instruction count)
 __device__ __forceinline__ void split4(const float (&v)[4], unsigned long long& hi, unsigned long long& lo, float& satmax) {
-    satmax = __builtin_fmaxf(__builtin_fmaxf(satmax, __builtin_fabsf(v[3])),
-                             __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])), __builtin_fabsf(v[2])));
+    satmax = sat_acc(sat_acc(satmax, v[0], v[1]), v[2], v[3]);
     unsigned h[2], l[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -309,14 +332,14 @@ __device__ __forceinline__ void split4(const float (&v)[4], unsigned long long& 
 __device__ __forceinline__ void split4_mix(const float (&v)[4], float lo_clamp, unsigned (&h)[2], unsigned (&l)[2], float& satmax) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        satmax = __builtin_fmaxf(__builtin_fmaxf(satmax, __builtin_fabsf(v[2 * i])), __builtin_fabsf(v[2 * i + 1]));
+        satmax = sat_acc(satmax, v[2 * i], v[2 * i + 1]);
         split2_mix(__builtin_amdgcn_fmed3f(v[2 * i], lo_clamp, HMMR_SPLIT_MAX), __builtin_amdgcn_fmed3f(v[2 * i + 1], lo_clamp, HMMR_SPLIT_MAX), h[i], l[i]);
     }
 }
 
 __device__ __forceinline__ void split4(const float (&v)[4], unsigned long long& hi, unsigned long long& lo, unsigned long long& satmask) {
-    const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])), __builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
-    satmask |= __builtin_amdgcn_ballot_w64(m > HMMR_SPLIT_MAX);
+    const float m = sat_acc(sat_acc(0.f, v[0], v[1]), v[2], v[3]);
+    satmask |= __builtin_amdgcn_ballot_w64(sat_bad(m));
     float unused = 0.f;
     split4(v, hi, lo, unused);
 }

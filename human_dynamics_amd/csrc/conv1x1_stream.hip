@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_stream_kernel(const S1Args a
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    satmax = __builtin_fmaxf(satmax, __builtin_fabsf(c[e]));
+                    satmax = sat_acc(satmax, c[e]);
                     c[e] = __builtin_amdgcn_fmed3f(c[e], lo_clamp, HMMR_SPLIT_MAX);
                 }
                 unsigned h01, l01, h23, l23;
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_stream_kernel(const S1Args a
                     u[3] = fmaf(split_sum_hi(h23, l23), s2v[3], b2v[3]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        satmax = __builtin_fmaxf(satmax, u[e]);
+                        satmax = sat_acc_signed(satmax, u[e]);
                         u[e] = __builtin_amdgcn_fmed3f(u[e], 0.f, HMMR_SPLIT_MAX);
                     }
                     unsigned p01, q01, p23, q23;
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_stream_kernel(const S1Args a
             }
         };
         s1_blocks(block, std::make_integer_sequence<int, B>{});
-        split_flag(satmax > HMMR_SPLIT_MAX);
+        split_flag_max(satmax);
         return;
     }
 
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_stream_kernel(const S1Args a
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float v = fmaf(acc[i][j][4 * g + e], s4[j][g][e], b4[j][g][e]);
-                    satmax = __builtin_fmaxf(satmax, __builtin_fabsf(v));
+                    satmax = sat_acc(satmax, v);
                     c[e] = __builtin_amdgcn_fmed3f(v, lo_clamp, HMMR_SPLIT_MAX);
                 }
                 unsigned h01, l01, h23, l23;
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_stream_kernel(const S1Args a
             for (int q = 0; q < 4; ++q) *(u32x4*)(orow[q] + j * 32) = xr[q];
         }
     }
-    split_flag(satmax > HMMR_SPLIT_MAX);
+    split_flag_max(satmax);
 }
 
 template <int FM, int FN, int WGM, int WGN, int D, int EPI = 0, bool IN2 = false, bool RES = false, bool OUT2 = false, int OCC = 1>

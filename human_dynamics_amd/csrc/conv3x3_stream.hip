@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_stream_kernel(const S3Args a) 
     #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float v = fmaf(acc[i][j][4 * g + e], s4[j][g][e], b4[j][g][e]);
-                        satmax = __builtin_fmaxf(satmax, __builtin_fabsf(v));
+                        satmax = sat_acc(satmax, v);
                         c[e] = __builtin_amdgcn_fmed3f(v, lo_clamp, HMMR_SPLIT_MAX);
                     }
                     const unsigned h01 = __builtin_bit_cast(unsigned, shalf2{(shalf_t)c[0], (shalf_t)c[1]});
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_stream_kernel(const S3Args a) 
                 for (int q = 0; q < 4; ++q) *(u32x4*)(orow[q] + j * 32) = xr[q];
             }
         }
-    split_flag(satmax > HMMR_SPLIT_MAX);
+    split_flag_max(satmax);
     } else {
         // bf16 rows: 32 channels = 64 bytes per pixel and accumulator; lane (pixel lr, k half lh) holds channels 8 g + 4 lh .. + 3 of group g
         // as 8 bytes; a 2 KB staging tile per accumulator, rows of 64 B, 16-byte slot g XOR (row >> 2) & 3

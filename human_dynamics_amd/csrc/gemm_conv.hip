@@ -631,7 +631,7 @@ void conv_gemm_kernel(const ConvArgs a0) {
             else store_tail(out2 + oo, u, a.cout - n);
         }
     }
-    if constexpr (std::is_same<TO, bsplit_t>::value) split_flag(satmax > HMMR_SPLIT_MAX);
+    if constexpr (std::is_same<TO, bsplit_t>::value) split_flag_max(satmax);
 }
 
 // Shared by the two 3x3 patch kernels below.
@@ -695,7 +695,7 @@ __device__ __forceinline__ void patch_epilogue(const ConvArgs& a, char* smem, co
         }
         store8<TO>(out + (long long)m * a.ldo + n, v, satmax);
     }
-    if constexpr (std::is_same<TO, bsplit_t>::value) split_flag(satmax > HMMR_SPLIT_MAX);
+    if constexpr (std::is_same<TO, bsplit_t>::value) split_flag_max(satmax);
 }
 
 // ------------------------------------------------------------------------- //

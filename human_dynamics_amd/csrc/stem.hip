@@ -285,6 +285,7 @@ __global__ __launch_bounds__(X3_NT) void stem_fused_split_kernel(const float* __
 
     // ---- 1. input patch -> two fp16 RGBX planes (hi = fp16(x), lo = fp16(x - hi): stem_repack_split_kernel's values)
     const float* im = img + (long long)n * IMG * IMG * 3;
+    float satin = 0.f;                            // (round 6) a NaN / inf / out-of-range PIXEL: the clamp below would make it a finite number
     for (int i = tid; i < IP * 11; i += X3_NT) {
         const int py = i / 11, q = i - py * 11;
         const int gy = iy0 + py, gx = ix0 - 1 + 4 * q;
@@ -296,6 +297,8 @@ __global__ __launch_bounds__(X3_NT) void stem_fused_split_kernel(const float* __
             const f32x4 v0 = p[0], v1 = p[1], v2 = p[2];
 #pragma unroll
             for (int e = 0; e < 4; ++e) { f[e] = v0[e]; f[4 + e] = v1[e]; f[8 + e] = v2[e]; }
+#pragma unroll
+            for (int e = 0; e < 12; e += 2) satin = sat_acc(satin, f[e], f[e + 1]);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -315,6 +318,7 @@ __global__ __launch_bounds__(X3_NT) void stem_fused_split_kernel(const float* __
             }
         }
     }
+    split_flag_max(satin);
     // Round 5: ONE workgroup per tile computes both halves of the 64 output channels, one after the other, from the patch it built once
     // (two workgroups per tile -- blockIdx.z -- each loaded and split the same 39 x 39 pixels: 0.75 GB of traffic for a 0.36 GB layer).
     // Per half the arithmetic is untouched: same bits.
@@ -491,7 +495,7 @@ __global__ __launch_bounds__(X3_NT) void stem_fused_split_kernel(const float* __
             *(unsigned long long*)og = (unsigned long long)h2[0] | ((unsigned long long)h2[1] << 32);
             *(unsigned long long*)(og + 16) = (unsigned long long)l2[0] | ((unsigned long long)l2[1] << 32);
         }
-        split_flag(satmax > HMMR_SPLIT_MAX);
+        split_flag_max(satmax);
     }
 }
 }  // namespace

@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256, 1) void unit_pair_kernel(const PairArgs a) {
                     c[j] = split_clamp(v);
                     vraw[j] = v;
                 }
-                satm = __builtin_fmaxf(__builtin_fmaxf(satm, __builtin_fabsf(vraw[0])), __builtin_fabsf(vraw[1]));   // (one v_max3_f32: hmmr_run_flags)
+                satm = sat_acc(satm, vraw[0], vraw[1]);          // (one v_maximum3_f32, NaN-propagating: hmmr_run_flags)
                 shalf2 ph = {(shalf_t)c[0], (shalf_t)c[1]};
                 asm volatile("" : "+v"(ph));                   // (one v_cvt_pk_f16_f32; its halves are read in place below)
                 const shalf2 pl = {(shalf_t)__builtin_fmaf((float)ph[0], -one, c[0]), (shalf_t)__builtin_fmaf((float)ph[1], -one, c[1])};
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(256, 1) void unit_pair_kernel(const PairArgs a) {
 #pragma unroll
     for (int j = 0; j < NF2; ++j) asm volatile("" : "+a"(acc2[j]));
     PAIR_STAMP(3);
-    split_flag(satm > HMMR_SPLIT_MAX);
+    split_flag_max(satm);
 #ifdef HMMR_GEMM_PROBE
     if (PAIR_PROBE(a, 64) && a.ts && lane == 0 && blockIdx.x == 0 && wave == 0)
         for (int k = 0; k < NU + 3; ++k) a.ts[4096 * 4 * 8 + k] = ut[k];
@@ -656,7 +656,7 @@ __global__ __launch_bounds__(256, 1) void unit_pair_kernel(const PairArgs a) {
             *(u32x4*)(hrow[q] + (m < a.M ? of * 32 : 0)) = xr[q];
         }
     }
-    split_flag(satmax > HMMR_SPLIT_MAX);
+    split_flag_max(satmax);
     PAIR_STAMP(5);
     satm = 0.f;
     }   // tiles of this workgroup
@@ -680,9 +680,7 @@ int launch_pair(const PairArgs& a, hipStream_t stream) {
     int grid = n_tiles;
     b.tpw = 1;
     if (DEPTH <= 512 && n_tiles >= two_min) {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (cus < 1) cus = 256;
+        const int cus = hmmr_cu_count(stream);                   // (cached per device; the STREAM's device, not the current one)
         grid = n_tiles < cus ? (n_tiles + 1) / 2 : cus;          // (forced on for a short launch: two tiles per workgroup)
         b.tpw = (n_tiles + grid - 1) / grid;
     }

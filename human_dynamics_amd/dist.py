@@ -119,7 +119,7 @@ class ShardedPredictor(object):
     input and replays it afterwards.  (Measured equal to eager launches: the step is GPU-bound.)"""
 
     def __init__(self, tester, n_frames, rank=None, world_size=None, group=None, use_graph=False,
-                 overlap_gather=False, pipeline=False, gather_mode="records", step_streams=True):
+                 overlap_gather=False, pipeline=False, gather_mode=None, step_streams=True):
         if world_size is None:
             world_size = dist.get_world_size() if dist.is_initialized() else 1
         if rank is None:
@@ -130,6 +130,11 @@ class ShardedPredictor(object):
         # frame instead of the 63 K floats of a full record) and every rank evaluates SMPL for the WHOLE video.
         # Same kernels on the same per-frame operands => the same bits as 'records'; it trades 250x less xGMI
         # traffic for world_size x the SMPL work, and pays when the gather is not hidden behind the next step.
+        # Default (round 6): ONE call = one video, whose gather nothing hides -- the omegas (4 MB for 4096 frames, + ~2 ms of SMPL for the
+        # whole video) instead of the records (1.04 GB, ~7 ms over one xGMI link); a caller that overlaps the gather with the next
+        # call (overlap_gather=True: a stream of videos) keeps the records, whose gather then costs nothing on the critical path.
+        if gather_mode is None:
+            gather_mode = "records" if overlap_gather else "theta"
         assert gather_mode in ("records", "theta")
         self.theta = gather_mode == "theta" and world_size > 1
         if self.theta:

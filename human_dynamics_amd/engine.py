@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 import time
 
 import numpy as np
@@ -109,6 +110,12 @@ class HmmrEngine(object):
         # every stage is packed only when its variables exist: a ResNet-only checkpoint (hmr_noS5.ckpt-642561, what
         # FeatureExtractor is given: src/datasets/resnet_extractor.py:31-40) has no AZ_FC_* / single_view_ief* names
         w = weights if weights is not None else {}
+        # (round 6) a NaN / inf variable is refused here, by name: the clamp of a split store would turn what it produces into finite
+        # numbers, and a pre-activation constant is not behind any of the kernels' range checks (hmmr_run_flags: HMMR_FLAG_NAN)
+        for name, v in w.items():
+            a_ = np.asarray(v)
+            if a_.dtype.kind == "f" and not np.isfinite(a_).all():
+                raise ValueError("variable %r holds %d non-finite value(s)" % (name, int((~np.isfinite(a_)).sum())))
         self.rw = (packing.pack_resnet(w, self.dtype, self.store, fuse_preact_blocks=fuse, fuse_tail=tail, fuse_sc=fsc,
                                        fuse_preact_first=pfirst, fold_sc=fold,
                                        patch_3x3=int(devflags.get("PATCH_3X3")) if patch_3x3 is None else patch_3x3,
@@ -246,7 +253,9 @@ class HmmrEngine(object):
             if cand == 11 and dtype == L.HMMR_BF16:          # the tile without a load segment is written for split operands
                 return 0
             return cand if (cand in (9, 11) and cout % 128 == 0) or (cand == 10 and cout % 256 == 0) else 0
-        if cand in (9, 10, 11) or (cand in (1, 5, 7) and cout % 128) or (cand == 8 and cout % 256):
+        # the generic kernel's tiles are 1 .. 8: anything else (a cached table written under another packing configuration, e.g. 22 .. 26
+        # of a 1x1 stream layer read back with STREAM_1X1 off) becomes the library's choice instead of a 'bad tile' error in the pass
+        if not 1 <= cand <= 8 or (cand in (1, 5, 7) and cout % 128) or (cand == 8 and cout % 256):
             return 0
         return cand
 
@@ -525,19 +534,38 @@ class HmmrEngine(object):
 
 
 class _FlagScope(object):
+    """See HmmrEngine.flag_scope.  The flag word is per DEVICE: two scopes on one device that overlapped would read (and clear) each
+    other's flags -- scope A's entry would move what B's in-flight call raised to 'carried', and B's exit would then read 0 and return
+    clamped results without falling back.  So scopes of one device are serialised: a per-device re-entrant lock is held from entry
+    to exit (two Testers on one device in two threads run their guarded calls one after the other; different devices do not wait for
+    each other)."""
+    _locks = {}
+    _locks_guard = threading.Lock()
+
     def __init__(self, engine):
         self.engine, self.flags = engine, 0
+        key = (engine.device.type, engine.device.index)
+        with _FlagScope._locks_guard:
+            self._lock = _FlagScope._locks.setdefault(key, threading.RLock())
 
     def __enter__(self):
-        e = self.engine
-        stale = e._device_flags(True)
-        if stale:
-            key = (e.device.type, e.device.index)
-            HmmrEngine._carried_flags[key] = HmmrEngine._carried_flags.get(key, 0) | stale
+        self._lock.acquire()
+        try:
+            e = self.engine
+            stale = e._device_flags(True)
+            if stale:
+                key = (e.device.type, e.device.index)
+                HmmrEngine._carried_flags[key] = HmmrEngine._carried_flags.get(key, 0) | stale
+        except BaseException:
+            self._lock.release()
+            raise
         return self
 
     def __exit__(self, *exc):
-        self.flags = self.engine._device_flags(True)
+        try:
+            self.flags = self.engine._device_flags(True)
+        finally:
+            self._lock.release()
         return False
 
 

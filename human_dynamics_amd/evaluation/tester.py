@@ -307,13 +307,18 @@ class Tester(object):
         if not (scope.flags & L.FLAG_SATURATED):
             return out
         import warnings
-        warnings.warn("human_dynamics_amd: an activation left the fp16 range of the f16x3 operand mode (clamped to +-65504) -- "
-                      "repeating the call with fp32 operands and keeping them for this Tester", RuntimeWarning, stacklevel=3)
+        e = self.engine
+        stages = [n for n, d in (("ResNet", e.dtype), ("f_movie", e.temporal_dtype), ("IEF", e.ief_dtype)) if d == L.HMMR_F16X3]
+        if e.sc is not None and e.sc.dirs_split:
+            stages.append("SMPL blend product")
+        what = "a NaN reached" if scope.flags & L.FLAG_NAN else "a value left the fp16 range (clamped to +-65504) in"
+        warnings.warn("human_dynamics_amd: %s a split-fp16 store (stages with split operands: %s) -- repeating the call with "
+                      "fp32 operands and keeping them for this Tester" % (what, ", ".join(stages)), RuntimeWarning, stacklevel=3)
         weights, smpl, device, kw = self._rebuild
         self.engine = HmmrEngine(weights, smpl, dtype="f32", device=device, **kw)
         self.smpl = SMPL(smpl, engine=self.engine)
         self._streamer = None
-        self.precision.update(saturated=True, operands="f32")
+        self.precision.update(saturated=True, operands="f32", nan=bool(scope.flags & L.FLAG_NAN))
         return run()
 
     # ------------------------------------------------------------------------

@@ -49,11 +49,13 @@ const char* hmmr_last_error(void);
  * beyond the fp16 range (+-65504, or +-inf) reached a split (HMMR_F16X3) store and was clamped -- the results of that call are not
  * the network's; run it with fp32 operands instead (the Python mirror does: Tester.precision["saturated"]).  Synchronises with the
  * device (hipDeviceSynchronize, then a 4-byte copy per translation unit): call it where the results are read, not per launch.
- * clear != 0 resets the flags.  NaN: the checks compare |v| against the range with fp32 max / compare instructions, which drop NaN --
- * but a NaN cannot be the FIRST non-finite value of a split pipeline: fp16 operands bound every product by 4.3e9 and every fp32
- * accumulation over K <= 4608 by 2e13, so an accumulator is finite, and an epilogue that overflows stores +-inf, which is flagged
- * (and clamped) at that store before anything downstream can turn it into inf - inf. */
+ * clear != 0 resets the flags.
+ * HMMR_FLAG_NAN (round 6, together with HMMR_FLAG_SATURATED): the value was a NaN -- a NaN pixel, weight or constant.  The clamp
+ * (v_med3_f32) turns a NaN into a finite number, so without this flag it would leave as a plausible result.  Every split store keeps
+ * its running maximum with gfx950's NaN-propagating v_maximum3_f32 and tests !(max <= 65504); the split stem applies the same test to
+ * the fp32 pixels it reads. */
 #define HMMR_FLAG_SATURATED 1u
+#define HMMR_FLAG_NAN 2u
 int hmmr_run_flags(unsigned* flags, int clear);
 
 /* Development switches for A/B measurements and tests.  Process-wide; all zero = the product defaults.  No

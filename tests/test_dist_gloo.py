@@ -226,6 +226,44 @@ def test_bench_self_launch_and_default_workload(tmp_path):
     assert bench.resolve_workload(ns(video_frames=1024), 2) == (True, 1024)
 
 
+def _mg_worker(rank, world, port, n, results):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        t = _FakeTester()
+        plan = hd.ShardPlan(n, 8, 20, 13, world, rank)
+        frames = torch.zeros((plan.f1 - plan.f0, 4, 4, 3))
+        frames[:, 0, 0, 0] = torch.arange(plan.f0, plan.f1).float()
+        results[rank] = bench.multi_gpu_fields(t, n, frames, world, rank, torch.device("cpu"), reps=2)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_multi_gpu_fields_world2():
+    """Round 6: what the N > 1 bench line says about the path's one collective -- `rccl_ranks` read after an actual all-gather, both
+    gather modes' isolated `all_gather_ms` / bytes and `single_video_ms` (one un-overlapped step of the whole video), and the mode the
+    measurement prefers (bench.py --gather auto takes it for a strong-scaling run) -- produced by bench.multi_gpu_fields on two gloo
+    ranks with the stand-in Tester for a 512-frame video (`bench.py --gpus 2 --video-frames 512`; the real thing needs two GPUs)."""
+    n = 512
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_mg_worker, args=(2, _free_port(), n, results), nprocs=2, join=True)
+    r0, r1 = results[0], results[1]
+    rec_len = _FakeTester().record_layout()[1]
+    for r in (r0, r1):
+        assert r["rccl_ranks"] == 2
+        assert set(r["all_gather_ms"]) == set(r["single_video_ms"]) == set(r["all_gather_bytes"]) == {"records", "theta"}
+        assert r["all_gather_bytes"] == {"records": n * rec_len * 4, "theta": n * 255 * 4}
+        assert all(v > 0 for v in r["all_gather_ms"].values()) and all(v > 0 for v in r["single_video_ms"].values())
+        assert r["gather_by_measurement"] == min(r["single_video_ms"], key=r["single_video_ms"].get)
+    # max-over-ranks figures: every rank holds the same numbers, so every rank picks the same mode
+    assert r0["single_video_ms"] == r1["single_video_ms"] and r0["all_gather_ms"] == r1["all_gather_ms"]
+
+
 def _choose_worker(rank, world, port, results):
     """precision.choose_engine's collective with DIFFERENT per-process caches: rank 0 already holds a decision for the weight set (a
     Tester built before init_process_group), rank 1 does not -- every rank must still take part in the one broadcast, and all end on

@@ -74,6 +74,20 @@ def test_conv1x1_stream_kernel_saturation_flag(gpu_device):
     out, _ = conv_gemm(x, w, scale=np.full(128, 1e6, np.float32), **kw)
     L.check(lib.hmmr_run_flags(C.byref(fl), 1), "hmmr_run_flags")
     assert fl.value & 1 and np.abs(out).max() == 65504.0
+    # round 6: a NaN (in a constant, or in an operand) is not a number the clamp may hide: FLAG_NAN | FLAG_SATURATED, in both epilogue forms
+    sc = np.ones(128, np.float32); sc[5] = np.nan
+    out, _ = conv_gemm(x, w, scale=sc, **kw)
+    L.check(lib.hmmr_run_flags(C.byref(fl), 1), "hmmr_run_flags")
+    assert fl.value == (L.FLAG_NAN | L.FLAG_SATURATED), fl.value
+    xn = x.copy(); xn[0, 3, 3, 17] = np.nan
+    for extra in (dict(), dict(res=np.zeros((1, 7, 7, 128), np.float32), relu=False)):
+        k2 = dict(kw); k2.update(extra)
+        out, _ = conv_gemm(xn, w, scale=np.ones(128, np.float32), **k2)
+        L.check(lib.hmmr_run_flags(C.byref(fl), 1), "hmmr_run_flags")
+        assert fl.value == (L.FLAG_NAN | L.FLAG_SATURATED), (extra.keys(), fl.value)
+    out, _ = conv_gemm(x, w, scale=np.ones(128, np.float32), **kw)
+    L.check(lib.hmmr_run_flags(C.byref(fl), 1), "hmmr_run_flags")
+    assert fl.value == 0
 
 
 def test_conv1x1_stream_kernel_refuses_what_it_is_not_built_for(gpu_device):

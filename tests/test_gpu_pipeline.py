@@ -168,7 +168,7 @@ def test_sharded_predictor_graph_replay_equals_eager(weights, smpl_consts, gpu_d
     # two ranks' shards tile the single-rank result bit-exactly (same kernels, same per-window math)
     parts = []
     for r in range(2):
-        p = hd.ShardedPredictor(t, 24, r, 2)
+        p = hd.ShardedPredictor(t, 24, r, 2, gather_mode="records")      # (the local RECORDS of each rank: the default for one video gathers omegas)
         loc = p.run(dev[p.plan.f0:p.plan.f1], gather=False)
         parts.append(loc[:p.plan.o1 - p.plan.o0])
     assert torch.equal(torch.cat(parts, 0), eager)

@@ -142,6 +142,44 @@ def test_saturating_frames_raise_the_flag_and_fall_back_to_f32(gpu_device):
     assert np.abs(again["verts"] - ok["verts"]).max() < 1e-4
 
 
+def test_a_nan_pixel_raises_the_flag_and_falls_back_to_f32(gpu_device):
+    """Round 6: the clamp of a split store (v_med3_f32) turns a NaN into a FINITE value and the fp32 max instructions drop it, so a NaN
+    pixel used to leave as a plausible mesh with hmmr_run_flags == 0.  The running maxima are NaN-propagating now (v_maximum3_f32,
+    csrc/common.h sat_acc) and the split stem checks the pixels it reads: ONE NaN pixel raises FLAG_NAN | FLAG_SATURATED, the Tester
+    warns, repeats the call on fp32 operands -- whose arithmetic shows the NaN instead of hiding it -- and frames without it stay clean."""
+    import warnings
+    from human_dynamics_amd import _lib as L
+    from human_dynamics_amd.evaluation.tester import Tester
+    from conftest import Config
+    w, s = assets.make_synthetic_weights(0), assets.make_synthetic_smpl(2)
+    frames = assets.make_synthetic_frames(20, seed=3)[None].copy()
+    t = Tester(Config(batch_size=1), weights=w, smpl=s, dtype="f16x3", device=gpu_device)
+    t.engine.run_flags(clear=True)
+    ok = t.predict(frames)
+    assert t.engine.run_flags() == 0 and np.isfinite(ok["verts"]).all()
+    bad = frames.copy()
+    bad[0, 7, 100, 57, 1] = np.nan                                # one channel of one pixel of frame 7
+    t.engine.resnet(torch.from_numpy(bad[0]).to(gpu_device))      # the raw engine call: flags only
+    fl = t.engine.run_flags(clear=True)
+    assert fl & L.FLAG_NAN and fl & L.FLAG_SATURATED, fl
+    # a NaN cannot come in through the weights: the engine refuses non-finite variables where it packs them (the in-network epilogues
+    # would catch most of them -- tests/test_gpu_conv1x1_stream.py, test_gpu_kernels.py -- but not a pre-activation constant)
+    w2 = dict(w)
+    v = np.array(w2["resnet_v2_50/block3/unit_2/bottleneck_v2/preact/beta"], dtype=np.float32).copy()
+    v[3] = np.nan
+    w2["resnet_v2_50/block3/unit_2/bottleneck_v2/preact/beta"] = v
+    with pytest.raises(ValueError, match="block3/unit_2/bottleneck_v2/preact/beta"):
+        Tester(Config(batch_size=1), weights=w2, smpl=s, dtype="f16x3", device=gpu_device)
+    with pytest.warns(RuntimeWarning, match="NaN"):
+        got = t.predict(bad)
+    assert t.precision["saturated"] is True and t.precision["nan"] is True and t.engine.dtype == L.HMMR_F32
+    assert np.isnan(got["verts"]).any()                           # fp32 operands show it
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        again = t.predict(frames)
+    assert np.abs(again["verts"] - ok["verts"]).max() < 1e-4
+
+
 @pytest.mark.parametrize("dt", ["f16x3", "bf16"])
 def test_tail_beside_the_resnet_is_deterministic(gpu_device, dt):
     """The per-window tail (f_movie -> IEF -> SMPL records) gives the same records whether it runs alone or beside the ResNet passes of the
