@@ -18,7 +18,7 @@ LIB_PATH = devflags.get("LIB_PATH") or os.path.join(HERE, "libhmmr_hip.so")
 HMMR_F32, HMMR_BF16, HMMR_F16X3 = 0, 1, 2
 FLAG_SATURATED = 1
 FLAG_NAN = 2          # with FLAG_SATURATED: the clamped value was a NaN (include/hmmr_hip.h)
-ABI_VERSION = 17
+ABI_VERSION = 18
 RESNET_UNITS = 16
 RESNET_PROF_SLOTS = 64
 MAX_TEMPORAL_BLOCKS = 8
@@ -67,7 +67,7 @@ class TailDesc(C.Structure):
 class Debug(C.Structure):
     """hmmr_debug_t: development switches, all zero = product defaults."""
     _fields_ = [("stem_route", C.c_int), ("stem_no_conv1", C.c_int), ("gemm_probe", C.c_int), ("smpl_blend_mfma", C.c_int), ("ief_no_group", C.c_int), ("reserved", C.c_int * 3),
-                ("pair_min_pixels", C.c_int), ("pair_two_tile_min", C.c_int)]
+                ("pair_min_pixels", C.c_int), ("pair_two_tile_min", C.c_int), ("pair_form", C.c_int)]
 
 
 class LaunchCounts(C.Structure):

@@ -27,14 +27,15 @@ DEFAULT_DTYPE = "f16x3"
 TILE_TABLES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tile_tables.json")
 
 
-def set_debug(stem_route=0, stem_no_conv1=0, gemm_probe=0, smpl_blend_mfma=0, ief_no_group=0, pair_min_pixels=0, pair_two_tile_min=0):
+def set_debug(stem_route=0, stem_no_conv1=0, gemm_probe=0, smpl_blend_mfma=0, ief_no_group=0, pair_min_pixels=0, pair_two_tile_min=0, pair_form=0):
     """Development switches of libhmmr_hip.so (hmmr_debug_t; process-wide, zeros = product defaults).
     pair_min_pixels: the unit-pair switch of hmmr_resnet50_fwd (0 = 12000 pixels, 1 = always the pair kernel, 2**31 - 1 = never);
-    pair_two_tile_min: tiles from which a block-2 unit pair runs two tiles per workgroup (0 = 512, 1 = always, 2**31 - 1 = never)."""
+    pair_two_tile_min: tiles from which a block-2 unit pair runs two tiles per workgroup (0 = 512, 1 = always, 2**31 - 1 = never);
+    pair_form: 0 = the one-wave-per-SIMD unit pair of round 4 (the default), 2 = the wave-specialised form of round 6 (two waves per SIMD; same bits)."""
     d = L.Debug()
     d.stem_route, d.stem_no_conv1, d.gemm_probe = int(stem_route), int(stem_no_conv1), int(gemm_probe)
     d.smpl_blend_mfma, d.ief_no_group, d.pair_min_pixels = int(smpl_blend_mfma), int(ief_no_group), int(pair_min_pixels)
-    d.pair_two_tile_min = int(pair_two_tile_min)
+    d.pair_two_tile_min, d.pair_form = int(pair_two_tile_min), int(pair_form)
     L.load().hmmr_set_debug(C.byref(d))
 
 

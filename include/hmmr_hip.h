@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HMMR_ABI_VERSION 17      /* 17: k_order = 2 on a 1x1 filter (the two-ring stream kernel of csrc/conv1x1_stream.hip, tiles 22 .. 26), hmmr_conv1x1_stream_bytes; 16: hmmr_tail_desc_t.unit_stream, hmmr_resnet_unit_t.unit_stream (the whole-unit kernel of block 1, csrc/b1_unit.hip), hmmr_b1_unit_stream_bytes, hmmr_debug_t.pair_min_pixels / pair_two_tile_min / launch counters, hmmr_resnet_unit_t.conv1_frag (block1/unit_1's conv1 inside the split stem); 15: k_order = 2 (the one-wave-per-SIMD 3x3 stream kernel, tiles 12 .. 18), hmmr_conv3x3_stream_bytes; 14: hmmr_tail_desc_t.pair_stream / c_xp, hmmr_resnet_unit_t.pair_stream (the register-resident unit pair of blocks 2-3), hmmr_run_flags; 13: hmmr_conv_desc_t.batch (grouped launches); 12: k_order = 1, 3x3 SAME convolutions out of an LDS-resident input patch (tiles 9, 10, 11) */
+#define HMMR_ABI_VERSION 18      /* 18: HMMR_FLAG_NAN, hmmr_debug_t.pair_form (the wave-specialised unit pair), the C-side packers hmmr_pack_*; 17: k_order = 2 on a 1x1 filter (the two-ring stream kernel of csrc/conv1x1_stream.hip, tiles 22 .. 26), hmmr_conv1x1_stream_bytes; 16: hmmr_tail_desc_t.unit_stream, hmmr_resnet_unit_t.unit_stream (the whole-unit kernel of block 1, csrc/b1_unit.hip), hmmr_b1_unit_stream_bytes, hmmr_debug_t.pair_min_pixels / pair_two_tile_min / launch counters, hmmr_resnet_unit_t.conv1_frag (block1/unit_1's conv1 inside the split stem); 15: k_order = 2 (the one-wave-per-SIMD 3x3 stream kernel, tiles 12 .. 18), hmmr_conv3x3_stream_bytes; 14: hmmr_tail_desc_t.pair_stream / c_xp, hmmr_resnet_unit_t.pair_stream (the register-resident unit pair of blocks 2-3), hmmr_run_flags; 13: hmmr_conv_desc_t.batch (grouped launches); 12: k_order = 1, 3x3 SAME convolutions out of an LDS-resident input patch (tiles 9, 10, 11) */
 
 /* HMMR_F16X3: "split" tensors -- every group of 8 consecutive channels is 32 bytes, [hi x8][lo x8] with
  * hi = fp16(x), lo = fp16(x - hi), x clamped to +-65504 (4 bytes per element, 22 mantissa bits while lo is a normal
@@ -79,6 +79,9 @@ typedef struct hmmr_debug_s {
                               1 = always the pair kernel, INT_MAX = never */
     int pair_two_tile_min; /* the pair kernel of the block-2 shapes runs as PERSISTENT workgroups (several 128-pixel tiles each) when the launch has at least
                               this many tiles (same bits; one workgroup per CU then walks tiles b, b + grid, ...): 0 = the default (512 = two rounds of workgroups), 1 = always, INT_MAX = never */
+    int pair_form;         /* (ABI 18) the unit pairs with a shortcut tensor (blocks 2-3): 0 = the default, the one-wave-per-SIMD form of round 4;
+                              2 = the wave-specialised form of round 6 (two waves per SIMD: conv3 + the trunk epilogue in one, conv1' + all
+                              memory traffic in the other).  Same bits; measured equal */
 } hmmr_debug_t;
 void hmmr_set_debug(const hmmr_debug_t* d);     /* NULL = defaults */
 void hmmr_get_debug(hmmr_debug_t* d);

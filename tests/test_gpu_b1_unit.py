@@ -145,6 +145,14 @@ def test_unit_pair_on_equals_unit_pair_off_on_one_batch(weights, gpu_device, n):
         torch.cuda.synchronize()
         L.launch_counts(clear=True)
         assert torch.equal(one, on)
+        # round 6: the wave-specialised form of the pairs with a shortcut tensor (hmmr_debug_t.pair_form = 2: two waves per SIMD, conv3 and
+        # the trunk epilogue in one, conv1' and all memory traffic in the other; unit_pair_ws_kernel) -- other waves, another ring depth,
+        # another epilogue split, the same products in the same order: the same bits, ragged last tiles included
+        E.set_debug(pair_min_pixels=1, pair_form=2)
+        ws = eng.resnet(frames, n_zero=1, parts=1)
+        torch.cuda.synchronize()
+        assert L.launch_counts(clear=True)["unit_pair"] == 8
+        assert torch.equal(ws, on), float((ws - on).abs().max())
     finally:
         E.set_debug()
     dflt = eng.resnet(frames, n_zero=1, parts=1)

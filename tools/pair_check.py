@@ -11,15 +11,21 @@ from human_dynamics_amd import _lib as L, packing  # noqa: E402
 
 lib = L.load()
 from human_dynamics_amd import devflags, engine  # noqa: E402
+blk = sys.argv[1] if len(sys.argv) > 1 else "b3"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 257
+form = int(sys.argv[3]) if len(sys.argv) > 3 else 0          # hmmr_debug_t.pair_form: 0 = one wave per SIMD (round 4, the default), 2 = wave-specialised (round 6)
+ws = form == 2 and blk != "b2f"
 ts = None
 if "probe" in L.LIB_PATH:
-    ts = torch.zeros((4097, 4, 8), dtype=torch.int64, device="cuda")
+    ts = torch.zeros((4097, 8 if ws else 4, 8), dtype=torch.int64, device="cuda")
     d_ = L.Debug()
     d_.gemm_probe = int(devflags.get("GEMM_PROBE") or 0)
     d_.reserved[0], d_.reserved[1] = ts.data_ptr() & 0xffffffff, ts.data_ptr() >> 32
+    d_.pair_form = form
     lib.hmmr_set_debug(C.byref(d_))
-blk = sys.argv[1] if len(sys.argv) > 1 else "b3"
-n = int(sys.argv[2]) if len(sys.argv) > 2 else 257
+else:
+    engine.set_debug(pair_form=form)
+print("pair_form %d%s" % (form, "  (%s)" % L.LIB_PATH if ts is not None else ""))
 cm, depth, n2, hw, cxp = {"b2": (128, 512, 128, 28, 0), "b3": (256, 1024, 256, 14, 0), "b2f": (128, 512, 128, 28, 256)}[blk]
 m = n * hw * hw
 dev = "cuda"
@@ -132,7 +138,21 @@ fl = 2.0 * m * (K3 * depth + depth * n2)
 print("%s (%d px): two launches %.4f ms | unit pair %.4f ms = %.0f TFLOP/s, %.2f TB/s of tensor traffic" % (
     blk, m, ms_ref, ms_pair, fl / ms_pair / 1e9, gb / ms_pair))
 
-if ts is not None:
+if ts is not None and ws:
+    run_pair()
+    torch.cuda.synchronize()
+    nb = (m + 127) // 128
+    t = ts[:nb].cpu().numpy().astype(np.float64)
+    t0 = t[:, :, 0].min()
+    for b in (0, min(255, nb - 1), nb - 1):
+        for w in (0, 4):
+            print("block %d wave %d (%s): start %+8.0f | prologue issue %6.0f | drain + sync %6.0f | loop %8.0f | tail %6.0f | in waits + barriers %8.0f | B block %7.0f   (100 MHz ticks)" % (
+                b, w, "A" if w < 4 else "B", t[b, w, 0] - t0, t[b, w, 1] - t[b, w, 0], t[b, w, 2] - t[b, w, 1], t[b, w, 3] - t[b, w, 2], t[b, w, 4] - t[b, w, 3], t[b, w, 5], t[b, w, 6]))
+    A, Bw = t[:, :4], t[:, 4:]
+    print("kernel span (ticks): %.0f | mean loop A %.0f B %.0f | mean prologue %.0f | mean tail A %.0f B %.0f | mean in waits + barriers A %.0f B %.0f | B block %.0f" % (
+        t[:, :, 4].max() - t0, (A[:, :, 3] - A[:, :, 2]).mean(), (Bw[:, :, 3] - Bw[:, :, 2]).mean(), (t[:, :, 2] - t[:, :, 0]).mean(),
+        (A[:, :, 4] - A[:, :, 3]).mean(), (Bw[:, :, 4] - Bw[:, :, 3]).mean(), A[:, :, 5].mean(), Bw[:, :, 5].mean(), Bw[:, :, 6].mean()))
+elif ts is not None:
     run_pair()
     torch.cuda.synchronize()
     nb = (m + 127) // 128
