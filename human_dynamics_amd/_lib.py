@@ -122,9 +122,30 @@ class SmplConsts(C.Structure):
                 ("dirs_split", _vp)]
 
 
+class Var(C.Structure):
+    """hmmr_var_t: one checkpoint variable for the C-side packers (csrc/pack.cpp)"""
+    _fields_ = [("name", C.c_char_p), ("data", _fp), ("numel", C.c_int64)]
+
+
+class SmplSource(C.Structure):
+    """hmmr_smpl_source_t: the body model in the src/tf_smpl layout"""
+    _fields_ = [("num_verts", C.c_int), ("num_kps", C.c_int), ("v_template", _fp), ("shapedirs", _fp), ("posedirs", _fp),
+                ("J_regressor", _fp), ("lbs_weights", _fp), ("kp_regressor", _fp), ("parents", _ip)]
+
+
 # name -> (restype, argtypes); mirrors include/hmmr_hip.h one to one
 SIGNATURES = {
     "hmmr_abi_version": (C.c_int, []),
+    "hmmr_pack_resnet_bytes": (C.c_size_t, [C.POINTER(Var), C.c_int, C.c_int]),
+    "hmmr_pack_resnet": (C.c_int, [C.POINTER(Var), C.c_int, C.c_int, _vp, C.c_size_t, _vp, C.POINTER(ResnetWeights)]),
+    "hmmr_pack_temporal_bytes": (C.c_size_t, [C.POINTER(Var), C.c_int, C.c_int, C.c_int]),
+    "hmmr_pack_temporal": (C.c_int, [C.POINTER(Var), C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, _vp, C.POINTER(TemporalWeights)]),
+    "hmmr_pack_hallucinator_bytes": (C.c_size_t, [C.POINTER(Var), C.c_int, C.c_int]),
+    "hmmr_pack_hallucinator": (C.c_int, [C.POINTER(Var), C.c_int, C.c_int, _vp, C.c_size_t, _vp, C.POINTER(HallucinatorWeights)]),
+    "hmmr_pack_ief_bytes": (C.c_size_t, [C.POINTER(Var), C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]),
+    "hmmr_pack_ief": (C.c_int, [C.POINTER(Var), C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, _vp, C.c_size_t, _vp, C.POINTER(IefWeights)]),
+    "hmmr_pack_smpl_bytes": (C.c_size_t, [C.POINTER(SmplSource), C.c_int, C.c_int]),
+    "hmmr_pack_smpl": (C.c_int, [C.POINTER(SmplSource), C.c_int, C.c_int, _vp, C.c_size_t, _vp, C.POINTER(SmplConsts)]),
     "hmmr_last_error": (C.c_char_p, []),
     "hmmr_run_flags": (C.c_int, [C.POINTER(C.c_uint), C.c_int]),
     "hmmr_set_debug": (None, [C.POINTER(Debug)]),

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libhmmr_hip.so")
-SOURCES = ["api.cpp", "gemm_conv.hip", "conv3x3_stream.hip", "conv1x1_stream.hip", "stem.hip", "bottleneck.hip", "bottleneck_split.hip", "unit_pair.hip", "b1_unit.hip", "resnet.hip", "temporal.hip", "ief.hip", "smpl.hip", "eval_metrics.hip", "preprocess.hip", "handoff.hip", "probe.hip"]
+SOURCES = ["api.cpp", "pack.cpp", "gemm_conv.hip", "conv3x3_stream.hip", "conv1x1_stream.hip", "stem.hip", "bottleneck.hip", "bottleneck_split.hip", "unit_pair.hip", "b1_unit.hip", "resnet.hip", "temporal.hip", "ief.hip", "smpl.hip", "eval_metrics.hip", "preprocess.hip", "handoff.hip", "probe.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -fno-slp-vectorize (every file, round 5): under plain -O3 the SLP vectoriser packs adjacent scalar fp32 operations into v_pk_*_f32 with
 # op_sel shuffles.  In smpl_pose_kernel's kinematic chain that code produced WRONG translations for the last quarter of a wave (lanes
@@ -28,8 +28,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vector
          "-Wall", "-Wno-unused-function"]
 
 
-# per-file flags (none at present)
-EXTRA_FLAGS = {}
+# per-file flags: the host-side packers fold in double exactly as written (no contraction of a * b + c into one fma: numpy does not)
+EXTRA_FLAGS = {"pack.cpp": ["-ffp-contract=off"]}
 
 
 def _newer(src, dst):

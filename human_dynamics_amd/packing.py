@@ -275,6 +275,35 @@ class DeviceStore(object):
         return self.put(_pad_rows(np.asarray(arr, np.float32), mult))
 
 
+# --------------------------------------------------------------------------- #
+# The C-side packers (csrc/pack.cpp, include/hmmr_hip.h "Packers"): ONE implementation of the shipped layouts, usable
+# without Python.  The pack_* functions below call them for the shipped configuration; their Python bodies serve the
+# development switches of devflags.py and are pinned to the C bytes by tests/test_packers.py.
+# --------------------------------------------------------------------------- #
+def _vars_table(w):
+    """dict of checkpoint-named arrays -> (hmmr_var_t array, count, the arrays kept alive)"""
+    import ctypes as C
+    items = [(k, np.ascontiguousarray(v, np.float32)) for k, v in w.items() if np.asarray(v).dtype.kind == "f"]
+    arr = (L.Var * len(items))()
+    for i, (k, a) in enumerate(items):
+        arr[i].name, arr[i].data, arr[i].numel = k.encode(), a.ctypes.data, a.size
+    return arr, len(items), items
+
+
+def _c_pack(store, nbytes, fill):
+    """Allocate the stage's blob on the store's device, let `fill(host_ptr, nbytes, device_base)` write the host image and the
+    struct, copy it over in one piece."""
+    if not nbytes:
+        raise L.HmmrError("packer: %s" % (L.load().hmmr_last_error() or b"?").decode())
+    dev = torch.empty(int(nbytes), dtype=torch.uint8, device=store.device)
+    host = dev if dev.device.type == "cpu" else torch.empty(int(nbytes), dtype=torch.uint8)
+    L.check(fill(host.data_ptr(), int(nbytes), dev.data_ptr()), "hmmr_pack_*")
+    if host is not dev:
+        dev.copy_(host)
+    store.tensors.append(dev)
+    return dev
+
+
 def _layer(store, w_packed, dtype, scale=None, shift=None):
     """One hmmr_layer_t.  Split (f16x3) filter banks are scaled row by row (row_pow2) and the epilogue scale takes the
     inverse factor -- a bias-only layer gets a scale vector of pure powers of two for it."""
@@ -326,7 +355,31 @@ def _layer_stream1x1(store, w_hwio, scale, shift):
 
 def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3", "block4"), fuse_tail=True,
                 fuse_sc=True, fuse_preact_first=False, fold_sc=None, patch_3x3=2, unit_pair=True, b1_stream=False, b1_unit=True,
-                stem_conv1=True, stream_1x1=True):
+                stem_conv1=True, stream_1x1=True, impl=None):
+    """The shipped configuration (every argument at its default: what HmmrEngine builds unless a development switch of devflags.py
+    says otherwise) is packed by the C-side packer hmmr_pack_resnet (csrc/pack.cpp); any other choice, or impl="py", by the Python
+    form below (_pack_resnet_py), whose bytes for the shipped configuration equal the C packer's (tests/test_packers.py)."""
+    shipped = (tuple(fuse_preact_blocks) == ("block1", "block2", "block3", "block4") and fuse_tail is True and fuse_sc is True and
+               not fuse_preact_first and fold_sc in (None, dtype == L.HMMR_F16X3) and patch_3x3 == 2 and patch_3x3 is not True and
+               unit_pair is True and not b1_stream and b1_unit is True and stem_conv1 is True and stream_1x1 is True)
+    if impl == "c" and not shipped:
+        raise ValueError("the C-side packer builds the shipped configuration only")
+    if impl == "py" or not shipped:
+        return _pack_resnet_py(w, dtype, store, fuse_preact_blocks, fuse_tail, fuse_sc, fuse_preact_first, fold_sc, patch_3x3, unit_pair,
+                               b1_stream, b1_unit, stem_conv1, stream_1x1)
+    lib = L.load()
+    import ctypes as C
+    arr, n, keep = _vars_table({k: v for k, v in w.items() if k.startswith("resnet_v2_50/")})
+    rw = L.ResnetWeights()
+    _c_pack(store, lib.hmmr_pack_resnet_bytes(arr, n, dtype),
+            lambda host, nb, base: lib.hmmr_pack_resnet(arr, n, dtype, host, nb, base, C.byref(rw)))
+    del keep
+    return rw
+
+
+def _pack_resnet_py(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3", "block4"), fuse_tail=True,
+                    fuse_sc=True, fuse_preact_first=False, fold_sc=None, patch_3x3=2, unit_pair=True, b1_stream=False, b1_unit=True,
+                    stem_conv1=True, stream_1x1=True):
     """fuse_preact_blocks: blocks whose units apply their `preact` BN+ReLU inside the operand
     staging of conv1/shortcut instead of reading a materialised preact tensor (csrc/resnet.hip;
     measured at batch 256: -4.5 % ResNet time with blocks 1-2 fused, neutral for blocks 3-4).
@@ -495,7 +548,16 @@ def pack_resnet(w, dtype, store, fuse_preact_blocks=("block1", "block2", "block3
     return rw
 
 
-def pack_temporal(w, dtype, store, num_conv_layers=3):
+def pack_temporal(w, dtype, store, num_conv_layers=3, impl=None):
+    if impl != "py":
+        lib = L.load()
+        import ctypes as C
+        arr, n, keep = _vars_table({k: v for k, v in w.items() if k.startswith("AZ_FC_block")})
+        tw = L.TemporalWeights()
+        _c_pack(store, lib.hmmr_pack_temporal_bytes(arr, n, dtype, num_conv_layers),
+                lambda host, nb, base: lib.hmmr_pack_temporal(arr, n, dtype, num_conv_layers, host, nb, base, C.byref(tw)))
+        del keep
+        return tw
     tw = L.TemporalWeights()
     tw.dtype, tw.num_blocks = dtype, num_conv_layers
     for i in range(num_conv_layers):
@@ -510,10 +572,19 @@ def pack_temporal(w, dtype, store, num_conv_layers=3):
     return tw
 
 
-def pack_hallucinator(w, dtype, store):
+def pack_hallucinator(w, dtype, store, impl=None):
     """fc2_res/fc{1,2,3} (src/models.py:283-294); None when the checkpoint has no hallucinator."""
     if "fc2_res/fc1/weights" not in w:
         return None
+    if impl != "py":
+        lib = L.load()
+        import ctypes as C
+        arr, n, keep = _vars_table({k: v for k, v in w.items() if k.startswith("fc2_res/")})
+        hw = L.HallucinatorWeights()
+        _c_pack(store, lib.hmmr_pack_hallucinator_bytes(arr, n, dtype),
+                lambda host, nb, base: lib.hmmr_pack_hallucinator(arr, n, dtype, host, nb, base, C.byref(hw)))
+        del keep
+        return hw
     hw = L.HallucinatorWeights()
     hw.dtype = dtype
     for k in ("fc1", "fc2", "fc3"):
@@ -523,10 +594,23 @@ def pack_hallucinator(w, dtype, store):
     return hw
 
 
-def pack_ief(w, dtype, store, delta_t_values=(-5, 5), num_stages=3):
-    iw = L.IefWeights()
+def pack_ief(w, dtype, store, delta_t_values=(-5, 5), num_stages=3, impl=None):
     scopes = assets.ief_scopes(delta_t_values)
     keys = [0] + sorted(k for k in scopes if k != 0)      # deltas in sorted order (tester.py:245)
+    if impl != "py":
+        lib = L.load()
+        import ctypes as C
+        arr, n, keep = _vars_table({k: v for k, v in w.items() if k.startswith("single_view_ief") or k == "mean_param"})
+        dts = (C.c_int * max(1, len(keys) - 1))(*keys[1:])
+        iw = L.IefWeights()
+        try:
+            _c_pack(store, lib.hmmr_pack_ief_bytes(arr, n, dtype, dts, len(keys) - 1),
+                    lambda host, nb, base: lib.hmmr_pack_ief(arr, n, dtype, dts, len(keys) - 1, num_stages, host, nb, base, C.byref(iw)))
+        except L.HmmrError as e:          # (a mis-shaped checkpoint is the caller's ValueError, as in the Python form)
+            raise ValueError(str(e))
+        del keep
+        return iw, keys
+    iw = L.IefWeights()
     iw.dtype, iw.num_regressors, iw.num_stages = dtype, len(keys), num_stages
     for r, key in enumerate(keys):
         scope, nd = scopes[key]
@@ -556,11 +640,26 @@ def pack_ief(w, dtype, store, delta_t_values=(-5, 5), num_stages=3):
     return iw, keys
 
 
-def pack_smpl(smpl, store, joint_type="cocoplus", split=True):
+def pack_smpl(smpl, store, joint_type="cocoplus", split=True, impl=None):
     """tf_smpl-layout constants (src/tf_smpl/batch_smpl.py:35-80) -> SmplConsts.
     split: also pack the blend basis as split-fp16 MFMA fragments (hmmr_smpl_consts_t.dirs_split: the default blend form of
     hmmr_smpl_fwd).  False -- what an all-fp32 engine passes -- or a basis whose entries x 2^13 leave the fp16 range: dirs_split = NULL,
     the library then takes the exact-fp32 vector form."""
+    if impl != "py":
+        lib = L.load()
+        import ctypes as C
+        f = lambda k: np.ascontiguousarray(smpl[k], np.float32)
+        keep = [f("v_template"), f("shapedirs"), f("posedirs"), f("J_regressor"), f("lbs_weights"), f("cocoplus_regressor"),
+                np.ascontiguousarray(np.asarray(smpl["parents"]).astype(np.int32))]
+        src = L.SmplSource()
+        src.num_verts, src.num_kps = keep[0].shape[0], keep[5].shape[1]
+        (src.v_template, src.shapedirs, src.posedirs, src.J_regressor, src.lbs_weights, src.kp_regressor, src.parents) = [a.ctypes.data for a in keep]
+        sc = L.SmplConsts()
+        lsp = int(joint_type == "lsp")
+        _c_pack(store, lib.hmmr_pack_smpl_bytes(C.byref(src), lsp, int(bool(split))),
+                lambda host, nb, base: lib.hmmr_pack_smpl(C.byref(src), lsp, int(bool(split)), host, nb, base, C.byref(sc)))
+        del keep
+        return sc
     nv = smpl["v_template"].shape[0]
     vpad = (nv + 255) // 256 * 256
     v_t = smpl["v_template"].astype(np.float64)

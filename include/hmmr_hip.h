@@ -534,6 +534,64 @@ int hmmr_eval_joints(const float* gt, const float* pred, int n, int k, int left_
 int hmmr_eval_verts(const float* gt, int64_t ld_gt, const float* pred, int64_t ld_pred, int n, int nv,
                     float* err, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * Packers (ABI 18; csrc/pack.cpp): checkpoint variables by name -> the layouts and structs above, WITHOUT Python.
+ *
+ * The reference restores its graph from a TensorFlow checkpoint (src/evaluation/tester.py:92-116); the variable names and shapes are
+ * SURVEY App. B's (resnet_v2_50/..., AZ_FC_block..., single_view_ief[_past5 | _future5]/3D_module/fc{1,2,3}, fc2_res/..., mean_param).  A caller
+ * hands them over as fp32 host arrays in the checkpoint's own element order (conv filters HWIO, fully-connected [in][out]) and gets,
+ * per stage, ONE blob in the device layout plus the stage's struct with every pointer already set to `device_base + offset`:
+ *
+ *     n = hmmr_pack_resnet_bytes(vars, n_vars, dtype);  hipMalloc(&dev, n);  host = malloc(n);
+ *     hmmr_pack_resnet(vars, n_vars, dtype, host, n, dev, &weights);  hipMemcpy(dev, host, n, hipMemcpyHostToDevice);
+ *     hmmr_resnet50_fwd(&weights, ...);
+ *
+ * No HIP call and no allocation in here; the functions are pure (same inputs -> same bytes) and return 0 or -1 with hmmr_last_error()
+ * naming the variable that is missing or mis-sized.  They produce the SHIPPED configuration of every operand mode (f16x3: fused stem
+ * with block1/unit_1's conv1, whole-unit kernels in block 1, unit pairs in blocks 2-3, the 3x3 / 1x1 filter streams, folded shortcuts;
+ * bf16: fused units of blocks 1-2, 3x3 streams of blocks 3-4; f32: layer per launch) -- human_dynamics_amd/packing.py calls them for
+ * exactly that and keeps Python forms only for its development switches, pinned to these bytes by tests/test_packers.py.
+ * *_bytes(): the blob size for the same arguments (0 on error).
+ * ------------------------------------------------------------------------- */
+typedef struct {
+    const char* name;      /* checkpoint variable name */
+    const float* data;     /* fp32, host memory, the checkpoint's element order */
+    int64_t numel;         /* number of values (the shape follows from the name; checked) */
+} hmmr_var_t;
+
+size_t hmmr_pack_resnet_bytes(const hmmr_var_t* vars, int n_vars, int dtype);
+int hmmr_pack_resnet(const hmmr_var_t* vars, int n_vars, int dtype, void* host_blob, size_t blob_bytes, const void* device_base,
+                     hmmr_resnet_weights_t* out);
+size_t hmmr_pack_temporal_bytes(const hmmr_var_t* vars, int n_vars, int dtype, int num_blocks);
+int hmmr_pack_temporal(const hmmr_var_t* vars, int n_vars, int dtype, int num_blocks, void* host_blob, size_t blob_bytes,
+                       const void* device_base, hmmr_temporal_weights_t* out);
+size_t hmmr_pack_hallucinator_bytes(const hmmr_var_t* vars, int n_vars, int dtype);
+int hmmr_pack_hallucinator(const hmmr_var_t* vars, int n_vars, int dtype, void* host_blob, size_t blob_bytes, const void* device_base,
+                           hmmr_hallucinator_weights_t* out);
+/* delta_t: the delta regressors' offsets (config.delta_t_values, e.g. {-5, 5}): scopes single_view_ief_past5 / _future5; packed in sorted order */
+size_t hmmr_pack_ief_bytes(const hmmr_var_t* vars, int n_vars, int dtype, const int* delta_t, int n_delta);
+int hmmr_pack_ief(const hmmr_var_t* vars, int n_vars, int dtype, const int* delta_t, int n_delta, int num_stages, void* host_blob,
+                  size_t blob_bytes, const void* device_base, hmmr_ief_weights_t* out);
+
+/* The body model in the src/tf_smpl layout (batch_smpl.py:35-80: what SMPL.__init__ builds from the pkl, or the checkpoint's own
+ * non-trainable variables of the same names), fp32 host arrays */
+typedef struct {
+    int num_verts;                 /* 6890 */
+    int num_kps;                   /* columns of kp_regressor: 25 (19 cocoplus + 6) */
+    const float* v_template;       /* [num_verts][3] */
+    const float* shapedirs;        /* [10][3 num_verts]: column 3 v + c */
+    const float* posedirs;         /* [207][3 num_verts] */
+    const float* J_regressor;      /* [num_verts][24] (stored transposed, batch_smpl.py:51-55) */
+    const float* lbs_weights;      /* [num_verts][24] */
+    const float* kp_regressor;     /* cocoplus_regressor [num_verts][num_kps] */
+    const int32_t* parents;        /* [24] */
+} hmmr_smpl_source_t;
+/* lsp != 0: joint_type 'lsp', the first 14 keypoints (batch_smpl.py:81-82); split != 0: also the split-fp16 MFMA form of the blend basis
+ * (hmmr_smpl_consts_t.dirs_split; 0 for an all-fp32 engine) */
+size_t hmmr_pack_smpl_bytes(const hmmr_smpl_source_t* src, int lsp, int split);
+int hmmr_pack_smpl(const hmmr_smpl_source_t* src, int lsp, int split, void* host_blob, size_t blob_bytes, const void* device_base,
+                   hmmr_smpl_consts_t* out);
+
 #ifdef __cplusplus
 }
 #endif

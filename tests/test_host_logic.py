@@ -60,7 +60,7 @@ def test_stem_pack_equals_7x7_conv_on_padded_rgbx(weights):
 
 def test_smpl_pack_joint_fold_and_sparse_forms(smpl_consts):
     st = _HostStore()
-    sc = packing.pack_smpl(smpl_consts, st)
+    sc = packing.pack_smpl(smpl_consts, st, impl="py")      # (one tensor per field to look at; the C packer's blob holds the same bytes: tests/test_packers.py)
     rng = np.random.default_rng(0)
     beta = rng.normal(size=10)
     v_shaped = (beta @ smpl_consts["shapedirs"].astype(np.float64)).reshape(-1, 3) + smpl_consts["v_template"]
@@ -90,7 +90,7 @@ def test_smpl_pack_joint_fold_and_sparse_forms(smpl_consts):
 
 def test_ief_pack_splits_fc1_and_orders_regressors(weights):
     st = _HostStore()
-    iw, keys = packing.pack_ief(weights, _lib.HMMR_F32, st, (5, -5))
+    iw, keys = packing.pack_ief(weights, _lib.HMMR_F32, st, (5, -5), impl="py")
     assert keys == [0, -5, 5] and iw.num_regressors == 3 and iw.num_stages == 3
     assert [iw.reg[i].nd for i in range(3)] == [85, 72, 72]
     W1 = weights["single_view_ief_past5/3D_module/fc1/weights"]
@@ -104,7 +104,7 @@ def test_ief_pack_splits_fc1_and_orders_regressors(weights):
 
 def test_resnet_pack_unit_table(weights):
     st = _HostStore()
-    rw = packing.pack_resnet(weights, _lib.HMMR_F32, st)
+    rw = packing.pack_resnet(weights, _lib.HMMR_F32, st, impl="py")
     strides = [rw.unit[i].stride for i in range(16)]
     assert strides == [1, 1, 2, 1, 1, 1, 2, 1, 1, 1, 1, 1, 2, 1, 1, 1]      # stride on the LAST unit of blocks 1-3
     assert [bool(rw.unit[i].shortcut.w) for i in range(16)] == [i in (0, 3, 7, 13) for i in range(16)]
@@ -122,7 +122,8 @@ def test_ctypes_struct_sizes_are_plausible():
     # catches accidental field drift between include/hmmr_hip.h and _lib.py
     assert C.sizeof(_lib.Layer) == 32
     assert C.sizeof(_lib.ResnetUnit) == 6 * 32 + 40 + 16 + 16 + 8
-    assert C.sizeof(_lib.Debug) == 10 * 4 and C.sizeof(_lib.LaunchCounts) == 40
+    assert C.sizeof(_lib.Debug) == 11 * 4 and C.sizeof(_lib.LaunchCounts) == 40      # (+ pair_form: ABI 18)
+    assert C.sizeof(_lib.Var) == 24 and C.sizeof(_lib.SmplSource) == 8 + 7 * 8
     assert C.sizeof(_lib.ConvDesc) % 8 == 0
 
 
