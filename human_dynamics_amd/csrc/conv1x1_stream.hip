@@ -535,11 +535,12 @@ int hmmr_conv1x1_stream(const hmmr_conv_desc_t* d, hipStream_t stream) {
     if (!tile) {
         // the library's choice: fewest rounds of 256 workgroups x (row blocks per tile + ~1.5 for a tile's prologue and epilogue); the 7 x 1 / 8 x 1
         // wave tiles read 16-18 fragments per 21-24 MFMAs and pay ~15 % for it (profiles/r05r: LDS bandwidth)
-        static const int cand[5][3] = {{25, 8, 6}, {24, 14, 4}, {26, 8, 3}, {22, 7, 6}, {23, 8, 6}};      // tile, row blocks, ring depth
+        // (29, round 6: a 128-pixel tile for SHORT launches -- block 4's conv1 at 64 frames is 98 row blocks x 4 channel tiles: 52 workgroups of tile 25)
+        static const int cand[6][3] = {{25, 8, 6}, {24, 14, 4}, {26, 8, 3}, {22, 7, 6}, {23, 8, 6}, {29, 4, 6}};      // tile, row blocks, ring depth
         const long long rbs = (M + 31) / 32;
         double best = 0;
         for (const auto& cd : cand) {
-            if (a.nk < cd[2] || (c3 && cd[0] != 24 && cd[0] != 25 && cd[0] != 26)) continue;
+            if (a.nk < cd[2] || (c3 && cd[0] != 24 && cd[0] != 25 && cd[0] != 26)) continue;      // (the conv3 form's epilogue tiles live in the idle rings: a 128-pixel tile's are too small)
             const long long tiles = ((rbs + cd[1] - 1) / cd[1]) * a.tiles_n;
             double cost = (double)((tiles + 255) / 256) * (cd[1] + 1.5) * (cd[0] == 22 || cd[0] == 23 ? 1.15 : 1.0);
             // tile 26 (two workgroups per CU): a round is 512 workgroups and takes two tiles' time, less what one workgroup's prologue,
@@ -560,8 +561,9 @@ int hmmr_conv1x1_stream(const hmmr_conv_desc_t* d, hipStream_t stream) {
     case 24: return launch_s1<7, 2, 2, 2, 4>(a, stream);       // 448 pixels, waves 2 x 2
     case 25: return launch_s1<4, 2, 2, 2, 6>(a, stream);       // 256 pixels, waves 2 x 2
     case 26: return launch_s1<4, 2, 2, 2, 3, 0, false, false, false, 2>(a, stream);       // 256 pixels, TWO workgroups per CU (rings 3 deep)
+    case 29: return launch_s1<2, 2, 2, 2, 6>(a, stream);       // 128 pixels, waves 2 x 2: short launches
     default: break;
     }
-    hmmr_set_error("hmmr_conv_gemm: k_order 2 (1x1) runs tiles 22 .. 26, not %d", tile);
+    hmmr_set_error("hmmr_conv_gemm: k_order 2 (1x1) runs tiles 22 .. 26 and 29, not %d", tile);
     return -1;
 }

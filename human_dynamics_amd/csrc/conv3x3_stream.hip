@@ -450,17 +450,19 @@ int hmmr_conv3x3_stream(const hmmr_conv_desc_t* d, hipStream_t stream) {
     const bool narrow = d->cout == 64, wide = d->win > 28;
     if (!tile) {
         // the library's choice: fewest rounds of 256 workgroups x (row blocks per tile + ~1.5 for a tile's prologue and epilogue)
-        static const int cand[7][3] = {{12, 14, 0}, {13, 8, 0}, {15, 12, 0}, {16, 10, 0}, {21, 7, 0}, {19, 20, 1}, {20, 16, 1}};
+        // (27 / 28, round 6: 128- and 192-pixel tiles for SHORT launches -- at the reference's own batch sizes, 64 frames of FeatureExtractor
+        //  and the 160 of Tester.predict, blocks 3-4 are 98 - 245 row blocks: 56 - 140 workgroups of the 224-pixel tile on 256 CUs)
+        static const int cand[9][3] = {{12, 14, 0}, {13, 8, 0}, {15, 12, 0}, {16, 10, 0}, {21, 7, 0}, {27, 4, 0}, {28, 6, 0}, {19, 20, 1}, {20, 16, 1}};
         const long long rbs = (a.M + 31) / 32, nts = narrow ? 1 : d->cout / 128;
         double best = 0;
         for (const auto& cd : cand) {
-            if ((cd[2] != 0) != narrow || (cd[0] == 21 && !split)) continue;
+            if ((cd[2] != 0) != narrow || ((cd[0] == 21 || cd[0] == 27 || cd[0] == 28) && !split)) continue;
             const long long tiles = ((rbs + cd[1] - 1) / cd[1]) * nts;
             const double cost = (double)((tiles + 255) / 256) * (cd[1] + 1.5);
             if (!tile || cost < best) { tile = cd[0]; best = cost; }
         }
     }
-    HMMR_REQUIRE((tile == 19 || tile == 20) == narrow && (!wide || narrow), "hmmr_conv_gemm: k_order 2: tiles 12 .. 18 take cout %% 128 == 0 and images up to 28 pixels wide, "
+    HMMR_REQUIRE((tile == 19 || tile == 20) == narrow && (!wide || narrow), "hmmr_conv_gemm: k_order 2: tiles 12 .. 18, 21, 27, 28 take cout %% 128 == 0 and images up to 28 pixels wide, "
                  "tiles 19 / 20 cout = 64 and up to 56 (tile %d, cout %d, win %d)", tile, d->cout, d->win);
     switch (tile) {
     case 12: return launch_s3<7, 2, 2, 2, 28>(a, d->cout, split, stream);       // 448 pixels
@@ -476,8 +478,13 @@ int hmmr_conv3x3_stream(const hmmr_conv_desc_t* d, hipStream_t stream) {
         HMMR_REQUIRE(split, "hmmr_conv_gemm: k_order 2, tile 21 (7 x 1 accumulators per wave) is built for split tensors: with two MFMAs per step "
                      "the bf16 form has no room for its 16 fragment reads");
         return launch_s3_t<7, 1, 1, 4, 28, true>(a, d->cout, stream);
+    case 27:                                                                    // 128 pixels x 128 channels (2 x 2 accumulators per wave): short launches
+    case 28:                                                                    // 192 pixels (3 x 2)
+        HMMR_REQUIRE(split, "hmmr_conv_gemm: k_order 2, tiles 27 / 28 (2 x 2 and 3 x 2 accumulators per wave) are built for split tensors: with two MFMAs "
+                     "per step the bf16 form has no room for their fragment reads");
+        return tile == 27 ? launch_s3_t<2, 2, 2, 2, 28, true>(a, d->cout, stream) : launch_s3_t<3, 2, 2, 2, 28, true>(a, d->cout, stream);
     default: break;
     }
-    hmmr_set_error("hmmr_conv_gemm: k_order 2 runs tiles 12 .. 21, not %d", tile);
+    hmmr_set_error("hmmr_conv_gemm: k_order 2 runs tiles 12 .. 21, 27 and 28, not %d", tile);
     return -1;
 }

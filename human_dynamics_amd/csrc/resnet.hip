@@ -294,7 +294,9 @@ static int resnet_fwd_t(const hmmr_resnet_weights_t* w, const float* images, int
         // pixels there are: below ~12 k pixels (61 frames in block 3) the two launches it replaces are faster (profiles/r04_unit_pair_check.log:
         // 0.064 against 0.096 ms at 33 frames), and they produce the same bits, so a short batch simply takes them
         // (hmmr_debug_t.pair_min_pixels moves the switch: tests run one batch on either side of it)
-        const long long pair_min = dbg->pair_min_pixels > 0 ? dbg->pair_min_pixels : 12000;
+        // round 6 (profiles/r06e_pair_ws_check.log): in block 3 the two launches still win at 12 544 pixels (64 frames, FeatureExtractor's batch:
+        // 0.085 against 0.093 ms) -- its switch is at 14 000; a block-2 pair is a shorter tile and wins from ~12 000 (0.034 against 0.043 ms at 15 680)
+        const long long pair_min = dbg->pair_min_pixels > 0 ? dbg->pair_min_pixels : (U.base >= 256 ? 14000 : 12000);
         const bool pair_off = w->dtype == HMMR_F16X3 && U.pair_stream && U.fuse_tail == 1 && (long long)n * Ho * Ho < pair_min;
         const int fuse_tail = pair_off ? 0 : U.fuse_tail;
         const bool sc_in_tail = fuse_tail == 3;          // the conv shortcut is computed inside the fused tail

@@ -31,7 +31,7 @@ FLAGS = {
     "AUTOTUNE": ("1", "0: no per-layer tile tuning pass (shipped table / library heuristic only)"),
     "TILE_TABLE": ("1", "0: ignore the shipped tile tables (tile_tables.json), tune or fall back to the heuristic"),
     "TILE_CACHE": ("", "json file the tuned tile tables are read from / written to (profiling runs)"),
-    "TUNE_TILES": ("5,6,3,1,2,7,8,11", "hmmr_conv_desc_t.tile candidates of the tuner"),
+    "TUNE_TILES": ("5,6,3,1,2,7,8,11,4", "hmmr_conv_desc_t.tile candidates of the tuner"),
     "RESNET_STREAMS": ("2", "contiguous parts a large batch is encoded as, on concurrent streams"),
     "RESNET_PRIORITY": ("-1", "HIP priority of the ResNet side streams"),
     "TAIL_PRIORITY": ("0", "HIP priority of the tail stream (dist.ShardedPredictor)"),

@@ -242,21 +242,21 @@ class HmmrEngine(object):
         tuner's candidates as its own tile shapes 13 .. 18; a k_order 2 layer with a 1x1 filter (any layer name but conv2; csrc/conv1x1_stream.hip)
         tiles 22 .. 26, its conv3 form 24 .. 26."""
         if lay.k_order == 2 and nm != "conv2":
-            t = {5: 22, 6: 23, 3: 24, 1: 25, 2: 26}.get(cand, cand if 22 <= cand <= 26 else 0)
-            return 0 if (nm == "conv3" and t in (22, 23)) else t
+            t = {5: 22, 6: 23, 3: 24, 1: 25, 2: 26, 4: 29}.get(cand, cand if (22 <= cand <= 26 or cand == 29) else 0)
+            return 0 if (nm == "conv3" and t in (22, 23, 29)) else t
         if lay.k_order == 2:                                 # the stream kernel's tiles: 12 .. 18 and 21 (128-channel tiles), 19 / 20 (64 channels)
             if cout == 64:
                 return {5: 19, 6: 20}.get(cand, cand if cand in (19, 20) else 0)
-            t = {5: 13, 6: 14, 3: 15, 1: 16, 2: 17, 7: 18, 8: 12, 11: 21}.get(cand, cand if (12 <= cand <= 18 or cand == 21) else 0)
-            return 0 if (t == 21 and dtype == L.HMMR_BF16) else t       # (the 7 x 1 wave tile is built for split tensors)
+            t = {5: 13, 6: 14, 3: 15, 1: 16, 2: 17, 7: 18, 8: 12, 11: 21, 4: 27, 9: 28}.get(cand, cand if (12 <= cand <= 18 or cand in (21, 27, 28)) else 0)
+            return 0 if (t in (21, 27, 28) and dtype == L.HMMR_BF16) else t       # (the 7 x 1, 2 x 2 and 3 x 2 wave tiles are built for split tensors)
         if lay.k_order:
             cand = {7: 9, 8: 10}.get(cand, cand)
             if cand == 11 and dtype == L.HMMR_BF16:          # the tile without a load segment is written for split operands
                 return 0
             return cand if (cand in (9, 11) and cout % 128 == 0) or (cand == 10 and cout % 256 == 0) else 0
-        # the generic kernel's tiles are 1 .. 8: anything else (a cached table written under another packing configuration, e.g. 22 .. 26
+        # the generic kernel's tiles are 1, 2, 3, 5 .. 8: anything else (the tuner's candidate 4 is a stream-kernel shape only; a cached table written under another packing configuration, e.g. 22 .. 26
         # of a 1x1 stream layer read back with STREAM_1X1 off) becomes the library's choice instead of a 'bad tile' error in the pass
-        if not 1 <= cand <= 8 or (cand in (1, 5, 7) and cout % 128) or (cand == 8 and cout % 256):
+        if cand not in (1, 2, 3, 5, 6, 7, 8) or (cand in (1, 5, 7) and cout % 128) or (cand == 8 and cout % 256):
             return 0
         return cand
 

@@ -75,7 +75,7 @@ typedef struct hmmr_debug_s {
     int ief_no_group;      /* 1: hmmr_ief_fwd runs the delta regressors one after the other instead of as grouped launches (same bits) */
     int reserved[3];
     int pair_min_pixels;   /* hmmr_resnet50_fwd runs a register-resident unit pair (csrc/unit_pair.hip) as the two launches it replaces when
-                              the unit has fewer pixels than this (same bits, faster for short batches): 0 = the default (12000),
+                              the unit has fewer pixels than this (same bits, faster for short batches): 0 = the default (12000 in block 2, 14000 in block 3),
                               1 = always the pair kernel, INT_MAX = never */
     int pair_two_tile_min; /* the pair kernel of the block-2 shapes runs as PERSISTENT workgroups (several 128-pixel tiles each) when the launch has at least
                               this many tiles (same bits; one workgroup per CU then walks tiles b, b + grid, ...): 0 = the default (512 = two rounds of workgroups), 1 = always, INT_MAX = never */

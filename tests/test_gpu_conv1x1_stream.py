@@ -38,7 +38,7 @@ def test_conv1x1_stream_kernel(case, gpu_device):
         kw = dict(stride=1, pad=0, scale=scale, shift=shift, relu=relu, in_dtype=X3, out_dtype=X3, device=gpu_device)
         if n_split:
             kw.update(n_split=n_split, relu_b=not relu)
-        outs = {tile: conv_gemm(x, w, tile=tile, k_order=2, **kw) for tile in ((0, 22, 23, 24, 25, 26) if relu else (0, 24, 26))}
+        outs = {tile: conv_gemm(x, w, tile=tile, k_order=2, **kw) for tile in ((0, 22, 23, 24, 25, 26, 29) if relu else (0, 24, 26, 29))}
         ref, _ = _ref_conv(_split_round(x), _split_round_w(w), 1, 0, scale, shift, None, False, None, None, 1)
         mag = max(1.0, np.abs(ref).max())
         if n_split:

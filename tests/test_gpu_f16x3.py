@@ -171,7 +171,7 @@ def test_conv3x3_stream_kernel(case, gpu_device):
     shift = rng.normal(size=cout).astype(np.float32)
     for relu in (True, False):
         kw = dict(stride=1, pad=1, scale=scale, shift=shift, relu=relu, in_dtype=X3, out_dtype=X3, device=gpu_device)
-        tiles = ((0, 19, 20) if relu else (0, 20)) if cout == 64 else ((0, 12, 13, 14, 15, 16, 17, 18, 21) if relu else (0, 13))
+        tiles = ((0, 19, 20) if relu else (0, 20)) if cout == 64 else ((0, 12, 13, 14, 15, 16, 17, 18, 21, 27, 28) if relu else (0, 13, 27))
         outs = {tile: conv_gemm(x, w, tile=tile, k_order=2, **kw)[0] for tile in tiles}
         ref, _ = _ref_conv(_split_round(x), _split_round_w(w), 1, 1, scale, shift, None, relu, None, None, 1)
         mag = max(1.0, np.abs(ref).max())
