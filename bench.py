@@ -654,6 +654,18 @@ def main():
         tester0 = Tester(Cfg(), weights=weights, smpl=smpl, dtype=args.dtype, device=str(device))
         mg = multi_gpu_fields(tester0, n_total, span, world, rank, device,
                               pipeline=not (args.no_pipeline or args.graph or args.serial), step_streams=not args.no_step_streams)
+    # the other BASELINE / reference sizes FIRST, on a tester of their own process state: measured after the headline's predictor exists
+    # (its step / tail / side streams share the runtime's few hardware queues with whatever comes later) a two-part ResNet pass and the
+    # 150-launch tail read 25 % and 3x slower than in a process of their own (profiles/r06a_bench.json against r06b_sizes_check.log)
+    by_config = None
+    if world == 1 and not args.no_by_config:
+        from human_dynamics_amd.evaluation.tester import Tester
+        tester0 = Tester(Cfg(), weights=weights, smpl=smpl, dtype=args.dtype, device=str(device))
+        try:
+            from human_dynamics_amd.engine import DTYPE_NAMES as _DN
+            by_config = by_config_leg(tester0, weights, device, _DN[tester0.engine.dtype], None)
+        except Exception as e:                                # a reporting leg: never lose the headline over it
+            by_config = {"error": repr(e)}
     gather_requested = args.gather
     if args.gather == "auto":
         args.gather = mg["gather_by_measurement"] if (mg is not None and strong) else "records"
@@ -704,12 +716,10 @@ def main():
         roofline["achieved_overlapped_note"] = ("ResNet FLOPs of one step / ms_per_step (the step also carries the f_movie / IEF / "
                                                 "SMPL tail on a second stream): the figure `value` corresponds to")
         single = world == 1
-        by_config = None
-        if single and not args.no_by_config:
-            try:
-                by_config = by_config_leg(tester, weights, device, args.dtype, roofline["frac"])
-            except Exception as e:                            # a reporting leg: never lose the headline over it
-                by_config = {"error": repr(e)}
+        if by_config and "error" not in by_config:
+            for ent in by_config.values():                    # relate every size to the headline's 257-frame pass
+                if isinstance(ent.get("roofline"), dict) and roofline["frac"]:
+                    ent["roofline"]["frac_vs_headline"] = round(ent["roofline"]["frac"] / roofline["frac"], 3)
         # ---- the other operand modes, same workload, same steps (extras: never the headline).  Timed BEFORE any host-side
         # work of this script (oracle, PCIe legs): under the container's CPU quota the oracle's thread pool slows the launch
         # thread down afterwards, and the 190-launch bf16 step is the first thing to become host-bound.

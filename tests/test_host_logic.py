@@ -288,7 +288,13 @@ def test_tuner_candidates_map_onto_the_stream_kernels_tiles():
     f = E.HmmrEngine._tile_for
     assert [f(lay, c, 256, _lib.HMMR_F16X3) for c in (0, 5, 6, 3, 1, 2, 7, 8, 11)] == [0, 13, 14, 15, 16, 17, 18, 12, 21]
     assert f(lay, 21, 256, _lib.HMMR_F16X3) == 21 and f(lay, 21, 256, _lib.HMMR_BF16) == 0 and f(lay, 11, 512, _lib.HMMR_BF16) == 0
-    assert f(lay, 9, 256, _lib.HMMR_F16X3) == 0 and f(lay, 12, 256, _lib.HMMR_BF16) == 12
+    assert f(lay, 12, 256, _lib.HMMR_BF16) == 12 and f(lay, 10, 256, _lib.HMMR_F16X3) == 0
+    # round 6: the 128- / 192-pixel tiles for short launches (27 / 28: candidates 4 / 9), split-only like 21
+    assert [f(lay, c, 256, _lib.HMMR_F16X3) for c in (4, 9, 27, 28)] == [27, 28, 27, 28] and f(lay, 4, 256, _lib.HMMR_BF16) == 0
+    # ... and of the 1x1 stream kernel (29: candidate 4), conv1 form only
+    assert f(lay, 4, 512, _lib.HMMR_F16X3, "conv1") == 29 and f(lay, 29, 2048, _lib.HMMR_F16X3, "conv3") == 0
+    plain = _lib.Layer()
+    assert f(plain, 4, 256, _lib.HMMR_F16X3, "conv3") == 0 and f(plain, 26, 256, _lib.HMMR_F16X3, "conv1") == 0      # (the generic kernel has no tile 4 / 26)
     assert [f(lay, c, 64, _lib.HMMR_F16X3) for c in (0, 5, 6, 19, 20, 12)] == [0, 19, 20, 19, 20, 0]
 
 
@@ -316,9 +322,9 @@ def test_shipped_tile_tables_fit_their_layers():
                 lay = U.c3sc if (nm == "conv3" and U.c3sc.w) else getattr(U, nm)
                 cout = U.depth + U.base if (nm == "shortcut" and U.sc_c1.w) else (U.base if nm in ("conv1", "conv2") else U.depth)
                 assert E.HmmrEngine._tile_for(lay, tile, cout, dt, nm) == tile, (key, lk, tile)
-                ok = {0: (0, 1, 2, 3, 5, 6, 7, 8), 1: (0, 9, 10, 11), 2: (0, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21)}[lay.k_order]
+                ok = {0: (0, 1, 2, 3, 5, 6, 7, 8), 1: (0, 9, 10, 11), 2: (0, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 27, 28)}[lay.k_order]
                 if lay.k_order == 2 and nm != "conv2":          # a 1x1 layer of csrc/conv1x1_stream.hip
-                    ok = (0, 24, 25, 26) if nm == "conv3" else (0, 22, 23, 24, 25, 26)
+                    ok = (0, 24, 25, 26) if nm == "conv3" else (0, 22, 23, 24, 25, 26, 29)
                 assert tile in ok, (key, lk, tile)
     assert {40, 64, 65, 128, 129, 256, 257, 512, 513, 1024} <= sizes
 
