@@ -597,6 +597,8 @@ def main():
     ap.add_argument("--sustain", type=float, default=2.0,
                     help="seconds of a second, longer timed leg of the same steps (`fps_sustained_2s`; 0 = skip)")
     ap.add_argument("--no-by-config", action="store_true", help="skip the `by_config` legs (the other BASELINE sizes)")
+    ap.add_argument("--by-config-only", action="store_true", help="run ONLY the `by_config` legs and print them as one JSON line (what the default run "
+                                                                  "starts as a child process; --dtype: the operand mode, not auto)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive leg (used for PMC passes)")
     ap.add_argument("--serial-gather", action="store_true",
                     help="N > 1: wait for each all-gather instead of overlapping it with the next step")
@@ -618,6 +620,18 @@ def main():
                          "ONE 4096-frame video sharded over the ranks")
     args = ap.parse_args()
 
+    if args.by_config_only:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no HIP device visible)")
+        from human_dynamics_amd import assets
+        from human_dynamics_amd.evaluation.tester import Tester
+        device = torch.device("cuda", 0)
+        torch.cuda.set_device(device)
+        weights, smpl = assets.make_synthetic_weights(0), assets.make_synthetic_smpl(2)
+        dt = "f16x3" if args.dtype == "auto" else args.dtype
+        t = Tester(Cfg(), weights=weights, smpl=smpl, dtype=dt, device=str(device))
+        print(json.dumps(by_config_leg(t, weights, device, dt, None)), flush=True)
+        return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # `python bench.py --gpus N` on its own: become the launcher (one rank per GPU over RCCL, the contract's command)
         raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
@@ -654,18 +668,6 @@ def main():
         tester0 = Tester(Cfg(), weights=weights, smpl=smpl, dtype=args.dtype, device=str(device))
         mg = multi_gpu_fields(tester0, n_total, span, world, rank, device,
                               pipeline=not (args.no_pipeline or args.graph or args.serial), step_streams=not args.no_step_streams)
-    # the other BASELINE / reference sizes FIRST, on a tester of their own process state: measured after the headline's predictor exists
-    # (its step / tail / side streams share the runtime's few hardware queues with whatever comes later) a two-part ResNet pass and the
-    # 150-launch tail read 25 % and 3x slower than in a process of their own (profiles/r06a_bench.json against r06b_sizes_check.log)
-    by_config = None
-    if world == 1 and not args.no_by_config:
-        from human_dynamics_amd.evaluation.tester import Tester
-        tester0 = Tester(Cfg(), weights=weights, smpl=smpl, dtype=args.dtype, device=str(device))
-        try:
-            from human_dynamics_amd.engine import DTYPE_NAMES as _DN
-            by_config = by_config_leg(tester0, weights, device, _DN[tester0.engine.dtype], None)
-        except Exception as e:                                # a reporting leg: never lose the headline over it
-            by_config = {"error": repr(e)}
     gather_requested = args.gather
     if args.gather == "auto":
         args.gather = mg["gather_by_measurement"] if (mg is not None and strong) else "records"
@@ -716,6 +718,19 @@ def main():
         roofline["achieved_overlapped_note"] = ("ResNet FLOPs of one step / ms_per_step (the step also carries the f_movie / IEF / "
                                                 "SMPL tail on a second stream): the figure `value` corresponds to")
         single = world == 1
+        # the other BASELINE / reference sizes in a PROCESS OF THEIR OWN (`bench.py --by-config-only`): HIP streams share a few hardware
+        # queues in creation order, and whichever of the two -- the headline's predictor (two step streams, tail stream) or these legs
+        # (side streams of the two-part ResNet pass) -- comes second in one process reads 20-25 % slow (profiles/r06a, r06m, r06n)
+        by_config = None
+        if single and not args.no_by_config:
+            import subprocess
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--by-config-only", "--dtype", args.dtype],
+                                   capture_output=True, text=True, timeout=600)
+                lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                by_config = json.loads(lines[-1]) if (r.returncode == 0 and lines) else {"error": (r.stderr or "no output")[-400:]}
+            except Exception as e:                            # a reporting leg: never lose the headline over it
+                by_config = {"error": repr(e)}
         if by_config and "error" not in by_config:
             for ent in by_config.values():                    # relate every size to the headline's 257-frame pass
                 if isinstance(ent.get("roofline"), dict) and roofline["frac"]:

@@ -214,7 +214,7 @@ def test_config5_4096_frame_video_on_one_gpu(weights, smpl_consts, gpu_device):
     torch.cuda.empty_cache()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--video-frames", str(n), "--steps", "1", "--warmup", "0",
-                        "--only-main", "--no-cpu-baseline", "--no-pcie", "--dtype", "f16x3"], cwd=root, capture_output=True,
+                        "--only-main", "--no-cpu-baseline", "--no-pcie", "--no-by-config", "--sustain", "0", "--dtype", "f16x3"], cwd=root, capture_output=True,
                        text=True, timeout=600)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and lines, r.stderr[-800:]
