@@ -35,14 +35,21 @@ OUTPUT_KEYS = ("cams", "joints", "kps", "poses", "shapes", "verts", "omegas")
 
 
 def mean_theta_from_file(path):
-    """The role of `neutral_smpl_meanwjoints.h5` (tester.py:118-135) from an .npy / .npz: either the assembled
-    [85] / [1,85] mean theta, or the h5's own fields `pose` [72] and `shape` [10], to which the reference's assembly is
-    applied: cam = [0.9, 0, 0], pose[:3] = [pi, 0, 0].  (The h5 itself is written by deepdish through PyTables' blosc
-    filter and cannot be decoded without that library; `python -c "import deepdish as dd, numpy as np;
-    np.savez('neutral_smpl_meanwjoints.npz', **dd.io.load('neutral_smpl_meanwjoints.h5'))"` converts it once.)"""
+    """The mean theta the reference initialises `mean_param` with (tester.py:118-135): from `neutral_smpl_meanwjoints.h5` itself (round 6:
+    human_dynamics_amd/hdf5_lite.py reads the deepdish / PyTables file -- HDF5 1.8 structures, Blosc-filtered arrays -- without h5py or blosc),
+    or from an .npy / .npz: either the assembled [85] / [1,85] mean theta, or the h5's own fields `pose` [72] and `shape` [10].  To the fields
+    the reference's assembly is applied: cam = [0.9, 0, 0], pose[:3] = [pi, 0, 0]."""
     if not os.path.exists(path):
         raise FileNotFoundError("{} doesnt exist..".format(path))
-    v = np.load(path)
+    if str(path).endswith((".h5", ".hdf5")):
+        # the file the reference reads (tester.py:120-123): deepdish / PyTables on HDF5, Blosc-filtered arrays, decoded here without
+        # either library (human_dynamics_amd/hdf5_lite.py)
+        from .. import hdf5_lite
+        v = hdf5_lite.load(path)
+        if "pose" not in v or "shape" not in v:
+            raise ValueError("%s has no 'pose' / 'shape' datasets (found %s)" % (path, sorted(v)))
+    else:
+        v = np.load(path)
     if isinstance(v, np.ndarray):
         if v.size != 85:
             raise ValueError("%s holds %d values, the mean theta has 85" % (path, v.size))
@@ -60,7 +67,7 @@ def load_weights(load_path, resnet_path="", mean_param_path=""):
     .npz with the same names, or 'synthetic[:seed]'.  ResNet variables come from `resnet_path`
     when given (tester.py:99-112).  mean_param_path: .npy / .npz initialiser of `mean_param` (mean_theta_from_file),
     used only when the checkpoint does not carry the variable -- Saver.restore overwrites it otherwise
-    (tester.py:114-116)."""
+    (tester.py:114-116).  An .h5 is the reference's own file (hdf5_lite)."""
     from .. import tf_checkpoint
 
     def one(path):
@@ -150,19 +157,20 @@ class Tester(object):
         self.f_temporal_enc = get_temporal_encoder()
         if "mean_param" not in weights:
             # the reference initialises this variable from neutral_smpl_meanwjoints.h5 (tester.py:118-141) and then restores
-            # it from the checkpoint (tester.py:114-116); the h5 (deepdish / blosc) is not read here -- see DESIGN.md section 7
+            # it from the checkpoint (tester.py:114-116); load_weights() reads the .h5 next to the SMPL model when the checkpoint lacks it
             raise KeyError("the loaded weights have no 'mean_param' variable (the 1 x 85 mean theta both published "
-                           "checkpoints carry); add it to the .npz, load a checkpoint that was saved by the reference, or "
-                           "set config.mean_param_path to an .npy / .npz conversion of neutral_smpl_meanwjoints.h5")
+                           "checkpoints carry) and no neutral_smpl_meanwjoints.h5 sits next to the SMPL model; add the variable to "
+                           "the .npz, load a checkpoint that was saved by the reference, or set config.mean_param_path to the .h5 "
+                           "(or an .npy / .npz of its pose / shape fields)")
         self.theta_mean = np.asarray(weights["mean_param"], np.float32).reshape(1, 85)
         self._streamer = None
 
     @staticmethod
     def _default_mean_path(config):
-        """neutral_smpl_meanwjoints.{npz,npy} next to the SMPL model, where the reference looks for the .h5
+        """neutral_smpl_meanwjoints.{h5,npz,npy} next to the SMPL model, where the reference looks for the .h5
         (tester.py:120-121); '' when there is none."""
         d = os.path.dirname(str(getattr(config, "smpl_model_path", "") or ""))
-        for ext in (".npz", ".npy"):
+        for ext in (".h5", ".npz", ".npy"):
             p = os.path.join(d, "neutral_smpl_meanwjoints" + ext)
             if d and os.path.exists(p):
                 return p
