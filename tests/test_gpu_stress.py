@@ -184,15 +184,20 @@ def test_a_nan_pixel_raises_the_flag_and_falls_back_to_f32(gpu_device):
     assert np.abs(again["verts"] - ok["verts"]).max() < 1e-4
 
 
-@pytest.mark.parametrize("dt", ["f16x3", "bf16"])
-def test_tail_beside_the_resnet_is_deterministic(gpu_device, dt):
+@pytest.mark.parametrize("dt,blend", [("f16x3", 0), ("bf16", 0), ("f32", 0), ("bf16", 2)], ids=["f16x3", "bf16", "f32", "bf16-packed-fma-blend"])
+def test_tail_beside_the_resnet_is_deterministic(gpu_device, dt, blend):
     """The per-window tail (f_movie -> IEF -> SMPL records) gives the same records whether it runs alone or beside the ResNet passes of the
     engine's two priority streams -- the overlap every streamed / sharded call runs with (evaluation/streaming.py, dist.ShardedPredictor).
     Round 5: with the SLP vectoriser's packed fp32 (v_pk_*_f32) in smpl_pose_kernel, 20-60 % of such launches returned a wrong bone
     translation for joints 16-23 of odd instances (lanes 48-55 of a wave) -- vertices off by centimetres in ~1 % of the streamed calls, none
     of it visible to a test that runs a call twice.  The library is now built with -fno-slp-vectorize (human_dynamics_amd/build.py); this
-    test repeats the overlap 80 times and compares every record word."""
+    test repeats the overlap 80 times and compares every record word.  Round 6 (the advisor's request): also the all-fp32 engine and the
+    packed-FMA form of the SMPL blend (hmmr_debug_t.smpl_blend_mfma = 2: smpl_verts_kernel's HAND-WRITTEN v_pk_fma_f32, the fp32 fallback's
+    path) -- tools/tail_race_check.py found neither failing in 300 / 600 overlaps (profiles/r06o_slp_race_study*.log), here they stay pinned."""
     from conftest import Config
+    from human_dynamics_amd import engine as E
+    if blend:
+        E.set_debug(smpl_blend_mfma=blend)
     from human_dynamics_amd import dist as hd
     from human_dynamics_amd.evaluation.tester import Tester
     w, s = assets.make_synthetic_weights(0), assets.make_synthetic_smpl(2)
@@ -222,4 +227,5 @@ def test_tail_beside_the_resnet_is_deterministic(gpu_device, dt):
         torch.cuda.synchronize()
         if not torch.equal(rec, ref):
             bad.append((rep, (rec != ref).any(1).nonzero().flatten().tolist()[:8]))
+    E.set_debug()
     assert not bad, "records differ beside the ResNet in %d of 80 runs: %s" % (len(bad), bad[:4])

@@ -14,6 +14,9 @@ import os
 t = Tester(Config(batch_size=8), weights=w, smpl=s, dtype=os.environ.get("DBG_DT", "bf16"), device="cuda:0")
 eng = t.engine
 dev = eng.device
+if os.environ.get("DBG_BLEND"):          # hmmr_debug_t.smpl_blend_mfma: 2 = the packed-FMA vector form (hand-written v_pk_fma_f32), 1 = exact-fp32 MFMA
+    from human_dynamics_amd import engine as E
+    E.set_debug(smpl_blend_mfma=int(os.environ["DBG_BLEND"]))
 n = 128
 g = torch.Generator().manual_seed(1)
 windows = torch.randn((16, 20, 2048), generator=g).to(dev)
@@ -28,11 +31,14 @@ mp = 384
 featA = lambda b: (b[:mp * LDF * 4].view(torch.float32).reshape(mp, LDF), b[mp * LDF * 4:mp * LDF * 4 + mp * LDA * 4].view(torch.float32).reshape(mp, LDA))
 frames = torch.rand((128, 224, 224, 3), device=dev) * 2 - 1
 phi = torch.empty((128, 2048), device=dev)
-s_tail = torch.cuda.Stream()
+s_tail = torch.cuda.Stream(priority=int(os.environ.get("DBG_TAIL_PRIORITY", "0")))
+REPS = int(os.environ.get("DBG_REPS", "300"))
 off = {k: (o, sz) for k, shp, o, sz in layout}
-for mode in ("with 2-part resnet on priority streams",):
+# DBG_MODE: "with 2-part resnet on priority streams" (default; HMMR_RESNET_PRIORITY sets the side streams' priority, 0 = none) | "alone" |
+# "smpl only beside the resnet"
+for mode in (os.environ.get("DBG_MODE", "with 2-part resnet on priority streams"),):
     bad = 0
-    for rep in range(300):
+    for rep in range(REPS):
         rec = torch.full((n, rec_len), float("nan"), device=dev)
         torch.cuda.synchronize()
         cur = torch.cuda.current_stream()
@@ -67,4 +73,4 @@ for mode in ("with 2-part resnet on priority streams",):
                       "| A rows differing", da.any(1).nonzero().flatten().tolist()[:6], "cols", da.any(0).nonzero().flatten().tolist()[:16])
             if bad <= 0:
                 print(mode, "rep", rep, "frames", fr[:10], "fields", ks, "nan", int(torch.isnan(rec).sum()))
-    print(os.environ.get("DBG_DT", "bf16"), {k: v for k, v in os.environ.items() if k.startswith("HMMR_")}, mode, ": bad", bad, "of 300")
+    print(os.environ.get("DBG_DT", "bf16"), {k: v for k, v in os.environ.items() if k.startswith("HMMR_")}, mode, "| tail priority", os.environ.get("DBG_TAIL_PRIORITY", "0"), "| blend form", os.environ.get("DBG_BLEND", "default"), "| library", os.path.basename(L.LIB_PATH), ": bad", bad, "of", REPS)
