@@ -35,6 +35,7 @@ FLAGS = {
     "RESNET_STREAMS": ("2", "contiguous parts a large batch is encoded as, on concurrent streams"),
     "RESNET_PRIORITY": ("-1", "HIP priority of the ResNet side streams"),
     "TAIL_PRIORITY": ("0", "HIP priority of the tail stream (dist.ShardedPredictor)"),
+    "STEP_BUFFERS": ("2", "calls in flight of a pipelined ShardedPredictor (record buffers, and encode streams with STEP_STREAMS): 2, or more to try"),
     "STEP_STREAMS": ("1", "0: keep consecutive steps' ResNet passes on one stream (dist.ShardedPredictor)"),
     "STREAM_POISON": ("", "1: evaluation/streaming.py fills a chunk's record buffer with NaN before its tail writes it (a row nobody wrote, or a download that ran early, shows on the host)"),
     "STREAM_TRACE": ("", "1: evaluation/streaming.py prints the host and device timeline of a call"),

@@ -152,7 +152,7 @@ class ShardedPredictor(object):
             self.idx = idx.to(eng.device)
         else:
             self.idx = None
-        nbuf = 2 if (self.overlap or self.pipeline) else 1
+        nbuf = max(2, int(devflags.get("STEP_BUFFERS"))) if (self.overlap or self.pipeline) else 1
         self.s_tail = (torch.cuda.Stream(device=eng.device, priority=int(devflags.get("TAIL_PRIORITY")))
                        if self.pipeline else None)
         # pipeline + step_streams: consecutive calls encode on ALTERNATING high-priority streams, each as ONE whole-batch
