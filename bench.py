@@ -591,8 +591,8 @@ def main():
     ap.add_argument("--gather", default="auto", choices=["auto", "records", "theta"],
                     help="N > 1: all-gather the packed per-frame records (253 KB/frame) or only the 3 x 85 omegas "
                          "(1 KB/frame) and evaluate SMPL for the whole video on every rank.  auto: weak scaling -> records "
-                         "(hidden under the next step); one video (--video-frames, the N > 1 default) -> whichever mode the "
-                         "measured `single_video_ms` of this run says is faster (theta, unless the fabric is very fast)")
+                         "(hidden under the next step); one video (--video-frames, the N > 1 default) -> theta.  Both modes are "
+                         "measured after the timed region (`single_video_ms_by_gather`, `gather_by_measurement`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sustain", type=float, default=2.0,
                     help="seconds of a second, longer timed leg of the same steps (`fps_sustained_2s`; 0 = skip)")
@@ -643,11 +643,18 @@ def main():
     strong, n_total = resolve_workload(args, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible)")
-    device = torch.device("cuda", local_rank)
+    # (test hook, tests/test_gpu_sizes.py: HMMR_BENCH_BACKEND=gloo with HMMR_BENCH_ONE_DEVICE=1 runs the N > 1 code path with every rank on
+    #  cuda:0 of a one-GPU box -- RCCL refuses two ranks on one device; the driver's command never sets them)
+    one_dev = os.environ.get("HMMR_BENCH_ONE_DEVICE") == "1"
+    backend = os.environ.get("HMMR_BENCH_BACKEND", "nccl")
+    device = torch.device("cuda", 0 if one_dev else local_rank)
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from human_dynamics_amd import assets, dist as hd
 
@@ -659,20 +666,19 @@ def main():
     gen.manual_seed(1234 + rank)
     span = torch.rand((plan.f1 - plan.f0, 224, 224, 3), generator=gen, device=device) * 2 - 1
 
-    # N > 1: the figures of the one collective first (outside the timed region), because the gather mode of a strong-scaling run is
-    # picked by them: ONE video is what `--video-frames` measures, and for one video the records gather (253 KB per frame) is exposed
-    # while the omegas gather (1 KB per frame + SMPL for all frames on every rank) is not
-    mg, tester0 = None, None
-    if world > 1:
-        from human_dynamics_amd.evaluation.tester import Tester
-        tester0 = Tester(Cfg(), weights=weights, smpl=smpl, dtype=args.dtype, device=str(device))
-        mg = multi_gpu_fields(tester0, n_total, span, world, rank, device,
-                              pipeline=not (args.no_pipeline or args.graph or args.serial), step_streams=not args.no_step_streams)
+    # N > 1, `--gather auto`: ONE video is what `--video-frames` measures, and for one video the records gather (253 KB per frame) is
+    # exposed while the omegas gather (1 KB per frame + SMPL for all frames on every rank) is not -> theta for a strong-scaling run, records
+    # (hidden under the next step) for weak scaling.  Both modes are MEASURED further down (multi_gpu_fields: `single_video_ms`,
+    # `gather_by_measurement`), after the headline: HIP streams share a few hardware queues in creation order, and predictors created in
+    # front of the headline's would slow it (profiles/r06n).
     gather_requested = args.gather
     if args.gather == "auto":
-        args.gather = mg["gather_by_measurement"] if (mg is not None and strong) else "records"
+        args.gather = "theta" if (world > 1 and strong) else "records"
     timing, tester, predictor, out = run_mode(args.dtype, args, world, rank, device, weights, smpl, span, n_total,
-                                              args.steps, args.warmup, sustain_s=args.sustain, tester=tester0)
+                                              args.steps, args.warmup, sustain_s=args.sustain)
+    mg = None
+    if world > 1:
+        mg = multi_gpu_fields(tester, n_total, span, world, rank, device, pipeline=False)
     value, ms_per_step = timing["fps"], timing["ms_per_step"]
     from human_dynamics_amd import precision
     from human_dynamics_amd.engine import DTYPE_NAMES
@@ -851,6 +857,7 @@ def main():
             "frames_total": n_total,
             "all_gather_ms": all_gather_ms, "all_gather_bytes": gather_bytes, "rccl_ranks": rccl_ranks,
             "gather": args.gather if world > 1 else None, "gather_requested": gather_requested if world > 1 else None,
+            "gather_by_measurement": (mg["gather_by_measurement"] if mg else None),
             # N > 1: both gather modes measured in this run -- one whole step with nothing overlapped across steps, and the bare gather
             "single_video_ms": (mg["single_video_ms"][args.gather] if mg else None),
             "single_video_ms_by_gather": (mg["single_video_ms"] if mg else None),

@@ -221,3 +221,28 @@ def test_config5_4096_frame_video_on_one_gpu(weights, smpl_consts, gpu_device):
     js = json.loads(lines[-1])
     assert js["scaling"] == "strong" and js["frames_total"] == n and js["n_gpus"] == 1 and js["steps"] == 1
     assert js["config"]["resnet_frames_encoded_per_gpu"] == n + 1 and js["value"] > 2000
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_code_path_on_one_gpu(gpu_device):
+    """The N > 1 path of bench.py end to end -- `torch.distributed.run`, the shard plans of two ranks, the omegas gather of a strong-scaling
+    run, `multi_gpu_fields` (both gather modes measured after the headline), the scaling-efficiency leg, one JSON line from rank 0 -- on a one-GPU
+    box: both ranks on cuda:0 with the gloo backend (test hooks HMMR_BENCH_BACKEND / HMMR_BENCH_ONE_DEVICE; RCCL refuses two ranks on one
+    device).  What it cannot show is RCCL's speed; that the line has every field the N > 1 contract names, it can."""
+    import socket
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    env = dict(os.environ, HMMR_BENCH_BACKEND="gloo", HMMR_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), "bench.py", "--gpus", "2", "--video-frames", "512", "--steps", "2", "--warmup", "1",
+                        "--sustain", "0", "--dtype", "f16x3"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-500:], r.stderr[-1500:])
+    js = json.loads(lines[0])
+    assert js["n_gpus"] == 2 and js["scaling"] == "strong" and js["frames_total"] == 512 and js["rccl_ranks"] == 2
+    assert js["gather"] == "theta" and js["gather_requested"] == "auto" and js["gather_by_measurement"] in ("theta", "records")
+    for k in ("single_video_ms_by_gather", "all_gather_ms_by_gather", "all_gather_bytes_by_gather"):
+        assert set(js[k]) == {"records", "theta"} and all(v > 0 for v in js[k].values()), k
+    assert js["single_video_ms"] == js["single_video_ms_by_gather"]["theta"] and js["all_gather_bytes"] == 512 * 255 * 4
+    assert js["value"] > 1000 and js["per_gpu_fps"] * 2 == pytest.approx(js["value"], rel=1e-3) and js["scaling_efficiency"] > 0
+    assert js["config"]["frames_per_gpu_per_step"] == 256 and "window-sharded x2" in js["config"]["parallelism"]
