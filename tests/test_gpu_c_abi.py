@@ -47,6 +47,8 @@ def test_c_program_packs_and_runs_the_resnet(weights, gpu_device, tmp_path, dt):
 
 def test_c_program_compiles_against_the_header(tmp_path):
     """no GPU: the C side of the boundary compiles (hipcc, host code only) and links against libhmmr_hip.so"""
+    from human_dynamics_amd import build
+    build.build(verbose=False)                              # (incremental: a no-op when the library is up to date)
     pkg = os.path.join(ROOT, "human_dynamics_amd")
     r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-x", "hip", os.path.join(ROOT, "tests", "c_abi", "pack_and_run.c"),
                         "-I", os.path.join(ROOT, "include"), "-L", pkg, "-lhmmr_hip", "-Wl,-rpath," + pkg, "-o", str(tmp_path / "pack_and_run")],

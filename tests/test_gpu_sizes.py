@@ -229,7 +229,11 @@ def test_bench_two_rank_code_path_on_one_gpu(gpu_device):
     run, `multi_gpu_fields` (both gather modes measured after the headline), the scaling-efficiency leg, one JSON line from rank 0 -- on a one-GPU
     box: both ranks on cuda:0 with the gloo backend (test hooks HMMR_BENCH_BACKEND / HMMR_BENCH_ONE_DEVICE; RCCL refuses two ranks on one
     device).  What it cannot show is RCCL's speed; that the line has every field the N > 1 contract names, it can."""
+    import json
+    import os
     import socket
+    import subprocess
+    import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
     env = dict(os.environ, HMMR_BENCH_BACKEND="gloo", HMMR_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
