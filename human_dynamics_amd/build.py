@@ -24,6 +24,9 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # ran alone -- a rare wrong frame in Tester.predict_all_images' streamed path (profiles/r05_smpl_pose_packed_fp32.log; tests/
 # test_gpu_stress.py::test_tail_beside_the_resnet_is_deterministic).  Without the flag-made packing: 0 of 600.  The flag changes no
 # arithmetic (the same IEEE operations, unpacked); the one-wave-per-SIMD kernels had it already because the packing costs them issue slots.
+# Round 6 found the instruction: packed-fp32 arithmetic whose LOW result reads the HIGH register of source 1 (op_sel bit 1) gets 0.0 for it
+# in a wave's last 16 lanes while a neighbour's MFMAs are in flight (isa_check.py) -- so the flag is only the usual way such an
+# instruction gets made, and build() checks the linked library's ISA for the form itself (`isa_check.unsafe_forms`).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-I", INCLUDE, "-I", CSRC,
          "-Wall", "-Wno-unused-function"]
 
@@ -64,6 +67,16 @@ def build(force=False, verbose=True):
             list(ex.map(run, jobs))
     if jobs or force or not os.path.exists(LIB):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        from . import isa_check
+        unsafe = isa_check.unsafe_forms(LIB)
+        if unsafe:
+            os.replace(LIB, LIB + ".rejected")
+            raise RuntimeError("the linked library holds packed-fp32 instructions gfx950 gets wrong beside MFMAs (isa_check.py, DESIGN 4.6); "
+                               "kept as %s.rejected:\n%s" % (LIB, "\n".join("  %d x %s %s in %s" % (n, op, mods, kern)
+                                                                             for (kern, op, mods), n in sorted(unsafe.items()))))
+        if verbose:
+            print("isa_check: %s" % ("no disassembler (%s): not checked" % isa_check.OBJDUMP if unsafe is None
+                                     else "no packed-fp32 instruction reads source 1's high register into its low result"), flush=True)
     return LIB
 
 

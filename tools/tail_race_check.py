@@ -71,6 +71,43 @@ for mode in (os.environ.get("DBG_MODE", "with 2-part resnet on priority streams"
             if bad <= 8:
                 print("  frames", fr[:6], "| feat rows differing", df.any(1).nonzero().flatten().tolist()[:6], "cols", df.any(0).nonzero().flatten().tolist()[:8],
                       "| A rows differing", da.any(1).nonzero().flatten().tolist()[:6], "cols", da.any(0).nonzero().flatten().tolist()[:16])
+            if os.environ.get("DBG_DUMP") and bad <= 6:
+                # the first wrong joint of each wrong instance: got / expected A[j][1][3], the error, and the candidates it might be made of
+                # (the parent's A row 1, this joint's A rows: everything the chain step G_i = G_p [R_i | t_i] touches)
+                PAR = [-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21]
+                for r_ in da.any(1).nonzero().flatten().tolist()[:3]:
+                    j_ = min(c // 12 for c in da[r_].nonzero().flatten().tolist())
+                    g_, e_ = a_g[r_].reshape(24, 12), a_r[r_].reshape(24, 12)
+                    print("    instance", r_, "first wrong joint", j_, "parent", PAR[j_], "| got", float(g_[j_, 7]), "expected", float(e_[j_, 7]),
+                          "err", float(g_[j_, 7] - e_[j_, 7]))
+
+                    def chain(inst):                             # float64 forward kinematics of one instance: the global (G) and local (Lc) transforms [24][12]
+                        o_ = om_ref.reshape(-1, 85)[inst].double().cpu().numpy()
+                        th, be = o_[3:75].reshape(24, 3), o_[75:85]
+                        vs = s["v_template"].astype(np.float64) + (be @ s["shapedirs"].astype(np.float64)).reshape(6890, 3)
+                        J = s["J_regressor"].astype(np.float64).T @ vs
+                        G, Lc = np.zeros((24, 12)), np.zeros((24, 12))
+                        for q in range(24):
+                            e3 = th[q] + 1e-8
+                            an = np.sqrt((e3 * e3).sum()); rr = th[q] / an; c_, s_ = np.cos(an), np.sin(an)
+                            K = np.array([[0, -rr[2], rr[1]], [rr[2], 0, -rr[0]], [-rr[1], rr[0], 0]])
+                            Lc[q, :9] = (c_ * np.eye(3) + (1 - c_) * np.outer(rr, rr) + s_ * K).reshape(9)
+                            Lc[q, 9:] = J[q] - (J[PAR[q]] if q else 0)
+                            if q == 0:
+                                G[0] = Lc[0]
+                            else:
+                                Gp = G[PAR[q]]
+                                G[q, :9] = (Gp[:9].reshape(3, 3) @ Lc[q, :9].reshape(3, 3)).reshape(9)
+                                G[q, 9:] = Gp[:9].reshape(3, 3) @ Lc[q, 9:] + Gp[9:]
+                        return G, Lc
+                    G, Lc = chain(r_)
+                    G2, Lc2 = chain(r_ - 1)
+                    p_ = PAR[j_]
+                    for nm, GG, LL in (("this", G, Lc), ("even", G2, Lc2)):
+                        print("      %s: G_p[3..5] %s G_p[9..11] %s Lc[9..11] %s | products row1 %s | o[9..11] %s" % (
+                            nm, np.round(GG[p_, 3:6], 5).tolist(), np.round(GG[p_, 9:12], 5).tolist(), np.round(LL[j_, 9:12], 5).tolist(),
+                            np.round(GG[p_, 3:6] * LL[j_, 9:12], 5).tolist(), np.round(GG[j_, 9:12], 5).tolist()))
+                    print("      Lc rot", np.round(Lc[j_, :9], 4).tolist(), "G_p rot", np.round(G[p_, :9], 4).tolist(), "G rot", np.round(G[j_, :9], 4).tolist())
             if bad <= 0:
                 print(mode, "rep", rep, "frames", fr[:10], "fields", ks, "nan", int(torch.isnan(rec).sum()))
     print(os.environ.get("DBG_DT", "bf16"), {k: v for k, v in os.environ.items() if k.startswith("HMMR_")}, mode, "| tail priority", os.environ.get("DBG_TAIL_PRIORITY", "0"), "| blend form", os.environ.get("DBG_BLEND", "default"), "| library", os.path.basename(L.LIB_PATH), ": bad", bad, "of", REPS)
