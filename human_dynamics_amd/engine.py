@@ -215,7 +215,9 @@ class HmmrEngine(object):
     # -- ResNet launch tuning ----------------------------------------------------
     _TUNE_TILES = tuple(int(t) for t in devflags.get("TUNE_TILES").split(","))   # hmmr_conv_desc_t.tile candidates (8-wave 128x128 / 128x64, 4-wave 64x64 / 128x128 / 128x64, 8-wave ping-pong 256x128 / 128x256)
     _TUNE_MIN_FRAMES = 32
-    _SPLIT_MIN_FRAMES = 128
+    # two contiguous parts on concurrent streams from this many frames on (tools/resnet_parts_small.py, profiles/r06t_resnet_parts_*.log, f16x3: one stream /
+    # two parts 3.35 / 3.44 ms at 128 frames, 4.01 / 4.17 at 160 -- the reference's default Tester.predict, B = 8 x T = 20 -- 5.21 / 4.80 at 192, 6.47 / 6.19 at 257)
+    _SPLIT_MIN_FRAMES = 176
 
     def _resnet_layers(self):
         """[(profile slot, unit index, layer name)] in launch order (csrc/resnet.hip)."""

@@ -204,7 +204,7 @@ def test_resnet_concurrent_half_batches_equal_one_pass(weights, gpu_device, monk
     """engine.resnet splits large batches over two HIP streams: same bits as one launch sequence."""
     import torch
     from human_dynamics_amd.engine import HmmrEngine
-    x = torch.from_numpy(assets.make_synthetic_frames(131, seed=9)).to(gpu_device)
+    x = torch.from_numpy(assets.make_synthetic_frames(179, seed=9)).to(gpu_device)
     monkeypatch.setenv("HMMR_RESNET_STREAMS", "1")
     one = HmmrEngine(weights, None, dtype="bf16", device=gpu_device)
     assert one.resnet_streams == 1
@@ -217,7 +217,7 @@ def test_resnet_concurrent_half_batches_equal_one_pass(weights, gpu_device, monk
     assert len(two._side_streams) == 2 and "resnet1" in two._ws
     three = HmmrEngine(weights, None, dtype="bf16", device=gpu_device)
     three.resnet_streams = 3
-    assert torch.equal(three.resnet(x, n_zero=0), ref[:131])
+    assert torch.equal(three.resnet(x, n_zero=0), ref[:179])
 
 
 def test_pipelined_predictor_with_asynchronous_gather(weights, smpl_consts, gpu_device, monkeypatch):

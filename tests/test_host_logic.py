@@ -172,7 +172,7 @@ def test_resnet_part_boundaries():
     e = HmmrEngine.__new__(HmmrEngine)
     e.resnet_streams, e.resnet_chunk = 2, 0
     assert e.resnet_cuts(256) == [0, 128, 256] and e.resnet_cuts(257) == [0, 128, 257]
-    assert e.resnet_cuts(127) == [0, 127] and e.resnet_cuts(128) == [0, 64, 128] and e.resnet_cuts(0) == [0, 0]
+    assert e.resnet_cuts(175) == [0, 175] and e.resnet_cuts(160) == [0, 160] and e.resnet_cuts(176) == [0, 88, 176] and e.resnet_cuts(0) == [0, 0]
     assert e.resnet_cuts(300, parts=3) == [0, 100, 200, 300] and e.resnet_cuts(300, parts=1) == [0, 300]
     e.resnet_chunk = 64                     # dev switch: sequential chunks, one stream
     assert e.resnet_cuts(256) == [0, 256]
