@@ -5,7 +5,8 @@ write them in the format `human_dynamics_amd/tile_tables.json` ships (dev aid, r
 
 Keys "<hmmr_dtype_t>:<frames>" -> {"<unit>:<layer>": tile}.  Sizes: 20-frame windows are below the tuner's floor; 40 (the operand-mode probe, precision.py); 64 / 65
 (config 2, FeatureExtractor batches), 128 / 129 (the two concurrent parts of a 256-frame shard + its zero image), 256 / 257
-(a 256-frame shard as one pass: the bench's step streams), 512 / 513 and 1024 (config 3 / long device-resident videos).
+(a 256-frame shard as one pass: the bench's step streams), 512 / 513 and 1024 (config 3 / long device-resident videos); round 6: 96 (the
+parts of a 192-frame call) and 160 / 161 (the reference's default Tester.predict, B = 8 x T = 20, one stream).  HMMR_TABLE_SIZES=a,b,... measures other sizes.
 The engine uses the nearest size within 30 %, so these cover 32 ... 1330 frames.  Per candidate tile the minimum over five timed passes (the on-line tuner takes two)."""
 import json
 import os
@@ -21,7 +22,7 @@ os.environ["HMMR_AUTOTUNE"] = "force"
 from human_dynamics_amd import assets                     # noqa: E402
 from human_dynamics_amd.engine import HmmrEngine, DTYPES  # noqa: E402
 
-SIZES = (40, 64, 65, 128, 129, 256, 257, 512, 513, 1024)
+SIZES = tuple(int(v) for v in os.environ["HMMR_TABLE_SIZES"].split(",")) if os.environ.get("HMMR_TABLE_SIZES") else (40, 64, 65, 96, 128, 129, 160, 161, 256, 257, 512, 513, 1024)
 w = assets.make_synthetic_weights(0)
 result = {"_comment": "per-layer hmmr_conv_desc_t.tile, measured by tools/make_tile_tables.py on one MI355X; "
                       "keys '<hmmr_dtype_t>:<frames>' -> {'<unit>:<layer>': tile}; tiles never change a result bit"}
