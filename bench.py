@@ -292,13 +292,20 @@ def run_mode(dtype, args, world, rank, device, weights, smpl, span, n_total, ste
         # the same steps for at least `sustain_s` seconds of GPU time (the K-step region above is ~0.1 s: too short to say what the box
         # does once its power management has settled): a step count from the measurement above, one timed region, same brackets
         n2 = int(sustain_s * 1.05 / (elapsed / steps)) + 1
+        smi = SmiSampler(device.index or 0) if rank == 0 else None
         barrier()
+        if smi is not None:
+            smi.start()
         t0 = time.perf_counter()
         for _ in range(n2):
             out = predictor.run(span)
         predictor.finish()
         barrier()
         el2 = time.perf_counter() - t0
+        power = smi.stop() if smi is not None else None
+        if isinstance(power, dict) and power.get("joules"):
+            power["joules_per_output_frame"] = round(power["joules"] / (n_total / world * n2), 4)       # this rank's socket, this rank's frames
+        timing["power"] = power
         if world > 1:
             t = torch.tensor([el2], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -364,6 +371,119 @@ def stress_leg(span, span_host, plan, n_total, smpl, device):
     return out
 
 
+class SmiSampler:
+    """Socket power and the XCDs' shader clocks while a region runs, read by a host thread from the driver's metrics table (amdsmi): nothing runs on
+    the GPU for it.  stop() -> means over the samples taken between start() and stop(), the energy the socket drew (the driver's accumulator),
+    the power cap; None when amdsmi is not importable, {"error": ...} when it fails."""
+
+    def __init__(self, device_index=0, period_s=0.01):
+        self.idx, self.period = device_index, period_s
+        self.samples, self.run, self.th, self.smi, self.h = [], False, None, None, None
+        try:
+            import amdsmi
+            amdsmi.amdsmi_init()
+            self.smi = amdsmi
+            self.h = amdsmi.amdsmi_get_processor_handles()[device_index]
+        except Exception:
+            self.smi = None
+
+    def _poll(self):
+        while self.run:
+            try:
+                m = self.smi.amdsmi_get_gpu_metrics_info(self.h)
+                clk = [c for c in (m.get("current_gfxclks") or []) if isinstance(c, (int, float)) and 0 < c < 10000]
+                pw = m.get("current_socket_power")
+                pw = pw if isinstance(pw, (int, float)) else m.get("average_socket_power")
+                self.samples.append((clk, pw if isinstance(pw, (int, float)) else None, m.get("temperature_hotspot")))
+            except Exception:
+                pass
+            time.sleep(self.period)
+
+    def _energy(self):
+        try:
+            e = self.smi.amdsmi_get_energy_count(self.h)
+            return float(e["energy_accumulator"]) * float(e["counter_resolution"]) * 1e-6       # J
+        except Exception:
+            return None
+
+    def start(self):
+        if self.smi is None:
+            return
+        import threading
+        self.samples, self.run = [], True
+        self.e0 = self._energy()
+        self.th = threading.Thread(target=self._poll, daemon=True)
+        self.th.start()
+
+    def stop(self):
+        if self.smi is None:
+            return None
+        e1 = self._energy()
+        self.run = False
+        self.th.join()
+        try:
+            clk = np.array([np.mean(c) for c, _, _ in self.samples if c])
+            clk_lo = np.array([np.min(c) for c, _, _ in self.samples if c])
+            pw = np.array([p for _, p, _ in self.samples if p is not None], dtype=np.float64)
+            hot = [t for _, _, t in self.samples if isinstance(t, (int, float))]
+            cap = None
+            try:
+                cap = self.smi.amdsmi_get_power_cap_info(self.h)["power_cap"] / 1e6
+            except Exception:
+                pass
+            return {"socket_w_mean": round(float(pw.mean()), 0) if len(pw) else None, "socket_w_max": round(float(pw.max()), 0) if len(pw) else None,
+                    "power_cap_w": cap,
+                    "gfxclk_mhz_mean": round(float(clk.mean()), 0) if len(clk) else None,
+                    "gfxclk_mhz_min_xcd": round(float(clk_lo.min()), 0) if len(clk_lo) else None,
+                    "gfxclk_mhz_max": round(float(clk.max()), 0) if len(clk) else None, "gfxclk_nominal_mhz": 2400,
+                    "hotspot_c_max": max(hot) if hot else None, "samples": len(self.samples),
+                    "joules": round(e1 - self.e0, 2) if (e1 is not None and self.e0 is not None) else None,
+                    "source": "amdsmi gpu_metrics (the driver's table: clocks per XCD as the firmware averages them, socket power), polled every %d ms by a host thread" % int(self.period * 1e3)}
+        except Exception as e:
+            return {"error": repr(e)}
+
+
+class ClockSampler:
+    """The shader clock beside a measured region (csrc/probe.hip hmmr_clock_probe): one wave on its own stream stores (s_memtime, s_memrealtime)
+    pairs every ~5 us until stop() -- shader ticks against the constant reference counter = the clock the part ran at under THAT load."""
+
+    def __init__(self, eng, n=16384):
+        self.eng, self.n = eng, n
+        self.buf = torch.zeros((n, 2), dtype=torch.int64, device=eng.device)
+        self.flag = torch.zeros((1,), dtype=torch.int32, device=eng.device)
+        self.one = torch.ones((1,), dtype=torch.int32, device=eng.device)
+        self.s_probe, self.s_stop = torch.cuda.Stream(device=eng.device), torch.cuda.Stream(device=eng.device)
+
+    def start(self):
+        from human_dynamics_amd import _lib as L
+        self.buf.zero_(); self.flag.zero_()
+        torch.cuda.synchronize(self.eng.device)
+        L.check(self.eng.lib.hmmr_clock_probe(self.buf.data_ptr(), self.n, 1, self.flag.data_ptr(), self.s_probe.cuda_stream), "hmmr_clock_probe")
+
+    def stop(self):
+        """-> {"mhz_mean", "mhz_min", "mhz_max" (over ~50 us windows), "samples", "ref_khz"} or None when too few samples landed."""
+        torch.cuda.current_stream(self.eng.device).synchronize()    # the measured work (enqueued, not necessarily done) ends first
+        with torch.cuda.stream(self.s_stop):
+            self.flag.copy_(self.one, non_blocking=True)
+        torch.cuda.synchronize(self.eng.device)
+        b = self.buf.cpu().numpy()
+        b = b[b[:, 1] > 0]
+        if len(b) < 12:
+            return None
+        try:
+            ref_khz = int(torch.cuda.get_device_properties(self.eng.device).wall_clock_rate) if hasattr(torch.cuda.get_device_properties(self.eng.device), "wall_clock_rate") else 100000
+        except Exception:
+            ref_khz = 100000
+        b = b[1:]                                                   # (the first sample precedes the region's first launch)
+        w = b[::10]
+        win = (w[1:, 0] - w[:-1, 0]) / np.maximum(w[1:, 1] - w[:-1, 1], 1) * ref_khz / 1e3
+        win = win[(win > 50) & (win < 3000)]                        # (a window that spans a counter glitch reads tens of GHz: dropped)
+        if len(win) < 3:
+            return None
+        return {"mhz_mean": round(float(win.mean()), 0), "mhz_median": round(float(np.median(win)), 0), "mhz_min": round(float(win.min()), 0), "mhz_max": round(float(win.max()), 0),
+                "samples": int(len(b)), "ref_khz": ref_khz}
+
+
 def roofline_leg(tester, plan, span, dtype, frames):
     """Per-launch timing of the ResNet's MFMA launches, one stream, HIP events inside the library."""
     eng = tester.engine
@@ -385,6 +505,23 @@ def roofline_leg(tester, plan, span, dtype, frames):
     e1.record()
     torch.cuda.synchronize(device)
     pass_ms = e0.elapsed_time(e1) / 5
+    # the clock the part runs these passes at: ~0.6 s of the same one-stream passes while a host thread reads the driver's metrics table
+    # (a separate run: the timing above is undisturbed, and nothing extra runs on the GPU)
+    clock_pass = None
+    try:
+        smi = SmiSampler(device.index or 0)
+        n_p = max(10, int(0.6 / (pass_ms * 1e-3)))
+        smi.start()
+        for _ in range(n_p):
+            eng.resnet(span, n_zero=1)
+        torch.cuda.synchronize(device)
+        clock_pass = smi.stop()
+        if isinstance(clock_pass, dict) and clock_pass.get("gfxclk_mhz_mean"):
+            clock_pass["mhz_mean"] = clock_pass["gfxclk_mhz_mean"]
+            clock_pass["passes"] = n_p
+    except Exception as e:                                # a reporting aid: never fail the bench over it
+        clock_pass = {"error": repr(e)}
+    sampler = ClockSampler(eng)                           # (for the MFMA-rate probes below: one wave beside kernels that leave room for it)
     eng.resnet(span, prof=True, n_zero=1)
     _, prof = eng.resnet(span, prof=True, n_zero=1)
     eng.resnet_streams = streams_used
@@ -426,26 +563,51 @@ def roofline_leg(tester, plan, span, dtype, frames):
             from human_dynamics_amd import _lib as L
             cus = torch.cuda.get_device_properties(device).multi_processor_count
             n8 = 2500                                     # 20 000 MFMAs per wave: ~0.35 ms
-            best = None
-            for _ in range(6):
-                p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                p0.record()
-                L.check(eng.lib.hmmr_mfma_rate_probe(cus, n8, None, torch.cuda.current_stream(device).cuda_stream), "hmmr_mfma_rate_probe")
-                p1.record()
-                torch.cuda.synchronize(device)
-                ms_ = p0.elapsed_time(p1)
-                best = ms_ if best is None else min(best, ms_)
-            rate = cus * 4 * 8 * n8 * 32768.0 / (best * 1e-3)
+
+            def mfma_rate(n8_):
+                best = None
+                for _ in range(6):
+                    p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    p0.record()
+                    L.check(eng.lib.hmmr_mfma_rate_probe(cus, n8_, None, torch.cuda.current_stream(device).cuda_stream), "hmmr_mfma_rate_probe")
+                    p1.record()
+                    torch.cuda.synchronize(device)
+                    ms_ = p0.elapsed_time(p1)
+                    best = ms_ if best is None else min(best, ms_)
+                clock = None
+                try:
+                    sampler.start()
+                    for _ in range(12):
+                        L.check(eng.lib.hmmr_mfma_rate_probe(cus, n8_, None, torch.cuda.current_stream(device).cuda_stream), "hmmr_mfma_rate_probe")
+                    clock = sampler.stop()
+                except Exception as e:
+                    clock = {"error": repr(e)}
+                return cus * 4 * 8 * abs(n8_) * 32768.0 / (best * 1e-3), clock
+
+            rate, clock_mfma = mfma_rate(n8)
+            # the same stream on operands that change from MFMA to MFMA (n8 < 0): what the cap allows when the multipliers toggle as on real tensors
+            rate_t, clock_t = mfma_rate(-n8)
             sustained = {"tflops": round(rate / 1e12, 1), "instruction": "v_mfma_f32_32x32x16_f16, one wave per SIMD, nothing else issued",
                          "frac_of_nominal": round(rate / PEAK_BF16, 4),
                          "ceiling_for_this_mode": round(rate / mfma_per_product / 1e12, 1),
                          "frac_of_sustained": round(achieved * mfma_per_product / rate, 4),
+                         "shader_clock": clock_mfma,
+                         "changing_operands": {"tflops": round(rate_t / 1e12, 1), "frac_of_nominal": round(rate_t / PEAK_BF16, 4),
+                                               "ceiling_for_this_mode": round(rate_t / mfma_per_product / 1e12, 1),
+                                               "frac_of_sustained": round(achieved * mfma_per_product / rate_t, 4), "shader_clock": clock_t,
+                                               "instruction": "the same stream, four hashed fp16 fragment pairs taken in turn"},
                          "note": "measured on this box in this run: the power cap, not the 2.4 GHz nominal clock, sets what a dense "
                                  "fp16 MFMA stream reaches; `frac` above stays against the nominal peak"}
         except Exception as e:                            # the probe is a reporting aid: never fail the bench over it
             sustained = {"error": repr(e)}
+    clock_adj = None
+    if isinstance(clock_pass, dict) and clock_pass.get("mhz_mean"):
+        # the same `achieved` against the peak AT THE CLOCK THE PASS RAN AT (nominal peak x measured clock / 2400 MHz): how busy the matrix
+        # pipes are in cycles, which is what the PMC figure (mfma_util_pmc) counts; `frac` stays against the nominal peak
+        clock_adj = round(achieved / (peak * clock_pass["mhz_mean"] / 2400.0), 4)
     return {"bound": "mfma",
             "mfma_sustained": sustained,
+            "shader_clock_during_pass": clock_pass, "frac_at_measured_clock": clock_adj,
             "kernel": "conv_gemm_kernel%s (ResNet-v2-50, %s operands: %d MFMA launches/pass, %d of them fused bottleneck units)"
                       % ({"bf16": " / bottleneck_tail_kernel / stem_fused_kernel", "f16x3": " / conv3x3_stream_kernel / conv1x1_stream_kernel / unit_pair_kernel / b1_unit_kernel / stem_fused_split_kernel"}.get(dtype, ""), dtype, n_conv, n_tails),
             "achieved": round(achieved / 1e12, 2), "peak": round(peak / 1e12, 1), "unit": "TFLOP/s",
@@ -854,6 +1016,9 @@ def main():
             "fps_sustained_2s": round(timing["sustained_fps"], 1) if "sustained_fps" in timing else None,
             "sustained_leg": ({"steps": timing["sustained_steps"], "seconds": round(timing["sustained_seconds"], 3)}
                               if "sustained_fps" in timing else None),
+            # rank 0's socket over that sustained leg (amdsmi, a host thread): the path runs AT the 1 400 W cap, and the cap -- not the 2.4 GHz
+            # nominal clock -- sets the clock the matrix pipes get
+            "power": timing.get("power"),
             "frames_total": n_total,
             "all_gather_ms": all_gather_ms, "all_gather_bytes": gather_bytes, "rccl_ranks": rccl_ranks,
             "gather": args.gather if world > 1 else None, "gather_requested": gather_requested if world > 1 else None,

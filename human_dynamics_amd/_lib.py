@@ -18,7 +18,7 @@ LIB_PATH = devflags.get("LIB_PATH") or os.path.join(HERE, "libhmmr_hip.so")
 HMMR_F32, HMMR_BF16, HMMR_F16X3 = 0, 1, 2
 FLAG_SATURATED = 1
 FLAG_NAN = 2          # with FLAG_SATURATED: the clamped value was a NaN (include/hmmr_hip.h)
-ABI_VERSION = 18
+ABI_VERSION = 19
 RESNET_UNITS = 16
 RESNET_PROF_SLOTS = 64
 MAX_TEMPORAL_BLOCKS = 8
@@ -174,6 +174,7 @@ SIGNATURES = {
     "hmmr_conv3x3_stream_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "hmmr_conv1x1_stream_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "hmmr_mfma_rate_probe": (C.c_int, [C.c_int, C.c_int, _fp, _vp]),
+    "hmmr_clock_probe": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "hmmr_render_handoff": (C.c_int, [_fp, C.c_int64, _fp, C.c_int64, _fp, C.c_int64, _fp, C.c_int, C.c_int, C.c_int,
                                       _fp, _fp, _fp, _vp]),
     "hmmr_eval_joints": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _vp]),

@@ -783,11 +783,13 @@ template <int OFF> __device__ __forceinline__ u32x4 lds_rd128u(unsigned addr) {
 // waits of wave A (128) / wave B (256), wave A's MFMAs only (512), wave B's MFMAs only (1024); -DWS_PRIO_A / -DWS_PRIO_B: s_setprio of the roles
 #ifdef HMMR_GEMM_PROBE
 #define WS_STAMP(k) do { if (a.ts) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) a.ts[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (k)] = t_; } } while (0)
+#define WS_RSTAMP(k) do { if (a.ts) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); if ((threadIdx.x & 63) == 0) a.ts[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (k)] = t_; } } while (0)   /* the constant 100 MHz counter: slots 6 / 7 = start / end, so (t4 - t0) / (r7 - r6) x 100 MHz = the clock this wave ran at */
 #define WS_ACC_BEGIN() const unsigned long long tb_ = a.ts ? __builtin_amdgcn_s_memtime() : 0ull
 #define WS_ACC_END(var) do { if (a.ts) var += __builtin_amdgcn_s_memtime() - tb_; } while (0)
 #define WS_ACC_STORE(k, var) do { if (a.ts && (threadIdx.x & 63) == 0) a.ts[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (k)] = var; } while (0)
 #else
 #define WS_STAMP(k) do { } while (0)
+#define WS_RSTAMP(k) do { } while (0)
 #define WS_ACC_BEGIN() do { } while (0)
 #define WS_ACC_END(var) do { } while (0)
 #define WS_ACC_STORE(k, var) do { } while (0)
@@ -807,6 +809,7 @@ __global__ __launch_bounds__(512, 1) void unit_pair_ws_kernel(const PairArgs a) 
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     WS_STAMP(0);
+    WS_RSTAMP(6);
     unsigned long long t_wait = 0ull;
     (void)t_wait;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -991,6 +994,7 @@ __global__ __launch_bounds__(512, 1) void unit_pair_ws_kernel(const PairArgs a) 
         WS_STAMP(3);
         split_flag_max(satm);
         WS_STAMP(4);
+        WS_RSTAMP(7);
         WS_ACC_STORE(5, t_wait);
         return;
     }
@@ -1221,6 +1225,7 @@ __global__ __launch_bounds__(512, 1) void unit_pair_ws_kernel(const PairArgs a) 
     }
     split_flag_max(satmax);
     WS_STAMP(4);
+    WS_RSTAMP(7);
     WS_ACC_STORE(5, t_wait);
 }
 

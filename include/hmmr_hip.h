@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define HMMR_ABI_VERSION 18      /* 18: HMMR_FLAG_NAN, hmmr_debug_t.pair_form (the wave-specialised unit pair), the C-side packers hmmr_pack_*; 17: k_order = 2 on a 1x1 filter (the two-ring stream kernel of csrc/conv1x1_stream.hip, tiles 22 .. 26), hmmr_conv1x1_stream_bytes; 16: hmmr_tail_desc_t.unit_stream, hmmr_resnet_unit_t.unit_stream (the whole-unit kernel of block 1, csrc/b1_unit.hip), hmmr_b1_unit_stream_bytes, hmmr_debug_t.pair_min_pixels / pair_two_tile_min / launch counters, hmmr_resnet_unit_t.conv1_frag (block1/unit_1's conv1 inside the split stem); 15: k_order = 2 (the one-wave-per-SIMD 3x3 stream kernel, tiles 12 .. 18), hmmr_conv3x3_stream_bytes; 14: hmmr_tail_desc_t.pair_stream / c_xp, hmmr_resnet_unit_t.pair_stream (the register-resident unit pair of blocks 2-3), hmmr_run_flags; 13: hmmr_conv_desc_t.batch (grouped launches); 12: k_order = 1, 3x3 SAME convolutions out of an LDS-resident input patch (tiles 9, 10, 11) */
+#define HMMR_ABI_VERSION 19      /* 19: hmmr_clock_probe (measurement aid); 18: HMMR_FLAG_NAN, hmmr_debug_t.pair_form (the wave-specialised unit pair), the C-side packers hmmr_pack_*; 17: k_order = 2 on a 1x1 filter (the two-ring stream kernel of csrc/conv1x1_stream.hip, tiles 22 .. 26), hmmr_conv1x1_stream_bytes; 16: hmmr_tail_desc_t.unit_stream, hmmr_resnet_unit_t.unit_stream (the whole-unit kernel of block 1, csrc/b1_unit.hip), hmmr_b1_unit_stream_bytes, hmmr_debug_t.pair_min_pixels / pair_two_tile_min / launch counters, hmmr_resnet_unit_t.conv1_frag (block1/unit_1's conv1 inside the split stem); 15: k_order = 2 (the one-wave-per-SIMD 3x3 stream kernel, tiles 12 .. 18), hmmr_conv3x3_stream_bytes; 14: hmmr_tail_desc_t.pair_stream / c_xp, hmmr_resnet_unit_t.pair_stream (the register-resident unit pair of blocks 2-3), hmmr_run_flags; 13: hmmr_conv_desc_t.batch (grouped launches); 12: k_order = 1, 3x3 SAME convolutions out of an LDS-resident input patch (tiles 9, 10, 11) */
 
 /* HMMR_F16X3: "split" tensors -- every group of 8 consecutive channels is 32 bytes, [hi x8][lo x8] with
  * hi = fp16(x), lo = fp16(x - hi), x clamped to +-65504 (4 bytes per element, 22 mantissa bits while lo is a normal
@@ -330,8 +330,14 @@ typedef struct {
 size_t hmmr_pair_stream_bytes(int kc3, int depth, int n2);
 size_t hmmr_b1_unit_stream_bytes(int c_xp);
 /* measurement aid (bench.py's `roofline.mfma_sustained`): one launch of `workgroups` x 4 waves, one wave per SIMD, each issuing 8 * n8
- * v_mfma_f32_32x32x16_f16 (32768 FLOP each) on four independent accumulators and nothing else.  out: NULL or workgroups * 256 floats. */
+ * v_mfma_f32_32x32x16_f16 (32768 FLOP each) on four independent accumulators and nothing else.  out: NULL or workgroups * 256 floats.
+ * n8 < 0 (ABI 19): -n8 iterations on operands that CHANGE from MFMA to MFMA (four hashed fragment pairs in turn) -- the constant-operand loop is the
+ * lowest-power case, so the clock the power cap allows it is higher than any real tensor gets. */
 int hmmr_mfma_rate_probe(int workgroups, int n8, float* out, void* stream);
+/* (ABI 19) measurement aid: one wave that stores n (s_memtime, s_memrealtime) pairs -- shader-clock ticks against the constant reference counter
+ * (hipDeviceAttributeWallClockRate) -- `sleep` x ~4 us apart into `samples` (2 n words, zeroed by the caller), until n are taken or *stop (NULL or a device
+ * int set from another stream) is non-zero.  Run on its own stream beside a measured region: the clock the part sustains under that load (bench.py). */
+int hmmr_clock_probe(unsigned long long* samples, int n, int sleep, const int* stop, void* stream);
 /* bytes of the filter stream of a k_order 2 layer of split tensors: (cout / 128) x 9 (cin / 16) K steps of 8 KB (bf16 tensors: half of it,
  * 9 (cin / 32) K steps) */
 size_t hmmr_conv3x3_stream_bytes(int cin, int cout);

@@ -24,7 +24,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "libhmmr_hip.so does not export %s" % n
     assert sorted(_lib.SIGNATURES) == names        # the ctypes table covers the header one to one
-    assert lib.hmmr_abi_version() == _lib.ABI_VERSION == 18
+    assert lib.hmmr_abi_version() == _lib.ABI_VERSION == 19
 
 
 def test_workspace_queries_need_no_gpu():

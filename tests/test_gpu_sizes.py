@@ -250,3 +250,46 @@ def test_bench_two_rank_code_path_on_one_gpu(gpu_device):
     assert js["single_video_ms"] == js["single_video_ms_by_gather"]["theta"] and js["all_gather_bytes"] == 512 * 255 * 4
     assert js["value"] > 1000 and js["per_gpu_fps"] * 2 == pytest.approx(js["value"], rel=1e-3) and js["scaling_efficiency"] > 0
     assert js["config"]["frames_per_gpu_per_step"] == 256 and "window-sharded x2" in js["config"]["parallelism"]
+
+
+@pytest.mark.gpu
+def test_bench_power_and_clock_samplers(weights, gpu_device):
+    """bench.py's two reporting aids of round 6 on hardware: SmiSampler (socket power + the XCDs' clocks from the driver's metrics table, a host
+    thread) around ResNet passes, ClockSampler (csrc/probe.hip hmmr_clock_probe: s_memtime against s_memrealtime in one wave) beside the bare
+    MFMA stream in both operand forms -- plausible numbers, and the changing-operand stream is not faster than the constant one."""
+    import time
+    import bench
+    from human_dynamics_amd import _lib as L
+    from human_dynamics_amd.engine import HmmrEngine
+    eng = HmmrEngine(weights, None, dtype="f16x3", device=gpu_device)
+    x = torch.rand((64, 224, 224, 3), device=gpu_device) * 2 - 1
+    for _ in range(3):
+        eng.resnet(x)
+    torch.cuda.synchronize()
+    smi = bench.SmiSampler(torch.device(gpu_device).index or 0)
+    smi.start()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.5:
+        for _ in range(8):
+            eng.resnet(x)
+        torch.cuda.synchronize()
+    p = smi.stop()
+    if p is None:
+        pytest.skip("amdsmi is not usable on this box")
+    assert "error" not in p, p
+    assert p["samples"] >= 10 and 200 < p["socket_w_mean"] < 2000 and 400 < p["gfxclk_mhz_mean"] < 2600 and p["joules"] > 50, p
+    cus = torch.cuda.get_device_properties(gpu_device).multi_processor_count
+    st = torch.cuda.current_stream().cuda_stream
+    rates = {}
+    for n8 in (2500, -2500):
+        cs = bench.ClockSampler(eng)
+        cs.start()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            L.check(eng.lib.hmmr_mfma_rate_probe(cus, n8, None, st), "hmmr_mfma_rate_probe")
+        e1.record()
+        c = cs.stop()
+        rates[n8] = cus * 4 * 8 * 2500 * 32768.0 * 10 / (e0.elapsed_time(e1) * 1e-3)
+        assert c is not None and 800 < c["mhz_median"] < 2600, c
+    assert 0.8e15 < rates[-2500] <= rates[2500] * 1.02 and rates[2500] < 2.6e15, rates

@@ -137,6 +137,25 @@ gb = (h2.numel() + (xp.numel() if cxp else res.numel()) + tr.numel() + hr.numel(
 fl = 2.0 * m * (K3 * depth + depth * n2)
 print("%s (%d px): two launches %.4f ms | unit pair %.4f ms = %.0f TFLOP/s, %.2f TB/s of tensor traffic" % (
     blk, m, ms_ref, ms_pair, fl / ms_pair / 1e9, gb / ms_pair))
+import os
+if os.environ.get("PAIR_POWER"):              # ~1 s of back-to-back launches under bench.SmiSampler: socket power and the XCDs' clocks while ONLY this kernel runs
+    import time
+    import bench
+    for label, fn, ms_ in (("unit pair", run_pair, ms_pair), ("two launches", run_ref, ms_ref)):
+        reps = int(1.0 / (ms_ * 1e-3))
+        smi = bench.SmiSampler(0)
+        smi.start()
+        t0 = time.perf_counter()
+        for i in range(reps):
+            fn()
+            if i % 64 == 63:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        pw = smi.stop() or {}
+        print("power, %s x %d back to back: %.4f ms each | %s W mean (max %s, cap %s) | clocks %s MHz mean, slowest XCD %s | %.3f mJ per launch" % (
+            label, reps, el / reps * 1e3, pw.get("socket_w_mean"), pw.get("socket_w_max"), pw.get("power_cap_w"), pw.get("gfxclk_mhz_mean"), pw.get("gfxclk_mhz_min_xcd"),
+            (pw.get("joules") or 0) / reps * 1e3))
 
 if ts is not None and ws:
     run_pair()
@@ -146,12 +165,20 @@ if ts is not None and ws:
     t0 = t[:, :, 0].min()
     for b in (0, min(255, nb - 1), nb - 1):
         for w in (0, 4):
-            print("block %d wave %d (%s): start %+8.0f | prologue issue %6.0f | drain + sync %6.0f | loop %8.0f | tail %6.0f | in waits + barriers %8.0f | B block %7.0f   (100 MHz ticks)" % (
+            print("block %d wave %d (%s): start %+8.0f | prologue issue %6.0f | drain + sync %6.0f | loop %8.0f | tail %6.0f | in waits + barriers %8.0f | B block %7.0f   (shader-clock ticks)" % (
                 b, w, "A" if w < 4 else "B", t[b, w, 0] - t0, t[b, w, 1] - t[b, w, 0], t[b, w, 2] - t[b, w, 1], t[b, w, 3] - t[b, w, 2], t[b, w, 4] - t[b, w, 3], t[b, w, 5], t[b, w, 6]))
     A, Bw = t[:, :4], t[:, 4:]
     print("kernel span (ticks): %.0f | mean loop A %.0f B %.0f | mean prologue %.0f | mean tail A %.0f B %.0f | mean in waits + barriers A %.0f B %.0f | B block %.0f" % (
         t[:, :, 4].max() - t0, (A[:, :, 3] - A[:, :, 2]).mean(), (Bw[:, :, 3] - Bw[:, :, 2]).mean(), (t[:, :, 2] - t[:, :, 0]).mean(),
         (A[:, :, 4] - A[:, :, 3]).mean(), (Bw[:, :, 4] - Bw[:, :, 3]).mean(), A[:, :, 5].mean(), Bw[:, :, 5].mean(), Bw[:, :, 6].mean()))
+    # s_memtime counts shader clocks, s_memrealtime (slots 6 / 7) the constant 100 MHz reference: the clock each wave ran at, first-round and second-round workgroups
+    dt_, dr_ = Bw[:, :, 4] - Bw[:, :, 0], Bw[:, :, 7] - Bw[:, :, 6]
+    ok = dr_ > 0
+    if ok.any():
+        first = np.arange(nb)[:, None].repeat(4, 1) < 256
+        f_ = lambda sel: (dt_[sel & ok].sum() / dr_[sel & ok].sum() * 100.0) if (sel & ok).any() else float("nan")
+        print("clock of the B waves (shader ticks per 100 MHz tick): all %.0f MHz | workgroups 0-255 %.0f MHz (%.1f us each) | the rest %.0f MHz (%.1f us each)" % (
+            f_(ok), f_(first), dr_[first & ok].mean() / 100.0, f_(~first), dr_[~first & ok].mean() / 100.0 if (~first & ok).any() else float("nan")))
 elif ts is not None:
     run_pair()
     torch.cuda.synchronize()
