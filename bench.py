@@ -383,7 +383,18 @@ class SmiSampler:
             import amdsmi
             amdsmi.amdsmi_init()
             self.smi = amdsmi
-            self.h = amdsmi.amdsmi_get_processor_handles()[device_index]
+            hs = amdsmi.amdsmi_get_processor_handles()
+            self.h = hs[device_index] if device_index < len(hs) else hs[0]
+            try:
+                # amdsmi lists every GPU of the node in ITS order; HIP's device numbering follows *_VISIBLE_DEVICES: match by PCI address
+                pr = torch.cuda.get_device_properties(device_index)
+                want = "%04x:%02x:%02x" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+                for h in hs:
+                    if amdsmi.amdsmi_get_gpu_device_bdf(h).lower().startswith(want):
+                        self.h = h
+                        break
+            except Exception:
+                pass
         except Exception:
             self.smi = None
 
