@@ -292,7 +292,7 @@ def run_mode(dtype, args, world, rank, device, weights, smpl, span, n_total, ste
         # the same steps for at least `sustain_s` seconds of GPU time (the K-step region above is ~0.1 s: too short to say what the box
         # does once its power management has settled): a step count from the measurement above, one timed region, same brackets
         n2 = int(sustain_s * 1.05 / (elapsed / steps)) + 1
-        smi = SmiSampler(device.index or 0) if rank == 0 else None
+        smi = SmiSampler(device.index or 0) if (rank == 0 and not args.no_power) else None
         barrier()
         if smi is not None:
             smi.start()
@@ -495,7 +495,7 @@ class ClockSampler:
                 "samples": int(len(b)), "ref_khz": ref_khz}
 
 
-def roofline_leg(tester, plan, span, dtype, frames):
+def roofline_leg(tester, plan, span, dtype, frames, power=True):
     """Per-launch timing of the ResNet's MFMA launches, one stream, HIP events inside the library."""
     eng = tester.engine
     device = eng.device
@@ -520,6 +520,8 @@ def roofline_leg(tester, plan, span, dtype, frames):
     # (a separate run: the timing above is undisturbed, and nothing extra runs on the GPU)
     clock_pass = None
     try:
+        if not power:
+            raise RuntimeError("--no-power")
         smi = SmiSampler(device.index or 0)
         n_p = max(10, int(0.6 / (pass_ms * 1e-3)))
         smi.start()
@@ -587,6 +589,8 @@ def roofline_leg(tester, plan, span, dtype, frames):
                     best = ms_ if best is None else min(best, ms_)
                 clock = None
                 try:
+                    if not power:
+                        raise RuntimeError("--no-power")
                     sampler.start()
                     for _ in range(12):
                         L.check(eng.lib.hmmr_mfma_rate_probe(cus, n8_, None, torch.cuda.current_stream(device).cuda_stream), "hmmr_mfma_rate_probe")
@@ -770,6 +774,9 @@ def main():
     ap.add_argument("--sustain", type=float, default=2.0,
                     help="seconds of a second, longer timed leg of the same steps (`fps_sustained_2s`; 0 = skip)")
     ap.add_argument("--no-by-config", action="store_true", help="skip the `by_config` legs (the other BASELINE sizes)")
+    ap.add_argument("--no-power", action="store_true",
+                    help="skip the power / clock sampling (SmiSampler's ~0.6 s of extra ResNet passes, the clock-probe wave): for runs under a profiler, "
+                         "whose per-pass averages should be taken over the steps' own passes")
     ap.add_argument("--by-config-only", action="store_true", help="run ONLY the `by_config` legs and print them as one JSON line (what the default run "
                                                                   "starts as a child process; --dtype: the operand mode, not auto)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive leg (used for PMC passes)")
@@ -890,7 +897,7 @@ def main():
 
     result = None
     if rank == 0:
-        roofline = roofline_leg(tester, plan, span, args.dtype, args.frames if not strong else -1)
+        roofline = roofline_leg(tester, plan, span, args.dtype, args.frames if not strong else -1, power=not args.no_power)
         # the overlapped reading of the same FLOPs: the timed steps run the ResNet passes of consecutive steps on two streams
         roofline["achieved_overlapped"] = round(RESNET_FLOPS_PER_FRAME * (plan.f1 - plan.f0 + 1) / (ms_per_step * 1e-3) / 1e12, 2)
         roofline["frac_overlapped"] = round(roofline["achieved_overlapped"] / roofline["peak"], 4)

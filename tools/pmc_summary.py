@@ -79,6 +79,9 @@ def main():
     rn = [k for k in fe if resnet_kernel(k, dtype)]
     n = sum(fe[k][0] for k in rn)
     rd = sum(2 * 1024 * fe[k][1] for k in rn)
+    # every counter is its OWN run of the command: if the runs held different numbers of passes (a time-based loop in the command), sums must not be
+    # mixed -- scale each kernel's WRITE_SIZE sum to the launch count the FETCH_SIZE run saw (per-launch values are what is stable; round 6)
+    wr = {k: [fe[k][0], v[1] * fe[k][0] / v[0]] if (k in fe and v[0]) else v for k, v in wr.items()}
     w = sum(1024 * wr[k][1] for k in rn if k in wr)
     busy = sum(mf[k][1] for k in rn if k in mf)
     g = sum(gui[k][1] for k in rn if k in gui)

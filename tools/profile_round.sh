@@ -8,13 +8,13 @@ TAG=${1:-x}; DT=${2:-f16x3}
 R=$(pwd); O=$R/gpurun_out/$TAG; mkdir -p $O
 export HMMR_TILE_CACHE=/tmp/tiles_$TAG.json
 cd /tmp && export TMPDIR=/tmp
-SER="python $R/bench.py --dtype $DT --serial --only-main --no-cpu-baseline --no-pcie --no-by-config --sustain 0 --steps 6 --warmup 2"
+SER="python $R/bench.py --dtype $DT --serial --only-main --no-cpu-baseline --no-pcie --no-by-config --no-power --sustain 0 --steps 6 --warmup 2"
 python $R/bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err      # the driver's command (dtype auto)
 $SER > $O/bench_serial.json 2>> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- $SER > $O/bench_serial_under_rocprof.json 2>> $O/rocprof.err
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES"; do
   n=$(echo $c | cut -d' ' -f1)
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$n -- timeout 600 python $R/bench.py --dtype $DT --serial --only-main --no-cpu-baseline --no-pcie --no-by-config --sustain 0 --steps 2 --warmup 1 > /dev/null 2>> $O/rocprof.err
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$n -- timeout 600 python $R/bench.py --dtype $DT --serial --only-main --no-cpu-baseline --no-pcie --no-by-config --no-power --sustain 0 --steps 2 --warmup 1 > /dev/null 2>> $O/rocprof.err
 done
 cd $R
 python tools/layer_table.py 257 $DT 5 > $O/layer_table_$DT.log 2>&1
