@@ -72,6 +72,6 @@ def scan(path):
 
 def unsafe_forms(path):
     """The unsafe packed-fp32 instructions of the library at `path` ({} = none), or None when there is no disassembler to look with."""
-    if not os.path.exists(OBJDUMP):
+    if not os.path.exists(OBJDUMP) or not code_objects(path):      # (no bundle found: a format this parser does not know -- "not checked", never "clean")
         return None
     return scan(path)[1]
